@@ -1,0 +1,120 @@
+/* vhp.h -- C ABI of the MI355X visibility-sweep / visibility-heuristic-planner library
+ * (libvhp_hip.so).  This is the drop-in boundary: plain pointers and sizes, no C++
+ * or torch types.
+ *
+ * The reference (IbrahimSquared/visibility-heuristic-path-planner) has no FFI or
+ * plugin interface; its de-facto boundary is the public surface of
+ * vbs::visibilityBasedSolver (include/solver/visibilityBasedSolver.h:23-71), whose
+ * methods return void and leave results in members.  Each entry point below names
+ * the reference code it replaces.
+ *
+ * Conventions
+ *   - grids are row-major, x fastest: index = x + y*nx (include/environment/field.h:24-29)
+ *   - occupancy is the reference's "occupancy complement": 1 = free, 0 = blocked
+ *     (environment.cpp:200-207), one uint8 per cell
+ *   - sources / pivots are int32 (x, y) pairs (parser.h:9 `point`)
+ *   - every call returns a vhp_status; vhp_last_error() gives the message
+ *   - a context is bound to one GPU and is not thread-safe (the reference object is
+ *     stateful and single-threaded as well, visibilityBasedSolver.h:148-171)
+ *   - there is NO CPU fallback: without a usable HIP device vhp_create fails.
+ */
+#ifndef VHP_H
+#define VHP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vhp_ctx vhp_ctx;
+
+typedef enum vhp_status {
+  VHP_OK = 0,
+  VHP_ERR_ARG = 1,            /* null pointer / bad size / bad enum */
+  VHP_ERR_SOURCE_OOB = 2,     /* a sweep source lies outside the grid */
+  VHP_ERR_NOTHING_LIT = 3,    /* planner: no cell reached the threshold (reference: top() of an empty heap) */
+  VHP_ERR_START_OOB = 10,     /* "Start point is out of bounds."        solver.cpp:89-95  */
+  VHP_ERR_END_OOB = 11,       /* "End point is out of bounds."          solver.cpp:96-102 */
+  VHP_ERR_START_OCCUPIED = 12,/* "Start point is not valid (occupied)"  solver.cpp:103-109 */
+  VHP_ERR_END_OCCUPIED = 13,  /* "End point is not valid (occupied)"    solver.cpp:110-116 */
+  VHP_ERR_MAX_ITER = 20,      /* "Max iters hit. ..."                   solver.cpp:134-139 */
+  VHP_ERR_HIP = 100,          /* a HIP runtime call failed */
+  VHP_ERR_NO_MAP = 101,       /* vhp_set_map has not been called */
+  VHP_ERR_TOO_LARGE = 102     /* grid side exceeds VHP_MAX_SIDE */
+} vhp_status;
+
+/* which sweep: computeVisibility (solver.cpp:570-696) or
+ * computeVisibilityUsingQueue (solver.cpp:701-893) */
+typedef enum vhp_variant { VHP_SWEEP_FULL = 0, VHP_SWEEP_QUEUE = 1 } vhp_variant;
+
+/* element type of the STORED field; arithmetic is always IEEE binary64 */
+typedef enum vhp_dtype { VHP_F64 = 0, VHP_F32 = 1 } vhp_dtype;
+
+#define VHP_MAX_SIDE 8192
+#define VHP_UNLABELLED 1000000000000000ULL /* (size_t)1e15, solver.cpp:46 */
+
+/* Replaces the visibilityBasedSolver constructor + reset() (solver.cpp:13-60).
+ * device_ordinal: HIP device index. */
+int vhp_create(int device_ordinal, vhp_ctx** out);
+int vhp_destroy(vhp_ctx* ctx);
+const char* vhp_last_error(const vhp_ctx* ctx);
+
+/* Launch everything on the caller's HIP stream (hipStream_t as void*; NULL = the
+ * context's own stream).  Lets a host framework time and order the work itself. */
+int vhp_set_stream(vhp_ctx* ctx, void* hip_stream);
+
+/* Replaces environment::getVisibilityField() hand-over (environment.h:58-60,
+ * solver.cpp:14-17): uploads the occupancy complement and builds the bit-packed
+ * row-major and column-major copies the kernels read.  The map is immutable until
+ * the next vhp_set_map. */
+int vhp_set_map(vhp_ctx* ctx, const uint8_t* occ_rowmajor, int nx, int ny);
+/* Same, the uint8 map already resident in device memory. */
+int vhp_set_map_device(vhp_ctx* ctx, const uint8_t* d_occ_rowmajor, int nx, int ny);
+
+/* Replaces computeVisibility() / computeVisibilityUsingQueue() for a batch of
+ * independent sources (the reference handles one source per call through the
+ * member ls_, solver.cpp:214-218).  out holds n_src fields of nx*ny elements of
+ * `dtype`, field s at out + s*nx*ny.  Cells the reference never writes (row 0 /
+ * column 0 unless the source lies on them; for the queue variant
+ * blocked and unreached cells) are returned as 0, i.e. the result of running the
+ * reference on a freshly reset() solver. */
+int vhp_sweep_batch(vhp_ctx* ctx, const int32_t* src_xy, int n_src, int variant, int dtype, void* out_host);
+/* Device-resident form: d_src_xy and d_out are device pointers; asynchronous on the
+ * context stream.  Sources are validated on the device; query with vhp_sync(). */
+int vhp_sweep_batch_device(vhp_ctx* ctx, const int32_t* d_src_xy, int n_src, int variant, int dtype, void* d_out);
+/* Waits for the stream and returns the status of device-side validation
+ * (VHP_ERR_SOURCE_OOB if any source of an earlier *_device call was out of range). */
+int vhp_sync(vhp_ctx* ctx);
+
+/* Replaces solve() (solver.cpp:76-160) incl. updateVisibility() (:379-565), the
+ * heap / top() arg-min (visibilityBasedSolver.h:16-21,138) and resetQueue().
+ * Coordinates are FIELD coordinates (the mode-2 y flip of solver.cpp:83-86 is the
+ * caller's).  Outputs (any may be NULL): came_from nx*ny (cameFrom_, VHP_UNLABELLED
+ * where unlabelled), vis_global / vis_local nx*ny (visibility_global_, visibility_ of
+ * the last pivot), pivots_xy 2*(max_iter+2) (lightSources_[0..*n_pivots], the last
+ * entry is `end`, solver.cpp:141), *n_pivots = nb_of_sources_.
+ * Returns VHP_OK, one of the four validation codes, VHP_ERR_MAX_ITER (outputs are
+ * still filled) or VHP_ERR_NOTHING_LIT. */
+int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold,
+                      uint64_t max_iter, uint64_t* came_from, double* vis_global, double* vis_local,
+                      int32_t* pivots_xy, uint32_t* n_pivots);
+
+/* Replaces reconstructPath() (solver.cpp:1183-1213): walks came_from -> pivots from
+ * `end` until the label repeats; writes the path start-first into path_xy (capacity
+ * cap points), its point count into *n_path, the summed eval_d length into *length. */
+int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, int nx, int ny, int end_x,
+                         int end_y, int32_t* path_xy, uint32_t cap, uint32_t* n_path, double* length);
+
+/* Elapsed milliseconds between the first and last kernel of the most recent
+ * vhp_sweep_batch_device / planner call, from hipEvents recorded on the context
+ * stream.  Blocks until that work has finished. */
+int vhp_last_elapsed_ms(vhp_ctx* ctx, float* ms);
+
+/* Library / build identification: "vhp-hip <version> gfx950". */
+const char* vhp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VHP_H */

@@ -1,0 +1,137 @@
+"""Parity of the HIP sweep (through the C ABI) with the CPU oracle.  Bit-exact: the
+kernels compute in IEEE binary64 with the reference's operation order."""
+import numpy as np
+import pytest
+
+import maps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vhp():
+    import torch  # noqa: F401  (first, so the extension shares torch's HIP runtime)
+    import vhp_amd
+    return vhp_amd
+
+
+def _ctx(vhp, occ):
+    c = vhp.Context(0)
+    c.set_map(occ)
+    return c
+
+
+def _assert_same(got, want, what):
+    if got.tobytes() != want.tobytes():
+        bad = np.argwhere(got != want)
+        y, x = bad[0][-2:]
+        raise AssertionError("%s: %d cells differ, first at (x=%d,y=%d): got %r want %r" % (
+            what, len(bad), x, y, got[tuple(bad[0])], want[tuple(bad[0])]))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_small_random_maps_bit_exact(vhp, oracle, seed):
+    occ = maps.random_rect_map(101, 77, 25, 2, 20, 2, 20, seed)
+    src = maps.free_sources(occ, 24, seed + 100)
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "seed %d source %d (%d,%d)" % (seed, k, sx, sy))
+
+
+def test_config1_101x101(vhp, oracle):
+    # BASELINE config 1: 101x101 random grid, single source (5,5)
+    occ = maps.random_rect_map(101, 101, 25, 2, 20, 2, 20, 1)
+    occ[5, 5] = 1
+    got = _ctx(vhp, occ).sweep_batch(np.array([[5, 5]], np.int32))
+    _assert_same(got[0], oracle.sweep_full(occ, 5, 5), "config 1")
+
+
+def test_border_blocked_and_thin(vhp, oracle):
+    occ = maps.random_rect_map(40, 33, 10, 2, 8, 2, 8, 5)
+    src = np.array([(0, 0), (39, 0), (0, 32), (39, 32), (0, 17), (20, 0), (39, 5), (7, 32), (1, 1)], np.int32)
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "border source (%d,%d)" % (sx, sy))
+    for nx, ny in [(1, 1), (1, 9), (9, 1), (2, 2), (3, 70), (70, 3), (65, 64), (64, 65), (129, 130)]:
+        occ = np.ones((ny, nx), np.uint8)
+        if nx > 2 and ny > 2:
+            occ[ny // 2, nx // 2] = 0
+        src = np.array([(x, y) for x in {0, nx // 2, nx - 1} for y in {0, ny // 2, ny - 1}], np.int32)
+        got = _ctx(vhp, occ).sweep_batch(src)
+        for k, (sx, sy) in enumerate(src):
+            _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d source (%d,%d)" % (nx, ny, sx, sy))
+
+
+@pytest.mark.parametrize("side", [200, 300, 640])
+def test_multi_strip_sizes(vhp, oracle, side):
+    # sides that need 1, several and many wavefront strips per octant
+    occ = maps.random_rect_map(side, side - 37, 30, 3, side // 8, 3, side // 8, side)
+    src = maps.free_sources(occ, 6, side)
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "side %d source %d" % (side, k))
+
+
+def test_config3_1000x1000_subset(vhp, oracle):
+    occ, src = maps.config_c3(256)
+    pick = src[[0, 17, 101, 255]]
+    extra = np.array([[0, 0], [999, 999], [999, 0], [500, 500]], np.int32)
+    extra = extra[[bool(occ[y, x]) for x, y in extra]]
+    pick = np.concatenate([pick, extra])
+    got = _ctx(vhp, occ).sweep_batch(pick)
+    for k, (sx, sy) in enumerate(pick):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "C3 source (%d,%d)" % (sx, sy))
+
+
+def test_config2_empty_1000(vhp):
+    # README benchmark case: empty grid, centre source -> everything visible, except the
+    # never-swept row 0 / column 0
+    occ = np.ones((1000, 1000), np.uint8)
+    got = _ctx(vhp, occ).sweep_batch(np.array([[500, 500]], np.int32))[0]
+    assert (got[1:, 1:] == 1.0).all() and not got[0].any() and not got[:, 0].any()
+
+
+def test_fp32_storage_is_rounded_fp64(vhp, oracle):
+    occ = maps.random_rect_map(300, 257, 30, 3, 40, 3, 40, 9)
+    src = maps.free_sources(occ, 5, 9)
+    got = _ctx(vhp, occ).sweep_batch(src, dtype=vhp.F32)
+    assert got.dtype == np.float32
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)).astype(np.float32), "fp32 source %d" % k)
+
+
+def test_device_resident_batch_and_full_size_properties(vhp):
+    import torch
+    occ, src = maps.config_c3(256)
+    c = _ctx(vhp, occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_src = torch.from_numpy(src).cuda()
+    d_out = torch.full((len(src), 1000, 1000), -1.0, dtype=torch.float64, device="cuda")
+    c.sweep_batch_device(d_src.data_ptr(), len(src), d_out.data_ptr())
+    c.sync()
+    assert c.last_elapsed_ms() > 0
+    # size-independent properties over the whole batch
+    assert float(d_out.min()) == 0.0 and float(d_out.max()) == 1.0      # every cell written, in [0,1]
+    blocked = torch.from_numpy(occ == 0).cuda()
+    assert float(d_out[:, blocked].abs().max()) == 0.0                  # blocked cells are dark
+    sx, sy = d_src[:, 0].long(), d_src[:, 1].long()
+    idx = torch.arange(len(src), device="cuda")
+    assert bool((d_out[idx, sy, sx] == 1.0).all())                      # the source sees itself
+    assert float(d_out[:, 0, :].abs().max()) == 0.0 and float(d_out[:, :, 0].abs().max()) == 0.0  # Q2
+    # idempotence: a second launch into the same buffer gives the same bytes
+    first = d_out.clone()
+    c.sweep_batch_device(d_src.data_ptr(), len(src), d_out.data_ptr())
+    c.sync()
+    assert torch.equal(first, d_out)
+
+
+def test_errors(vhp):
+    c = vhp.Context(0)
+    with pytest.raises(vhp.VhpError) as e:
+        c.sweep_batch(np.array([[0, 0]], np.int32))
+    assert e.value.code == vhp.VHP_ERR_NO_MAP
+    c.set_map(np.ones((8, 8), np.uint8))
+    with pytest.raises(vhp.VhpError) as e:
+        c.sweep_batch(np.array([[8, 0]], np.int32))
+    assert e.value.code == vhp.VHP_ERR_SOURCE_OOB
+    assert c.sweep_batch(np.zeros((0, 2), np.int32)).shape == (0, 8, 8)

@@ -1,0 +1,178 @@
+"""visibility-heuristic-path-planner_amd -- MI355X-native visibility sweep + visibility-heuristic planner.
+
+Python is plumbing only: this module binds the C ABI of include/vhp.h (libvhp_hip.so, HIP
+kernels for gfx950) with ctypes so tests, bench.py and the torch.distributed sharding helper
+can drive it.  There is no CPU implementation behind these calls: if the library or a HIP
+device is missing they raise.
+
+The directory name is not a Python identifier; import it through the `vhp_amd` shim at the
+repo root (``import vhp_amd``) or ``importlib.import_module("visibility-heuristic-path-planner_amd")``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvhp_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+VHP_OK = 0
+VHP_ERR_ARG = 1
+VHP_ERR_SOURCE_OOB = 2
+VHP_ERR_NOTHING_LIT = 3
+VHP_ERR_START_OOB = 10
+VHP_ERR_END_OOB = 11
+VHP_ERR_START_OCCUPIED = 12
+VHP_ERR_END_OCCUPIED = 13
+VHP_ERR_MAX_ITER = 20
+VHP_ERR_HIP = 100
+VHP_ERR_NO_MAP = 101
+VHP_ERR_TOO_LARGE = 102
+SWEEP_FULL, SWEEP_QUEUE = 0, 1
+F64, F32 = 0, 1
+UNLABELLED = 1000000000000000
+
+# every symbol include/vhp.h declares (tests check the library exports exactly these)
+ABI_SYMBOLS = (
+    "vhp_create", "vhp_destroy", "vhp_last_error", "vhp_set_stream", "vhp_set_map", "vhp_set_map_device",
+    "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
+    "vhp_last_elapsed_ms", "vhp_version",
+)
+
+
+class VhpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vhp status %d: %s" % (code, msg))
+        self.code = code
+
+
+def build_library(force=False):
+    """Compile libvhp_hip.so in-tree with hipcc (cross-compiles gfx950 without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", CSRC])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libvhp_hip.so.  Import torch first if you use it: both then share one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libvhp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C %s`" % CSRC)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64, f64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_double
+    lib.vhp_create.argtypes = [i32, C.POINTER(vp)]
+    lib.vhp_destroy.argtypes = [vp]
+    lib.vhp_last_error.argtypes = [vp]
+    lib.vhp_last_error.restype = C.c_char_p
+    lib.vhp_set_stream.argtypes = [vp, vp]
+    lib.vhp_set_map.argtypes = [vp, vp, i32, i32]
+    lib.vhp_set_map_device.argtypes = [vp, vp, i32, i32]
+    lib.vhp_sweep_batch.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.vhp_sweep_batch_device.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.vhp_sync.argtypes = [vp]
+    lib.vhp_planner_solve.argtypes = [vp, i32, i32, i32, i32, f64, u64, vp, vp, vp, vp, C.POINTER(u32)]
+    lib.vhp_reconstruct_path.argtypes = [vp, vp, i32, i32, i32, i32, vp, u32, C.POINTER(u32), C.POINTER(f64)]
+    lib.vhp_last_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.vhp_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU, one occupancy map.  Mirrors the lifetime of vbs::visibilityBasedSolver."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.vhp_create(int(device), C.byref(h))
+        if rc != VHP_OK:
+            raise VhpError(rc, "vhp_create failed (no usable HIP device %d?)" % device)
+        self.h = h
+        self.nx = self.ny = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vhp_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc, ok=(VHP_OK,)):
+        if rc not in ok:
+            raise VhpError(rc, (self.lib.vhp_last_error(self.h) or b"").decode())
+        return rc
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.vhp_set_stream(self.h, C.c_void_p(stream_handle or 0)))
+
+    def set_map(self, occ):
+        occ = np.ascontiguousarray(occ, np.uint8)
+        self.ny, self.nx = occ.shape
+        self._check(self.lib.vhp_set_map(self.h, _ptr(occ), self.nx, self.ny))
+
+    def set_map_device(self, dptr, nx, ny):
+        self.nx, self.ny = nx, ny
+        self._check(self.lib.vhp_set_map_device(self.h, C.c_void_p(dptr), nx, ny))
+
+    def sweep_batch(self, sources, variant=SWEEP_FULL, dtype=F64):
+        """Host-buffer form.  sources int32 [n, 2] (x, y) -> fields [n, ny, nx]."""
+        src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
+        out = np.empty((len(src), self.ny, self.nx), np.float64 if dtype == F64 else np.float32)
+        self._check(self.lib.vhp_sweep_batch(self.h, _ptr(src), len(src), variant, dtype, _ptr(out)))
+        return out
+
+    def sweep_batch_device(self, d_src, n_src, d_out, variant=SWEEP_FULL, dtype=F64):
+        """Device-resident, asynchronous on the context stream.  d_src / d_out are raw device pointers."""
+        self._check(self.lib.vhp_sweep_batch_device(self.h, C.c_void_p(d_src), n_src, variant, dtype, C.c_void_p(d_out)))
+
+    def sync(self):
+        self._check(self.lib.vhp_sync(self.h))
+
+    def last_elapsed_ms(self):
+        ms = C.c_float(0)
+        self._check(self.lib.vhp_last_elapsed_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def planner_solve(self, start, end, threshold, max_iter):
+        n = self.nx * self.ny
+        came = np.empty((self.ny, self.nx), np.uint64)
+        vg = np.empty((self.ny, self.nx), np.float64)
+        vl = np.empty((self.ny, self.nx), np.float64)
+        piv = np.zeros((int(max_iter) + 2, 2), np.int32)
+        npiv = C.c_uint32(0)
+        rc = self.lib.vhp_planner_solve(self.h, start[0], start[1], end[0], end[1], float(threshold), int(max_iter),
+                                        _ptr(came), _ptr(vg), _ptr(vl), _ptr(piv), C.byref(npiv))
+        if rc in (VHP_ERR_HIP, VHP_ERR_NO_MAP, VHP_ERR_ARG, VHP_ERR_TOO_LARGE):
+            self._check(rc)
+        return dict(status=rc, came_from=came, vis_global=vg, vis_local=vl, pivots=piv[: npiv.value + 1].copy(),
+                    n_pivots=npiv.value)
+
+    def reconstruct_path(self, came_from, pivots, end):
+        ny, nx = came_from.shape
+        cap = 1 << 16
+        path = np.zeros((cap, 2), np.int32)
+        n = C.c_uint32(0)
+        d = C.c_double(0)
+        came = np.ascontiguousarray(came_from, np.uint64)
+        piv = np.ascontiguousarray(pivots, np.int32)
+        rc = self.lib.vhp_reconstruct_path(_ptr(came), _ptr(piv), nx, ny, end[0], end[1], _ptr(path), cap,
+                                           C.byref(n), C.byref(d))
+        self._check(rc)
+        return d.value, path[: n.value].copy()
+
+
+def version():
+    return load_library().vhp_version().decode()

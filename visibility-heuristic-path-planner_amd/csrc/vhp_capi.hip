@@ -1,0 +1,357 @@
+// vhp_capi.hip -- the C ABI of include/vhp.h over the HIP kernels (gfx950).
+// No CPU fallback lives here: every compute entry point launches HIP kernels and
+// fails with VHP_ERR_HIP when the device or the runtime is unusable.
+#include "vhp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "vhp_sweep.cuh"
+#include "vhp_planner.cuh"
+
+struct vhp_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  std::string err;
+
+  int nx = 0, ny = 0;
+  uint8_t* d_occ = nullptr;    // uint8 map (kept for the planner's validation and packing)
+  uint64_t* d_rows = nullptr;  // packed along x
+  uint64_t* d_cols = nullptr;  // packed along y
+  double* d_recip = nullptr;
+  int wpr = 0, wpc = 0;
+  int* d_err = nullptr;
+
+  // scratch for the host-buffer sweep entry point
+  int32_t* d_src = nullptr;
+  size_t d_src_cap = 0;
+  void* d_out = nullptr;
+  size_t d_out_cap = 0;
+
+  vhp::PlannerState pl;  // device-resident planner state (allocated by set_map)
+  size_t pl_cells = 0;
+};
+
+namespace {
+
+int fail(vhp_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define VHP_HIP(call)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, VHP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+vhp::DevMap dev_map(const vhp_ctx* c) {
+  vhp::DevMap m;
+  m.rows = c->d_rows;
+  m.cols = c->d_cols;
+  m.recip = c->d_recip;
+  m.wpr = c->wpr;
+  m.wpc = c->wpc;
+  m.nx = c->nx;
+  m.ny = c->ny;
+  return m;
+}
+
+// strips per workgroup (W wavefronts) and register rows per lane (R): W*64*R must
+// cover the longest front.  Overridable for tuning with VHP_R / VHP_W.
+void pick_shape(int maxdim, int* R, int* W) {
+  if (maxdim <= 64) { *R = 1; *W = 1; }
+  else if (maxdim <= 128) { *R = 1; *W = 2; }
+  else if (maxdim <= 256) { *R = 1; *W = 4; }
+  else if (maxdim <= 512) { *R = 1; *W = 8; }
+  else if (maxdim <= 1024) { *R = 2; *W = 8; }
+  else { *R = 4; *W = 8; }
+  if (const char* e = getenv("VHP_R")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) *R = v; }
+  if (const char* e = getenv("VHP_W")) { int v = atoi(e); if (v >= 1 && v <= 16) *W = v; }
+  while ((*W) * 64 * (*R) < maxdim && *W < 16) ++*W;
+}
+
+void free_map(vhp_ctx* c) {
+  if (c->d_occ) hipFree(c->d_occ);
+  if (c->d_rows) hipFree(c->d_rows);
+  if (c->d_cols) hipFree(c->d_cols);
+  if (c->d_recip) hipFree(c->d_recip);
+  c->d_occ = nullptr; c->d_rows = nullptr; c->d_cols = nullptr; c->d_recip = nullptr;
+  vhp::planner_free(c->pl);
+  c->pl_cells = 0;
+  c->nx = c->ny = 0;
+}
+
+template <int R, typename OutT>
+hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, int W) {
+  const size_t lds = vhp::sweep_lds_bytes(R, W);
+  auto k = vhp::vhp_sweep_fronts<R, OutT>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const long long stride = (long long)c->nx * c->ny;
+  hipLaunchKernelGGL(k, dim3((unsigned)n_src * vhp::kUnitsPerSource), dim3(64 * W), lds, c->stream, dev_map(c),
+                     d_src, d_out, stride, c->d_err);
+  return hipGetLastError();
+}
+
+template <typename OutT>
+hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
+  int R, W;
+  pick_shape(std::max(c->nx, c->ny), &R, &W);
+  switch (R) {
+    case 1: return launch_sweep_t<1, OutT>(c, d_src, n_src, d_out, W);
+    case 2: return launch_sweep_t<2, OutT>(c, d_src, n_src, d_out, W);
+    default: return launch_sweep_t<4, OutT>(c, d_src, n_src, d_out, W);
+  }
+}
+
+int finish_set_map(vhp_ctx* ctx, int nx, int ny) {
+  // packed copies + reciprocal table
+  ctx->wpr = (nx + 63) / 64 + 2;
+  ctx->wpc = (ny + 63) / 64 + 2;
+  const size_t rows_words = (size_t)ny * ctx->wpr, cols_words = (size_t)nx * ctx->wpc;
+  VHP_HIP(hipMalloc(&ctx->d_rows, rows_words * 8));
+  VHP_HIP(hipMalloc(&ctx->d_cols, cols_words * 8));
+  VHP_HIP(hipMemsetAsync(ctx->d_rows, 0, rows_words * 8, ctx->stream));
+  VHP_HIP(hipMemsetAsync(ctx->d_cols, 0, cols_words * 8, ctx->stream));
+  {
+    const long long waves = (long long)(ctx->wpr - 2) * ny;
+    const int blocks = (int)((waves * 64 + 255) / 256);
+    hipLaunchKernelGGL(vhp::vhp_pack_rows, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_occ, ctx->d_rows, nx, ny, ctx->wpr);
+    VHP_HIP(hipGetLastError());
+  }
+  {
+    const long long waves = (long long)(ctx->wpc - 2) * nx;
+    const int blocks = (int)((waves * 64 + 255) / 256);
+    hipLaunchKernelGGL(vhp::vhp_pack_cols, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_occ, ctx->d_cols, nx, ny, ctx->wpc);
+    VHP_HIP(hipGetLastError());
+  }
+  const int nrec = std::max(nx, ny) + 1;
+  std::vector<double> recip(nrec);
+  recip[0] = 0.0;
+  for (int k = 1; k < nrec; ++k) {
+    volatile double d = (double)k;
+    recip[k] = 1.0 / d;  // correctly rounded IEEE division on the host
+  }
+  VHP_HIP(hipMalloc(&ctx->d_recip, nrec * sizeof(double)));
+  VHP_HIP(hipMemcpyAsync(ctx->d_recip, recip.data(), nrec * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VHP_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->nx = nx;
+  ctx->ny = ny;
+  return VHP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vhp_version(void) { return "vhp-hip 0.1 gfx950"; }
+
+int vhp_create(int device_ordinal, vhp_ctx** out) {
+  if (!out) return VHP_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VHP_ERR_HIP;
+  if (device_ordinal < 0 || device_ordinal >= n) return VHP_ERR_ARG;
+  vhp_ctx* ctx = new vhp_ctx();
+  ctx->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      hipMalloc(&ctx->d_err, sizeof(int)) != hipSuccess || hipMemset(ctx->d_err, 0, sizeof(int)) != hipSuccess) {
+    delete ctx;
+    return VHP_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return VHP_OK;
+}
+
+int vhp_destroy(vhp_ctx* ctx) {
+  if (!ctx) return VHP_ERR_ARG;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  free_map(ctx);
+  if (ctx->d_src) hipFree(ctx->d_src);
+  if (ctx->d_out) hipFree(ctx->d_out);
+  if (ctx->d_err) hipFree(ctx->d_err);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return VHP_OK;
+}
+
+const char* vhp_last_error(const vhp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vhp_set_stream(vhp_ctx* ctx, void* hip_stream) {
+  if (!ctx) return VHP_ERR_ARG;
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return VHP_OK;
+}
+
+static int set_map_common(vhp_ctx* ctx, const uint8_t* src, int nx, int ny, bool from_device) {
+  if (!ctx || !src || nx <= 0 || ny <= 0) return fail(ctx, VHP_ERR_ARG, "vhp_set_map: bad argument");
+  if (nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return fail(ctx, VHP_ERR_TOO_LARGE, "vhp_set_map: grid side exceeds VHP_MAX_SIDE");
+  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_HIP(hipStreamSynchronize(ctx->stream));
+  free_map(ctx);
+  const size_t n = (size_t)nx * ny;
+  VHP_HIP(hipMalloc(&ctx->d_occ, n));
+  VHP_HIP(hipMemcpyAsync(ctx->d_occ, src, n, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  return finish_set_map(ctx, nx, ny);
+}
+
+int vhp_set_map(vhp_ctx* ctx, const uint8_t* occ, int nx, int ny) { return set_map_common(ctx, occ, nx, ny, false); }
+int vhp_set_map_device(vhp_ctx* ctx, const uint8_t* d_occ, int nx, int ny) { return set_map_common(ctx, d_occ, nx, ny, true); }
+
+int vhp_sweep_batch_device(vhp_ctx* ctx, const int32_t* d_src_xy, int n_src, int variant, int dtype, void* d_out) {
+  if (!ctx || !d_src_xy || !d_out || n_src < 0) return fail(ctx, VHP_ERR_ARG, "vhp_sweep_batch_device: bad argument");
+  if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_sweep_batch_device: no map set");
+  if (dtype != VHP_F64 && dtype != VHP_F32) return fail(ctx, VHP_ERR_ARG, "bad dtype");
+  if (variant != VHP_SWEEP_FULL && variant != VHP_SWEEP_QUEUE) return fail(ctx, VHP_ERR_ARG, "bad variant");
+  if (std::max(ctx->nx, ctx->ny) > 2048)
+    return fail(ctx, VHP_ERR_TOO_LARGE, "sweep: grid side above 2048 not supported by this build");
+  if (n_src == 0) return VHP_OK;
+  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  hipError_t e;
+  if (variant == VHP_SWEEP_QUEUE) {
+    e = vhp::launch_queue_sweep(dev_map(ctx), ctx->d_occ, d_src_xy, n_src, dtype, d_out, ctx->d_err, ctx->stream);
+  } else if (dtype == VHP_F64) {
+    e = launch_sweep<double>(ctx, d_src_xy, n_src, static_cast<double*>(d_out));
+  } else {
+    e = launch_sweep<float>(ctx, d_src_xy, n_src, static_cast<float*>(d_out));
+  }
+  if (e != hipSuccess) return fail(ctx, VHP_ERR_HIP, std::string("sweep launch: ") + hipGetErrorString(e));
+  VHP_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->timed = true;
+  return VHP_OK;
+}
+
+int vhp_sync(vhp_ctx* ctx) {
+  if (!ctx) return VHP_ERR_ARG;
+  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_HIP(hipStreamSynchronize(ctx->stream));
+  int flag = 0;
+  VHP_HIP(hipMemcpy(&flag, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) {
+    VHP_HIP(hipMemset(ctx->d_err, 0, sizeof(int)));
+    return fail(ctx, VHP_ERR_SOURCE_OOB, "a sweep source lies outside the grid");
+  }
+  return VHP_OK;
+}
+
+int vhp_sweep_batch(vhp_ctx* ctx, const int32_t* src_xy, int n_src, int variant, int dtype, void* out_host) {
+  if (!ctx || !src_xy || !out_host || n_src < 0) return fail(ctx, VHP_ERR_ARG, "vhp_sweep_batch: bad argument");
+  if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_sweep_batch: no map set");
+  if (dtype != VHP_F64 && dtype != VHP_F32) return fail(ctx, VHP_ERR_ARG, "bad dtype");
+  for (int s = 0; s < n_src; ++s)
+    if (src_xy[2 * s] < 0 || src_xy[2 * s + 1] < 0 || src_xy[2 * s] >= ctx->nx || src_xy[2 * s + 1] >= ctx->ny)
+      return fail(ctx, VHP_ERR_SOURCE_OOB, "a sweep source lies outside the grid");
+  if (n_src == 0) return VHP_OK;
+  VHP_HIP(hipSetDevice(ctx->device));
+  const size_t esz = dtype == VHP_F64 ? 8 : 4;
+  const size_t cells = (size_t)ctx->nx * ctx->ny;
+  // bound device scratch: process the batch in slices of at most ~1 GiB of output
+  const int slice = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_src, ((size_t)1 << 30) / (cells * esz)));
+  if (ctx->d_src_cap < (size_t)slice) {
+    if (ctx->d_src) hipFree(ctx->d_src);
+    ctx->d_src = nullptr;
+    VHP_HIP(hipMalloc(&ctx->d_src, (size_t)slice * 2 * sizeof(int32_t)));
+    ctx->d_src_cap = slice;
+  }
+  if (ctx->d_out_cap < (size_t)slice * cells * esz) {
+    if (ctx->d_out) hipFree(ctx->d_out);
+    ctx->d_out = nullptr;
+    VHP_HIP(hipMalloc(&ctx->d_out, (size_t)slice * cells * esz));
+    ctx->d_out_cap = (size_t)slice * cells * esz;
+  }
+  for (int s0 = 0; s0 < n_src; s0 += slice) {
+    const int n = std::min(slice, n_src - s0);
+    VHP_HIP(hipMemcpyAsync(ctx->d_src, src_xy + 2 * (size_t)s0, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    int rc = vhp_sweep_batch_device(ctx, ctx->d_src, n, variant, dtype, ctx->d_out);
+    if (rc != VHP_OK) return rc;
+    VHP_HIP(hipMemcpyAsync(static_cast<char*>(out_host) + (size_t)s0 * cells * esz, ctx->d_out, (size_t)n * cells * esz,
+                           hipMemcpyDeviceToHost, ctx->stream));
+    VHP_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return vhp_sync(ctx);
+}
+
+int vhp_last_elapsed_ms(vhp_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return VHP_ERR_ARG;
+  if (!ctx->timed) return fail(ctx, VHP_ERR_ARG, "nothing timed yet");
+  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_HIP(hipEventSynchronize(ctx->ev1));
+  VHP_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return VHP_OK;
+}
+
+int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold,
+                      uint64_t max_iter, uint64_t* came_from, double* vis_global, double* vis_local,
+                      int32_t* pivots_xy, uint32_t* n_pivots) {
+  if (!ctx) return VHP_ERR_ARG;
+  if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_planner_solve: no map set");
+  if (std::max(ctx->nx, ctx->ny) > 2048)
+    return fail(ctx, VHP_ERR_TOO_LARGE, "planner: grid side above 2048 not supported by this build");
+  VHP_HIP(hipSetDevice(ctx->device));
+  std::string msg;
+  int rc = vhp::planner_solve(ctx->pl, dev_map(ctx), ctx->d_occ, ctx->stream, ctx->ev0, ctx->ev1, start_x, start_y, end_x,
+                              end_y, threshold, max_iter, came_from, vis_global, vis_local, pivots_xy, n_pivots, &msg);
+  ctx->timed = true;
+  if (rc != VHP_OK) ctx->err = msg;
+  return rc;
+}
+
+// eval_d of visibilityBasedSolver.h:112-115 (host side, used only for the path length)
+static inline double eval_d_host(int ax, int ay, int bx, int by) {
+  return std::sqrt((double)(ax - bx) * (ax - bx) + (ay - by) * (ay - by));
+}
+
+int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, int nx, int ny, int end_x, int end_y,
+                         int32_t* path_xy, uint32_t cap, uint32_t* n_path, double* length) {
+  if (!came_from || !pivots_xy || nx <= 0 || ny <= 0) return VHP_ERR_ARG;
+  if (end_x < 0 || end_y < 0 || end_x >= nx || end_y >= ny) return VHP_ERR_END_OOB;
+  // walk labels back to the start: the label of a pivot's own cell is the pivot that
+  // lit it, the start labels itself, so the walk stops when the label repeats
+  std::vector<std::pair<int, int>> rev;
+  int x = end_x, y = end_y;
+  uint64_t t = came_from[(size_t)x + (size_t)y * nx];
+  uint64_t t_old = std::numeric_limits<uint64_t>::max();
+  while (t != t_old) {
+    rev.push_back({x, y});
+    t_old = t;
+    if (t >= VHP_UNLABELLED) return VHP_ERR_ARG;  // unlabelled cell on the path: nothing to follow
+    x = pivots_xy[2 * t];
+    y = pivots_xy[2 * t + 1];
+    if (x < 0 || y < 0 || x >= nx || y >= ny) return VHP_ERR_ARG;
+    t = came_from[(size_t)x + (size_t)y * nx];
+  }
+  rev.push_back({x, y});
+  std::reverse(rev.begin(), rev.end());
+  double total = 0.0;
+  for (size_t k = 0; k + 1 < rev.size(); ++k)
+    total += eval_d_host(rev[k].first, rev[k].second, rev[k + 1].first, rev[k + 1].second);
+  if (n_path) *n_path = (uint32_t)rev.size();
+  if (length) *length = total;
+  if (path_xy)
+    for (size_t k = 0; k < rev.size() && k < cap; ++k) {
+      path_xy[2 * k] = rev[k].first;
+      path_xy[2 * k + 1] = rev[k].second;
+    }
+  return VHP_OK;
+}
+
+}  // extern "C"
