@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- visibility fields/s of the HIP front sweep on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one launch of the batched sweep (computeVisibility for S independent
+sources) over synthetic input already resident in HBM.  Default workload = BASELINE
+config 3, the configuration the metric "visibility fields/sec on 1000x1000 grid at
+1/2/4/8 GPUs" is quoted on: 1000x1000 random grid (50 rectangles), 256 seeded sources
+per GPU, fp64 fields.  Sources are sharded over ranks (each rank sweeps its own 256;
+the sweep has no exchange step, so there is no data-path collective in the timed
+region: weak scaling).  `--workload c2` times the single-source README case instead,
+`--gather` adds the RCCL all-gather of the per-source fields after each step.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_CELL = {"f64": 9, "f32": 5}  # 1 B occupancy read + sizeof(field element) written
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c1k-empty"])
+    ap.add_argument("--sources", type=int, default=0, help="sources per GPU (default: workload's)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--gather", action="store_true", help="all-gather the fields over RCCL inside the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_workload(name, rank, n_src):
+    import numpy as np
+    import vhp_amd
+    from importlib import import_module
+    synth = import_module("visibility-heuristic-path-planner_amd.synth")
+    if name == "c3":
+        n = n_src or 256
+        occ = synth.random_rect_map(1000, 1000, 50, 20, 100, 20, 100, seed=1)
+        src = synth.free_sources(occ, n, seed=7 + 1000 * rank)
+        label = "C3: 1000x1000 random grid (50 rectangles 20..100, map seed 1), %d seeded sources per GPU" % n
+    elif name == "c2":
+        n = n_src or 1
+        occ = np.ones((1000, 1000), np.uint8)
+        src = np.array([[500, 500]] * n, np.int32)
+        label = "C2: 1000x1000 empty grid, centre source, %d source(s) per launch" % n
+    else:
+        n = n_src or 256
+        occ = np.ones((1000, 1000), np.uint8)
+        src = synth.free_sources(occ, n, seed=7 + 1000 * rank)
+        label = "1000x1000 empty grid, %d seeded sources per GPU" % n
+    return occ, src, label
+
+
+def cpu_baseline(occ, src, seconds):
+    """Times the CPU oracle (the port of computeVisibility) on this host's cores.
+
+    Built here, on the machine that runs it, with the flags the reference ships
+    (-O3 -Ofast -march=native, CMakeLists.txt:10); falls back to the strict build.
+    """
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    fast = os.path.join(ROOT, "oracle", "libvhp_oracle_fast.so")
+    flags = "-O3 -Ofast -march=native"
+    try:
+        if os.path.exists(fast):
+            os.remove(fast)
+        oracle_lib.build(fast=True)
+        orc = oracle_lib.Oracle(fast)
+    except Exception:
+        oracle_lib.build()
+        orc = oracle_lib.Oracle()
+        flags = "-O2 -ffp-contract=off"
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # single thread (the reference's mode)
+    n1 = max(4, min(len(src), 16))
+    wall1, best1 = orc.time_sweeps(occ, src[:n1], 1)
+    one = n1 / wall1
+    # all cores, one independent source per thread, bounded to ~`seconds`
+    per = max(1, min(len(src), cores * 2))
+    done, t0 = 0, time.time()
+    wall = 0.0
+    while True:
+        w, _ = orc.time_sweeps(occ, src[:per] if per <= len(src) else src, cores)
+        wall += w
+        done += min(per, len(src))
+        if time.time() - t0 > seconds:
+            break
+    return {
+        "value": round(done / wall, 2), "unit": "fields/s", "cores": cores, "kind": "port",
+        "sample": "oracle computeVisibility port (%s), %d sweeps of the same 1000x1000 workload on %d threads; "
+                  "single thread: %.1f fields/s (best sweep %.2f ms)" % (flags, done, cores, one, best1 * 1e3),
+        "single_thread_value": round(one, 2),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import vhp_amd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    occ, src, label = make_workload(args.workload, rank, args.sources)
+    ny, nx = occ.shape
+    n_src = len(src)
+    ctx = vhp_amd.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_map(occ)  # uploads + packs: the map is resident before the timed region
+    d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).to(dev)
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    d_out = torch.empty((n_src, ny, nx), dtype=tdt, device=dev)
+    vdt = vhp_amd.F64 if args.dtype == "f64" else vhp_amd.F32
+    gathered = None
+    if args.gather and world > 1:
+        gathered = torch.empty((world * n_src, ny, nx), dtype=tdt, device=dev)
+
+    def step():
+        ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_out.data_ptr(), dtype=vdt)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, d_out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)  # HIP events on the stream the kernel is launched on
+        ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_out.data_ptr(), dtype=vdt)
+        b.record(stream)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, d_out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.sync()  # surfaces device-side validation errors
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    if rank == 0:
+        fields = world * n_src * args.steps
+        alg_bytes = BYTES_PER_CELL[args.dtype] * nx * ny * n_src  # per launch
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, args.dtype))
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "visibility fields/sec on 1000x1000 grid",
+            "value": round(fields / elapsed, 2),
+            "unit": "fields/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": label, "grid": [nx, ny], "sources_per_gpu": n_src, "sharding": "sources/%d" % world,
+                       "collective": "rccl all_gather of fields" if gathered is not None else "none (independent sources)"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "vhp_sweep_fronts", "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(occ, src, args.cpu_seconds)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "fields/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,9 @@
 #include <cstring>
 #include <limits>
 #include <algorithm>
+#include <chrono>
 #include <queue>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -407,6 +409,39 @@ int vhp_oracle_raycast_all(const uint8_t* occ, int nx, int ny, int sx, int sy, d
       }
     }
   return 0;
+}
+
+// Timing harness for bench.py's cpu_baseline leg.  Protocol of benchmark()
+// (src/visibilityBasedSolver.cpp:217-222): a steady clock around computeVisibility()
+// only, buffers allocated beforehand.  n_threads > 1 runs one independent source per
+// thread over a shared read-only map (the reference itself is single-threaded).
+// Returns wall seconds for all n_src sweeps; per_sweep_best receives the fastest
+// single sweep.
+double vhp_oracle_time_sweeps(const uint8_t* occ, int nx, int ny, const int32_t* src_xy, int n_src,
+                              int n_threads, double* per_sweep_best) {
+  if (!occ || !src_xy || n_src <= 0 || n_threads <= 0) return -1.0;
+  const Grid g = make_grid(occ, nx, ny);
+  std::vector<std::vector<double>> bufs(n_threads, std::vector<double>((size_t)nx * ny, 0.0));
+  std::vector<double> best(n_threads, 1e30);
+  auto worker = [&](int t) {
+    for (int s = t; s < n_src; s += n_threads) {
+      const auto t0 = std::chrono::steady_clock::now();
+      four_quadrants(g, bufs[t].data(), src_xy[2 * s], src_xy[2 * s + 1], [](size_t, size_t, double) {});
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      best[t] = std::min(best[t], dt);
+    }
+  };
+  const auto w0 = std::chrono::steady_clock::now();
+  if (n_threads == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, t);
+    for (auto& x : th) x.join();
+  }
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  if (per_sweep_best) *per_sweep_best = *std::min_element(best.begin(), best.end());
+  return wall;
 }
 
 }  // extern "C"

@@ -1,70 +1,6 @@
-"""Seeded synthetic inputs shared by tests and bench.py (pure numpy; no reference, no oracle).
+"""Synthetic maps live in the package (synth.py); tests import them through this alias."""
+import vhp_amd  # noqa: F401
+from importlib import import_module
 
-The random-rectangle recipe is the reference generator's (src/environment.cpp:57-78)
-driven by a local 64-bit LCG instead of glibc rand(), so the maps are identical
-on every machine.
-"""
-import os
-
-import numpy as np
-
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-
-
-class Lcg:
-    """Knuth MMIX LCG; deterministic across platforms."""
-
-    def __init__(self, seed):
-        self.s = (int(seed) * 2862933555777941757 + 3037000493) & 0xFFFFFFFFFFFFFFFF
-
-    def next(self):
-        self.s = (self.s * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
-        return self.s >> 33
-
-    def below(self, n):
-        return self.next() % n
-
-
-def random_rect_map(nx, ny, nb, min_w, max_w, min_h, max_h, seed):
-    """occ[y, x] uint8, 1 = free.  Same clamping and half-open fill as the reference."""
-    rng = Lcg(seed)
-    occ = np.ones((ny, nx), np.uint8)
-    for _ in range(nb):
-        c1 = 1 + rng.below(nx + 1)
-        c2 = c1 + min_w + rng.below(max_w - min_w + 1)
-        c1, c2 = min(c1, nx - 1), min(c2, nx - 1)
-        r1 = 1 + rng.below(ny + 1)
-        r2 = r1 + min_h + rng.below(max_h - min_h + 1)
-        r1, r2 = min(r1, ny - 1), min(r2, ny - 1)
-        occ[r1:r2, c1:c2] = 0
-    return occ
-
-
-def free_sources(occ, n, seed):
-    """n distinct-ish seeded sources on free cells, int32 [n, 2] as (x, y)."""
-    rng = Lcg(seed)
-    ny, nx = occ.shape
-    out = []
-    while len(out) < n:
-        x, y = rng.below(nx), rng.below(ny)
-        if occ[y, x]:
-            out.append((x, y))
-    return np.array(out, np.int32).reshape(n, 2)
-
-
-def config_c3(n_sources=256):
-    """BASELINE config 3: 1000x1000, 50 obstacles (20..100 wide/high), seeded sources."""
-    occ = random_rect_map(1000, 1000, 50, 20, 100, 20, 100, seed=1)
-    return occ, free_sources(occ, n_sources, seed=7)
-
-
-def config_c5(n_sources=128):
-    """BASELINE config 5 (per-GPU share): 4096x4096, 50 obstacles scaled x4."""
-    occ = random_rect_map(4096, 4096, 50, 80, 400, 80, 400, seed=1)
-    return occ, free_sources(occ, n_sources, seed=11)
-
-
-def maze_6():
-    z = np.load(os.path.join(GOLDEN, "maze_6.npz"))
-    nx, ny = int(z["nx"]), int(z["ny"])
-    return np.unpackbits(z["packed"], axis=1)[:, :nx].astype(np.uint8).reshape(ny, nx)
+_s = import_module("visibility-heuristic-path-planner_amd.synth")
+globals().update({k: getattr(_s, k) for k in dir(_s) if not k.startswith("__")})

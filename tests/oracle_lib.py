@@ -43,6 +43,8 @@ def load(path=None):
     lib.vhp_oracle_generate_env.argtypes = [
         C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _u8p]
     lib.vhp_oracle_raycast_all.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f64p]
+    lib.vhp_oracle_time_sweeps.restype = C.c_double
+    lib.vhp_oracle_time_sweeps.argtypes = [_u8p, C.c_int, C.c_int, _i32p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     return lib
 
 
@@ -106,6 +108,15 @@ class Oracle:
         rc = self.lib.vhp_oracle_generate_env(nx, ny, nb, min_w, max_w, min_h, max_h, seed, occ)
         assert rc == 0
         return occ
+
+    def time_sweeps(self, occ, sources, n_threads=1):
+        """(wall seconds for all sweeps, best single-sweep seconds); steady clock around the sweep only."""
+        ny, nx = occ.shape
+        src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
+        best = C.c_double(0)
+        wall = self.lib.vhp_oracle_time_sweeps(np.ascontiguousarray(occ, np.uint8), nx, ny, src, len(src),
+                                               int(n_threads), C.byref(best))
+        return wall, best.value
 
     def raycast_all(self, occ, sx, sy):
         ny, nx = occ.shape

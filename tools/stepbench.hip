@@ -1,0 +1,59 @@
+// Micro-benchmark of the sweep's per-step body on ONE wavefront: cycles per step for
+// variants of the dependent chain.  Diagnostic only.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "../visibility-heuristic-path-planner_amd/csrc/vhp_sweep.cuh"
+using namespace vhp;
+
+template <int MODE, int R>
+__global__ void body(double* out, unsigned long long* cyc, int steps, uint64_t occbits) {
+  const int lane = threadIdx.x & 63;
+  double prev[R], jd[R];
+  for (int r = 0; r < R; ++r) { prev[r] = 1.0 - 1e-3 * lane; jd[r] = (double)(64 * r + lane); }
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 1000; i < 1000 + steps; ++i) {
+    const double di = (double)i;
+    const double ri = __builtin_amdgcn_rcp(di);
+    double fill = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const double a = prev[r];
+      double b;
+      if (MODE & 1) b = shift_up(a, fill); else b = a * 0.5;
+      double c;
+      if (MODE & 2) c = ratio(jd[r], di, ri); else c = jd[r] * ri;
+      double v = stencil(a, b, c);
+      if (MODE & 4) v = gate(v, occbits + i);
+      if (MODE & 8) fill = lane63(a);
+      prev[r] = v;
+    }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  double s = 0; for (int r = 0; r < R; ++r) s += prev[r];
+  out[threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int MODE, int R> void run(const char* name, double* d, unsigned long long* c) {
+  const int steps = 4000;
+  for (int k = 0; k < 2; ++k) hipLaunchKernelGGL((body<MODE, R>), dim3(1), dim3(64), 0, 0, d, c, steps, ~0ull);
+  hipDeviceSynchronize();
+  unsigned long long h; hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
+  printf("%-44s R=%d: %7.1f cycles/step  %6.1f cycles/row-step\n", name, R, (double)h / steps, (double)h / steps / R);
+}
+
+int main() {
+  double* d; unsigned long long* c; hipMalloc(&d, 4096); hipMalloc(&c, 64);
+  run<0, 1>("stencil only (3 dep fp64)", d, c);
+  run<2, 1>("+ratio (3 more fp64, independent of chain)", d, c);
+  run<1, 1>("stencil + dpp shift", d, c);
+  run<3, 1>("stencil + dpp + ratio", d, c);
+  run<7, 1>("stencil + dpp + ratio + gate", d, c);
+  run<15, 1>("all (+lane63 readlane)", d, c);
+  run<15, 2>("all", d, c);
+  run<15, 4>("all", d, c);
+  run<7, 2>("no readlane", d, c);
+  run<7, 4>("no readlane", d, c);
+  run<0, 4>("stencil only", d, c);
+  return 0;
+}

@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvhp_hip.so")
+LIB_PATH = os.environ.get("VHP_LIB") or os.path.join(_HERE, "libvhp_hip.so")  # VHP_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
 
 VHP_OK = 0

@@ -69,18 +69,20 @@ vhp::DevMap dev_map(const vhp_ctx* c) {
   return m;
 }
 
-// strips per workgroup (W wavefronts) and register rows per lane (R): W*64*R must
-// cover the longest front.  Overridable for tuning with VHP_R / VHP_W.
+// A workgroup sweeps one quadrant with 2*W wavefronts (W strips per octant) and R
+// rows/columns per lane: W*64*R must cover the longest front.  Overridable for tuning
+// with VHP_R / VHP_W.
 void pick_shape(int maxdim, int* R, int* W) {
   if (maxdim <= 64) { *R = 1; *W = 1; }
   else if (maxdim <= 128) { *R = 1; *W = 2; }
   else if (maxdim <= 256) { *R = 1; *W = 4; }
-  else if (maxdim <= 512) { *R = 1; *W = 8; }
+  else if (maxdim <= 512) { *R = 2; *W = 4; }
   else if (maxdim <= 1024) { *R = 2; *W = 8; }
   else { *R = 4; *W = 8; }
   if (const char* e = getenv("VHP_R")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) *R = v; }
-  if (const char* e = getenv("VHP_W")) { int v = atoi(e); if (v >= 1 && v <= 16) *W = v; }
-  while ((*W) * 64 * (*R) < maxdim && *W < 16) ++*W;
+  if (const char* e = getenv("VHP_W")) { int v = atoi(e); if (v >= 1 && v <= 8) *W = v; }
+  while ((*W) * 64 * (*R) < maxdim && *W < 8) ++*W;
+  while ((*W) * 64 * (*R) < maxdim && *R < 4) *R *= 2;
 }
 
 void free_map(vhp_ctx* c) {
@@ -101,7 +103,7 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const long long stride = (long long)c->nx * c->ny;
-  hipLaunchKernelGGL(k, dim3((unsigned)n_src * vhp::kUnitsPerSource), dim3(64 * W), lds, c->stream, dev_map(c),
+  hipLaunchKernelGGL(k, dim3((unsigned)n_src * vhp::kUnitsPerSource), dim3(128 * W), lds, c->stream, dev_map(c),
                      d_src, d_out, stride, c->d_err);
   return hipGetLastError();
 }

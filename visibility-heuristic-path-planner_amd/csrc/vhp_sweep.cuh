@@ -1,32 +1,40 @@
 // vhp_sweep.cuh -- CDNA4 (gfx950) device code of the visibility-transport sweep.
 //
 // Replaces the four loop nests of computeVisibility()
-// (reference src/visibilityBasedSolver.cpp:570-696) for a batch of sources.
+// (reference src/visibilityBasedSolver.cpp:570-696) for a batch of sources, and --
+// through the Emit policy -- the same nests inside updateVisibility() (:379-565).
 //
 // Decomposition (tests/schedule_model.py is the executable statement of it and is
 // checked bit-for-bit against the oracle):
-//   source -> 4 quadrants -> 2 octants each = 8 work units (+1 zero-fill unit),
-//   one workgroup per unit.  Inside an octant a cell depends only on the previous
-//   "front" (the previous column for the x-major octant, the previous row for the
-//   y-major one), on itself and on its neighbour one lane below:
-//       v = (a - c*(a - b)) * occ,   a = own previous, b = lower neighbour's previous.
-//   So a front is swept by the lanes of a wavefront: lane <-> row (x-major) or column
-//   (y-major), the neighbour exchange is one DPP wave shift, nothing but registers
-//   sits on the dependent chain.  A workgroup is W wavefronts; wavefront p owns strip
-//   p (64*R consecutive lanes-worth of rows/columns) and runs one pipeline slot
-//   (kChunk steps) behind wavefront p-1, which hands it the boundary lane through a
-//   small LDS ring -- the LDS-staged active front.
+//   source -> 4 quadrants, one workgroup each; a quadrant = an x-major octant
+//   (|dx| > |dy|, plus the diagonal) and a y-major octant (|dy| > |dx|).  Inside an
+//   octant a cell depends only on the previous "front" (previous column for x-major,
+//   previous row for y-major): on itself and on its neighbour one row/column below,
+//       v = (a - c*(a - b)) * occ,   a = own previous, b = lower neighbour's previous,
+//   so a front is swept by lanes.  A lane owns R consecutive rows (x-major) or
+//   columns (y-major): the neighbour of its register r > 0 is its own register r-1
+//   and only register 0 needs the lane below, one DPP wave shift.  Nothing but
+//   registers sits on the dependent chain.
+//   A workgroup is 2*W wavefronts: wavefronts 0..W-1 sweep strips of the x-major
+//   octant, W..2W-1 strips of the y-major one (strip = 64*R rows/columns).  Strip p
+//   runs one pipeline slot (kChunk steps, one workgroup barrier) behind strip p-1,
+//   which hands it its boundary lane through a small LDS ring: the LDS-staged front.
 //
-//   x-major octant: a lane produces consecutive x of ONE row, i.e. a wavefront
-//   produces a column per step.  Values are staged in a wave-private LDS tile and
-//   flushed as 64-byte row segments (coalesced, sector aligned).
-//   y-major octant: a wavefront produces 64 consecutive x of one row per step and
-//   stores them directly (512 contiguous bytes per instruction).
+//   x-major: a lane produces consecutive x of its rows, i.e. the wavefront produces a
+//   column per step.  Values are staged in a wave-private LDS tile and emitted as
+//   64-byte row segments with 16-byte stores (coalesced, sector aligned).
+//   y-major: a wavefront produces 64*R consecutive x of one row per step and emits
+//   them directly, 16 bytes per lane.
 //
 //   The reference's stale diagonal (cell (k,k) = cell (k,k-1) * occ) is
-//   produced by the x-major unit (the lane below hands its NEW value up); the
-//   y-major unit needs diag(k) as the seed of lane k and recomputes it from the
+//   produced by the x-major strips (the row below hands its NEW value up); the
+//   y-major strips need diag(k) as the seed of column k and recompute it from the
 //   private two-term recurrence sub(k) = V(k,k-1), diag(k) = sub(k)*occ(k,k).
+//
+// Memory: occupancy is read from two bit-packed copies of the map.  A lane keeps one
+// 64-bit word per owned row/column, packed along the marching direction: 64 steps of
+// occupancy per load, refilled (with the reciprocal table) once per 64 steps by
+// prefetched loads, so the steady-state step issues no loads at all.
 //
 // Arithmetic is IEEE binary64 with contraction off.  The per-cell division
 // c = j/i is replaced by Markstein's correction with a host-computed table of
@@ -41,13 +49,13 @@ namespace vhp {
 constexpr int kChunk = 16;       // steps per pipeline slot
 constexpr int kRing = 64;        // entries of a boundary ring (>= 4*kChunk)
 constexpr int kTileCols = 8;     // columns staged per flush = 64 B of fp64
-constexpr int kTileStride = 9;   // doubles per staged row (odd: conflict-free column writes)
-constexpr int kUnitsPerSource = 9;
+constexpr int kTileStride = 9;   // doubles per staged row (odd: spreads column writes over banks)
+constexpr int kUnitsPerSource = 4;
 
 struct DevMap {
-  const uint64_t* rows;  // bit x&63 of rows[y*wpr + 1 + (x>>6)] = occ(x,y); word 0 and the last word of a row are zero pads
+  const uint64_t* rows;  // bit x&63 of rows[y*wpr + 1 + (x>>6)] = occ(x,y); word 0 and the last word of a line are zero pads
   const uint64_t* cols;  // bit y&63 of cols[x*wpc + 1 + (y>>6)] = occ(x,y)
-  const double* recip;   // recip[k] = RN(1/k), k = 1..max(nx,ny)
+  const double* recip;   // recip[k] = RN(1/k), k = 1..max(nx,ny); recip[0] = 0
   int wpr, wpc;
   int nx, ny;
 };
@@ -62,9 +70,10 @@ __device__ __forceinline__ double shift_up(double v, double fill) {
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double lane63(double v) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+// wave-uniform read of lane `l` (l uniform)
+__device__ __forceinline__ double read_lane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
 
@@ -82,61 +91,97 @@ __device__ __forceinline__ double stencil(double a, double b, double c) {
   return a - u;
 }
 
-// v * occ for occ in {0,1} and finite v >= 0 (solver.cpp:602)
-__device__ __forceinline__ double gate(double v, uint64_t word, int bit) {
-  return ((word >> bit) & 1ull) ? v : 0.0;
+// v * occ for occ in {0,1} and finite v >= 0 (solver.cpp:602): AND with 0 / ~0
+__device__ __forceinline__ double and_mask(double v, int msk) {
+  return __hiloint2double(__double2hiint(v) & msk, __double2loint(v) & msk);
 }
-
-template <typename OutT>
-__device__ __forceinline__ OutT to_out(double v) { return static_cast<OutT>(v); }
+// bit `b` (uniform, 0..63) of a lane-private word as 0 / ~0
+__device__ __forceinline__ int bit_mask(uint64_t w, int b) {
+  const uint32_t half = (b & 32) ? (uint32_t)(w >> 32) : (uint32_t)w;
+  return __builtin_amdgcn_sbfe(half, b & 31, 1);
+}
 
 struct UnitGeom {
   int sx, sy, dirx, diry, ni, nj;
 };
 
+// Emit policy of the plain sweep: store cells.  pair(): cells (x, y) and (x+1, y).
+template <typename OutT>
+struct StoreEmit {
+  OutT* __restrict__ out;
+  int nx;
+  __device__ __forceinline__ void pair(int x, int y, double v0, double v1, bool ok0, bool ok1) {
+    OutT* p = out + (size_t)y * nx + x;
+    if (ok0 && ok1) {
+      struct alignas(2 * sizeof(OutT)) Two { OutT a, b; };
+      *reinterpret_cast<Two*>(p) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};  // one 16-byte (fp64) store
+    } else {
+      if (ok0) p[0] = static_cast<OutT>(v0);
+      if (ok1) p[1] = static_cast<OutT>(v1);
+    }
+  }
+  __device__ __forceinline__ void zero(int x, int y) { out[(size_t)y * nx + x] = OutT(0); }
+  __device__ __forceinline__ void finish() {}
+};
+
+// Per-64-step refill state shared by both strip kinds: each lane holds the reciprocal
+// of "its" step of the current 64-aligned block of the marching coordinate.
+// (marching coordinate = x for x-major strips, y for y-major ones)
+
 // ---------------------------------------------------------------------------
-// x-major octant: cells (i, j), i > j, plus the diagonal (k, k) and the origin.
+// x-major strip: rows j = j0 + R*lane + r, steps i = j0 .. ni-1, cells (i, j), i >= j.
 // ---------------------------------------------------------------------------
-template <int R, typename OutT>
-__device__ void x_unit(const DevMap& m, OutT* __restrict__ out, const UnitGeom g, double* lds) {
+template <int R, typename Emit>
+__device__ __forceinline__ void x_strip_init(const DevMap& m, const UnitGeom& g, int j0, int rows_total, int lane,
+                                             double (&jd)[R], int (&dmask)[R], const uint64_t* (&rowp)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int j = j0 + R * lane + r;
+    const bool on = j < rows_total;
+    const int y = on ? g.sy + g.diry * j : g.sy;
+    const int xd = on ? g.sx + g.dirx * j : g.sx;  // x of this row's diagonal cell
+    jd[r] = (double)j;
+    rowp[r] = m.rows + (size_t)y * m.wpr + 1;
+    dmask[r] = ((rowp[r][xd >> 6] >> (xd & 63)) & 1ull) ? -1 : 0;
+  }
+}
+
+template <int R, typename Emit>
+__device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* tile) {
   constexpr int S = 64 * R;
   const int lane = threadIdx.x & 63;
-  const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wavefront index, made provably uniform
-  const int W = blockDim.x >> 6;
   const int rows_total = min(g.nj, g.ni);
   const int P = (rows_total + S - 1) / S;
   const int glast = (g.ni - 1) / kChunk;
-  const int tmax = glast + P - 1;
   const int j0 = p * S;
   const bool strip_on = p < P;
-
-  double* ring = lds;                                    // W rings
-  double* tile = lds + (size_t)W * (kRing + 2) + (size_t)p * S * kTileStride;
-  double* ring_out = ring + p * kRing;
-  const double* ring_in = ring + (p > 0 ? p - 1 : 0) * kRing;
+  double* ring_out = ring_base + p * kRing;
+  const double* ring_in = ring_base + (p > 0 ? p - 1 : 0) * kRing;
 
   double prev[R], jd[R];
-  uint32_t dmask[R];
-  uint64_t ow[R], own[R];
-  const uint64_t* orow[R];
-  int cur_xw = 0;
+  int dmask[R];
+  const uint64_t* rowp[R];
+  uint64_t ow[R], own[R];   // occupancy words of the current / next 64-block of x, one per owned row
+  double rv = 0.0, rvn = 0.0;  // reciprocals: lane t holds 1/i of the step whose x is (block, t)
+  int cur_blk = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) { prev[r] = 0.0; jd[r] = 0.0; dmask[r] = 0; rowp[r] = m.rows + 1; ow[r] = own[r] = 0; }
   if (strip_on) {
-    const int x0 = g.sx + g.dirx * j0;  // x of the strip's first step
-    cur_xw = x0 >> 6;
+    x_strip_init<R, Emit>(m, g, j0, rows_total, lane, jd, dmask, rowp);
+    const int x0 = g.sx + g.dirx * j0;
+    cur_blk = x0 >> 6;
+    auto recip_of = [&](int blk) {
+      const int xt = blk * 64 + lane;
+      const int it = g.dirx > 0 ? xt - g.sx : g.sx - xt;
+      return (it >= 0 && it < g.ni) ? m.recip[it] : 0.0;
+    };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int j = j0 + 64 * r + lane;
-      const bool on = j < rows_total;
-      const int y = on ? g.sy + g.diry * j : g.sy;
-      const int xd = on ? g.sx + g.dirx * j : g.sx;  // x of this row's diagonal cell
-      prev[r] = 0.0;
-      jd[r] = (double)j;
-      orow[r] = m.rows + (size_t)y * m.wpr + 1;
-      const uint64_t dw = orow[r][xd >> 6];
-      dmask[r] = ((dw >> (xd & 63)) & 1ull) ? 0xffffffffu : 0u;
-      ow[r] = orow[r][cur_xw];
-      own[r] = orow[r][cur_xw + g.dirx];
+      ow[r] = rowp[r][cur_blk];
+      own[r] = rowp[r][cur_blk + g.dirx];
     }
+    rv = recip_of(cur_blk);
+    rvn = recip_of(cur_blk + g.dirx);
   }
 
   for (int T = 0; T <= tmax; ++T) {
@@ -144,66 +189,87 @@ __device__ void x_unit(const DevMap& m, OutT* __restrict__ out, const UnitGeom g
     if (strip_on && gch >= j0 / kChunk && gch <= glast) {
       const int ibeg = max(gch * kChunk, j0);
       const int iend = min(gch * kChunk + kChunk - 1, g.ni - 1);
+      // boundary row of the strip below for this chunk: lane t holds its value at step ibeg-1+t
+      double ringv = 0.0;
+      if (p > 0) ringv = ring_in[(ibeg - 1 + lane) & (kRing - 1)];
       for (int i = ibeg; i <= iend; ++i) {
         const int x = g.sx + g.dirx * i;
-        const int xw = x >> 6, xb = x & 63;
-        if (xw != cur_xw) {
-          cur_xw = xw;
+        const int blk = x >> 6, t = x & 63;
+        if (blk != cur_blk) {  // crossed into the next 64-block of x: rotate the prefetched words in
+          cur_blk = blk;
+          const int xt = (blk + g.dirx) * 64 + lane;
+          const int it = g.dirx > 0 ? xt - g.sx : g.sx - xt;
+          rv = rvn;
+          rvn = (it >= 0 && it < g.ni) ? m.recip[it] : 0.0;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             ow[r] = own[r];
-            own[r] = orow[r][xw + g.dirx];
+            own[r] = rowp[r][blk + g.dirx];
           }
         }
         const double di = (double)i;
-        const double ri = m.recip[i];
-        double fill = 0.0;   // OLD value of the row just below this register row's lane 0
-        double dsrc = 1.0;   // NEW value of that row (source of the diagonal cell); 1.0 = light strength at the origin
+        const double ri = read_lane(rv, t);
+        double fill = 0.0;  // OLD value of the row just below lane 0's first row
+        double dsrc = 1.0;  // NEW value of that row (feeds the diagonal cell); 1.0 = light strength at the origin
         if (p > 0) {
-          fill = ring_in[(i - 1) & (kRing - 1)];
-          dsrc = ring_in[i & (kRing - 1)];
+          fill = read_lane(ringv, i - ibeg);
+          dsrc = read_lane(ringv, i - ibeg + 1);
+        }
+        double v[R];
+        {
+          const double b0 = shift_up(prev[R - 1], fill);
+          v[0] = and_mask(stencil(prev[0], b0, ratio(jd[0], di, ri)), bit_mask(ow[0], t));
+        }
+#pragma unroll
+        for (int r = 1; r < R; ++r) v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(jd[r], di, ri)), bit_mask(ow[r], t));
+        if (i < j0 + S && i < rows_total) {
+          // the diagonal cell (i,i) is one of this strip's rows: it inherits the NEW value of
+          // the row below it times its own occupancy
+          const int k = i - j0;
+          const int ld = k / R, rd = k - ld * R;
+          const double up = shift_up(v[R - 1], dsrc);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (rd == r) {
+              const double below = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
+              if (lane == ld) v[r] = and_mask(below, dmask[r]);
+            }
+          }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int jr0 = j0 + 64 * r;
-          if (i >= jr0) {
-            const double a = prev[r];
-            const double b = shift_up(a, fill);
-            const double c = ratio(jd[r], di, ri);
-            double v = gate(stencil(a, b, c), ow[r], xb);
-            if (i < jr0 + 64) {
-              // the diagonal cell (i,i) lives in this register row: it inherits the NEW
-              // value of the row below it times its own occupancy
-              const double below = shift_up(v, dsrc);
-              if (jr0 + lane == i) {
-                v = __hiloint2double(__double2hiint(below) & (int)dmask[r], __double2loint(below) & (int)dmask[r]);
-              }
-            }
-            fill = lane63(a);
-            dsrc = lane63(v);
-            prev[r] = v;
-            tile[(64 * r + lane) * kTileStride + (x & (kTileCols - 1))] = v;
-          }
+          prev[r] = v[r];
+          tile[(R * lane + r) * kTileStride + (x & (kTileCols - 1))] = v[r];
         }
-        if (lane == 63) ring_out[i & (kRing - 1)] = prev[R - 1];
+        if (lane == 63) ring_out[i & (kRing - 1)] = v[R - 1];
 
         const bool endwin = g.dirx > 0 ? ((x & (kTileCols - 1)) == kTileCols - 1) : ((x & (kTileCols - 1)) == 0);
         if (endwin || i == g.ni - 1) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
+          // lane <-> (row-in-group = lane>>2, column pair = lane&3): 16 rows x 64 B per pass
           const int xbase = x & ~(kTileCols - 1);
-          const int col = lane & (kTileCols - 1), rsub = lane >> 3;
-          const int xc = xbase + col;
-          const int ic = g.dirx > 0 ? xc - g.sx : g.sx - xc;
-          const bool colok = ic >= 0 && ic <= i;
+          const int cp = lane & 3, rsub = lane >> 2;
+          const int xc = xbase + 2 * cp;
+          const int ic0 = g.dirx > 0 ? xc - g.sx : g.sx - xc;
+          const int ic1 = g.dirx > 0 ? ic0 + 1 : ic0 - 1;
+          const bool c0 = ic0 >= 0 && ic0 <= i, c1 = ic1 >= 0 && ic1 <= i;
           const int rows_here = min(S, rows_total - j0);
-          for (int rb = 0; rb < rows_here; rb += 8) {
-            if (j0 + rb > i) break;
-            const int rl = rb + rsub;
-            const int j = j0 + rl;
-            if (colok && rl < rows_here && j <= ic) {
-              const int y = g.sy + g.diry * j;
-              out[(size_t)y * m.nx + xc] = to_out<OutT>(tile[rl * kTileStride + col]);
+          const int rows_live = min(rows_here, i - j0 + 1);  // rows j <= i
+          for (int rb = 0; rb < rows_live; rb += 32) {
+            double ta[2], tb[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const double* q = tile + (rb + 16 * u + rsub) * kTileStride + 2 * cp;
+              ta[u] = q[0];
+              tb[u] = q[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int rl = rb + 16 * u + rsub;
+              const int j = j0 + rl;
+              const bool rowok = rl < rows_here;
+              emit.pair(xc, g.sy + g.diry * j, ta[u], tb[u], rowok && c0 && j <= ic0, rowok && c1 && j <= ic1);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -216,58 +282,65 @@ __device__ void x_unit(const DevMap& m, OutT* __restrict__ out, const UnitGeom g
 }
 
 // ---------------------------------------------------------------------------
-// y-major octant: cells (i, j), j > i.
+// y-major strip: columns i = i0 + R*lane + r, steps j = i0 .. nj-1, cells (i, j), j > i.
 // ---------------------------------------------------------------------------
-template <int R, typename OutT>
-__device__ void y_unit(const DevMap& m, OutT* __restrict__ out, const UnitGeom g, double* lds) {
+template <int R, typename Emit>
+__device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* dstate) {
   constexpr int S = 64 * R;
   const int lane = threadIdx.x & 63;
-  const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wavefront index, made provably uniform
-  const int W = blockDim.x >> 6;
-  const int cols_total = min(g.ni, g.nj - 1);
-  if (cols_total <= 0) return;  // uniform for the workgroup
+  const int cols_total = max(min(g.ni, g.nj - 1), 0);
   const int P = (cols_total + S - 1) / S;
   const int glast = (g.nj - 1) / kChunk;
-  const int tmax = glast + P - 1;
   const int i0 = p * S;
   const bool strip_on = p < P;
-
-  double* ring = lds;
-  double* dstate = lds + (size_t)W * kRing;  // 2 doubles per strip: (diag, sub) handed to the next strip
-  double* ring_out = ring + p * kRing;
-  const double* ring_in = ring + (p > 0 ? p - 1 : 0) * kRing;
+  double* ring_out = ring_base + p * kRing;
+  const double* ring_in = ring_base + (p > 0 ? p - 1 : 0) * kRing;
 
   double prev[R], id[R];
+  const uint64_t* colp[R];
   uint64_t ow[R], own[R], b1[R], b2[R];
-  const uint64_t* ocol[R];
-  int xs[R];
-  int cur_yw = 0;
-  // private diagonal recurrence state
-  double dg = 0.0, sb = 0.0;
+  double rv = 0.0, rvn = 0.0;
+  int cur_blk = 0;
+  double dg = 0.0, sb = 0.0;  // private diagonal recurrence state
+  // the pair this lane stores each step: columns i0 + R*lane + (0..R-1) are x-consecutive
+  const int icol0 = i0 + R * lane;
+  const int xlo = g.dirx > 0 ? g.sx + icol0 : g.sx - icol0 - (R - 1);  // lowest x of the lane's R columns
+#pragma unroll
+  for (int r = 0; r < R; ++r) { prev[r] = 0.0; id[r] = 0.0; colp[r] = m.cols + 1; ow[r] = own[r] = b1[r] = b2[r] = 0; }
   if (strip_on) {
     const int y0 = g.sy + g.diry * i0;
-    cur_yw = y0 >> 6;
+    cur_blk = y0 >> 6;
+    auto recip_of = [&](int blk) {
+      const int yt = blk * 64 + lane;
+      const int jt = g.diry > 0 ? yt - g.sy : g.sy - yt;
+      return (jt >= 0 && jt < g.nj) ? m.recip[jt] : 0.0;
+    };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int i = i0 + 64 * r + lane;
+      const int i = icol0 + r;
       const bool on = i < g.ni;
       const int x = on ? g.sx + g.dirx * i : g.sx;
-      xs[r] = x;
-      prev[r] = 0.0;
       id[r] = (double)i;
-      ocol[r] = m.cols + (size_t)x * m.wpc + 1;
-      ow[r] = ocol[r][cur_yw];
-      own[r] = ocol[r][cur_yw + g.diry];
-      // occupancy of (X(k), Y(k-1)) and (X(k), Y(k)) for k = this lane's index: the two
-      // factors of the diagonal recurrence at step k, gathered once and balloted
+      colp[r] = m.cols + (size_t)x * m.wpc + 1;
+      ow[r] = colp[r][cur_blk];
+      own[r] = colp[r][cur_blk + g.diry];
+    }
+    rv = recip_of(cur_blk);
+    rvn = recip_of(cur_blk + g.diry);
+    // occupancy of (X(k), Y(k-1)) and (X(k), Y(k)) for k = i0 + 64*q + lane: the two factors of
+    // the diagonal recurrence at step k, gathered once and balloted (bit = lane)
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int k = i0 + 64 * q + lane;
       bool f1 = false, f2 = false;
-      if (on && i >= 1 && i < g.nj) {
-        const int yk = g.sy + g.diry * i, ykm = g.sy + g.diry * (i - 1);
-        f1 = (ocol[r][ykm >> 6] >> (ykm & 63)) & 1ull;
-        f2 = (ocol[r][yk >> 6] >> (yk & 63)) & 1ull;
+      if (k >= 1 && k < g.ni && k < g.nj) {
+        const uint64_t* col = m.cols + (size_t)(g.sx + g.dirx * k) * m.wpc + 1;
+        const int yk = g.sy + g.diry * k, ykm = g.sy + g.diry * (k - 1);
+        f1 = (col[ykm >> 6] >> (ykm & 63)) & 1ull;
+        f2 = (col[yk >> 6] >> (yk & 63)) & 1ull;
       }
-      b1[r] = __ballot(f1);
-      b2[r] = __ballot(f2);
+      b1[q] = __ballot(f1);
+      b2[q] = __ballot(f2);
     }
     if (p == 0) {
       const uint64_t sw = m.cols[(size_t)g.sx * m.wpc + 1 + (g.sy >> 6)];
@@ -280,22 +353,29 @@ __device__ void y_unit(const DevMap& m, OutT* __restrict__ out, const UnitGeom g
     if (strip_on && gch >= i0 / kChunk && gch <= glast) {
       const int jbeg = max(gch * kChunk, i0);
       const int jend = min(gch * kChunk + kChunk - 1, g.nj - 1);
+      double ringv = 0.0;
+      if (p > 0) ringv = ring_in[(jbeg - 1 + lane) & (kRing - 1)];
       for (int j = jbeg; j <= jend; ++j) {
         const int y = g.sy + g.diry * j;
-        const int yw = y >> 6, yb = y & 63;
-        if (yw != cur_yw) {
-          cur_yw = yw;
+        const int blk = y >> 6, t = y & 63;
+        if (blk != cur_blk) {
+          cur_blk = blk;
+          const int yt = (blk + g.diry) * 64 + lane;
+          const int jt = g.diry > 0 ? yt - g.sy : g.sy - yt;
+          rv = rvn;
+          rvn = (jt >= 0 && jt < g.nj) ? m.recip[jt] : 0.0;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             ow[r] = own[r];
-            own[r] = ocol[r][yw + g.diry];
+            own[r] = colp[r][blk + g.diry];
           }
         }
         const double dj = (double)j;
-        const double rj = m.recip[j];
+        const double rj = read_lane(rv, t);
         // advance the private diagonal recurrence to diag(j) while j is one of this
-        // strip's own lanes (the previous strip hands over the state at j = i0 - 1)
-        if (j >= i0 && j < i0 + S && j < g.ni) {
+        // strip's own columns (the previous strip hands over the state at j = i0 - 1)
+        const bool own_diag = j >= i0 && j < i0 + S && j < g.ni;
+        if (own_diag) {
           if (j >= 1) {
             if (j == i0) {  // p > 0 here
               dg = dstate[2 * (p - 1)];
@@ -304,8 +384,8 @@ __device__ void y_unit(const DevMap& m, OutT* __restrict__ out, const UnitGeom g
             const int k = j - i0;
             uint64_t m1 = b1[0], m2 = b2[0];
 #pragma unroll
-            for (int r = 1; r < R; ++r) {
-              if ((k >> 6) == r) { m1 = b1[r]; m2 = b2[r]; }
+            for (int q = 1; q < R; ++q) {
+              if ((k >> 6) == q) { m1 = b1[q]; m2 = b2[q]; }
             }
             const double cj = ratio(dj - 1.0, dj, rj);
             const double s = stencil(dg, sb, cj);
@@ -318,59 +398,47 @@ __device__ void y_unit(const DevMap& m, OutT* __restrict__ out, const UnitGeom g
           }
         }
         double fill = 0.0;
-        if (p > 0) fill = ring_in[(j - 1) & (kRing - 1)];
-        OutT* orow = out + (size_t)y * m.nx;
+        if (p > 0) fill = read_lane(ringv, j - jbeg);
+        double v[R];
+        {
+          const double b0 = shift_up(prev[R - 1], fill);
+          v[0] = and_mask(stencil(prev[0], b0, ratio(id[0], dj, rj)), bit_mask(ow[0], t));
+        }
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int ir0 = i0 + 64 * r;
-          if (j >= ir0) {
-            const int i = ir0 + lane;
-            const double a = prev[r];
-            const double b = shift_up(a, fill);
-            const double c = ratio(id[r], dj, rj);
-            double v = gate(stencil(a, b, c), ow[r], yb);
-            if (i < j && i < cols_total) orow[xs[r]] = to_out<OutT>(v);
-            if (i == j) v = dg;  // seed: the diagonal cell is this column's first "previous"
-            fill = lane63(a);
-            prev[r] = v;
+        for (int r = 1; r < R; ++r) v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(id[r], dj, rj)), bit_mask(ow[r], t));
+        // emit the row segment: the lane's R columns are x-consecutive, pairs of 16 bytes
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+          if (R == 1) {
+            const int i = icol0;
+            emit.pair(xlo, y, v[0], 0.0, i < j && i < cols_total, false);
+          } else {
+            const int ia = icol0 + r, ib = ia + 1;
+            const bool oka = ia < j && ia < cols_total, okb = ib < j && ib < cols_total;
+            if (g.dirx > 0)
+              emit.pair(xlo + r, y, v[r], v[r + 1], oka, okb);
+            else
+              emit.pair(xlo + (R - 2 - r), y, v[r + 1], v[r], okb, oka);
           }
         }
-        if (lane == 63) ring_out[j & (kRing - 1)] = prev[R - 1];
+        if (own_diag) {  // seed: the diagonal cell is column j's first "previous"
+          const int k = j - i0;
+          const int ld = k / R, rd = k - ld * R;
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (rd == r && lane == ld) v[r] = dg;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) prev[r] = v[r];
+        if (lane == 63) ring_out[j & (kRing - 1)] = v[R - 1];
       }
     }
     __syncthreads();
   }
 }
 
-// rows/columns no quadrant covers read as zero
-template <typename OutT>
-__device__ void zero_unit(const DevMap& m, OutT* __restrict__ out, int sx, int sy) {
-  if (sx > 0)
-    for (int y = threadIdx.x; y < m.ny; y += blockDim.x) out[(size_t)y * m.nx] = OutT(0);
-  if (sy > 0)
-    for (int x = threadIdx.x; x < m.nx; x += blockDim.x) out[x] = OutT(0);
-}
-
-// grid = n_src * kUnitsPerSource workgroups of 64*W threads;
-// dynamic LDS = sweep_lds_bytes(R, W)
-template <int R, typename OutT>
-__global__ void __launch_bounds__(1024)
-vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
-                 int* __restrict__ err_flag) {
-  extern __shared__ double lds[];
-  const int s = blockIdx.x / kUnitsPerSource;
-  const int unit = blockIdx.x - s * kUnitsPerSource;
-  const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
-  if (sx < 0 || sy < 0 || sx >= m.nx || sy >= m.ny) {
-    if (threadIdx.x == 0 && unit == 0) atomicOr(err_flag, 1);
-    return;
-  }
-  OutT* o = out + (size_t)s * field_stride;
-  if (unit == 8) {
-    zero_unit<OutT>(m, o, sx, sy);
-    return;
-  }
-  const int q = unit >> 1;
+// geometry of quadrant q of a source
+__device__ __forceinline__ UnitGeom unit_geom(const DevMap& m, int sx, int sy, int q) {
   UnitGeom g;
   g.sx = sx;
   g.sy = sy;
@@ -378,15 +446,58 @@ vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict_
   g.diry = (q < 2) ? 1 : -1;
   g.ni = g.dirx > 0 ? m.nx - sx : sx;    // negative directions stop short of the border (Q2)
   g.nj = g.diry > 0 ? m.ny - sy : sy;
-  if (g.ni <= 0 || g.nj <= 0) return;
-  if (unit & 1)
-    y_unit<R, OutT>(m, o, g, lds);
-  else
-    x_unit<R, OutT>(m, o, g, lds);
+  return g;
 }
 
 inline size_t sweep_lds_bytes(int R, int W) {
-  return ((size_t)W * (kRing + 2) + (size_t)W * 64 * R * kTileStride) * sizeof(double);
+  // x rings, y rings, diagonal hand-over state, W staging tiles
+  return ((size_t)2 * W * kRing + 2 * W + (size_t)W * 64 * R * kTileStride) * sizeof(double);
+}
+
+// One quadrant of one source: called by all 2*W wavefronts of a workgroup.
+template <int R, typename Emit>
+__device__ void sweep_quadrant(const DevMap& m, Emit& emit, int sx, int sy, int q, double* lds) {
+  constexpr int S = 64 * R;
+  const int W = blockDim.x >> 7;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
+  const UnitGeom g = unit_geom(m, sx, sy, q);
+  if (q == 0) {
+    // rows/columns no quadrant covers read as zero; quadrant 1 always exists
+    if (sx > 0)
+      for (int y = threadIdx.x; y < m.ny; y += blockDim.x) emit.zero(0, y);
+    if (sy > 0)
+      for (int x = threadIdx.x; x < m.nx; x += blockDim.x) emit.zero(x, 0);
+  }
+  if (g.ni <= 0 || g.nj <= 0) return;  // uniform for the workgroup
+  const int rows_total = min(g.nj, g.ni);
+  const int cols_total = max(min(g.ni, g.nj - 1), 0);
+  const int Px = (rows_total + S - 1) / S, Py = (cols_total + S - 1) / S;
+  const int tmax = max((g.ni - 1) / kChunk + Px - 1, (g.nj - 1) / kChunk + max(Py, 1) - 1);
+  double* ring_x = lds;
+  double* ring_y = lds + (size_t)W * kRing;
+  double* dstate = lds + (size_t)2 * W * kRing;
+  double* tiles = dstate + 2 * W;
+  if (wave < W)
+    x_strip<R>(m, emit, g, wave, tmax, ring_x, tiles + (size_t)wave * S * kTileStride);
+  else
+    y_strip<R>(m, emit, g, wave - W, tmax, ring_y, dstate);
+}
+
+// grid = n_src * 4 workgroups of 128*W threads; dynamic LDS = sweep_lds_bytes(R, W)
+template <int R, typename OutT>
+__global__ void __launch_bounds__(1024)
+vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
+                 int* __restrict__ err_flag) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x / kUnitsPerSource;
+  const int q = blockIdx.x - s * kUnitsPerSource;
+  const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
+  if (sx < 0 || sy < 0 || sx >= m.nx || sy >= m.ny) {
+    if (threadIdx.x == 0 && q == 0) atomicOr(err_flag, 1);
+    return;
+  }
+  StoreEmit<OutT> emit{out + (size_t)s * field_stride, m.nx};
+  sweep_quadrant<R>(m, emit, sx, sy, q, lds);
 }
 
 // ---------------------------------------------------------------------------
