@@ -16,6 +16,7 @@
 
 #include "vhp_sweep.cuh"
 #include "vhp_planner.cuh"
+#include "vhp_queue.cuh"
 
 struct vhp_ctx {
   int device = 0;
@@ -39,8 +40,8 @@ struct vhp_ctx {
   void* d_out = nullptr;
   size_t d_out_cap = 0;
 
-  vhp::PlannerState pl;  // device-resident planner state (allocated by set_map)
-  size_t pl_cells = 0;
+  vhp::PlannerState pl;  // device-resident planner state
+  vhp::QueueScratch qs;  // scratch of the queue-variant sweep
 };
 
 namespace {
@@ -85,6 +86,12 @@ void pick_shape(int maxdim, int* R, int* W) {
   while ((*W) * 64 * (*R) < maxdim && *R < 4) *R *= 2;
 }
 
+}  // namespace
+namespace vhp {
+void pick_shape_for(int maxdim, int* R, int* W) { pick_shape(maxdim, R, W); }
+}
+namespace {
+
 void free_map(vhp_ctx* c) {
   if (c->d_occ) hipFree(c->d_occ);
   if (c->d_rows) hipFree(c->d_rows);
@@ -92,7 +99,7 @@ void free_map(vhp_ctx* c) {
   if (c->d_recip) hipFree(c->d_recip);
   c->d_occ = nullptr; c->d_rows = nullptr; c->d_cols = nullptr; c->d_recip = nullptr;
   vhp::planner_free(c->pl);
-  c->pl_cells = 0;
+  vhp::queue_scratch_free(c->qs);
   c->nx = c->ny = 0;
 }
 
@@ -230,7 +237,7 @@ int vhp_sweep_batch_device(vhp_ctx* ctx, const int32_t* d_src_xy, int n_src, int
   VHP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   hipError_t e;
   if (variant == VHP_SWEEP_QUEUE) {
-    e = vhp::launch_queue_sweep(dev_map(ctx), ctx->d_occ, d_src_xy, n_src, dtype, d_out, ctx->d_err, ctx->stream);
+    e = vhp::launch_queue_sweep_impl(ctx->qs, dev_map(ctx), ctx->d_occ, d_src_xy, n_src, dtype, d_out, ctx->d_err, ctx->stream);
   } else if (dtype == VHP_F64) {
     e = launch_sweep<double>(ctx, d_src_xy, n_src, static_cast<double*>(d_out));
   } else {

@@ -1,17 +1,354 @@
-// placeholder while the sweep is brought up on hardware; replaced by the real planner
+// vhp_planner.cuh -- the visibility-heuristic planner loop on the GPU.
+//
+// Replaces solve() (reference src/visibilityBasedSolver.cpp:76-160), updateVisibility()
+// (:379-565) and the std::priority_queue / top() arg-min
+// (include/solver/visibilityBasedSolver.h:16-21,138; resetQueue() .cpp:65-71).
+//
+// All planner state lives in HBM for the whole solve: vis_global, vis_local, labels
+// (cameFrom_ as uint32), the pivot list (lightSources_) and a small control block.
+// One iteration = two kernels on one stream, no host round trip:
+//   vhp_planner_fronts : the front sweep of vhp_sweep.cuh from the current pivot with
+//                        the planner epilogue fused into the emit path -- local field
+//                        store, max-union into vis_global, first-lit labelling, and
+//                        the heuristic h of every lit cell reduced to the arg-min.
+//   vhp_planner_pick   : merges the four quadrant partials, appends the next pivot,
+//                        evaluates the loop condition, raises `done`.
+// The host enqueues a few iterations at a time and polls the control block; kernels
+// of iterations queued past the end see `done` and return at once.
+//
+// The reference heap is only ever asked for top() and never popped, and libstdc++'s
+// push_heap sifts up on strict comparison only, so top() is the FIRST-pushed node of
+// minimal h.  Here that is a lexicographic min over (h, push rank): the
+// rank of a cell is its position in the reference's push order, a closed form of
+// (dx, dy) (tests/schedule_model.py first_touch_rank, checked against the oracle).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
+
 #include <string>
+#include <vector>
+
+#include "vhp.h"
 #include "vhp_sweep.cuh"
+
 namespace vhp {
-struct PlannerState { int dummy = 0; };
-inline void planner_free(PlannerState&) {}
-inline int planner_solve(PlannerState&, const DevMap&, const uint8_t*, hipStream_t, hipEvent_t, hipEvent_t, int, int, int, int,
-                         double, uint64_t, uint64_t*, double*, double*, int32_t*, uint32_t*, std::string* msg) {
-  *msg = "planner not built yet";
-  return 100;
+
+constexpr uint32_t kUnlabelled32 = 0xffffffffu;
+
+struct PlannerCtl {
+  int nb;        // nb_of_sources_
+  int done;      // loop finished (any reason)
+  int status;    // vhp_status of the solve
+  int iters;     // planner steps executed
+};
+
+struct PlannerKey {
+  unsigned long long h;     // bits of the heuristic (h >= 0, so the bit pattern orders like the value)
+  unsigned long long rank;  // push order, lower = earlier
+  int x, y;
+};
+
+struct PlannerDev {
+  double* vis_global;
+  double* vis_local;
+  uint32_t* label;
+  int32_t* pivots;      // (x, y) pairs, lightSources_
+  PlannerCtl* ctl;
+  PlannerKey* partial;  // one per quadrant workgroup
+  double threshold, scale;
+  int end_x, end_y;
+  unsigned long long max_iter;
+};
+
+__device__ __forceinline__ bool key_less(const PlannerKey& a, const PlannerKey& b) {
+  return a.h < b.h || (a.h == b.h && a.rank < b.rank);
 }
-inline hipError_t launch_queue_sweep(const DevMap&, const uint8_t*, const int32_t*, int, int, void*, int*, hipStream_t) {
-  return hipErrorNotSupported;
+
+// eval_d, visibilityBasedSolver.h:112-115: first product in double, second in int
+__device__ __forceinline__ double eval_d_dev(int ax, int ay, int bx, int by) {
+  const int dx = ax - bx, dy = ay - by;
+  return __builtin_sqrt((double)dx * dx + (double)(dy * dy));
 }
+
+// push-order rank of cell (x, y) for the pivot (sx, sy): quadrants in the order Q1..Q4,
+// inside a quadrant the x offset is the outer loop and the y offset the inner one
+// (solver.cpp:392-395 etc.); a cell several quadrants visit counts where it is first pushed.
+__device__ __forceinline__ unsigned long long push_rank(int nx, int ny, int sx, int sy, int x, int y) {
+  const long long dx = x - sx, dy = y - sy;
+  long long q, r;
+  if (dx >= 0 && dy >= 0) { q = 0; r = dx * (ny - sy) + dy; }
+  else if (dx < 0 && dy >= 0) { q = 1; r = (-dx) * (ny - sy) + dy; }
+  else if (dy < 0 && (dx < 0 || (dx == 0 && sx >= 1))) { q = 2; r = (-dx) * (long long)sy + (-dy); }
+  else { q = 3; r = dx * (long long)sy + (-dy); }
+  (void)nx;
+  return ((unsigned long long)q << 40) | (unsigned long long)r;
+}
+
+// Emit policy of the planner step: the per-cell body of updateVisibility()
+// (solver.cpp:415-430) in the coalesced domain.
+struct PlannerEmit {
+  PlannerDev d;
+  int nx, ny, sx, sy;
+  uint32_t nb;
+  PlannerKey best;
+
+  __device__ __forceinline__ void cell(int x, int y, double v) {
+    const size_t k = (size_t)y * nx + x;
+    d.vis_local[k] = v;                                  // :416
+    const double g = fmax(v, d.vis_global[k]);           // :417-418
+    d.vis_global[k] = g;
+    uint32_t lab = d.label[k];
+    if (v >= d.threshold && lab == kUnlabelled32) {      // :419-423
+      lab = nb;
+      d.label[k] = lab;
+    }
+    if (g >= d.threshold) {                              // :424-430
+      const int px = d.pivots[2 * lab], py = d.pivots[2 * lab + 1];
+      const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, px, py));
+      PlannerKey c;
+      c.h = (unsigned long long)__double_as_longlong(h);
+      c.rank = push_rank(nx, ny, sx, sy, x, y);
+      c.x = x;
+      c.y = y;
+      if (key_less(c, best)) best = c;
+    }
+  }
+  __device__ __forceinline__ void pair(int x, int y, double v0, double v1, bool ok0, bool ok1) {
+    if (ok0) cell(x, y, v0);
+    if (ok1) cell(x + 1, y, v1);
+  }
+  __device__ __forceinline__ void zero(int x, int y) { d.vis_local[(size_t)y * nx + x] = 0.0; }  // visibility_.reset(), :386
+};
+
+__device__ __forceinline__ PlannerKey key_shuffle_xor(const PlannerKey& k, int mask) {
+  PlannerKey o;
+  o.h = ((unsigned long long)(unsigned)__shfl_xor((int)(k.h >> 32), mask) << 32) | (unsigned)__shfl_xor((int)k.h, mask);
+  o.rank = ((unsigned long long)(unsigned)__shfl_xor((int)(k.rank >> 32), mask) << 32) | (unsigned)__shfl_xor((int)k.rank, mask);
+  o.x = __shfl_xor(k.x, mask);
+  o.y = __shfl_xor(k.y, mask);
+  return o;
+}
+
+template <int R>
+__global__ void __launch_bounds__(1024) vhp_planner_fronts(DevMap m, PlannerDev d) {
+  extern __shared__ double lds[];
+  if (d.ctl->done) return;
+  const int nb = d.ctl->nb;
+  const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
+  PlannerEmit emit;
+  emit.d = d;
+  emit.nx = m.nx;
+  emit.ny = m.ny;
+  emit.sx = sx;
+  emit.sy = sy;
+  emit.nb = (uint32_t)nb;
+  emit.best.h = ~0ull;
+  emit.best.rank = ~0ull;
+  emit.best.x = emit.best.y = -1;
+  sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x, lds);
+  // workgroup arg-min of (h, rank)
+  PlannerKey k = emit.best;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const PlannerKey o = key_shuffle_xor(k, s);
+    if (key_less(o, k)) k = o;
+  }
+  __syncthreads();
+  PlannerKey* slots = reinterpret_cast<PlannerKey*>(lds);
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) slots[wave] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PlannerKey b = slots[0];
+    for (int w = 1; w < nw; ++w)
+      if (key_less(slots[w], b)) b = slots[w];
+    d.partial[blockIdx.x] = b;
+  }
+}
+
+__global__ void vhp_planner_pick(DevMap m, PlannerDev d) {
+  if (threadIdx.x != 0 || d.ctl->done) return;
+  PlannerKey b = d.partial[0];
+  for (int q = 1; q < 4; ++q)
+    if (key_less(d.partial[q], b)) b = d.partial[q];
+  d.ctl->iters += 1;
+  if (b.x < 0) {  // nothing reached the threshold: the reference would call top() on an empty heap
+    d.ctl->status = VHP_ERR_NOTHING_LIT;
+    d.ctl->done = 1;
+    return;
+  }
+  const int nb = d.ctl->nb + 1;  // ls_ = top(); ++nb_of_sources_; lightSources_[nb] = ls_   (solver.cpp:130-133)
+  d.ctl->nb = nb;
+  d.pivots[2 * nb] = b.x;
+  d.pivots[2 * nb + 1] = b.y;
+  if ((unsigned long long)nb > d.max_iter) {  // :134-139
+    d.ctl->status = VHP_ERR_MAX_ITER;
+    d.ctl->done = 1;
+    return;
+  }
+  if (d.vis_global[(size_t)d.end_y * m.nx + d.end_x] > d.threshold) {  // loop condition, :127
+    d.pivots[2 * nb] = d.end_x;  // :141
+    d.pivots[2 * nb + 1] = d.end_y;
+    d.ctl->status = VHP_OK;
+    d.ctl->done = 1;
+  }
+}
+
+__global__ void vhp_planner_init(PlannerDev d, int nx, int start_x, int start_y) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    d.ctl->nb = 0;
+    d.ctl->done = 0;
+    d.ctl->status = VHP_OK;
+    d.ctl->iters = 0;
+    d.pivots[0] = start_x;  // lightSources_[0] = start; cameFrom_(start) = 0   (solver.cpp:121-122)
+    d.pivots[1] = start_y;
+    d.label[(size_t)start_y * nx + start_x] = 0;
+  }
+}
+
+// labels -> cameFrom_ as the reference stores it (size_t, (size_t)1e15 where unlabelled)
+__global__ void vhp_labels_to_u64(const uint32_t* __restrict__ lab, unsigned long long* __restrict__ out, size_t n) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = lab[k] == kUnlabelled32 ? VHP_UNLABELLED : (unsigned long long)lab[k];
+}
+
+struct PlannerState {
+  size_t cells = 0;
+  size_t pivot_cap = 0;
+  double* vis_global = nullptr;
+  double* vis_local = nullptr;
+  uint32_t* label = nullptr;
+  unsigned long long* came64 = nullptr;
+  int32_t* pivots = nullptr;
+  PlannerCtl* ctl = nullptr;
+  PlannerKey* partial = nullptr;
+};
+
+inline void planner_free(PlannerState& s) {
+  if (s.vis_global) (void)hipFree(s.vis_global);
+  if (s.vis_local) (void)hipFree(s.vis_local);
+  if (s.label) (void)hipFree(s.label);
+  if (s.came64) (void)hipFree(s.came64);
+  if (s.pivots) (void)hipFree(s.pivots);
+  if (s.ctl) (void)hipFree(s.ctl);
+  if (s.partial) (void)hipFree(s.partial);
+  s = PlannerState();
+}
+
+void pick_shape_for(int maxdim, int* R, int* W);  // defined in vhp_capi.hip
+
+#define VHP_PL_HIP(call)                                                      \
+  do {                                                                        \
+    hipError_t e_ = (call);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      *msg = std::string(#call) + ": " + hipGetErrorString(e_);               \
+      return (int)VHP_ERR_HIP;                                                \
+    }                                                                         \
+  } while (0)
+
+template <int R>
+inline hipError_t launch_planner_fronts(const DevMap& m, const PlannerDev& d, int W, hipStream_t stream) {
+  const size_t lds = sweep_lds_bytes(R, W);
+  auto k = vhp_planner_fronts<R>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(4), dim3(128 * W), lds, stream, m, d);
+  return hipGetLastError();
+}
+
+inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ, hipStream_t stream, hipEvent_t ev0,
+                         hipEvent_t ev1, int start_x, int start_y, int end_x, int end_y, double threshold,
+                         uint64_t max_iter, uint64_t* came_from, double* vis_global, double* vis_local,
+                         int32_t* pivots_xy, uint32_t* n_pivots, std::string* msg) {
+  const int nx = m.nx, ny = m.ny;
+  // the four validity checks of solve(), in the reference's order (solver.cpp:89-116)
+  auto valid = [&](int x, int y) { return (size_t)x < (size_t)nx && (size_t)y < (size_t)ny; };
+  if (!valid(start_x, start_y)) { *msg = "Start point is out of bounds."; return VHP_ERR_START_OOB; }
+  if (!valid(end_x, end_y)) { *msg = "End point is out of bounds."; return VHP_ERR_END_OOB; }
+  uint8_t occ_s = 0, occ_e = 0;
+  VHP_PL_HIP(hipMemcpyAsync(&occ_s, d_occ + (size_t)start_y * nx + start_x, 1, hipMemcpyDeviceToHost, stream));
+  VHP_PL_HIP(hipMemcpyAsync(&occ_e, d_occ + (size_t)end_y * nx + end_x, 1, hipMemcpyDeviceToHost, stream));
+  VHP_PL_HIP(hipStreamSynchronize(stream));
+  if (!occ_s) { *msg = "Start point is not valid (occupied)"; return VHP_ERR_START_OCCUPIED; }
+  if (!occ_e) { *msg = "End point is not valid (occupied)"; return VHP_ERR_END_OCCUPIED; }
+  if (max_iter > (1u << 24)) { *msg = "max_iter too large"; return VHP_ERR_ARG; }
+
+  const size_t cells = (size_t)nx * ny;
+  const size_t pcap = 2 * (size_t)(max_iter + 2);
+  if (s.cells != cells) {
+    planner_free(s);
+    VHP_PL_HIP(hipMalloc(&s.vis_global, cells * 8));
+    VHP_PL_HIP(hipMalloc(&s.vis_local, cells * 8));
+    VHP_PL_HIP(hipMalloc(&s.label, cells * 4));
+    VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
+    VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
+    VHP_PL_HIP(hipMalloc(&s.partial, 4 * sizeof(PlannerKey)));
+    s.cells = cells;
+  }
+  if (s.pivot_cap < pcap) {
+    if (s.pivots) (void)hipFree(s.pivots);
+    s.pivots = nullptr;
+    VHP_PL_HIP(hipMalloc(&s.pivots, pcap * sizeof(int32_t)));
+    s.pivot_cap = pcap;
+  }
+  // reset(): visibility_global_ = 0, visibility_ = 0, cameFrom_ = 1e15   (solver.cpp:42-47)
+  VHP_PL_HIP(hipMemsetAsync(s.vis_global, 0, cells * 8, stream));
+  VHP_PL_HIP(hipMemsetAsync(s.vis_local, 0, cells * 8, stream));
+  VHP_PL_HIP(hipMemsetAsync(s.label, 0xff, cells * 4, stream));
+  VHP_PL_HIP(hipMemsetAsync(s.pivots, 0, pcap * sizeof(int32_t), stream));
+
+  PlannerDev d;
+  d.vis_global = s.vis_global;
+  d.vis_local = s.vis_local;
+  d.label = s.label;
+  d.pivots = s.pivots;
+  d.ctl = s.ctl;
+  d.partial = s.partial;
+  d.threshold = threshold;
+  {
+    volatile double q = (double)((size_t)ny * ny + (size_t)nx * nx);
+    d.scale = std::sqrt(q);  // scale_, solver.cpp:49
+  }
+  d.end_x = end_x;
+  d.end_y = end_y;
+  d.max_iter = max_iter;
+
+  int R, W;
+  pick_shape_for(std::max(nx, ny), &R, &W);
+  VHP_PL_HIP(hipEventRecord(ev0, stream));
+  hipLaunchKernelGGL(vhp_planner_init, dim3(1), dim3(64), 0, stream, d, nx, start_x, start_y);
+  VHP_PL_HIP(hipGetLastError());
+  PlannerCtl ctl{};
+  const int batch = 4;  // iterations enqueued per host poll
+  for (;;) {
+    for (int b = 0; b < batch; ++b) {
+      hipError_t e = R == 1 ? launch_planner_fronts<1>(m, d, W, stream)
+                   : R == 2 ? launch_planner_fronts<2>(m, d, W, stream)
+                            : launch_planner_fronts<4>(m, d, W, stream);
+      if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
+      hipLaunchKernelGGL(vhp_planner_pick, dim3(1), dim3(64), 0, stream, m, d);
+      VHP_PL_HIP(hipGetLastError());
+    }
+    VHP_PL_HIP(hipMemcpyAsync(&ctl, s.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
+    VHP_PL_HIP(hipStreamSynchronize(stream));
+    if (ctl.done) break;
+  }
+  VHP_PL_HIP(hipEventRecord(ev1, stream));
+
+  const uint32_t nb = (uint32_t)ctl.nb;
+  if (n_pivots) *n_pivots = nb;
+  if (pivots_xy) VHP_PL_HIP(hipMemcpyAsync(pivots_xy, s.pivots, 2 * (size_t)(nb + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  if (came_from) {
+    hipLaunchKernelGGL(vhp_labels_to_u64, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, s.label, s.came64, cells);
+    VHP_PL_HIP(hipGetLastError());
+    VHP_PL_HIP(hipMemcpyAsync(came_from, s.came64, cells * 8, hipMemcpyDeviceToHost, stream));
+  }
+  if (vis_global) VHP_PL_HIP(hipMemcpyAsync(vis_global, s.vis_global, cells * 8, hipMemcpyDeviceToHost, stream));
+  if (vis_local) VHP_PL_HIP(hipMemcpyAsync(vis_local, s.vis_local, cells * 8, hipMemcpyDeviceToHost, stream));
+  VHP_PL_HIP(hipStreamSynchronize(stream));
+  if (ctl.status == VHP_ERR_MAX_ITER) *msg = "Max iters hit. Solution could not be found. Try lowering visibility threshold.";
+  if (ctl.status == VHP_ERR_NOTHING_LIT) *msg = "no cell reached the visibility threshold";
+  return ctl.status;
+}
+
 }  // namespace vhp
