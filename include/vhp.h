@@ -106,6 +106,13 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
 int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, int nx, int ny, int end_x,
                          int end_y, int32_t* path_xy, uint32_t cap, uint32_t* n_path, double* length);
 
+/* Replaces raycasting() driven over all targets as benchmark() does (solver.cpp:226-232,
+ * 267-290): a Bresenham ray from the source to every cell; a blocked cell met on the way
+ * zeroes that cell and the target.  out: nx*ny doubles, 1 = visible (visibilityRayCasting_,
+ * initialised to 1, solver.cpp:45).  Every write is a zero, so the union does not depend
+ * on the order the rays are cast in and one thread per ray reproduces the reference. */
+int vhp_raycast_all(vhp_ctx* ctx, int src_x, int src_y, double* out_host);
+
 /* Elapsed milliseconds between the first and last kernel of the most recent
  * vhp_sweep_batch_device / planner call, from hipEvents recorded on the context
  * stream.  Blocks until that work has finished. */

@@ -38,6 +38,7 @@ UNLABELLED = 1000000000000000
 ABI_SYMBOLS = (
     "vhp_create", "vhp_destroy", "vhp_last_error", "vhp_set_stream", "vhp_set_map", "vhp_set_map_device",
     "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
+    "vhp_raycast_all",
     "vhp_last_elapsed_ms", "vhp_version",
 )
 
@@ -81,6 +82,7 @@ def load_library():
     lib.vhp_sync.argtypes = [vp]
     lib.vhp_planner_solve.argtypes = [vp, i32, i32, i32, i32, f64, u64, vp, vp, vp, vp, C.POINTER(u32)]
     lib.vhp_reconstruct_path.argtypes = [vp, vp, i32, i32, i32, i32, vp, u32, C.POINTER(u32), C.POINTER(f64)]
+    lib.vhp_raycast_all.argtypes = [vp, i32, i32, vp]
     lib.vhp_last_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.vhp_version.restype = C.c_char_p
     _lib = lib
@@ -159,6 +161,11 @@ class Context:
             self._check(rc)
         return dict(status=rc, came_from=came, vis_global=vg, vis_local=vl, pivots=piv[: npiv.value + 1].copy(),
                     n_pivots=npiv.value)
+
+    def raycast_all(self, sx, sy):
+        out = np.empty((self.ny, self.nx), np.float64)
+        self._check(self.lib.vhp_raycast_all(self.h, int(sx), int(sy), _ptr(out)))
+        return out
 
     def reconstruct_path(self, came_from, pivots, end):
         ny, nx = came_from.shape

@@ -299,6 +299,31 @@ int vhp_sweep_batch(vhp_ctx* ctx, const int32_t* src_xy, int n_src, int variant,
   return vhp_sync(ctx);
 }
 
+int vhp_raycast_all(vhp_ctx* ctx, int src_x, int src_y, double* out_host) {
+  if (!ctx || !out_host) return fail(ctx, VHP_ERR_ARG, "vhp_raycast_all: bad argument");
+  if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_raycast_all: no map set");
+  if (src_x < 0 || src_y < 0 || src_x >= ctx->nx || src_y >= ctx->ny) return fail(ctx, VHP_ERR_SOURCE_OOB, "source outside the grid");
+  VHP_HIP(hipSetDevice(ctx->device));
+  const size_t cells = (size_t)ctx->nx * ctx->ny;
+  if (ctx->d_out_cap < cells * 8) {
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    ctx->d_out = nullptr;
+    VHP_HIP(hipMalloc(&ctx->d_out, cells * 8));
+    ctx->d_out_cap = cells * 8;
+  }
+  double* d = static_cast<double*>(ctx->d_out);
+  const unsigned blocks = (unsigned)((cells + 255) / 256);
+  VHP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(vhp::vhp_fill_f64, dim3(blocks), dim3(256), 0, ctx->stream, d, 1.0, cells);
+  hipLaunchKernelGGL(vhp::vhp_raycast, dim3(blocks), dim3(256), 0, ctx->stream, ctx->nx, ctx->ny, ctx->d_occ, src_x, src_y, d);
+  VHP_HIP(hipGetLastError());
+  VHP_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->timed = true;
+  VHP_HIP(hipMemcpyAsync(out_host, d, cells * 8, hipMemcpyDeviceToHost, ctx->stream));
+  VHP_HIP(hipStreamSynchronize(ctx->stream));
+  return VHP_OK;
+}
+
 int vhp_last_elapsed_ms(vhp_ctx* ctx, float* ms) {
   if (!ctx || !ms) return VHP_ERR_ARG;
   if (!ctx->timed) return fail(ctx, VHP_ERR_ARG, "nothing timed yet");

@@ -83,6 +83,32 @@ __global__ void vhp_queue_flood(int nx, int ny, const uint8_t* __restrict__ occ,
   for (long long k = threadIdx.x; k < cells; k += blockDim.x) out[k] = bad ? OutT(0) : static_cast<OutT>(vis[k]);
 }
 
+// raycasting(), reference solver.cpp:267-290: one thread per target cell
+__global__ void vhp_raycast(int nx, int ny, const uint8_t* __restrict__ occ, int sx, int sy, double* __restrict__ ray) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (long long)nx * ny) return;
+  const int x1 = (int)(k % nx), y1 = (int)(k / nx);
+  int x0 = sx, y0 = sy;
+  const int dx = abs(x1 - x0), dy = abs(y1 - y0);
+  const int stepx = x0 < x1 ? 1 : -1, stepy = y0 < y1 ? 1 : -1;
+  int err = dx - dy;
+  while (x0 != x1 || y0 != y1) {
+    if (occ[(size_t)x0 + (size_t)y0 * nx] == 0) {
+      ray[(size_t)x0 + (size_t)y0 * nx] = 0.0;
+      ray[(size_t)x1 + (size_t)y1 * nx] = 0.0;
+      return;
+    }
+    const int e2 = 2 * err;
+    if (e2 > -dy) { err -= dy; x0 += stepx; }
+    if (e2 < dx) { err += dx; y0 += stepy; }
+  }
+}
+
+__global__ void vhp_fill_f64(double* __restrict__ p, double v, size_t n) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) p[k] = v;
+}
+
 struct QueueScratch {
   double* work = nullptr;
   QCell* queue = nullptr;
