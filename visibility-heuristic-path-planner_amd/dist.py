@@ -1,0 +1,91 @@
+"""Sharding of independent light sources over the GPUs of one node (torch.distributed / RCCL).
+
+The sweep has no exchange step -- every source only reads the shared occupancy map -- so
+sources are block-partitioned over ranks and each rank sweeps its own shard with no
+collective on the data path.  What a caller does with the per-source fields decides the
+collective afterwards:
+
+  gather_fields  : every rank gets every field (RCCL all-gather over xGMI).  Volume is
+                   world * S_local * nx*ny * sizeof(elem) per rank: for BASELINE config 5
+                   (4096^2, 1024 sources, fp64) that is 137 GB landed on every GPU, far more
+                   time than the sweeps themselves -- use fp32 fields or the union below.
+  union_fields   : what a multi-source planner needs: per cell the best visibility over all
+                   sources and which source gave it (max-union + arg-source).  One all-gather
+                   of world partial unions (nx*ny elements each) instead of all fields.
+
+The planner's pivot sequence itself does not shard (pivot k+1 depends on the union after
+pivot k): run replicas, one planner per GPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_sources, rank, world):
+    """[lo, hi) of the contiguous block of sources rank `rank` owns (sizes differ by at most 1)."""
+    base, extra = divmod(n_sources, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_sources(sources, rank=None, world=None):
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    lo, hi = shard_bounds(len(sources), rank, world)
+    return sources[lo:hi], lo
+
+
+def gather_fields(local_fields, n_sources):
+    """local_fields [n_local, ny, nx] on this rank's device -> [n_sources, ny, nx] on every rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cap = (n_sources + world - 1) // world  # all_gather_into_tensor needs equal shards: pad to the largest
+    pad = local_fields.new_zeros((cap,) + tuple(local_fields.shape[1:]))
+    pad[: local_fields.shape[0]] = local_fields
+    out = local_fields.new_empty((world * cap,) + tuple(local_fields.shape[1:]))
+    dist.all_gather_into_tensor(out, pad)
+    pieces = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_sources, r, world)
+        pieces.append(out[r * cap: r * cap + (hi - lo)])
+    return torch.cat(pieces, 0)
+
+
+def union_fields(local_fields, first_index, n_sources):
+    """Max-union over ALL sources and the index of the (first) source attaining it.
+
+    Returns (best [ny, nx], arg_source int64 [ny, nx]); ties resolve to the lowest source index,
+    like a sequential max-union that only replaces on strict improvement."""
+    world = dist.get_world_size()
+    if local_fields.shape[0]:
+        best, arg = local_fields.max(dim=0)
+        # torch.max returns an arbitrary index among ties: recompute the first index explicitly
+        eq = local_fields == best.unsqueeze(0)
+        arg = eq.to(torch.int64).argmax(dim=0) + first_index
+    else:
+        shape = tuple(local_fields.shape[1:])
+        best = local_fields.new_full(shape, -1.0)
+        arg = torch.full(shape, n_sources, dtype=torch.int64, device=local_fields.device)
+    # concatenated-along-dim-0 form: accepted by both RCCL and gloo
+    all_best = best.new_empty((world * best.shape[0],) + tuple(best.shape[1:]))
+    all_arg = arg.new_empty((world * arg.shape[0],) + tuple(arg.shape[1:]))
+    dist.all_gather_into_tensor(all_best, best.contiguous())
+    dist.all_gather_into_tensor(all_arg, arg.contiguous())
+    all_best = all_best.view((world,) + tuple(best.shape))
+    all_arg = all_arg.view((world,) + tuple(arg.shape))
+    gbest, _ = all_best.max(dim=0)
+    cand = torch.where(all_best == gbest.unsqueeze(0), all_arg, torch.full_like(all_arg, n_sources))
+    return gbest, cand.min(dim=0).values
+
+
+def sweep_sharded(compute, sources, mode="none"):
+    """compute(shard [n,2] int32) -> fields [n, ny, nx] tensor on this rank's device.
+
+    mode: "none" -> (local fields, first index); "gather" -> all fields; "union" -> (best, arg_source)."""
+    shard, lo = shard_sources(sources)
+    local = compute(shard)
+    if mode == "none":
+        return local, lo
+    if mode == "gather":
+        return gather_fields(local, len(sources))
+    if mode == "union":
+        return union_fields(local, lo, len(sources))
+    raise ValueError(mode)
