@@ -11,6 +11,6 @@ for rep in range(3):
     ctx.sweep_batch(src)
     lib.vhp_debug_fetch(buf, 1)
     v = list(buf)
-    print("pre %.0f rows %.0f ringwr %.0f per step |" % (v[6]/500, v[7]/500, v[8]/500), end=" ")
-    print("init %d | slots-work %d | flush-part %d | barrier-wait %d | total %d | steps %d  -> per step: work %.0f flush %.0f; total us %.1f" % (
-        v[0], v[1], v[2], v[3], v[4], v[5], (v[1]) / max(v[5], 1), v[2] / max(v[5], 1), v[4] / 2400.0))
+    nw = max(v[3], 1)
+    print("fast windows %d: preamble %.0f  steps(8) %.0f  flush %.0f cycles each | slow steps %d: %.0f each | slots %d: work %.0f barrier-wait %.0f each | kernel-loop total %.1f us" % (
+        v[3], v[0] / nw, v[1] / nw, v[2] / nw, v[7], v[6] / max(v[7], 1), v[9], v[4] / max(v[9], 1), v[5] / max(v[9], 1), v[8] / 2400.0))

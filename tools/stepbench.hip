@@ -23,8 +23,8 @@ __global__ void body(double* out, unsigned long long* cyc, int steps, uint64_t o
       double c;
       if (MODE & 2) c = ratio(jd[r], di, ri); else c = jd[r] * ri;
       double v = stencil(a, b, c);
-      if (MODE & 4) v = gate(v, occbits + i);
-      if (MODE & 8) fill = lane63(a);
+      if (MODE & 4) v = and_mask(v, bit_mask(occbits + lane, i & 63));
+      if (MODE & 8) fill = read_lane(a, 63);
       prev[r] = v;
     }
   }
@@ -34,12 +34,13 @@ __global__ void body(double* out, unsigned long long* cyc, int steps, uint64_t o
   if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
-template <int MODE, int R> void run(const char* name, double* d, unsigned long long* c) {
+template <int MODE, int R> void run(const char* name, double* d, unsigned long long* c, int waves = 1) {
   const int steps = 4000;
-  for (int k = 0; k < 2; ++k) hipLaunchKernelGGL((body<MODE, R>), dim3(1), dim3(64), 0, 0, d, c, steps, ~0ull);
+  for (int k = 0; k < 2; ++k) hipLaunchKernelGGL((body<MODE, R>), dim3(1), dim3(64 * waves), 0, 0, d, c, steps, ~0ull);
   hipDeviceSynchronize();
   unsigned long long h; hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
-  printf("%-44s R=%d: %7.1f cycles/step  %6.1f cycles/row-step\n", name, R, (double)h / steps, (double)h / steps / R);
+  printf("%-44s R=%d waves/CU=%2d: %7.1f cycles/step  %6.1f cycles/row-step (per wave); SIMD cycles per row-step %.1f\n", name, R, waves,
+         (double)h / steps, (double)h / steps / R, (double)h / steps / R / (waves > 4 ? waves / 4.0 : 1.0));
 }
 
 int main() {
@@ -55,5 +56,6 @@ int main() {
   run<7, 2>("no readlane", d, c);
   run<7, 4>("no readlane", d, c);
   run<0, 4>("stencil only", d, c);
+  for (int w : {4, 8, 16}) { run<0, 4>("stencil only", d, c, w); run<7, 2>("no readlane", d, c, w); run<15, 2>("all", d, c, w); }
   return 0;
 }

@@ -147,7 +147,7 @@ int finish_set_map(vhp_ctx* ctx, int nx, int ny) {
     hipLaunchKernelGGL(vhp::vhp_pack_cols, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_occ, ctx->d_cols, nx, ny, ctx->wpc);
     VHP_HIP(hipGetLastError());
   }
-  const int nrec = std::max(nx, ny) + 1;
+  const int nrec = std::max(nx, ny) + 1 + vhp::kRecipPad;
   std::vector<double> recip(nrec);
   recip[0] = 0.0;
   for (int k = 1; k < nrec; ++k) {

@@ -87,6 +87,8 @@ __device__ __forceinline__ unsigned long long push_rank(int nx, int ny, int sx, 
 // Emit policy of the planner step: the per-cell body of updateVisibility()
 // (solver.cpp:415-430) in the coalesced domain.
 struct PlannerEmit {
+  static constexpr int kCellBytes = 8;
+  static constexpr bool kFastPath = false;  // the epilogue dominates a planner step: keep the compact generic path
   PlannerDev d;
   int nx, ny, sx, sy;
   uint32_t nb;
@@ -116,6 +118,11 @@ struct PlannerEmit {
   __device__ __forceinline__ void pair(int x, int y, double v0, double v1, bool ok0, bool ok1) {
     if (ok0) cell(x, y, v0);
     if (ok1) cell(x + 1, y, v1);
+  }
+  __device__ __forceinline__ void single_at(uint32_t, int x, int y, double v) { cell(x, y, v); }
+  __device__ __forceinline__ void pair_at(uint32_t, int x, int y, double v0, double v1) {
+    cell(x, y, v0);
+    cell(x + 1, y, v1);
   }
   __device__ __forceinline__ void zero(int x, int y) { d.vis_local[(size_t)y * nx + x] = 0.0; }  // visibility_.reset(), :386
 };

@@ -17,8 +17,9 @@
 //   registers sits on the dependent chain.
 //   A workgroup is 2*W wavefronts: wavefronts 0..W-1 sweep strips of the x-major
 //   octant, W..2W-1 strips of the y-major one (strip = 64*R rows/columns).  Strip p
-//   runs one pipeline slot (kChunk steps, one workgroup barrier) behind strip p-1,
-//   which hands it its boundary lane through a small LDS ring: the LDS-staged front.
+//   runs one pipeline slot (a 16-aligned chunk of the marching coordinate, one
+//   workgroup barrier) behind strip p-1, which hands it its boundary lane through a
+//   small LDS ring: the LDS-staged front.
 //
 //   x-major: a lane produces consecutive x of its rows, i.e. the wavefront produces a
 //   column per step.  Values are staged in a wave-private LDS tile and emitted as
@@ -31,10 +32,19 @@
 //   y-major strips need diag(k) as the seed of column k and recompute it from the
 //   private two-term recurrence sub(k) = V(k,k-1), diag(k) = sub(k)*occ(k,k).
 //
+// Each strip has two code paths.  The generic step handles everything (triangular
+// start-up where the diagonal lives inside the strip, partial windows, ragged edges).
+// Once a strip is past its diagonal, full 8-aligned windows of the marching coordinate
+// run the fast path: 8 fully unrolled steps with no branches, no loads and no scalar
+// bookkeeping -- reciprocals arrive by one scalar load per window, occupancy bits come
+// from a lane-private word that is pre-shifted once per window, the boundary lane of
+// the strip below rides in a register that is rotated by DPP.  (A wavefront issues
+// about one instruction per 4-5 cycles whatever its kind, so instruction count per
+// step, scalar ones included, is what sets the latency of a front.)
+//
 // Memory: occupancy is read from two bit-packed copies of the map.  A lane keeps one
 // 64-bit word per owned row/column, packed along the marching direction: 64 steps of
-// occupancy per load, refilled (with the reciprocal table) once per 64 steps by
-// prefetched loads, so the steady-state step issues no loads at all.
+// occupancy per load, refilled once per 64 steps.
 //
 // Arithmetic is IEEE binary64 with contraction off.  The per-cell division
 // c = j/i is replaced by Markstein's correction with a host-computed table of
@@ -44,13 +54,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace vhp {
 
-constexpr int kChunk = 16;       // steps per pipeline slot
-constexpr int kRing = 64;        // entries of a boundary ring (>= 4*kChunk)
+constexpr int kChunk = 16;       // marching-coordinate cells per pipeline slot (16-aligned)
+constexpr int kRing = 64;        // entries of a boundary ring (>= 4*kChunk), indexed by marching coordinate & 63
 constexpr int kTileCols = 8;     // columns staged per flush = 64 B of fp64
 constexpr int kTileStride = 9;   // doubles per staged row (odd: spreads column writes over banks)
 constexpr int kUnitsPerSource = 4;
+constexpr int kRecipPad = 8;     // the reciprocal table is readable 8 entries past max(nx,ny)
 
 struct DevMap {
   const uint64_t* rows;  // bit x&63 of rows[y*wpr + 1 + (x>>6)] = occ(x,y); word 0 and the last word of a line are zero pads
@@ -60,13 +73,24 @@ struct DevMap {
   int nx, ny;
 };
 
-// lane l <- lane l-1, lane 0 <- fill.  DPP wave_shr:1 (gfx9 encoding 0x138); with
-// bound_ctrl off the lane without a source keeps `old`, which carries the fill.
+// the reciprocal table never changes during a launch: wave-uniform reads through the
+// constant address space become scalar loads
+typedef const __attribute__((address_space(4))) double* crecip_p;
+
+// lane l <- lane l-1, lane 0 keeps `fill`'s lane 0.  DPP wave_shr:1 (gfx9 encoding
+// 0x138); with bound_ctrl off the lane without a source keeps `old`.
 __device__ __forceinline__ double shift_up(double v, double fill) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   const int flo = __double2loint(fill), fhi = __double2hiint(fill);
   lo = __builtin_amdgcn_update_dpp(flo, lo, 0x138, 0xf, 0xf, false);
   hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// lane l <- lane l+1 (lane 63 <- lane 0): DPP wave_rol:1 (0x134)
+__device__ __forceinline__ double rotate_down(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
@@ -101,179 +125,316 @@ __device__ __forceinline__ int bit_mask(uint64_t w, int b) {
   return __builtin_amdgcn_sbfe(half, b & 31, 1);
 }
 
+// Makes a just-loaded value count as "used here": the compiler then waits for the load at
+// this point instead of at the first real use.
+__device__ __forceinline__ void pin_loaded(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin_loaded(uint64_t& v) { asm volatile("" : "+v"(v)); }
+
 struct UnitGeom {
-  int sx, sy, dirx, diry, ni, nj;
+  int sx, sy, ni, nj;
 };
 
-// Emit policy of the plain sweep: store cells.  pair(): cells (x, y) and (x+1, y).
+// Pipeline chunks are 16-aligned in the marching coordinate mc = s + DIR*step.
+template <int DIR>
+__device__ __forceinline__ int chunk_seq(int s, int step) {
+  const int mc = s + DIR * step;
+  return DIR > 0 ? (mc >> 4) - (s >> 4) : (s >> 4) - (mc >> 4);
+}
+template <int DIR>
+__device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
+  const int c = DIR > 0 ? (s >> 4) + n : (s >> 4) - n;
+  if (DIR > 0) { *lo = 16 * c - s; *hi = 16 * c + 15 - s; }
+  else { *lo = s - (16 * c + 15); *hi = s - 16 * c; }
+}
+
+// Emit policy of the plain sweep: store cells.  A "pair" is cells (x, y) and (x+1, y).
 template <typename OutT>
 struct StoreEmit {
+  static constexpr int kCellBytes = sizeof(OutT);
+  static constexpr bool kFastPath = true;  // use the unrolled steady-state windows
   OutT* __restrict__ out;
   int nx;
+  struct alignas(2 * sizeof(OutT)) Two { OutT a, b; };
+  // both cells valid; off = (y*nx + x) * kCellBytes, maintained incrementally by the caller
+  __device__ __forceinline__ void pair_at(uint32_t off, int, int, double v0, double v1) {
+    *reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
+  }
+  __device__ __forceinline__ void single_at(uint32_t off, int, int, double v) {
+    *reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off) = static_cast<OutT>(v);
+  }
   __device__ __forceinline__ void pair(int x, int y, double v0, double v1, bool ok0, bool ok1) {
     OutT* p = out + (size_t)y * nx + x;
     if (ok0 && ok1) {
-      struct alignas(2 * sizeof(OutT)) Two { OutT a, b; };
-      *reinterpret_cast<Two*>(p) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};  // one 16-byte (fp64) store
+      *reinterpret_cast<Two*>(p) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
     } else {
       if (ok0) p[0] = static_cast<OutT>(v0);
       if (ok1) p[1] = static_cast<OutT>(v1);
     }
   }
   __device__ __forceinline__ void zero(int x, int y) { out[(size_t)y * nx + x] = OutT(0); }
-  __device__ __forceinline__ void finish() {}
 };
-
-// Per-64-step refill state shared by both strip kinds: each lane holds the reciprocal
-// of "its" step of the current 64-aligned block of the marching coordinate.
-// (marching coordinate = x for x-major strips, y for y-major ones)
 
 // ---------------------------------------------------------------------------
 // x-major strip: rows j = j0 + R*lane + r, steps i = j0 .. ni-1, cells (i, j), i >= j.
+// x = sx + DX*i, y = sy + DY*j.
 // ---------------------------------------------------------------------------
-template <int R, typename Emit>
-__device__ __forceinline__ void x_strip_init(const DevMap& m, const UnitGeom& g, int j0, int rows_total, int lane,
-                                             double (&jd)[R], int (&dmask)[R], const uint64_t* (&rowp)[R]) {
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int j = j0 + R * lane + r;
-    const bool on = j < rows_total;
-    const int y = on ? g.sy + g.diry * j : g.sy;
-    const int xd = on ? g.sx + g.dirx * j : g.sx;  // x of this row's diagonal cell
-    jd[r] = (double)j;
-    rowp[r] = m.rows + (size_t)y * m.wpr + 1;
-    dmask[r] = ((rowp[r][xd >> 6] >> (xd & 63)) & 1ull) ? -1 : 0;
-  }
-}
-
-template <int R, typename Emit>
+template <int R, int DX, int DY, typename Emit>
 __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* tile) {
   constexpr int S = 64 * R;
+  constexpr int CB = Emit::kCellBytes;
   const int lane = threadIdx.x & 63;
   const int rows_total = min(g.nj, g.ni);
   const int P = (rows_total + S - 1) / S;
-  const int glast = (g.ni - 1) / kChunk;
   const int j0 = p * S;
   const bool strip_on = p < P;
+  const bool has_consumer = p + 1 < P;
+  const int nlast = chunk_seq<DX>(g.sx, g.ni - 1);
+  const int nfirst = chunk_seq<DX>(g.sx, min(j0, g.ni - 1));
   double* ring_out = ring_base + p * kRing;
   const double* ring_in = ring_base + (p > 0 ? p - 1 : 0) * kRing;
+  const crecip_p crecip = (crecip_p)m.recip;
+  const int rows_here = max(min(S, rows_total - j0), 0);
 
   double prev[R], jd[R];
   int dmask[R];
   const uint64_t* rowp[R];
-  uint64_t ow[R], own[R];   // occupancy words of the current / next 64-block of x, one per owned row
-  double rv = 0.0, rvn = 0.0;  // reciprocals: lane t holds 1/i of the step whose x is (block, t)
-  int cur_blk = 0;
+  uint64_t ow[R];   // occupancy word of the current 64-block of x, one per owned row
+  double rv = 0.0;  // generic path: lane t holds 1/i of the step whose x is (block, t)
+  int cur_blk = INT32_MIN;
 #pragma unroll
-  for (int r = 0; r < R; ++r) { prev[r] = 0.0; jd[r] = 0.0; dmask[r] = 0; rowp[r] = m.rows + 1; ow[r] = own[r] = 0; }
-  if (strip_on) {
-    x_strip_init<R, Emit>(m, g, j0, rows_total, lane, jd, dmask, rowp);
-    const int x0 = g.sx + g.dirx * j0;
-    cur_blk = x0 >> 6;
-    auto recip_of = [&](int blk) {
-      const int xt = blk * 64 + lane;
-      const int it = g.dirx > 0 ? xt - g.sx : g.sx - xt;
-      return (it >= 0 && it < g.ni) ? m.recip[it] : 0.0;
-    };
+  for (int r = 0; r < R; ++r) {
+    const int j = j0 + R * lane + r;
+    const bool on = strip_on && j < rows_total;
+    const int y = on ? g.sy + DY * j : g.sy;
+    const int xd = on ? g.sx + DX * j : g.sx;  // x of this row's diagonal cell
+    prev[r] = 0.0;
+    jd[r] = (double)j;
+    rowp[r] = m.rows + (size_t)y * m.wpr + 1;
+    ow[r] = 0;
+    dmask[r] = 0;
+    if (strip_on) dmask[r] = ((rowp[r][xd >> 6] >> (xd & 63)) & 1ull) ? -1 : 0;
+  }
+  double* tile_lane = tile + R * lane * kTileStride;
+  // flush geometry: lane <-> (row-in-group = lane>>2, column pair = lane&3), 16 rows x 64 B per pass
+  const int cp = lane & 3, rsub = lane >> 2;
+  const uint32_t flush_lane_off = (uint32_t)(((g.sy + DY * (j0 + rsub)) * m.nx + 2 * cp) * CB);
+  const uint32_t flush_pass_stride = (uint32_t)(16 * DY * m.nx * CB);
+
+  auto refill = [&](int blk) {  // blocking: once per 64 steps
+    cur_blk = blk;
+    const int xt = blk * 64 + lane;
+    const int it = DX > 0 ? xt - g.sx : g.sx - xt;
+    rv = (it >= 0 && it < g.ni) ? m.recip[it] : 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) ow[r] = rowp[r][blk];
+    // pin the s_waitcnt vmcnt for these loads INSIDE this (rare) block: left to the compiler it
+    // lands at the first use in the common path, where it would also drain every store in flight
+    pin_loaded(rv);
+#pragma unroll
+    for (int r = 0; r < R; ++r) pin_loaded(ow[r]);
+  };
+
+  // ---- generic step: any i, diagonal handling, predicated flush ----------------
+  auto slow_step = [&](int i) {
+    const int x = g.sx + DX * i;
+    const int blk = x >> 6, t = x & 63;
+    if (blk != cur_blk) refill(blk);
+    const double di = (double)i;
+    const double ri = read_lane(rv, t);
+    double fill = 0.0;  // OLD value of the row just below lane 0's first row
+    double dsrc = 1.0;  // NEW value of that row (feeds the diagonal cell); 1.0 = light strength at the origin
+    if (p > 0) {
+      fill = ring_in[(x - DX) & (kRing - 1)];
+      dsrc = ring_in[x & (kRing - 1)];
+    }
+    double v[R];
+    {
+      const double b0 = shift_up(prev[R - 1], fill);
+      v[0] = and_mask(stencil(prev[0], b0, ratio(jd[0], di, ri)), bit_mask(ow[0], t));
+    }
+#pragma unroll
+    for (int r = 1; r < R; ++r) v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(jd[r], di, ri)), bit_mask(ow[r], t));
+    if (i < j0 + S && i < rows_total) {
+      // the diagonal cell (i,i) is one of this strip's rows: it inherits the NEW value of
+      // the row below it times its own occupancy
+      const int k = i - j0;
+      const int ld = k / R, rd = k - ld * R;
+      const double up = shift_up(v[R - 1], dsrc);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (rd == r) {
+          const double below = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
+          if (lane == ld) v[r] = and_mask(below, dmask[r]);
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      ow[r] = rowp[r][cur_blk];
-      own[r] = rowp[r][cur_blk + g.dirx];
+      prev[r] = v[r];
+      tile_lane[r * kTileStride + (x & (kTileCols - 1))] = v[r];
     }
-    rv = recip_of(cur_blk);
-    rvn = recip_of(cur_blk + g.dirx);
-  }
+    if (has_consumer && lane == 63) ring_out[x & (kRing - 1)] = v[R - 1];
 
-  for (int T = 0; T <= tmax; ++T) {
-    const int gch = T - p;
-    if (strip_on && gch >= j0 / kChunk && gch <= glast) {
-      const int ibeg = max(gch * kChunk, j0);
-      const int iend = min(gch * kChunk + kChunk - 1, g.ni - 1);
-      // boundary row of the strip below for this chunk: lane t holds its value at step ibeg-1+t
-      double ringv = 0.0;
-      if (p > 0) ringv = ring_in[(ibeg - 1 + lane) & (kRing - 1)];
-      for (int i = ibeg; i <= iend; ++i) {
-        const int x = g.sx + g.dirx * i;
-        const int blk = x >> 6, t = x & 63;
-        if (blk != cur_blk) {  // crossed into the next 64-block of x: rotate the prefetched words in
-          cur_blk = blk;
-          const int xt = (blk + g.dirx) * 64 + lane;
-          const int it = g.dirx > 0 ? xt - g.sx : g.sx - xt;
-          rv = rvn;
-          rvn = (it >= 0 && it < g.ni) ? m.recip[it] : 0.0;
+    const bool endwin = DX > 0 ? ((x & (kTileCols - 1)) == kTileCols - 1) : ((x & (kTileCols - 1)) == 0);
+    if (endwin || i == g.ni - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int xbase = x & ~(kTileCols - 1);
+      const int xc = xbase + 2 * cp;
+      const int ic0 = DX > 0 ? xc - g.sx : g.sx - xc;
+      const int ic1 = DX > 0 ? ic0 + 1 : ic0 - 1;
+      const bool c0 = ic0 >= 0 && ic0 <= i, c1 = ic1 >= 0 && ic1 <= i;
+      const int rows_live = min(rows_here, i - j0 + 1);  // rows j <= i
+      for (int rb = 0; rb < rows_live; rb += 32) {
+        double ta[2], tb[2];
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            ow[r] = own[r];
-            own[r] = rowp[r][blk + g.dirx];
-          }
-        }
-        const double di = (double)i;
-        const double ri = read_lane(rv, t);
-        double fill = 0.0;  // OLD value of the row just below lane 0's first row
-        double dsrc = 1.0;  // NEW value of that row (feeds the diagonal cell); 1.0 = light strength at the origin
-        if (p > 0) {
-          fill = read_lane(ringv, i - ibeg);
-          dsrc = read_lane(ringv, i - ibeg + 1);
-        }
-        double v[R];
-        {
-          const double b0 = shift_up(prev[R - 1], fill);
-          v[0] = and_mask(stencil(prev[0], b0, ratio(jd[0], di, ri)), bit_mask(ow[0], t));
+        for (int u = 0; u < 2; ++u) {
+          const double* q = tile + (rb + 16 * u + rsub) * kTileStride + 2 * cp;
+          ta[u] = q[0];
+          tb[u] = q[1];
         }
 #pragma unroll
-        for (int r = 1; r < R; ++r) v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(jd[r], di, ri)), bit_mask(ow[r], t));
-        if (i < j0 + S && i < rows_total) {
-          // the diagonal cell (i,i) is one of this strip's rows: it inherits the NEW value of
-          // the row below it times its own occupancy
-          const int k = i - j0;
-          const int ld = k / R, rd = k - ld * R;
-          const double up = shift_up(v[R - 1], dsrc);
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            if (rd == r) {
-              const double below = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
-              if (lane == ld) v[r] = and_mask(below, dmask[r]);
-            }
-          }
+        for (int u = 0; u < 2; ++u) {
+          const int rl = rb + 16 * u + rsub;
+          const int j = j0 + rl;
+          const bool rowok = rl < rows_here;
+          emit.pair(xc, g.sy + DY * j, ta[u], tb[u], rowok && c0 && j <= ic0, rowok && c1 && j <= ic1);
         }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+
+  // ---- fast window: 8 steps i..i+7 covering one 8-aligned window of x, strip past its
+  // diagonal (i >= j0 + S): every row active, every staged cell valid -------------------
+  int ji[R];  // row indices as integers, for the "am I this step's diagonal cell" test
+#pragma unroll
+  for (int r = 0; r < R; ++r) ji[r] = j0 + R * lane + r;
+  auto fast_window = [&](int i, auto diag_tag) {
+    constexpr bool DIAG = decltype(diag_tag)::value;  // the strip's diagonal may fall inside this window
+    const int x0 = g.sx + DX * i;             // x of the first step
+    const int xb = x0 & ~(kTileCols - 1);     // lowest x of the window
+    const int blk = x0 >> 6, t0 = x0 & 63;
+    if (blk != cur_blk) refill(blk);
+    // eight reciprocals by scalar load
+    double rr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rr[k] = crecip[i + k];
+    // occupancy bits of the window, pre-shifted so that step k's bit sits at a fixed position
+    int hs[R];
+    const int sh = DX > 0 ? (t0 & 31) : (t0 & 31) - 7;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t half = (t0 & 32) ? (uint32_t)(ow[r] >> 32) : (uint32_t)ow[r];
+      hs[r] = (int)(half >> sh);
+    }
+    // boundary row of the strip below: lane t holds its value at step i-1+t
+    double ringv = 0.0;
+    if (p > 0) ringv = ring_in[(x0 - DX + DX * lane) & (kRing - 1)];
+    double* ring_w = ring_out + (xb & (kRing - 1));
+    double di = (double)i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int col = DX > 0 ? k : 7 - k;  // x & 7 of this step, compile time
+      double v[R];
+      {
+        const double b0 = shift_up(prev[R - 1], ringv);
+        v[0] = and_mask(stencil(prev[0], b0, ratio(jd[0], di, rr[k])), __builtin_amdgcn_sbfe(hs[0], col, 1));
+      }
+#pragma unroll
+      for (int r = 1; r < R; ++r)
+        v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(jd[r], di, rr[k])), __builtin_amdgcn_sbfe(hs[r], col, 1));
+      double ringn = 1.0;  // lane 0: NEW value of the row below this strip (1.0 = light strength at the origin)
+      if (p > 0) ringn = rotate_down(ringv);
+      if (DIAG) {
+        // the diagonal cell (i,i) inherits the NEW value of the row below it times its own
+        // occupancy; it is row ji[r] of the lane for which ji[r] == i
+        const double up = shift_up(v[R - 1], ringn);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          prev[r] = v[r];
-          tile[(R * lane + r) * kTileStride + (x & (kTileCols - 1))] = v[r];
+          const double below = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
+          if (ji[r] == i + k) v[r] = and_mask(below, dmask[r]);
         }
-        if (lane == 63) ring_out[i & (kRing - 1)] = v[R - 1];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        prev[r] = v[r];
+        tile_lane[r * kTileStride + col] = v[r];
+      }
+      if (has_consumer && lane == 63) ring_w[col] = v[R - 1];
+      if (p > 0) ringv = ringn;
+      di += 1.0;
+    }
+    // flush the whole window: S rows x 64 B
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t off0 = flush_lane_off + (uint32_t)(xb * CB);
+    const int xc = xb + 2 * cp;
+    const int y0 = g.sy + DY * (j0 + rsub);
+    const double* q0 = tile + rsub * kTileStride + 2 * cp;
+    if (DIAG) {
+      // staged cell (column step ic, row j) is real iff j <= ic: below the diagonal both cells of
+      // a pair are, on it only the later column's
+      const int ic0 = DX > 0 ? xc - g.sx : g.sx - xc;  // step index of the pair's first cell
+      const int ic1 = DX > 0 ? ic0 + 1 : ic0 - 1;
+      const int icmin = min(ic0, ic1), icmax = max(ic0, ic1);
+      const int rows_live = min(rows_here, i + 8 - j0);  // rows j <= last step of the window
+      for (int pass = 0; pass * 16 < rows_live; ++pass) {
+        const double a = q0[pass * 16 * kTileStride], b = q0[pass * 16 * kTileStride + 1];
+        const int rl = pass * 16 + rsub;
+        const int j = j0 + rl;
+        if (rl < rows_here) {
+          const uint32_t off = off0 + (uint32_t)pass * flush_pass_stride;
+          if (j <= icmin)
+            emit.pair_at(off, xc, y0 + DY * 16 * pass, a, b);
+          else if (j == icmax)
+            emit.single_at(off + (uint32_t)(DX > 0 ? CB : 0), xc + (DX > 0 ? 1 : 0), y0 + DY * 16 * pass, DX > 0 ? b : a);
+        }
+      }
+    } else if (rows_here == S) {
+#pragma unroll
+      for (int pass = 0; pass < S / 16; pass += 4) {
+        double ta[4], tb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ta[u] = q0[(pass + u) * 16 * kTileStride];
+          tb[u] = q0[(pass + u) * 16 * kTileStride + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          emit.pair_at(off0 + (uint32_t)(pass + u) * flush_pass_stride, xc, y0 + DY * 16 * (pass + u), ta[u], tb[u]);
+      }
+    } else {
+      for (int pass = 0; pass * 16 < rows_here; ++pass) {
+        const double a = q0[pass * 16 * kTileStride], b = q0[pass * 16 * kTileStride + 1];
+        if (pass * 16 + rsub < rows_here) emit.pair_at(off0 + (uint32_t)pass * flush_pass_stride, xc, y0 + DY * 16 * pass, a, b);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
 
-        const bool endwin = g.dirx > 0 ? ((x & (kTileCols - 1)) == kTileCols - 1) : ((x & (kTileCols - 1)) == 0);
-        if (endwin || i == g.ni - 1) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          // lane <-> (row-in-group = lane>>2, column pair = lane&3): 16 rows x 64 B per pass
-          const int xbase = x & ~(kTileCols - 1);
-          const int cp = lane & 3, rsub = lane >> 2;
-          const int xc = xbase + 2 * cp;
-          const int ic0 = g.dirx > 0 ? xc - g.sx : g.sx - xc;
-          const int ic1 = g.dirx > 0 ? ic0 + 1 : ic0 - 1;
-          const bool c0 = ic0 >= 0 && ic0 <= i, c1 = ic1 >= 0 && ic1 <= i;
-          const int rows_here = min(S, rows_total - j0);
-          const int rows_live = min(rows_here, i - j0 + 1);  // rows j <= i
-          for (int rb = 0; rb < rows_live; rb += 32) {
-            double ta[2], tb[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const double* q = tile + (rb + 16 * u + rsub) * kTileStride + 2 * cp;
-              ta[u] = q[0];
-              tb[u] = q[1];
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int rl = rb + 16 * u + rsub;
-              const int j = j0 + rl;
-              const bool rowok = rl < rows_here;
-              emit.pair(xc, g.sy + g.diry * j, ta[u], tb[u], rowok && c0 && j <= ic0, rowok && c1 && j <= ic1);
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
+  for (int T = 0; T <= tmax; ++T) {
+    const int n = T - p;
+    if (strip_on && n >= nfirst && n <= nlast) {
+      int ilo, ihi;
+      chunk_steps<DX>(g.sx, n, &ilo, &ihi);
+      ilo = max(ilo, j0);
+      ihi = min(ihi, g.ni - 1);
+      int i = ilo;
+      while (i <= ihi) {
+        const int x = g.sx + DX * i;
+        const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
+        if (Emit::kFastPath && R >= 2 && aligned && i + 7 <= ihi) {
+          if (i >= j0 + S)
+            fast_window(i, std::false_type());
+          else
+            fast_window(i, std::true_type());
+          i += 8;
+        } else {
+          slow_step(i);
+          i += 1;
         }
       }
     }
@@ -284,49 +445,43 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
 // ---------------------------------------------------------------------------
 // y-major strip: columns i = i0 + R*lane + r, steps j = i0 .. nj-1, cells (i, j), j > i.
 // ---------------------------------------------------------------------------
-template <int R, typename Emit>
+template <int R, int DX, int DY, typename Emit>
 __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* dstate) {
   constexpr int S = 64 * R;
+  constexpr int CB = Emit::kCellBytes;
   const int lane = threadIdx.x & 63;
   const int cols_total = max(min(g.ni, g.nj - 1), 0);
   const int P = (cols_total + S - 1) / S;
-  const int glast = (g.nj - 1) / kChunk;
   const int i0 = p * S;
   const bool strip_on = p < P;
+  const bool has_consumer = p + 1 < P;
+  const int nlast = chunk_seq<DY>(g.sy, g.nj - 1);
+  const int nfirst = chunk_seq<DY>(g.sy, min(i0, g.nj - 1));
   double* ring_out = ring_base + p * kRing;
   const double* ring_in = ring_base + (p > 0 ? p - 1 : 0) * kRing;
+  const crecip_p crecip = (crecip_p)m.recip;
 
   double prev[R], id[R];
   const uint64_t* colp[R];
-  uint64_t ow[R], own[R], b1[R], b2[R];
-  double rv = 0.0, rvn = 0.0;
-  int cur_blk = 0;
+  uint64_t ow[R], b1[R], b2[R];
+  double rv = 0.0;
+  int cur_blk = INT32_MIN;
   double dg = 0.0, sb = 0.0;  // private diagonal recurrence state
-  // the pair this lane stores each step: columns i0 + R*lane + (0..R-1) are x-consecutive
+  // the lane's R columns are x-consecutive; xlo = the lowest x among them
   const int icol0 = i0 + R * lane;
-  const int xlo = g.dirx > 0 ? g.sx + icol0 : g.sx - icol0 - (R - 1);  // lowest x of the lane's R columns
+  const int xlo = DX > 0 ? g.sx + icol0 : g.sx - icol0 - (R - 1);
+  const bool all_cols = strip_on && i0 + S <= cols_total;  // every lane's every column is real
 #pragma unroll
-  for (int r = 0; r < R; ++r) { prev[r] = 0.0; id[r] = 0.0; colp[r] = m.cols + 1; ow[r] = own[r] = b1[r] = b2[r] = 0; }
+  for (int r = 0; r < R; ++r) {
+    const int i = icol0 + r;
+    const bool on = strip_on && i < g.ni;
+    const int x = on ? g.sx + DX * i : g.sx;
+    prev[r] = 0.0;
+    id[r] = (double)i;
+    colp[r] = m.cols + (size_t)x * m.wpc + 1;
+    ow[r] = b1[r] = b2[r] = 0;
+  }
   if (strip_on) {
-    const int y0 = g.sy + g.diry * i0;
-    cur_blk = y0 >> 6;
-    auto recip_of = [&](int blk) {
-      const int yt = blk * 64 + lane;
-      const int jt = g.diry > 0 ? yt - g.sy : g.sy - yt;
-      return (jt >= 0 && jt < g.nj) ? m.recip[jt] : 0.0;
-    };
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = icol0 + r;
-      const bool on = i < g.ni;
-      const int x = on ? g.sx + g.dirx * i : g.sx;
-      id[r] = (double)i;
-      colp[r] = m.cols + (size_t)x * m.wpc + 1;
-      ow[r] = colp[r][cur_blk];
-      own[r] = colp[r][cur_blk + g.diry];
-    }
-    rv = recip_of(cur_blk);
-    rvn = recip_of(cur_blk + g.diry);
     // occupancy of (X(k), Y(k-1)) and (X(k), Y(k)) for k = i0 + 64*q + lane: the two factors of
     // the diagonal recurrence at step k, gathered once and balloted (bit = lane)
 #pragma unroll
@@ -334,8 +489,8 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
       const int k = i0 + 64 * q + lane;
       bool f1 = false, f2 = false;
       if (k >= 1 && k < g.ni && k < g.nj) {
-        const uint64_t* col = m.cols + (size_t)(g.sx + g.dirx * k) * m.wpc + 1;
-        const int yk = g.sy + g.diry * k, ykm = g.sy + g.diry * (k - 1);
+        const uint64_t* col = m.cols + (size_t)(g.sx + DX * k) * m.wpc + 1;
+        const int yk = g.sy + DY * k, ykm = g.sy + DY * (k - 1);
         f1 = (col[ykm >> 6] >> (ykm & 63)) & 1ull;
         f2 = (col[yk >> 6] >> (yk & 63)) & 1ull;
       }
@@ -348,105 +503,205 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     }
   }
 
-  for (int T = 0; T <= tmax; ++T) {
-    const int gch = T - p;
-    if (strip_on && gch >= i0 / kChunk && gch <= glast) {
-      const int jbeg = max(gch * kChunk, i0);
-      const int jend = min(gch * kChunk + kChunk - 1, g.nj - 1);
-      double ringv = 0.0;
-      if (p > 0) ringv = ring_in[(jbeg - 1 + lane) & (kRing - 1)];
-      for (int j = jbeg; j <= jend; ++j) {
-        const int y = g.sy + g.diry * j;
-        const int blk = y >> 6, t = y & 63;
-        if (blk != cur_blk) {
-          cur_blk = blk;
-          const int yt = (blk + g.diry) * 64 + lane;
-          const int jt = g.diry > 0 ? yt - g.sy : g.sy - yt;
-          rv = rvn;
-          rvn = (jt >= 0 && jt < g.nj) ? m.recip[jt] : 0.0;
+  auto refill = [&](int blk) {
+    cur_blk = blk;
+    const int yt = blk * 64 + lane;
+    const int jt = DY > 0 ? yt - g.sy : g.sy - yt;
+    rv = (jt >= 0 && jt < g.nj) ? m.recip[jt] : 0.0;
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            ow[r] = own[r];
-            own[r] = colp[r][blk + g.diry];
-          }
+    for (int r = 0; r < R; ++r) ow[r] = colp[r][blk];
+    pin_loaded(rv);
+#pragma unroll
+    for (int r = 0; r < R; ++r) pin_loaded(ow[r]);
+  };
+
+  auto slow_step = [&](int j) {
+    const int y = g.sy + DY * j;
+    const int blk = y >> 6, t = y & 63;
+    if (blk != cur_blk) refill(blk);
+    const double dj = (double)j;
+    const double rj = read_lane(rv, t);
+    // advance the private diagonal recurrence to diag(j) while j is one of this
+    // strip's own columns (the previous strip hands over the state at j = i0 - 1)
+    const bool own_diag = j >= i0 && j < i0 + S && j < g.ni;
+    if (own_diag) {
+      if (j >= 1) {
+        if (j == i0) {  // p > 0 here
+          dg = dstate[2 * (p - 1)];
+          sb = dstate[2 * (p - 1) + 1];
         }
-        const double dj = (double)j;
-        const double rj = read_lane(rv, t);
-        // advance the private diagonal recurrence to diag(j) while j is one of this
-        // strip's own columns (the previous strip hands over the state at j = i0 - 1)
-        const bool own_diag = j >= i0 && j < i0 + S && j < g.ni;
+        const int k = j - i0;
+        uint64_t m1 = b1[0], m2 = b2[0];
+#pragma unroll
+        for (int q = 1; q < R; ++q) {
+          if ((k >> 6) == q) { m1 = b1[q]; m2 = b2[q]; }
+        }
+        const double cj = ratio(dj - 1.0, dj, rj);
+        const double s = stencil(dg, sb, cj);
+        sb = ((m1 >> (k & 63)) & 1ull) ? s : 0.0;
+        dg = ((m2 >> (k & 63)) & 1ull) ? sb : 0.0;
+      }
+      if (j == i0 + S - 1 && lane == 0) {
+        dstate[2 * p] = dg;
+        dstate[2 * p + 1] = sb;
+      }
+    }
+    double fill = 0.0;
+    if (p > 0) fill = ring_in[(y - DY) & (kRing - 1)];
+    double v[R];
+    {
+      const double b0 = shift_up(prev[R - 1], fill);
+      v[0] = and_mask(stencil(prev[0], b0, ratio(id[0], dj, rj)), bit_mask(ow[0], t));
+    }
+#pragma unroll
+    for (int r = 1; r < R; ++r) v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(id[r], dj, rj)), bit_mask(ow[r], t));
+    // emit the row segment: the lane's R columns are x-consecutive, pairs of 16 bytes
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      if (R == 1) {
+        emit.pair(xlo, y, v[0], 0.0, icol0 < j && icol0 < cols_total, false);
+      } else {
+        const int ia = icol0 + r, ib = ia + 1;
+        const bool oka = ia < j && ia < cols_total, okb = ib < j && ib < cols_total;
+        if (DX > 0)
+          emit.pair(xlo + r, y, v[r], v[r + 1 < R ? r + 1 : r], oka, okb);
+        else
+          emit.pair(xlo + (R - 2 - r), y, v[r + 1 < R ? r + 1 : r], v[r], okb, oka);
+      }
+    }
+    if (own_diag) {  // seed: the diagonal cell is column j's first "previous"
+      const int k = j - i0;
+      const int ld = k / R, rd = k - ld * R;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (rd == r && lane == ld) v[r] = dg;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) prev[r] = v[r];
+    if (has_consumer && lane == 63) ring_out[y & (kRing - 1)] = v[R - 1];
+  };
+
+  // fast window: 8 steps j..j+7 inside one 8-aligned window of y, strip past its diagonal
+  // (j >= i0 + S) and entirely inside the octant (all_cols): every lane stores every step
+  int ii[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) ii[r] = icol0 + r;
+  auto fast_window = [&](int j, auto diag_tag) {
+    constexpr bool DIAG = decltype(diag_tag)::value;  // triangular start-up: seeding, private recurrence, ragged stores
+    const int y0 = g.sy + DY * j;
+    const int yb = y0 & ~7;
+    const int blk = y0 >> 6, t0 = y0 & 63;
+    if (blk != cur_blk) refill(blk);
+    double rr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rr[k] = crecip[j + k];
+    int hs[R];
+    const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t half = (t0 & 32) ? (uint32_t)(ow[r] >> 32) : (uint32_t)ow[r];
+      hs[r] = (int)(half >> sh);
+    }
+    double ringv = 0.0;
+    if (p > 0) ringv = ring_in[(y0 - DY + DY * lane) & (kRing - 1)];
+    double* ring_w = ring_out + (yb & (kRing - 1));
+    double dj = (double)j;
+    uint32_t off = (uint32_t)((y0 * m.nx + xlo) * CB);
+    const uint32_t stride = (uint32_t)(DY * m.nx * CB);
+    int y = y0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bit = DY > 0 ? k : 7 - k;
+      double v[R];
+      {
+        const double b0 = shift_up(prev[R - 1], ringv);
+        v[0] = and_mask(stencil(prev[0], b0, ratio(id[0], dj, rr[k])), __builtin_amdgcn_sbfe(hs[0], bit, 1));
+      }
+#pragma unroll
+      for (int r = 1; r < R; ++r)
+        v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(id[r], dj, rr[k])), __builtin_amdgcn_sbfe(hs[r], bit, 1));
+      if (DIAG) {
+        const int jk = j + k;
+        const bool own_diag = jk < i0 + S && jk < g.ni;  // jk >= i0 always
         if (own_diag) {
-          if (j >= 1) {
-            if (j == i0) {  // p > 0 here
+          if (jk >= 1) {
+            if (jk == i0) {  // p > 0 here
               dg = dstate[2 * (p - 1)];
               sb = dstate[2 * (p - 1) + 1];
             }
-            const int k = j - i0;
+            const int kk = jk - i0;
             uint64_t m1 = b1[0], m2 = b2[0];
 #pragma unroll
             for (int q = 1; q < R; ++q) {
-              if ((k >> 6) == q) { m1 = b1[q]; m2 = b2[q]; }
+              if ((kk >> 6) == q) { m1 = b1[q]; m2 = b2[q]; }
             }
-            const double cj = ratio(dj - 1.0, dj, rj);
+            const double cj = ratio(dj - 1.0, dj, rr[k]);
             const double s = stencil(dg, sb, cj);
-            sb = ((m1 >> (k & 63)) & 1ull) ? s : 0.0;
-            dg = ((m2 >> (k & 63)) & 1ull) ? sb : 0.0;
+            sb = ((m1 >> (kk & 63)) & 1ull) ? s : 0.0;
+            dg = ((m2 >> (kk & 63)) & 1ull) ? sb : 0.0;
           }
-          if (j == i0 + S - 1 && lane == 0) {
+          if (jk == i0 + S - 1 && lane == 0) {
             dstate[2 * p] = dg;
             dstate[2 * p + 1] = sb;
           }
         }
-        double fill = 0.0;
-        if (p > 0) fill = read_lane(ringv, j - jbeg);
-        double v[R];
-        {
-          const double b0 = shift_up(prev[R - 1], fill);
-          v[0] = and_mask(stencil(prev[0], b0, ratio(id[0], dj, rj)), bit_mask(ow[0], t));
-        }
 #pragma unroll
-        for (int r = 1; r < R; ++r) v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(id[r], dj, rj)), bit_mask(ow[r], t));
-        // emit the row segment: the lane's R columns are x-consecutive, pairs of 16 bytes
-#pragma unroll
-        for (int r = 0; r < R; r += 2) {
-          if (R == 1) {
-            const int i = icol0;
-            emit.pair(xlo, y, v[0], 0.0, i < j && i < cols_total, false);
-          } else {
-            const int ia = icol0 + r, ib = ia + 1;
-            const bool oka = ia < j && ia < cols_total, okb = ib < j && ib < cols_total;
-            if (g.dirx > 0)
-              emit.pair(xlo + r, y, v[r], v[r + 1], oka, okb);
-            else
-              emit.pair(xlo + (R - 2 - r), y, v[r + 1], v[r], okb, oka);
-          }
+        for (int r = 0; r + 1 < R; r += 2) {
+          const bool oka = ii[r] < jk && ii[r] < cols_total, okb = ii[r + 1] < jk && ii[r + 1] < cols_total;
+          if (DX > 0)
+            emit.pair(xlo + r, y, v[r], v[r + 1], oka, okb);
+          else
+            emit.pair(xlo + (R - 2 - r), y, v[r + 1], v[r], okb, oka);
         }
-        if (own_diag) {  // seed: the diagonal cell is column j's first "previous"
-          const int k = j - i0;
-          const int ld = k / R, rd = k - ld * R;
+        if (own_diag) {  // seed: the diagonal cell is column jk's first "previous"
 #pragma unroll
           for (int r = 0; r < R; ++r)
-            if (rd == r && lane == ld) v[r] = dg;
+            if (ii[r] == jk) v[r] = dg;
         }
+      } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) prev[r] = v[r];
-        if (lane == 63) ring_out[j & (kRing - 1)] = v[R - 1];
+        for (int r = 0; r + 1 < R; r += 2) {
+          if (DX > 0)
+            emit.pair_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1]);
+          else
+            emit.pair_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) prev[r] = v[r];
+      if (has_consumer && lane == 63) ring_w[bit] = v[R - 1];
+      if (p > 0) ringv = rotate_down(ringv);
+      dj += 1.0;
+      off += stride;
+      y += DY;
+    }
+  };
+
+  for (int T = 0; T <= tmax; ++T) {
+    const int n = T - p;
+    if (strip_on && n >= nfirst && n <= nlast) {
+      int jlo, jhi;
+      chunk_steps<DY>(g.sy, n, &jlo, &jhi);
+      jlo = max(jlo, i0);
+      jhi = min(jhi, g.nj - 1);
+      int j = jlo;
+      while (j <= jhi) {
+        const int y = g.sy + DY * j;
+        const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
+        if (Emit::kFastPath && R >= 2 && aligned && j + 7 <= jhi) {
+          if (all_cols && j >= i0 + S)
+            fast_window(j, std::false_type());
+          else
+            fast_window(j, std::true_type());
+          j += 8;
+        } else {
+          slow_step(j);
+          j += 1;
+        }
       }
     }
     __syncthreads();
   }
-}
-
-// geometry of quadrant q of a source
-__device__ __forceinline__ UnitGeom unit_geom(const DevMap& m, int sx, int sy, int q) {
-  UnitGeom g;
-  g.sx = sx;
-  g.sy = sy;
-  g.dirx = (q == 0 || q == 3) ? 1 : -1;  // Q1 (+,+) Q2 (-,+) Q3 (-,-) Q4 (+,-), solver.cpp:575-695
-  g.diry = (q < 2) ? 1 : -1;
-  g.ni = g.dirx > 0 ? m.nx - sx : sx;    // negative directions stop short of the border (Q2)
-  g.nj = g.diry > 0 ? m.ny - sy : sy;
-  return g;
 }
 
 inline size_t sweep_lds_bytes(int R, int W) {
@@ -455,32 +710,48 @@ inline size_t sweep_lds_bytes(int R, int W) {
 }
 
 // One quadrant of one source: called by all 2*W wavefronts of a workgroup.
-template <int R, typename Emit>
-__device__ void sweep_quadrant(const DevMap& m, Emit& emit, int sx, int sy, int q, double* lds) {
+// Q1 (+,+) Q2 (-,+) Q3 (-,-) Q4 (+,-), reference solver.cpp:575-695.
+template <int R, int DX, int DY, typename Emit>
+__device__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, int sx, int sy, double* lds) {
   constexpr int S = 64 * R;
   const int W = blockDim.x >> 7;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
-  const UnitGeom g = unit_geom(m, sx, sy, q);
+  UnitGeom g;
+  g.sx = sx;
+  g.sy = sy;
+  g.ni = DX > 0 ? m.nx - sx : sx;  // negative directions stop short of the border
+  g.nj = DY > 0 ? m.ny - sy : sy;
+  if (g.ni <= 0 || g.nj <= 0) return;  // uniform for the workgroup
+  const int rows_total = min(g.nj, g.ni);
+  const int cols_total = max(min(g.ni, g.nj - 1), 0);
+  const int Px = (rows_total + S - 1) / S, Py = (cols_total + S - 1) / S;
+  const int tmax = max(chunk_seq<DX>(sx, g.ni - 1) + Px - 1, chunk_seq<DY>(sy, g.nj - 1) + max(Py, 1) - 1);
+  double* ring_x = lds;
+  double* ring_y = lds + (size_t)W * kRing;
+  double* dstate = lds + (size_t)2 * W * kRing;
+  double* tiles = dstate + 2 * W;
+  if (wave < W)
+    x_strip<R, DX, DY>(m, emit, g, wave, tmax, ring_x, tiles + (size_t)wave * S * kTileStride);
+  else
+    y_strip<R, DX, DY>(m, emit, g, wave - W, tmax, ring_y, dstate);
+}
+
+template <int R, typename Emit>
+__device__ void sweep_quadrant(const DevMap& m, Emit& emit, int sx, int sy, int q, double* lds) {
   if (q == 0) {
     // rows/columns no quadrant covers read as zero; quadrant 1 always exists
     if (sx > 0)
       for (int y = threadIdx.x; y < m.ny; y += blockDim.x) emit.zero(0, y);
     if (sy > 0)
       for (int x = threadIdx.x; x < m.nx; x += blockDim.x) emit.zero(x, 0);
+    sweep_quadrant_dir<R, +1, +1>(m, emit, sx, sy, lds);
+  } else if (q == 1) {
+    sweep_quadrant_dir<R, -1, +1>(m, emit, sx, sy, lds);
+  } else if (q == 2) {
+    sweep_quadrant_dir<R, -1, -1>(m, emit, sx, sy, lds);
+  } else {
+    sweep_quadrant_dir<R, +1, -1>(m, emit, sx, sy, lds);
   }
-  if (g.ni <= 0 || g.nj <= 0) return;  // uniform for the workgroup
-  const int rows_total = min(g.nj, g.ni);
-  const int cols_total = max(min(g.ni, g.nj - 1), 0);
-  const int Px = (rows_total + S - 1) / S, Py = (cols_total + S - 1) / S;
-  const int tmax = max((g.ni - 1) / kChunk + Px - 1, (g.nj - 1) / kChunk + max(Py, 1) - 1);
-  double* ring_x = lds;
-  double* ring_y = lds + (size_t)W * kRing;
-  double* dstate = lds + (size_t)2 * W * kRing;
-  double* tiles = dstate + 2 * W;
-  if (wave < W)
-    x_strip<R>(m, emit, g, wave, tmax, ring_x, tiles + (size_t)wave * S * kTileStride);
-  else
-    y_strip<R>(m, emit, g, wave - W, tmax, ring_y, dstate);
 }
 
 // grid = n_src * 4 workgroups of 128*W threads; dynamic LDS = sweep_lds_bytes(R, W)
