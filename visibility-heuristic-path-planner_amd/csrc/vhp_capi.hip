@@ -107,8 +107,12 @@ template <int R, typename OutT>
 hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, int W) {
   const size_t lds = vhp::sweep_lds_bytes(R, W);
   auto k = vhp::vhp_sweep_fronts<R, OutT>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  static size_t lds_allowed = 0;  // per instantiation: raise the dynamic-LDS limit once, not per launch
+  if (lds > lds_allowed) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    lds_allowed = lds;
+  }
   const long long stride = (long long)c->nx * c->ny;
   hipLaunchKernelGGL(k, dim3((unsigned)n_src * vhp::kUnitsPerSource), dim3(128 * W), lds, c->stream, dev_map(c),
                      d_src, d_out, stride, c->d_err);

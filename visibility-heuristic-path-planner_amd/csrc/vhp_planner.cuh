@@ -119,7 +119,11 @@ struct PlannerEmit {
     if (ok0) cell(x, y, v0);
     if (ok1) cell(x + 1, y, v1);
   }
-  __device__ __forceinline__ void single_at(uint32_t, int x, int y, double v) { cell(x, y, v); }
+  __device__ __forceinline__ void pair_or_single_at(uint32_t, int x, int y, double v0, double v1, bool both, bool one, int sel,
+                                                    double vs) {
+    if (both) { cell(x, y, v0); cell(x + 1, y, v1); }
+    else if (one) cell(x + sel, y, vs);
+  }
   __device__ __forceinline__ void pair_at(uint32_t, int x, int y, double v0, double v1) {
     cell(x, y, v0);
     cell(x + 1, y, v1);
@@ -257,8 +261,12 @@ template <int R>
 inline hipError_t launch_planner_fronts(const DevMap& m, const PlannerDev& d, int W, hipStream_t stream) {
   const size_t lds = sweep_lds_bytes(R, W);
   auto k = vhp_planner_fronts<R>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  static size_t lds_allowed = 0;
+  if (lds > lds_allowed) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    lds_allowed = lds;
+  }
   hipLaunchKernelGGL(k, dim3(4), dim3(128 * W), lds, stream, m, d);
   return hipGetLastError();
 }

@@ -63,6 +63,7 @@ constexpr int kRing = 64;        // entries of a boundary ring (>= 4*kChunk), in
 constexpr int kTileCols = 8;     // columns staged per flush = 64 B of fp64
 constexpr int kTileStride = 9;   // doubles per staged row (odd: spreads column writes over banks)
 constexpr int kUnitsPerSource = 4;
+constexpr int kYLag = 2;         // y-major strips run this many slots behind the x-major ones (they consume diag(k))
 constexpr int kRecipPad = 8;     // the reciprocal table is readable 8 entries past max(nx,ny)
 
 struct DevMap {
@@ -148,28 +149,34 @@ __device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
 }
 
 // Emit policy of the plain sweep: store cells.  A "pair" is cells (x, y) and (x+1, y).
+// (Raw buffer stores with out-of-range offsets as predication were measured slower than
+// exec-masked global stores here: every store instruction costs the issuing wavefront
+// ~60-80 cycles whether or not its lanes are dropped.)
 template <typename OutT>
 struct StoreEmit {
   static constexpr int kCellBytes = sizeof(OutT);
-  static constexpr bool kFastPath = true;  // use the unrolled steady-state windows
+  static constexpr bool kFastPath = true;  // use the unrolled windows
   OutT* __restrict__ out;
   int nx;
   struct alignas(2 * sizeof(OutT)) Two { OutT a, b; };
+  __device__ __forceinline__ StoreEmit(OutT* field, int nx_, int) : out(field), nx(nx_) {}
   // both cells valid; off = (y*nx + x) * kCellBytes, maintained incrementally by the caller
   __device__ __forceinline__ void pair_at(uint32_t off, int, int, double v0, double v1) {
     *reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
   }
-  __device__ __forceinline__ void single_at(uint32_t off, int, int, double v) {
-    *reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off) = static_cast<OutT>(v);
+  // `both`: store the pair; else `one`: store only the cell at off + sel*kCellBytes (value vs)
+  __device__ __forceinline__ void pair_or_single_at(uint32_t off, int, int, double v0, double v1, bool both, bool one,
+                                                    int sel, double vs) {
+    asm volatile("" : "+v"(vs));  // keep the compiler from splitting the 16-byte store to share a half with the single
+    if (both)
+      *reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
+    else if (one)
+      *reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off + (uint32_t)(sel * kCellBytes)) = static_cast<OutT>(vs);
   }
   __device__ __forceinline__ void pair(int x, int y, double v0, double v1, bool ok0, bool ok1) {
     OutT* p = out + (size_t)y * nx + x;
-    if (ok0 && ok1) {
-      *reinterpret_cast<Two*>(p) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
-    } else {
-      if (ok0) p[0] = static_cast<OutT>(v0);
-      if (ok1) p[1] = static_cast<OutT>(v1);
-    }
+    if (ok0) p[0] = static_cast<OutT>(v0);
+    if (ok1) p[1] = static_cast<OutT>(v1);
   }
   __device__ __forceinline__ void zero(int x, int y) { out[(size_t)y * nx + x] = OutT(0); }
 };
@@ -179,7 +186,8 @@ struct StoreEmit {
 // x = sx + DX*i, y = sy + DY*j.
 // ---------------------------------------------------------------------------
 template <int R, int DX, int DY, typename Emit>
-__device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* tile) {
+__device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* tile,
+                        double* diag_ring) {
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
   const int lane = threadIdx.x & 63;
@@ -264,7 +272,10 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
       for (int r = 0; r < R; ++r) {
         if (rd == r) {
           const double below = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
-          if (lane == ld) v[r] = and_mask(below, dmask[r]);
+          if (lane == ld) {
+            v[r] = and_mask(below, dmask[r]);
+            diag_ring[i & (kRing - 1)] = v[r];  // the y-major strips seed column i with it two slots later
+          }
         }
       }
     }
@@ -317,10 +328,11 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     const int xb = x0 & ~(kTileCols - 1);     // lowest x of the window
     const int blk = x0 >> 6, t0 = x0 & 63;
     if (blk != cur_blk) refill(blk);
-    // eight reciprocals by scalar load
+    // eight reciprocals: one scalar load (steady) or lane reads of the block's table (diagonal phase,
+    // where scalar registers are scarce)
     double rr[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rr[k] = crecip[i + k];
+    for (int k = 0; k < 8; ++k) rr[k] = DIAG ? read_lane(rv, t0 + DX * k) : crecip[i + k];
     // occupancy bits of the window, pre-shifted so that step k's bit sits at a fixed position
     int hs[R];
     const int sh = DX > 0 ? (t0 & 31) : (t0 & 31) - 7;
@@ -351,11 +363,18 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
         // the diagonal cell (i,i) inherits the NEW value of the row below it times its own
         // occupancy; it is row ji[r] of the lane for which ji[r] == i
         const double up = shift_up(v[R - 1], ringn);
+        bool hit_any = false;
+        double dval = 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const double below = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
-          if (ji[r] == i + k) v[r] = and_mask(below, dmask[r]);
+          const bool hit = ji[r] == i + k;
+          const double dcell = and_mask(below, dmask[r]);
+          v[r] = hit ? dcell : v[r];
+          dval = hit ? dcell : dval;
+          hit_any |= hit;
         }
+        if (hit_any) diag_ring[(i + k) & (kRing - 1)] = dval;  // the y-major strips seed column i+k with it
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -375,21 +394,36 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     const double* q0 = tile + rsub * kTileStride + 2 * cp;
     if (DIAG) {
       // staged cell (column step ic, row j) is real iff j <= ic: below the diagonal both cells of
-      // a pair are, on it only the later column's
+      // a pair are, on the diagonal only the later column's
       const int ic0 = DX > 0 ? xc - g.sx : g.sx - xc;  // step index of the pair's first cell
-      const int ic1 = DX > 0 ? ic0 + 1 : ic0 - 1;
-      const int icmin = min(ic0, ic1), icmax = max(ic0, ic1);
+      const int icmin = DX > 0 ? ic0 : ic0 - 1;         // the later column is icmin + 1
+      const int jrow = j0 + rsub;
+      const int room = rows_here - 1 - rsub;            // 16*pass must not exceed this (ragged last strip)
+      const int lim_both = min(icmin - jrow, room);
+      const int at_single = (icmin + 1 - jrow <= room) ? icmin + 1 - jrow : -1;
       const int rows_live = min(rows_here, i + 8 - j0);  // rows j <= last step of the window
-      for (int pass = 0; pass * 16 < rows_live; ++pass) {
-        const double a = q0[pass * 16 * kTileStride], b = q0[pass * 16 * kTileStride + 1];
-        const int rl = pass * 16 + rsub;
-        const int j = j0 + rl;
-        if (rl < rows_here) {
-          const uint32_t off = off0 + (uint32_t)pass * flush_pass_stride;
-          if (j <= icmin)
-            emit.pair_at(off, xc, y0 + DY * 16 * pass, a, b);
-          else if (j == icmax)
-            emit.single_at(off + (uint32_t)(DX > 0 ? CB : 0), xc + (DX > 0 ? 1 : 0), y0 + DY * 16 * pass, DX > 0 ? b : a);
+      const int rows_full = min(rows_here, i - j0 + 1) & ~15;  // whole passes of rows j <= first step: no predicate
+#pragma unroll
+      for (int pass = 0; pass < S / 16; pass += 4) {
+        if (pass * 16 < rows_live) {
+          double ta[4], tb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            ta[u] = q0[(pass + u) * 16 * kTileStride];
+            tb[u] = q0[(pass + u) * 16 * kTileStride + 1];
+          }
+          if ((pass + 4) * 16 <= rows_full) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              emit.pair_at(off0 + (uint32_t)(pass + u) * flush_pass_stride, xc, y0 + DY * 16 * (pass + u), ta[u], tb[u]);
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int d = 16 * (pass + u);
+              emit.pair_or_single_at(off0 + (uint32_t)(pass + u) * flush_pass_stride, xc, y0 + DY * d, ta[u], tb[u],
+                                     d <= lim_both, d == at_single, DX > 0 ? 1 : 0, DX > 0 ? tb[u] : ta[u]);
+            }
+          }
         }
       }
     } else if (rows_here == S) {
@@ -446,7 +480,8 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
 // y-major strip: columns i = i0 + R*lane + r, steps j = i0 .. nj-1, cells (i, j), j > i.
 // ---------------------------------------------------------------------------
 template <int R, int DX, int DY, typename Emit>
-__device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* dstate) {
+__device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base,
+                        const double* diag_ring) {
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
   const int lane = threadIdx.x & 63;
@@ -463,10 +498,9 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
 
   double prev[R], id[R];
   const uint64_t* colp[R];
-  uint64_t ow[R], b1[R], b2[R];
+  uint64_t ow[R];
   double rv = 0.0;
   int cur_blk = INT32_MIN;
-  double dg = 0.0, sb = 0.0;  // private diagonal recurrence state
   // the lane's R columns are x-consecutive; xlo = the lowest x among them
   const int icol0 = i0 + R * lane;
   const int xlo = DX > 0 ? g.sx + icol0 : g.sx - icol0 - (R - 1);
@@ -479,30 +513,8 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     prev[r] = 0.0;
     id[r] = (double)i;
     colp[r] = m.cols + (size_t)x * m.wpc + 1;
-    ow[r] = b1[r] = b2[r] = 0;
+    ow[r] = 0;
   }
-  if (strip_on) {
-    // occupancy of (X(k), Y(k-1)) and (X(k), Y(k)) for k = i0 + 64*q + lane: the two factors of
-    // the diagonal recurrence at step k, gathered once and balloted (bit = lane)
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const int k = i0 + 64 * q + lane;
-      bool f1 = false, f2 = false;
-      if (k >= 1 && k < g.ni && k < g.nj) {
-        const uint64_t* col = m.cols + (size_t)(g.sx + DX * k) * m.wpc + 1;
-        const int yk = g.sy + DY * k, ykm = g.sy + DY * (k - 1);
-        f1 = (col[ykm >> 6] >> (ykm & 63)) & 1ull;
-        f2 = (col[yk >> 6] >> (yk & 63)) & 1ull;
-      }
-      b1[q] = __ballot(f1);
-      b2[q] = __ballot(f2);
-    }
-    if (p == 0) {
-      const uint64_t sw = m.cols[(size_t)g.sx * m.wpc + 1 + (g.sy >> 6)];
-      dg = ((sw >> (g.sy & 63)) & 1ull) ? 1.0 : 0.0;  // origin = lightStrength * occ(source)
-    }
-  }
-
   auto refill = [&](int blk) {
     cur_blk = blk;
     const int yt = blk * 64 + lane;
@@ -521,31 +533,11 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     if (blk != cur_blk) refill(blk);
     const double dj = (double)j;
     const double rj = read_lane(rv, t);
-    // advance the private diagonal recurrence to diag(j) while j is one of this
-    // strip's own columns (the previous strip hands over the state at j = i0 - 1)
+    // column j (if it is one of this strip's) is seeded with diag(j), which the x-major strip
+    // owning row j published two pipeline slots ago
     const bool own_diag = j >= i0 && j < i0 + S && j < g.ni;
-    if (own_diag) {
-      if (j >= 1) {
-        if (j == i0) {  // p > 0 here
-          dg = dstate[2 * (p - 1)];
-          sb = dstate[2 * (p - 1) + 1];
-        }
-        const int k = j - i0;
-        uint64_t m1 = b1[0], m2 = b2[0];
-#pragma unroll
-        for (int q = 1; q < R; ++q) {
-          if ((k >> 6) == q) { m1 = b1[q]; m2 = b2[q]; }
-        }
-        const double cj = ratio(dj - 1.0, dj, rj);
-        const double s = stencil(dg, sb, cj);
-        sb = ((m1 >> (k & 63)) & 1ull) ? s : 0.0;
-        dg = ((m2 >> (k & 63)) & 1ull) ? sb : 0.0;
-      }
-      if (j == i0 + S - 1 && lane == 0) {
-        dstate[2 * p] = dg;
-        dstate[2 * p + 1] = sb;
-      }
-    }
+    double dg = 0.0;
+    if (own_diag) dg = diag_ring[j & (kRing - 1)];
     double fill = 0.0;
     if (p > 0) fill = ring_in[(y - DY) & (kRing - 1)];
     double v[R];
@@ -594,7 +586,7 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     if (blk != cur_blk) refill(blk);
     double rr[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rr[k] = crecip[j + k];
+    for (int k = 0; k < 8; ++k) rr[k] = DIAG ? read_lane(rv, t0 + DY * k) : crecip[j + k];
     int hs[R];
     const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
 #pragma unroll
@@ -604,6 +596,8 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     }
     double ringv = 0.0;
     if (p > 0) ringv = ring_in[(y0 - DY + DY * lane) & (kRing - 1)];
+    double dgv = 0.0;  // lane t: diag(j + t), published by the x-major strips
+    if (DIAG) dgv = diag_ring[(j + lane) & (kRing - 1)];
     double* ring_w = ring_out + (yb & (kRing - 1));
     double dj = (double)j;
     uint32_t off = (uint32_t)((y0 * m.nx + xlo) * CB);
@@ -623,37 +617,18 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
       if (DIAG) {
         const int jk = j + k;
         const bool own_diag = jk < i0 + S && jk < g.ni;  // jk >= i0 always
-        if (own_diag) {
-          if (jk >= 1) {
-            if (jk == i0) {  // p > 0 here
-              dg = dstate[2 * (p - 1)];
-              sb = dstate[2 * (p - 1) + 1];
-            }
-            const int kk = jk - i0;
-            uint64_t m1 = b1[0], m2 = b2[0];
-#pragma unroll
-            for (int q = 1; q < R; ++q) {
-              if ((kk >> 6) == q) { m1 = b1[q]; m2 = b2[q]; }
-            }
-            const double cj = ratio(dj - 1.0, dj, rr[k]);
-            const double s = stencil(dg, sb, cj);
-            sb = ((m1 >> (kk & 63)) & 1ull) ? s : 0.0;
-            dg = ((m2 >> (kk & 63)) & 1ull) ? sb : 0.0;
-          }
-          if (jk == i0 + S - 1 && lane == 0) {
-            dstate[2 * p] = dg;
-            dstate[2 * p + 1] = sb;
-          }
-        }
+        // column ia = ii[r] lights up one step before ib = ia + 1: both / only ia / none
+        const int lim = min(jk, cols_total);
 #pragma unroll
         for (int r = 0; r + 1 < R; r += 2) {
-          const bool oka = ii[r] < jk && ii[r] < cols_total, okb = ii[r + 1] < jk && ii[r + 1] < cols_total;
+          const bool okb = ii[r + 1] < lim, oka = ii[r] < lim;
           if (DX > 0)
-            emit.pair(xlo + r, y, v[r], v[r + 1], oka, okb);
+            emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1], okb, oka && !okb, 0, v[r]);
           else
-            emit.pair(xlo + (R - 2 - r), y, v[r + 1], v[r], okb, oka);
+            emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r], okb, oka && !okb, 1, v[r]);
         }
         if (own_diag) {  // seed: the diagonal cell is column jk's first "previous"
+          const double dg = read_lane(dgv, k);
 #pragma unroll
           for (int r = 0; r < R; ++r)
             if (ii[r] == jk) v[r] = dg;
@@ -678,7 +653,7 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
   };
 
   for (int T = 0; T <= tmax; ++T) {
-    const int n = T - p;
+    const int n = T - p - kYLag;
     if (strip_on && n >= nfirst && n <= nlast) {
       int jlo, jhi;
       chunk_steps<DY>(g.sy, n, &jlo, &jhi);
@@ -705,8 +680,8 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
 }
 
 inline size_t sweep_lds_bytes(int R, int W) {
-  // x rings, y rings, diagonal hand-over state, W staging tiles
-  return ((size_t)2 * W * kRing + 2 * W + (size_t)W * 64 * R * kTileStride) * sizeof(double);
+  // x rings, y rings, the diagonal ring, W staging tiles
+  return ((size_t)2 * W * kRing + kRing + (size_t)W * 64 * R * kTileStride) * sizeof(double);
 }
 
 // One quadrant of one source: called by all 2*W wavefronts of a workgroup.
@@ -725,15 +700,15 @@ __device__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, int sx, int sy, 
   const int rows_total = min(g.nj, g.ni);
   const int cols_total = max(min(g.ni, g.nj - 1), 0);
   const int Px = (rows_total + S - 1) / S, Py = (cols_total + S - 1) / S;
-  const int tmax = max(chunk_seq<DX>(sx, g.ni - 1) + Px - 1, chunk_seq<DY>(sy, g.nj - 1) + max(Py, 1) - 1);
+  const int tmax = max(chunk_seq<DX>(sx, g.ni - 1) + Px - 1, chunk_seq<DY>(sy, g.nj - 1) + max(Py, 1) - 1 + kYLag);
   double* ring_x = lds;
   double* ring_y = lds + (size_t)W * kRing;
-  double* dstate = lds + (size_t)2 * W * kRing;
-  double* tiles = dstate + 2 * W;
+  double* diag_ring = lds + (size_t)2 * W * kRing;
+  double* tiles = diag_ring + kRing;
   if (wave < W)
-    x_strip<R, DX, DY>(m, emit, g, wave, tmax, ring_x, tiles + (size_t)wave * S * kTileStride);
+    x_strip<R, DX, DY>(m, emit, g, wave, tmax, ring_x, tiles + (size_t)wave * S * kTileStride, diag_ring);
   else
-    y_strip<R, DX, DY>(m, emit, g, wave - W, tmax, ring_y, dstate);
+    y_strip<R, DX, DY>(m, emit, g, wave - W, tmax, ring_y, diag_ring);
 }
 
 template <int R, typename Emit>
@@ -767,7 +742,7 @@ vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict_
     if (threadIdx.x == 0 && q == 0) atomicOr(err_flag, 1);
     return;
   }
-  StoreEmit<OutT> emit{out + (size_t)s * field_stride, m.nx};
+  StoreEmit<OutT> emit(out + (size_t)s * field_stride, m.nx, m.ny);
   sweep_quadrant<R>(m, emit, sx, sy, q, lds);
 }
 
