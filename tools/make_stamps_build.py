@@ -11,52 +11,36 @@ def rep(old, new, count=1):
     global s
     assert old in s, old[:60]
     s = s.replace(old, new, count)
-rep('''          if (i >= j0 + S)
-            fast_window(i, std::false_type());
-          else
-            fast_window(i, std::true_type());
-          i += 8;
-        } else {
+rep('''          const bool steady = i >= j0 + S;
+          if (p > 0) {''', '''          const bool steady = i >= j0 + S;
+          unsigned long long tq = __builtin_amdgcn_s_memtime();
+          if (p > 0) {''')
+rep('''          const bool steady = all_cols && j >= i0 + S;
+          if (p > 0) {''', '''          const bool steady = all_cols && j >= i0 + S;
+          unsigned long long tq = __builtin_amdgcn_s_memtime();
+          if (p > 0) {''')
+rep('''            else fast_window(i, std::true_type(), std::false_type());
+          }
+          i += 8;''', '''            else fast_window(i, std::true_type(), std::false_type());
+          }
+          { const int o = steady ? 0 : 2; dacc[o] += __builtin_amdgcn_s_memtime() - tq; dacc[o + 1] += 1; }
+          i += 8;''')
+rep('''            else fast_window(j, std::true_type(), std::false_type());
+          }
+          j += 8;''', '''            else fast_window(j, std::true_type(), std::false_type());
+          }
+          { const int o = steady ? 0 : 2; dacc[o] += __builtin_amdgcn_s_memtime() - tq; dacc[o + 1] += 1; }
+          j += 8;''')
+rep('''          slow_step(i);
+          i += 1;''', '''          unsigned long long tq = __builtin_amdgcn_s_memtime();
           slow_step(i);
           i += 1;
-        }''', '''          unsigned long long tq = __builtin_amdgcn_s_memtime();
-          if (i >= j0 + S) {
-            fast_window(i, std::false_type());
-            dacc[0] += __builtin_amdgcn_s_memtime() - tq; dacc[1] += 1;
-          } else {
-            fast_window(i, std::true_type());
-            dacc[2] += __builtin_amdgcn_s_memtime() - tq; dacc[3] += 1;
-          }
-          i += 8;
-        } else {
-          unsigned long long tq = __builtin_amdgcn_s_memtime();
-          slow_step(i);
-          i += 1;
-          dacc[4] += __builtin_amdgcn_s_memtime() - tq; dacc[5] += 1;
-        }''')
-rep('''          if (all_cols && j >= i0 + S)
-            fast_window(j, std::false_type());
-          else
-            fast_window(j, std::true_type());
-          j += 8;
-        } else {
+          dacc[4] += __builtin_amdgcn_s_memtime() - tq; dacc[5] += 1;''')
+rep('''          slow_step(j);
+          j += 1;''', '''          unsigned long long tq = __builtin_amdgcn_s_memtime();
           slow_step(j);
           j += 1;
-        }''', '''          unsigned long long tq = __builtin_amdgcn_s_memtime();
-          if (all_cols && j >= i0 + S) {
-            fast_window(j, std::false_type());
-            dacc[0] += __builtin_amdgcn_s_memtime() - tq; dacc[1] += 1;
-          } else {
-            fast_window(j, std::true_type());
-            dacc[2] += __builtin_amdgcn_s_memtime() - tq; dacc[3] += 1;
-          }
-          j += 8;
-        } else {
-          unsigned long long tq = __builtin_amdgcn_s_memtime();
-          slow_step(j);
-          j += 1;
-          dacc[4] += __builtin_amdgcn_s_memtime() - tq; dacc[5] += 1;
-        }''')
+          dacc[4] += __builtin_amdgcn_s_memtime() - tq; dacc[5] += 1;''')
 rep("  for (int T = 0; T <= tmax; ++T) {\n    const int n = T - p;\n    if (strip_on && n >= nfirst && n <= nlast) {\n      int ilo, ihi;",
     "  unsigned long long dacc[8] = {0,0,0,0,0,0,0,0};\n  const int dbg_slot = p;\n  for (int T = 0; T <= tmax; ++T) {\n    const int n = T - p;\n    if (strip_on && n >= nfirst && n <= nlast) {\n      int ilo, ihi;")
 rep("  for (int T = 0; T <= tmax; ++T) {\n    const int n = T - p - kYLag;\n    if (strip_on && n >= nfirst && n <= nlast) {\n      int jlo, jhi;",

@@ -58,8 +58,9 @@
 
 namespace vhp {
 
-constexpr int kChunk = 16;       // marching-coordinate cells per pipeline slot (16-aligned)
-constexpr int kRing = 64;        // entries of a boundary ring (>= 4*kChunk), indexed by marching coordinate & 63
+constexpr int kChunk = 8;        // marching-coordinate cells per pipeline slot (aligned): one 8-step window
+constexpr int kRing = 32;        // entries of a boundary ring (>= 4*kChunk), indexed by marching coordinate & (kRing-1);
+                                 // sized so that a 16-wavefront workgroup at 1000^2 needs < 80 KB of LDS (two per CU)
 constexpr int kTileCols = 8;     // columns staged per flush = 64 B of fp64
 constexpr int kTileStride = 9;   // doubles per staged row (odd: spreads column writes over banks)
 constexpr int kUnitsPerSource = 4;
@@ -135,17 +136,18 @@ struct UnitGeom {
   int sx, sy, ni, nj;
 };
 
-// Pipeline chunks are 16-aligned in the marching coordinate mc = s + DIR*step.
+// Pipeline chunks are kChunk-aligned in the marching coordinate mc = s + DIR*step.
+constexpr int kChunkShift = 3;  // log2(kChunk)
 template <int DIR>
 __device__ __forceinline__ int chunk_seq(int s, int step) {
   const int mc = s + DIR * step;
-  return DIR > 0 ? (mc >> 4) - (s >> 4) : (s >> 4) - (mc >> 4);
+  return DIR > 0 ? (mc >> kChunkShift) - (s >> kChunkShift) : (s >> kChunkShift) - (mc >> kChunkShift);
 }
 template <int DIR>
 __device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
-  const int c = DIR > 0 ? (s >> 4) + n : (s >> 4) - n;
-  if (DIR > 0) { *lo = 16 * c - s; *hi = 16 * c + 15 - s; }
-  else { *lo = s - (16 * c + 15); *hi = s - 16 * c; }
+  const int c = DIR > 0 ? (s >> kChunkShift) + n : (s >> kChunkShift) - n;
+  if (DIR > 0) { *lo = kChunk * c - s; *hi = kChunk * c + kChunk - 1 - s; }
+  else { *lo = s - (kChunk * c + kChunk - 1); *hi = s - kChunk * c; }
 }
 
 // Emit policy of the plain sweep: store cells.  A "pair" is cells (x, y) and (x+1, y).
@@ -186,7 +188,7 @@ struct StoreEmit {
 // x = sx + DX*i, y = sy + DY*j.
 // ---------------------------------------------------------------------------
 template <int R, int DX, int DY, typename Emit>
-__device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* tile,
+__device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* tile,
                         double* diag_ring) {
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
@@ -205,7 +207,6 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
 
   double prev[R], jd[R];
   int dmask[R];
-  const uint64_t* rowp[R];
   uint64_t ow[R];   // occupancy word of the current 64-block of x, one per owned row
   double rv = 0.0;  // generic path: lane t holds 1/i of the step whose x is (block, t)
   int cur_blk = INT32_MIN;
@@ -217,10 +218,9 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     const int xd = on ? g.sx + DX * j : g.sx;  // x of this row's diagonal cell
     prev[r] = 0.0;
     jd[r] = (double)j;
-    rowp[r] = m.rows + (size_t)y * m.wpr + 1;
     ow[r] = 0;
     dmask[r] = 0;
-    if (strip_on) dmask[r] = ((rowp[r][xd >> 6] >> (xd & 63)) & 1ull) ? -1 : 0;
+    if (strip_on) dmask[r] = ((m.rows[(size_t)y * m.wpr + 1 + (xd >> 6)] >> (xd & 63)) & 1ull) ? -1 : 0;
   }
   double* tile_lane = tile + R * lane * kTileStride;
   // flush geometry: lane <-> (row-in-group = lane>>2, column pair = lane&3), 16 rows x 64 B per pass
@@ -234,7 +234,11 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     const int it = DX > 0 ? xt - g.sx : g.sx - xt;
     rv = (it >= 0 && it < g.ni) ? m.recip[it] : 0.0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) ow[r] = rowp[r][blk];
+    for (int r = 0; r < R; ++r) {
+      const int j = j0 + R * lane + r;
+      const int y = (strip_on && j < rows_total) ? g.sy + DY * j : g.sy;
+      ow[r] = m.rows[(size_t)y * m.wpr + 1 + blk];
+    }
     // pin the s_waitcnt vmcnt for these loads INSIDE this (rare) block: left to the compiler it
     // lands at the first use in the common path, where it would also drain every store in flight
     pin_loaded(rv);
@@ -319,11 +323,10 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
 
   // ---- fast window: 8 steps i..i+7 covering one 8-aligned window of x, strip past its
   // diagonal (i >= j0 + S): every row active, every staged cell valid -------------------
-  int ji[R];  // row indices as integers, for the "am I this step's diagonal cell" test
-#pragma unroll
-  for (int r = 0; r < R; ++r) ji[r] = j0 + R * lane + r;
-  auto fast_window = [&](int i, auto diag_tag) {
+  const int jbase = j0 + R * lane;  // row index of register 0, for the "am I this step's diagonal cell" test
+  auto fast_window = [&](int i, auto diag_tag, auto prod_tag) {
     constexpr bool DIAG = decltype(diag_tag)::value;  // the strip's diagonal may fall inside this window
+    constexpr bool PROD = decltype(prod_tag)::value;  // a strip below feeds lane 0 (p > 0)
     const int x0 = g.sx + DX * i;             // x of the first step
     const int xb = x0 & ~(kTileCols - 1);     // lowest x of the window
     const int blk = x0 >> 6, t0 = x0 & 63;
@@ -343,7 +346,7 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     }
     // boundary row of the strip below: lane t holds its value at step i-1+t
     double ringv = 0.0;
-    if (p > 0) ringv = ring_in[(x0 - DX + DX * lane) & (kRing - 1)];
+    if (PROD) ringv = ring_in[(x0 - DX + DX * lane) & (kRing - 1)];
     double* ring_w = ring_out + (xb & (kRing - 1));
     double di = (double)i;
 #pragma unroll
@@ -358,7 +361,7 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
       for (int r = 1; r < R; ++r)
         v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(jd[r], di, rr[k])), __builtin_amdgcn_sbfe(hs[r], col, 1));
       double ringn = 1.0;  // lane 0: NEW value of the row below this strip (1.0 = light strength at the origin)
-      if (p > 0) ringn = rotate_down(ringv);
+      if (PROD) ringn = rotate_down(ringv);
       if (DIAG) {
         // the diagonal cell (i,i) inherits the NEW value of the row below it times its own
         // occupancy; it is row ji[r] of the lane for which ji[r] == i
@@ -368,7 +371,7 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const double below = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
-          const bool hit = ji[r] == i + k;
+          const bool hit = jbase + r == i + k;
           const double dcell = and_mask(below, dmask[r]);
           v[r] = hit ? dcell : v[r];
           dval = hit ? dcell : dval;
@@ -381,8 +384,8 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
         prev[r] = v[r];
         tile_lane[r * kTileStride + col] = v[r];
       }
-      if (has_consumer && lane == 63) ring_w[col] = v[R - 1];
-      if (p > 0) ringv = ringn;
+      if (lane == 63) ring_w[col] = v[R - 1];
+      if (PROD) ringv = ringn;
       di += 1.0;
     }
     // flush the whole window: S rows x 64 B
@@ -404,21 +407,21 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
       const int rows_live = min(rows_here, i + 8 - j0);  // rows j <= last step of the window
       const int rows_full = min(rows_here, i - j0 + 1) & ~15;  // whole passes of rows j <= first step: no predicate
 #pragma unroll
-      for (int pass = 0; pass < S / 16; pass += 4) {
+      for (int pass = 0; pass < S / 16; pass += 2) {
         if (pass * 16 < rows_live) {
-          double ta[4], tb[4];
+          double ta[2], tb[2];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 2; ++u) {
             ta[u] = q0[(pass + u) * 16 * kTileStride];
             tb[u] = q0[(pass + u) * 16 * kTileStride + 1];
           }
-          if ((pass + 4) * 16 <= rows_full) {
+          if ((pass + 2) * 16 <= rows_full) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 2; ++u)
               emit.pair_at(off0 + (uint32_t)(pass + u) * flush_pass_stride, xc, y0 + DY * 16 * (pass + u), ta[u], tb[u]);
           } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
               const int d = 16 * (pass + u);
               emit.pair_or_single_at(off0 + (uint32_t)(pass + u) * flush_pass_stride, xc, y0 + DY * d, ta[u], tb[u],
                                      d <= lim_both, d == at_single, DX > 0 ? 1 : 0, DX > 0 ? tb[u] : ta[u]);
@@ -428,15 +431,15 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
       }
     } else if (rows_here == S) {
 #pragma unroll
-      for (int pass = 0; pass < S / 16; pass += 4) {
-        double ta[4], tb[4];
+      for (int pass = 0; pass < S / 16; pass += 2) {
+        double ta[2], tb[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
           ta[u] = q0[(pass + u) * 16 * kTileStride];
           tb[u] = q0[(pass + u) * 16 * kTileStride + 1];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 2; ++u)
           emit.pair_at(off0 + (uint32_t)(pass + u) * flush_pass_stride, xc, y0 + DY * 16 * (pass + u), ta[u], tb[u]);
       }
     } else {
@@ -461,10 +464,14 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
         const int x = g.sx + DX * i;
         const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
         if (Emit::kFastPath && R >= 2 && aligned && i + 7 <= ihi) {
-          if (i >= j0 + S)
-            fast_window(i, std::false_type());
-          else
-            fast_window(i, std::true_type());
+          const bool steady = i >= j0 + S;
+          if (p > 0) {
+            if (steady) fast_window(i, std::false_type(), std::true_type());
+            else fast_window(i, std::true_type(), std::true_type());
+          } else {
+            if (steady) fast_window(i, std::false_type(), std::false_type());
+            else fast_window(i, std::true_type(), std::false_type());
+          }
           i += 8;
         } else {
           slow_step(i);
@@ -480,7 +487,7 @@ __device__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
 // y-major strip: columns i = i0 + R*lane + r, steps j = i0 .. nj-1, cells (i, j), j > i.
 // ---------------------------------------------------------------------------
 template <int R, int DX, int DY, typename Emit>
-__device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base,
+__device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base,
                         const double* diag_ring) {
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
@@ -497,7 +504,6 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
   const crecip_p crecip = (crecip_p)m.recip;
 
   double prev[R], id[R];
-  const uint64_t* colp[R];
   uint64_t ow[R];
   double rv = 0.0;
   int cur_blk = INT32_MIN;
@@ -505,14 +511,12 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
   const int icol0 = i0 + R * lane;
   const int xlo = DX > 0 ? g.sx + icol0 : g.sx - icol0 - (R - 1);
   const bool all_cols = strip_on && i0 + S <= cols_total;  // every lane's every column is real
+  const bool edge_free = strip_on && i0 + S <= g.ni && i0 + S <= g.nj;  // the diagonal cells (k,k) of all this strip's columns exist
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = icol0 + r;
-    const bool on = strip_on && i < g.ni;
-    const int x = on ? g.sx + DX * i : g.sx;
     prev[r] = 0.0;
     id[r] = (double)i;
-    colp[r] = m.cols + (size_t)x * m.wpc + 1;
     ow[r] = 0;
   }
   auto refill = [&](int blk) {
@@ -521,7 +525,11 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
     const int jt = DY > 0 ? yt - g.sy : g.sy - yt;
     rv = (jt >= 0 && jt < g.nj) ? m.recip[jt] : 0.0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) ow[r] = colp[r][blk];
+    for (int r = 0; r < R; ++r) {
+      const int i = icol0 + r;
+      const int x = (strip_on && i < g.ni) ? g.sx + DX * i : g.sx;
+      ow[r] = m.cols[(size_t)x * m.wpc + 1 + blk];
+    }
     pin_loaded(rv);
 #pragma unroll
     for (int r = 0; r < R; ++r) pin_loaded(ow[r]);
@@ -575,11 +583,9 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
 
   // fast window: 8 steps j..j+7 inside one 8-aligned window of y, strip past its diagonal
   // (j >= i0 + S) and entirely inside the octant (all_cols): every lane stores every step
-  int ii[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) ii[r] = icol0 + r;
-  auto fast_window = [&](int j, auto diag_tag) {
-    constexpr bool DIAG = decltype(diag_tag)::value;  // triangular start-up: seeding, private recurrence, ragged stores
+  auto fast_window = [&](int j, auto diag_tag, auto prod_tag) {
+    constexpr bool DIAG = decltype(diag_tag)::value;  // triangular start-up: seeding, ragged stores
+    constexpr bool PROD = decltype(prod_tag)::value;  // a strip below feeds lane 0 (p > 0)
     const int y0 = g.sy + DY * j;
     const int yb = y0 & ~7;
     const int blk = y0 >> 6, t0 = y0 & 63;
@@ -595,7 +601,7 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
       hs[r] = (int)(half >> sh);
     }
     double ringv = 0.0;
-    if (p > 0) ringv = ring_in[(y0 - DY + DY * lane) & (kRing - 1)];
+    if (PROD) ringv = ring_in[(y0 - DY + DY * lane) & (kRing - 1)];
     double dgv = 0.0;  // lane t: diag(j + t), published by the x-major strips
     if (DIAG) dgv = diag_ring[(j + lane) & (kRing - 1)];
     double* ring_w = ring_out + (yb & (kRing - 1));
@@ -616,22 +622,36 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
         v[r] = and_mask(stencil(prev[r], prev[r - 1], ratio(id[r], dj, rr[k])), __builtin_amdgcn_sbfe(hs[r], bit, 1));
       if (DIAG) {
         const int jk = j + k;
-        const bool own_diag = jk < i0 + S && jk < g.ni;  // jk >= i0 always
-        // column ia = ii[r] lights up one step before ib = ia + 1: both / only ia / none
-        const int lim = min(jk, cols_total);
+        // seed first: column jk's "previous" is diag(jk).  Unguarded on purpose -- a lane matches only
+        // if it owns column jk; if that column lies beyond the quadrant its value is never stored.
+        const double dg = read_lane(dgv, k);
 #pragma unroll
-        for (int r = 0; r + 1 < R; r += 2) {
-          const bool okb = ii[r + 1] < lim, oka = ii[r] < lim;
-          if (DX > 0)
-            emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1], okb, oka && !okb, 0, v[r]);
-          else
-            emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r], okb, oka && !okb, 1, v[r]);
-        }
-        if (own_diag) {  // seed: the diagonal cell is column jk's first "previous"
-          const double dg = read_lane(dgv, k);
+        for (int r = 0; r < R; ++r) v[r] = ((icol0 + r) == jk) ? dg : v[r];
+        // ragged stores.  For a pair of columns (ia, ia+1) with ia < jk either both are below the
+        // diagonal, or ia+1 == jk: then the second cell is the diagonal cell (jk,jk) itself, which the
+        // seeding has just put into v -- the x-major strip stores the same value there.  So away from
+        // the quadrant's right edge a pair is stored whole or not at all.
+        if (edge_free) {
 #pragma unroll
-          for (int r = 0; r < R; ++r)
-            if (ii[r] == jk) v[r] = dg;
+          for (int r = 0; r + 1 < R; r += 2) {
+            if ((icol0 + r) < jk) {
+              if (DX > 0)
+                emit.pair_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1]);
+              else
+                emit.pair_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r]);
+            }
+          }
+        } else {
+          const int lim = min(jk, cols_total);
+#pragma unroll
+          for (int r = 0; r + 1 < R; r += 2) {
+            const bool okb = (icol0 + r + 1) < lim, oka = (icol0 + r) < lim;
+            const double va = ((icol0 + r) == jk) ? prev[r] : v[r];  // (never stored when seeded: oka is false then)
+            if (DX > 0)
+              emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, va, v[r + 1], okb, oka && !okb, 0, va);
+            else
+              emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], va, okb, oka && !okb, 1, va);
+          }
         }
       } else {
 #pragma unroll
@@ -644,8 +664,8 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) prev[r] = v[r];
-      if (has_consumer && lane == 63) ring_w[bit] = v[R - 1];
-      if (p > 0) ringv = rotate_down(ringv);
+      if (lane == 63) ring_w[bit] = v[R - 1];
+      if (PROD) ringv = rotate_down(ringv);
       dj += 1.0;
       off += stride;
       y += DY;
@@ -664,10 +684,14 @@ __device__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, in
         const int y = g.sy + DY * j;
         const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
         if (Emit::kFastPath && R >= 2 && aligned && j + 7 <= jhi) {
-          if (all_cols && j >= i0 + S)
-            fast_window(j, std::false_type());
-          else
-            fast_window(j, std::true_type());
+          const bool steady = all_cols && j >= i0 + S;
+          if (p > 0) {
+            if (steady) fast_window(j, std::false_type(), std::true_type());
+            else fast_window(j, std::true_type(), std::true_type());
+          } else {
+            if (steady) fast_window(j, std::false_type(), std::false_type());
+            else fast_window(j, std::true_type(), std::false_type());
+          }
           j += 8;
         } else {
           slow_step(j);
@@ -687,7 +711,7 @@ inline size_t sweep_lds_bytes(int R, int W) {
 // One quadrant of one source: called by all 2*W wavefronts of a workgroup.
 // Q1 (+,+) Q2 (-,+) Q3 (-,-) Q4 (+,-), reference solver.cpp:575-695.
 template <int R, int DX, int DY, typename Emit>
-__device__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, int sx, int sy, double* lds) {
+__device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, int sx, int sy, double* lds) {
   constexpr int S = 64 * R;
   const int W = blockDim.x >> 7;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
@@ -712,7 +736,7 @@ __device__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, int sx, int sy, 
 }
 
 template <int R, typename Emit>
-__device__ void sweep_quadrant(const DevMap& m, Emit& emit, int sx, int sy, int q, double* lds) {
+__device__ __forceinline__ void sweep_quadrant(const DevMap& m, Emit& emit, int sx, int sy, int q, double* lds) {
   if (q == 0) {
     // rows/columns no quadrant covers read as zero; quadrant 1 always exists
     if (sx > 0)
@@ -731,7 +755,7 @@ __device__ void sweep_quadrant(const DevMap& m, Emit& emit, int sx, int sy, int 
 
 // grid = n_src * 4 workgroups of 128*W threads; dynamic LDS = sweep_lds_bytes(R, W)
 template <int R, typename OutT>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024, R <= 2 ? 8 : 4)  // R <= 2: fit 64 VGPRs so two 16-wave workgroups share a CU
 vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
                  int* __restrict__ err_flag) {
   extern __shared__ double lds[];
