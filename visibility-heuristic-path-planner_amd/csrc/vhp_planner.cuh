@@ -6,13 +6,13 @@
 //
 // All planner state lives in HBM for the whole solve: vis_global, vis_local, labels
 // (cameFrom_ as uint32), the pivot list (lightSources_) and a small control block.
-// One iteration = two kernels on one stream, no host round trip:
-//   vhp_planner_fronts : the front sweep of vhp_sweep.cuh from the current pivot with
-//                        the planner epilogue fused into the emit path -- local field
-//                        store, max-union into vis_global, first-lit labelling, and
-//                        the heuristic h of every lit cell reduced to the arg-min.
-//   vhp_planner_pick   : merges the four quadrant partials, appends the next pivot,
-//                        evaluates the loop condition, raises `done`.
+// One iteration = three kernels on one stream, no host round trip:
+//   vhp_planner_sweep    : the front sweep of vhp_sweep.cuh (its fast path) from the current
+//                          pivot into vis_local;
+//   vhp_planner_epilogue : per visited cell max-union into vis_global, first-lit labelling,
+//                          heuristic h of every lit cell, block arg-min of (h, push rank);
+//   vhp_planner_pick     : merges the block partials, appends the next pivot, evaluates the
+//                          loop condition, raises `done`.
 // The host enqueues a few iterations at a time and polls the control block; kernels
 // of iterations queued past the end see `done` and return at once.
 //
@@ -84,27 +84,56 @@ __device__ __forceinline__ unsigned long long push_rank(int nx, int ny, int sx, 
   return ((unsigned long long)q << 40) | (unsigned long long)r;
 }
 
-// Emit policy of the planner step: the per-cell body of updateVisibility()
-// (solver.cpp:415-430) in the coalesced domain.
-struct PlannerEmit {
-  static constexpr int kCellBytes = 8;
-  static constexpr bool kFastPath = false;  // the epilogue dominates a planner step: keep the compact generic path
-  PlannerDev d;
-  int nx, ny, sx, sy;
-  uint32_t nb;
-  PlannerKey best;
+__device__ __forceinline__ PlannerKey key_shuffle_xor(const PlannerKey& k, int mask) {
+  PlannerKey o;
+  o.h = ((unsigned long long)(unsigned)__shfl_xor((int)(k.h >> 32), mask) << 32) | (unsigned)__shfl_xor((int)k.h, mask);
+  o.rank = ((unsigned long long)(unsigned)__shfl_xor((int)(k.rank >> 32), mask) << 32) | (unsigned)__shfl_xor((int)k.rank, mask);
+  o.x = __shfl_xor(k.x, mask);
+  o.y = __shfl_xor(k.y, mask);
+  return o;
+}
 
-  __device__ __forceinline__ void cell(int x, int y, double v) {
-    const size_t k = (size_t)y * nx + x;
-    d.vis_local[k] = v;                                  // :416
-    const double g = fmax(v, d.vis_global[k]);           // :417-418
+// Step 1 of a planner iteration: the plain front sweep (vhp_sweep.cuh, fast path) from the
+// current pivot into vis_local -- the reference's visibility_ (solver.cpp:386-416).
+template <int R>
+__global__ void __launch_bounds__(1024, R <= 2 ? 8 : 4) vhp_planner_sweep(DevMap m, PlannerDev d) {
+  extern __shared__ double lds[];
+  if (d.ctl->done) return;
+  const int nb = d.ctl->nb;
+  const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
+  StoreEmit<double> emit(d.vis_local, m.nx, m.ny);
+  sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x, lds);
+}
+
+// Step 2: the per-cell body of updateVisibility() that follows the store (solver.cpp:417-430)
+// over every cell the sweep visited: max-union into vis_global, first-lit labelling, heuristic
+// of every lit cell, arg-min of (h, push rank).  Embarrassingly parallel and coalesced.
+constexpr int kEpilogueBlocks = 256;
+__global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev d) {
+  __shared__ PlannerKey slots[4];
+  if (d.ctl->done) return;
+  const int nb = d.ctl->nb;
+  const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
+  const int nx = m.nx, ny = m.ny;
+  PlannerKey best;
+  best.h = ~0ull;
+  best.rank = ~0ull;
+  best.x = best.y = -1;
+  const size_t cells = (size_t)nx * ny;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < cells; k += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(k / nx), x = (int)(k - (size_t)y * nx);
+    // column 0 / row 0 are swept only when the pivot lies on them: unvisited cells are
+    // neither united, labelled nor pushed
+    if ((x == 0 && sx > 0) || (y == 0 && sy > 0)) continue;
+    const double v = d.vis_local[k];
+    const double g = fmax(v, d.vis_global[k]);  // :417-418
     d.vis_global[k] = g;
     uint32_t lab = d.label[k];
-    if (v >= d.threshold && lab == kUnlabelled32) {      // :419-423
-      lab = nb;
+    if (v >= d.threshold && lab == kUnlabelled32) {  // :419-423
+      lab = (uint32_t)nb;
       d.label[k] = lab;
     }
-    if (g >= d.threshold) {                              // :424-430
+    if (g >= d.threshold) {  // :424-430
       const int px = d.pivots[2 * lab], py = d.pivots[2 * lab + 1];
       const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, px, py));
       PlannerKey c;
@@ -115,63 +144,17 @@ struct PlannerEmit {
       if (key_less(c, best)) best = c;
     }
   }
-  __device__ __forceinline__ void pair(int x, int y, double v0, double v1, bool ok0, bool ok1) {
-    if (ok0) cell(x, y, v0);
-    if (ok1) cell(x + 1, y, v1);
-  }
-  __device__ __forceinline__ void pair_or_single_at(uint32_t, int x, int y, double v0, double v1, bool both, bool one, int sel,
-                                                    double vs) {
-    if (both) { cell(x, y, v0); cell(x + 1, y, v1); }
-    else if (one) cell(x + sel, y, vs);
-  }
-  __device__ __forceinline__ void pair_at(uint32_t, int x, int y, double v0, double v1) {
-    cell(x, y, v0);
-    cell(x + 1, y, v1);
-  }
-  __device__ __forceinline__ void zero(int x, int y) { d.vis_local[(size_t)y * nx + x] = 0.0; }  // visibility_.reset(), :386
-};
-
-__device__ __forceinline__ PlannerKey key_shuffle_xor(const PlannerKey& k, int mask) {
-  PlannerKey o;
-  o.h = ((unsigned long long)(unsigned)__shfl_xor((int)(k.h >> 32), mask) << 32) | (unsigned)__shfl_xor((int)k.h, mask);
-  o.rank = ((unsigned long long)(unsigned)__shfl_xor((int)(k.rank >> 32), mask) << 32) | (unsigned)__shfl_xor((int)k.rank, mask);
-  o.x = __shfl_xor(k.x, mask);
-  o.y = __shfl_xor(k.y, mask);
-  return o;
-}
-
-template <int R>
-__global__ void __launch_bounds__(1024) vhp_planner_fronts(DevMap m, PlannerDev d) {
-  extern __shared__ double lds[];
-  if (d.ctl->done) return;
-  const int nb = d.ctl->nb;
-  const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
-  PlannerEmit emit;
-  emit.d = d;
-  emit.nx = m.nx;
-  emit.ny = m.ny;
-  emit.sx = sx;
-  emit.sy = sy;
-  emit.nb = (uint32_t)nb;
-  emit.best.h = ~0ull;
-  emit.best.rank = ~0ull;
-  emit.best.x = emit.best.y = -1;
-  sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x, lds);
-  // workgroup arg-min of (h, rank)
-  PlannerKey k = emit.best;
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
-    const PlannerKey o = key_shuffle_xor(k, s);
-    if (key_less(o, k)) k = o;
+    const PlannerKey o = key_shuffle_xor(best, s);
+    if (key_less(o, best)) best = o;
   }
-  __syncthreads();
-  PlannerKey* slots = reinterpret_cast<PlannerKey*>(lds);
-  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if ((threadIdx.x & 63) == 0) slots[wave] = k;
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) slots[wave] = best;
   __syncthreads();
   if (threadIdx.x == 0) {
     PlannerKey b = slots[0];
-    for (int w = 1; w < nw; ++w)
+    for (int w = 1; w < 4; ++w)
       if (key_less(slots[w], b)) b = slots[w];
     d.partial[blockIdx.x] = b;
   }
@@ -180,7 +163,7 @@ __global__ void __launch_bounds__(1024) vhp_planner_fronts(DevMap m, PlannerDev 
 __global__ void vhp_planner_pick(DevMap m, PlannerDev d) {
   if (threadIdx.x != 0 || d.ctl->done) return;
   PlannerKey b = d.partial[0];
-  for (int q = 1; q < 4; ++q)
+  for (int q = 1; q < kEpilogueBlocks; ++q)
     if (key_less(d.partial[q], b)) b = d.partial[q];
   d.ctl->iters += 1;
   if (b.x < 0) {  // nothing reached the threshold: the reference would call top() on an empty heap
@@ -260,7 +243,7 @@ void pick_shape_for(int maxdim, int* R, int* W);  // defined in vhp_capi.hip
 template <int R>
 inline hipError_t launch_planner_fronts(const DevMap& m, const PlannerDev& d, int W, hipStream_t stream) {
   const size_t lds = sweep_lds_bytes(R, W);
-  auto k = vhp_planner_fronts<R>;
+  auto k = vhp_planner_sweep<R>;
   static size_t lds_allowed = 0;
   if (lds > lds_allowed) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -297,7 +280,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
     VHP_PL_HIP(hipMalloc(&s.label, cells * 4));
     VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
     VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
-    VHP_PL_HIP(hipMalloc(&s.partial, 4 * sizeof(PlannerKey)));
+    VHP_PL_HIP(hipMalloc(&s.partial, kEpilogueBlocks * sizeof(PlannerKey)));
     s.cells = cells;
   }
   if (s.pivot_cap < pcap) {
@@ -341,6 +324,8 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
                    : R == 2 ? launch_planner_fronts<2>(m, d, W, stream)
                             : launch_planner_fronts<4>(m, d, W, stream);
       if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
+      hipLaunchKernelGGL(vhp_planner_epilogue, dim3(kEpilogueBlocks), dim3(256), 0, stream, m, d);
+      VHP_PL_HIP(hipGetLastError());
       hipLaunchKernelGGL(vhp_planner_pick, dim3(1), dim3(64), 0, stream, m, d);
       VHP_PL_HIP(hipGetLastError());
     }
