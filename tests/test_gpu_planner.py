@@ -71,6 +71,14 @@ def test_1000_shipped_config_seed1(vhp, oracle):
     assert "%.6g" % d == "1346.71"
 
 
+def test_large_grid_planner(vhp, oracle):
+    occ = maps.random_rect_map(2300, 2100, 30, 60, 300, 60, 300, 8)
+    pts = maps.free_sources(occ, 2, 3)
+    start, end = tuple(int(v) for v in pts[0]), tuple(int(v) for v in pts[1])
+    _, got, want = _solve_both(vhp, oracle, occ, start, end, 0.3, 40)
+    _assert_same_solution(got, want, "2300x2100")
+
+
 def test_max_iter_livelock(vhp, oracle):
     # maze_6 at thr 0.25 repeats a pivot until max_iter; outputs still match
     occ = maps.maze_6()

@@ -83,6 +83,28 @@ def test_config3_1000x1000_subset(vhp, oracle):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "C3 source (%d,%d)" % (sx, sy))
 
 
+@pytest.mark.parametrize("nx,ny", [(1500, 1100), (2500, 2300), (2049, 700)])
+def test_large_grids_multi_round(vhp, oracle, nx, ny):
+    # sides above 1024 use 4 rows per lane; above 2048 the strips of an octant are swept in rounds
+    occ = maps.random_rect_map(nx, ny, 40, 10, nx // 6, 10, ny // 6, nx)
+    src = maps.free_sources(occ, 3, ny)
+    corner = np.array([[0, 0], [nx - 1, ny - 1], [nx - 1, 0]], np.int32)
+    corner = corner[[bool(occ[y, x]) for x, y in corner]]
+    src = np.concatenate([src, corner])
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d source (%d,%d)" % (nx, ny, sx, sy))
+
+
+def test_config5_4096_subset(vhp, oracle):
+    # BASELINE config 5 map (4096x4096, 50 obstacles scaled x4), a few of its sources
+    occ, src = maps.config_c5(128)
+    pick = np.concatenate([src[[0, 77]], np.array([[0, 0]], np.int32) if occ[0, 0] else src[[5]]])
+    got = _ctx(vhp, occ).sweep_batch(pick)
+    for k, (sx, sy) in enumerate(pick):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "C5 source (%d,%d)" % (sx, sy))
+
+
 def test_config2_empty_1000(vhp):
     # README benchmark case: empty grid, centre source -> everything visible, except the
     # never-swept row 0 / column 0

@@ -39,6 +39,8 @@ struct vhp_ctx {
   size_t d_src_cap = 0;
   void* d_out = nullptr;
   size_t d_out_cap = 0;
+  double* d_bnd = nullptr;  // boundary rows of multi-round sweeps (sides above W*64*R)
+  size_t d_bnd_cap = 0;
 
   vhp::PlannerState pl;  // device-resident planner state
   vhp::QueueScratch qs;  // scratch of the queue-variant sweep
@@ -67,6 +69,8 @@ vhp::DevMap dev_map(const vhp_ctx* c) {
   m.wpc = c->wpc;
   m.nx = c->nx;
   m.ny = c->ny;
+  m.bnd = nullptr;
+  m.bnd_len = 0;
   return m;
 }
 
@@ -114,8 +118,11 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     lds_allowed = lds;
   }
   const long long stride = (long long)c->nx * c->ny;
-  hipLaunchKernelGGL(k, dim3((unsigned)n_src * vhp::kUnitsPerSource), dim3(128 * W), lds, c->stream, dev_map(c),
-                     d_src, d_out, stride, c->d_err);
+  vhp::DevMap m = dev_map(c);
+  hipError_t eb = vhp::attach_round_scratch(m, W * 64 * R, (size_t)n_src * vhp::kUnitsPerSource, &c->d_bnd, &c->d_bnd_cap);
+  if (eb != hipSuccess) return eb;
+  hipLaunchKernelGGL(k, dim3((unsigned)n_src * vhp::kUnitsPerSource), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride,
+                     c->d_err);
   return hipGetLastError();
 }
 
@@ -198,6 +205,7 @@ int vhp_destroy(vhp_ctx* ctx) {
   free_map(ctx);
   if (ctx->d_src) hipFree(ctx->d_src);
   if (ctx->d_out) hipFree(ctx->d_out);
+  if (ctx->d_bnd) hipFree(ctx->d_bnd);
   if (ctx->d_err) hipFree(ctx->d_err);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -234,8 +242,6 @@ int vhp_sweep_batch_device(vhp_ctx* ctx, const int32_t* d_src_xy, int n_src, int
   if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_sweep_batch_device: no map set");
   if (dtype != VHP_F64 && dtype != VHP_F32) return fail(ctx, VHP_ERR_ARG, "bad dtype");
   if (variant != VHP_SWEEP_FULL && variant != VHP_SWEEP_QUEUE) return fail(ctx, VHP_ERR_ARG, "bad variant");
-  if (std::max(ctx->nx, ctx->ny) > 2048)
-    return fail(ctx, VHP_ERR_TOO_LARGE, "sweep: grid side above 2048 not supported by this build");
   if (n_src == 0) return VHP_OK;
   VHP_HIP(hipSetDevice(ctx->device));
   VHP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -342,11 +348,16 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
                       int32_t* pivots_xy, uint32_t* n_pivots) {
   if (!ctx) return VHP_ERR_ARG;
   if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_planner_solve: no map set");
-  if (std::max(ctx->nx, ctx->ny) > 2048)
-    return fail(ctx, VHP_ERR_TOO_LARGE, "planner: grid side above 2048 not supported by this build");
   VHP_HIP(hipSetDevice(ctx->device));
   std::string msg;
-  int rc = vhp::planner_solve(ctx->pl, dev_map(ctx), ctx->d_occ, ctx->stream, ctx->ev0, ctx->ev1, start_x, start_y, end_x,
+  vhp::DevMap pm = dev_map(ctx);
+  {
+    int R, W;
+    pick_shape(std::max(ctx->nx, ctx->ny), &R, &W);
+    hipError_t eb = vhp::attach_round_scratch(pm, W * 64 * R, 4, &ctx->d_bnd, &ctx->d_bnd_cap);
+    if (eb != hipSuccess) return fail(ctx, VHP_ERR_HIP, std::string("scratch: ") + hipGetErrorString(eb));
+  }
+  int rc = vhp::planner_solve(ctx->pl, pm, ctx->d_occ, ctx->stream, ctx->ev0, ctx->ev1, start_x, start_y, end_x,
                               end_y, threshold, max_iter, came_from, vis_global, vis_local, pivots_xy, n_pivots, &msg);
   ctx->timed = true;
   if (rc != VHP_OK) ctx->err = msg;

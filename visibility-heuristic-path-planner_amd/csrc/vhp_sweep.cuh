@@ -65,6 +65,7 @@ constexpr int kTileCols = 8;     // columns staged per flush = 64 B of fp64
 constexpr int kTileStride = 9;   // doubles per staged row (odd: spreads column writes over banks)
 constexpr int kUnitsPerSource = 4;
 constexpr int kYLag = 2;         // y-major strips run this many slots behind the x-major ones (they consume diag(k))
+constexpr int kStage = 128;      // LDS staging of a boundary row that arrives from the previous round (per octant)
 constexpr int kRecipPad = 8;     // the reciprocal table is readable 8 entries past max(nx,ny)
 
 struct DevMap {
@@ -73,6 +74,10 @@ struct DevMap {
   const double* recip;   // recip[k] = RN(1/k), k = 1..max(nx,ny); recip[0] = 0
   int wpr, wpc;
   int nx, ny;
+  // multi-round sweeps (fronts longer than one workgroup's W*64*R rows): per workgroup
+  // 4 arrays of `bnd_len` doubles (x-major / y-major boundary rows, double-buffered by round)
+  double* bnd;
+  int bnd_len;
 };
 
 // the reciprocal table never changes during a launch: wave-uniform reads through the
@@ -132,8 +137,28 @@ __device__ __forceinline__ int bit_mask(uint64_t w, int b) {
 __device__ __forceinline__ void pin_loaded(double& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin_loaded(uint64_t& v) { asm volatile("" : "+v"(v)); }
 
+// Load of a value that another wavefront (same workgroup, earlier round) stored to global
+// memory: agent-scope atomic load = sc1, served from L2 rather than this CU's L1.
+__device__ __forceinline__ double load_shared_f64(const double* p) {
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)u);
+}
+
 struct UnitGeom {
   int sx, sy, ni, nj;
+};
+
+// Where a strip sits in the current round of a quadrant sweep.
+struct StripSlot {
+  int pg;      // global strip index: rows/columns [pg*S, (pg+1)*S)
+  int w;       // wavefront slot inside the round: pipeline position and ring index
+  int nbase;   // chunk sequence number the round starts at (slot T works on chunk T - w + nbase)
+  int tmax;    // last slot of the round (uniform for the workgroup)
+  bool tail;   // last wavefront of a round that is followed by another: publish the boundary row to global memory
+  const double* bnd_in;  // boundary row from the previous round (w == 0, pg > 0), else unused
+  double* bnd_out;       // boundary row for the next round (tail)
+  double* stage;         // kStage doubles of LDS for bnd_in
 };
 
 // Pipeline chunks are kChunk-aligned in the marching coordinate mc = s + DIR*step.
@@ -188,8 +213,9 @@ struct StoreEmit {
 // x = sx + DX*i, y = sy + DY*j.
 // ---------------------------------------------------------------------------
 template <int R, int DX, int DY, typename Emit>
-__device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base, double* tile,
-                        double* diag_ring) {
+__device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, const StripSlot ss, double* ring_base,
+                                        double* tile, double* diag_ring) {
+  const int p = ss.pg, tmax = ss.tmax;
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
   const int lane = threadIdx.x & 63;
@@ -200,8 +226,13 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
   const bool has_consumer = p + 1 < P;
   const int nlast = chunk_seq<DX>(g.sx, g.ni - 1);
   const int nfirst = chunk_seq<DX>(g.sx, min(j0, g.ni - 1));
-  double* ring_out = ring_base + p * kRing;
-  const double* ring_in = ring_base + (p > 0 ? p - 1 : 0) * kRing;
+  double* ring_out = ring_base + ss.w * kRing;
+  // lane 0's lower neighbour: the LDS ring of the wavefront below, or (first wavefront of a later
+  // round) the staged copy of the boundary row the previous round left in global memory
+  constexpr bool kMulti = R >= 4;  // only the large-grid shape sweeps in rounds; keeps the small shapes lean
+  const bool from_prev_round = kMulti && ss.w == 0 && p > 0;
+  const double* ring_in = from_prev_round ? ss.stage : ring_base + (ss.w > 0 ? ss.w - 1 : 0) * kRing;
+  const int rin_mask = from_prev_round ? kStage - 1 : kRing - 1;
   const crecip_p crecip = (crecip_p)m.recip;
   const int rows_here = max(min(S, rows_total - j0), 0);
 
@@ -210,6 +241,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
   uint64_t ow[R];   // occupancy word of the current 64-block of x, one per owned row
   double rv = 0.0;  // generic path: lane t holds 1/i of the step whose x is (block, t)
   int cur_blk = INT32_MIN;
+  bool first_refill = true;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int j = j0 + R * lane + r;
@@ -244,6 +276,20 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
     pin_loaded(rv);
 #pragma unroll
     for (int r = 0; r < R; ++r) pin_loaded(ow[r]);
+    if (from_prev_round) {
+      // stage this 64-block of the previous round's boundary row (and, the first time, the block
+      // before it in marching order, which holds step j0-1) into LDS, indexed like the rings
+      for (int b = first_refill ? blk - DX : blk; DX > 0 ? b <= blk : b >= blk; b += DX) {
+        const int xs = b * 64 + lane;
+        const int is = DX > 0 ? xs - g.sx : g.sx - xs;
+        double bv = 0.0;
+        if (is >= 0 && is < g.ni) bv = load_shared_f64(ss.bnd_in + is);
+        ss.stage[xs & (kStage - 1)] = bv;
+      }
+      first_refill = false;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   };
 
   // ---- generic step: any i, diagonal handling, predicated flush ----------------
@@ -256,8 +302,8 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
     double fill = 0.0;  // OLD value of the row just below lane 0's first row
     double dsrc = 1.0;  // NEW value of that row (feeds the diagonal cell); 1.0 = light strength at the origin
     if (p > 0) {
-      fill = ring_in[(x - DX) & (kRing - 1)];
-      dsrc = ring_in[x & (kRing - 1)];
+      fill = ring_in[(x - DX) & rin_mask];
+      dsrc = ring_in[x & rin_mask];
     }
     double v[R];
     {
@@ -288,7 +334,10 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
       prev[r] = v[r];
       tile_lane[r * kTileStride + (x & (kTileCols - 1))] = v[r];
     }
-    if (has_consumer && lane == 63) ring_out[x & (kRing - 1)] = v[R - 1];
+    if (has_consumer && lane == 63) {
+      ring_out[x & (kRing - 1)] = v[R - 1];
+      if (kMulti && ss.tail) ss.bnd_out[i] = v[R - 1];
+    }
 
     const bool endwin = DX > 0 ? ((x & (kTileCols - 1)) == kTileCols - 1) : ((x & (kTileCols - 1)) == 0);
     if (endwin || i == g.ni - 1) {
@@ -346,7 +395,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
     }
     // boundary row of the strip below: lane t holds its value at step i-1+t
     double ringv = 0.0;
-    if (PROD) ringv = ring_in[(x0 - DX + DX * lane) & (kRing - 1)];
+    if (PROD) ringv = ring_in[(x0 - DX + DX * lane) & rin_mask];
     double* ring_w = ring_out + (xb & (kRing - 1));
     double di = (double)i;
 #pragma unroll
@@ -384,7 +433,10 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
         prev[r] = v[r];
         tile_lane[r * kTileStride + col] = v[r];
       }
-      if (lane == 63) ring_w[col] = v[R - 1];
+      if (lane == 63) {
+        ring_w[col] = v[R - 1];
+        if (kMulti && ss.tail) ss.bnd_out[i + k] = v[R - 1];
+      }
       if (PROD) ringv = ringn;
       di += 1.0;
     }
@@ -453,7 +505,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
   };
 
   for (int T = 0; T <= tmax; ++T) {
-    const int n = T - p;
+    const int n = T - ss.w + ss.nbase;
     if (strip_on && n >= nfirst && n <= nlast) {
       int ilo, ihi;
       chunk_steps<DX>(g.sx, n, &ilo, &ihi);
@@ -487,8 +539,9 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
 // y-major strip: columns i = i0 + R*lane + r, steps j = i0 .. nj-1, cells (i, j), j > i.
 // ---------------------------------------------------------------------------
 template <int R, int DX, int DY, typename Emit>
-__device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, int p, int tmax, double* ring_base,
-                        const double* diag_ring) {
+__device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, const StripSlot ss, double* ring_base,
+                                        const double* diag_ring) {
+  const int p = ss.pg, tmax = ss.tmax;
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
   const int lane = threadIdx.x & 63;
@@ -499,9 +552,13 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
   const bool has_consumer = p + 1 < P;
   const int nlast = chunk_seq<DY>(g.sy, g.nj - 1);
   const int nfirst = chunk_seq<DY>(g.sy, min(i0, g.nj - 1));
-  double* ring_out = ring_base + p * kRing;
-  const double* ring_in = ring_base + (p > 0 ? p - 1 : 0) * kRing;
+  double* ring_out = ring_base + ss.w * kRing;
+  constexpr bool kMulti = R >= 4;  // only the large-grid shape sweeps in rounds; keeps the small shapes lean
+  const bool from_prev_round = kMulti && ss.w == 0 && p > 0;
+  const double* ring_in = from_prev_round ? ss.stage : ring_base + (ss.w > 0 ? ss.w - 1 : 0) * kRing;
+  const int rin_mask = from_prev_round ? kStage - 1 : kRing - 1;
   const crecip_p crecip = (crecip_p)m.recip;
+  bool first_refill = true;
 
   double prev[R], id[R];
   uint64_t ow[R];
@@ -533,6 +590,18 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
     pin_loaded(rv);
 #pragma unroll
     for (int r = 0; r < R; ++r) pin_loaded(ow[r]);
+    if (from_prev_round) {
+      for (int b = first_refill ? blk - DY : blk; DY > 0 ? b <= blk : b >= blk; b += DY) {
+        const int ys = b * 64 + lane;
+        const int js = DY > 0 ? ys - g.sy : g.sy - ys;
+        double bv = 0.0;
+        if (js >= 0 && js < g.nj) bv = load_shared_f64(ss.bnd_in + js);
+        ss.stage[ys & (kStage - 1)] = bv;
+      }
+      first_refill = false;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   };
 
   auto slow_step = [&](int j) {
@@ -547,7 +616,7 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
     double dg = 0.0;
     if (own_diag) dg = diag_ring[j & (kRing - 1)];
     double fill = 0.0;
-    if (p > 0) fill = ring_in[(y - DY) & (kRing - 1)];
+    if (p > 0) fill = ring_in[(y - DY) & rin_mask];
     double v[R];
     {
       const double b0 = shift_up(prev[R - 1], fill);
@@ -578,7 +647,10 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) prev[r] = v[r];
-    if (has_consumer && lane == 63) ring_out[y & (kRing - 1)] = v[R - 1];
+    if (has_consumer && lane == 63) {
+      ring_out[y & (kRing - 1)] = v[R - 1];
+      if (kMulti && ss.tail) ss.bnd_out[j] = v[R - 1];
+    }
   };
 
   // fast window: 8 steps j..j+7 inside one 8-aligned window of y, strip past its diagonal
@@ -601,7 +673,7 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
       hs[r] = (int)(half >> sh);
     }
     double ringv = 0.0;
-    if (PROD) ringv = ring_in[(y0 - DY + DY * lane) & (kRing - 1)];
+    if (PROD) ringv = ring_in[(y0 - DY + DY * lane) & rin_mask];
     double dgv = 0.0;  // lane t: diag(j + t), published by the x-major strips
     if (DIAG) dgv = diag_ring[(j + lane) & (kRing - 1)];
     double* ring_w = ring_out + (yb & (kRing - 1));
@@ -664,7 +736,10 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) prev[r] = v[r];
-      if (lane == 63) ring_w[bit] = v[R - 1];
+      if (lane == 63) {
+        ring_w[bit] = v[R - 1];
+        if (kMulti && ss.tail) ss.bnd_out[j + k] = v[R - 1];
+      }
       if (PROD) ringv = rotate_down(ringv);
       dj += 1.0;
       off += stride;
@@ -673,7 +748,7 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
   };
 
   for (int T = 0; T <= tmax; ++T) {
-    const int n = T - p - kYLag;
+    const int n = T - ss.w - kYLag + ss.nbase;
     if (strip_on && n >= nfirst && n <= nlast) {
       int jlo, jhi;
       chunk_steps<DY>(g.sy, n, &jlo, &jhi);
@@ -703,9 +778,28 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
   }
 }
 
+// Sweeps whose fronts exceed one round (rows_per_round = W*64*R) need 4 boundary rows per
+// workgroup in global memory; grows the caller's scratch as needed and points the map at it.
+inline hipError_t attach_round_scratch(DevMap& m, int rows_per_round, size_t n_workgroups, double** scratch, size_t* cap) {
+  const int maxdim = m.nx > m.ny ? m.nx : m.ny;
+  if (maxdim <= rows_per_round) return hipSuccess;
+  const size_t need = n_workgroups * 4 * (size_t)maxdim * sizeof(double);
+  if (*cap < need) {
+    if (*scratch) (void)hipFree(*scratch);
+    *scratch = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc(scratch, need);
+    if (e != hipSuccess) return e;
+    *cap = need;
+  }
+  m.bnd = *scratch;
+  m.bnd_len = maxdim;
+  return hipSuccess;
+}
+
 inline size_t sweep_lds_bytes(int R, int W) {
-  // x rings, y rings, the diagonal ring, W staging tiles
-  return ((size_t)2 * W * kRing + kRing + (size_t)W * 64 * R * kTileStride) * sizeof(double);
+  // x rings, y rings, the diagonal ring, two boundary staging areas, W staging tiles
+  return ((size_t)2 * W * kRing + kRing + 2 * kStage + (size_t)W * 64 * R * kTileStride) * sizeof(double);
 }
 
 // One quadrant of one source: called by all 2*W wavefronts of a workgroup.
@@ -724,15 +818,47 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
   const int rows_total = min(g.nj, g.ni);
   const int cols_total = max(min(g.ni, g.nj - 1), 0);
   const int Px = (rows_total + S - 1) / S, Py = (cols_total + S - 1) / S;
-  const int tmax = max(chunk_seq<DX>(sx, g.ni - 1) + Px - 1, chunk_seq<DY>(sy, g.nj - 1) + max(Py, 1) - 1 + kYLag);
   double* ring_x = lds;
   double* ring_y = lds + (size_t)W * kRing;
   double* diag_ring = lds + (size_t)2 * W * kRing;
-  double* tiles = diag_ring + kRing;
-  if (wave < W)
-    x_strip<R, DX, DY>(m, emit, g, wave, tmax, ring_x, tiles + (size_t)wave * S * kTileStride, diag_ring);
-  else
-    y_strip<R, DX, DY>(m, emit, g, wave - W, tmax, ring_y, diag_ring);
+  double* stage = diag_ring + kRing;  // 2 * kStage
+  double* tiles = stage + 2 * kStage;
+  // Fronts longer than W strips are swept in rounds of W strips; the last strip of a round leaves
+  // its boundary row in global memory for the first strip of the next round.
+  const int rounds = R >= 4 ? max((max(Px, Py) + W - 1) / W, 1) : 1;
+  double* bnd = m.bnd ? m.bnd + (size_t)blockIdx.x * 4 * m.bnd_len : nullptr;
+  for (int rho = 0; rho < rounds; ++rho) {
+    const int pg0 = rho * W;
+    const int nbase_x = chunk_seq<DX>(sx, min(pg0 * S, g.ni - 1));
+    const int nbase_y = chunk_seq<DY>(sy, min(pg0 * S, g.nj - 1));
+    const int wx = max(min(Px - pg0, W), 1), wy = max(min(Py - pg0, W), 1);
+    StripSlot ss;
+    ss.tmax = max(chunk_seq<DX>(sx, g.ni - 1) - nbase_x + wx - 1, chunk_seq<DY>(sy, g.nj - 1) - nbase_y + wy - 1 + kYLag);
+    if (wave < W) {
+      ss.pg = pg0 + wave;
+      ss.w = wave;
+      ss.nbase = nbase_x;
+      ss.tail = wave == W - 1 && ss.pg + 1 < Px;
+      ss.bnd_in = bnd ? bnd + ((rho + 1) & 1) * m.bnd_len : nullptr;
+      ss.bnd_out = bnd ? bnd + (rho & 1) * m.bnd_len : nullptr;
+      ss.stage = stage;
+      x_strip<R, DX, DY>(m, emit, g, ss, ring_x, tiles + (size_t)wave * S * kTileStride, diag_ring);
+    } else {
+      ss.pg = pg0 + wave - W;
+      ss.w = wave - W;
+      ss.nbase = nbase_y;
+      ss.tail = ss.w == W - 1 && ss.pg + 1 < Py;
+      ss.bnd_in = bnd ? bnd + (2 + ((rho + 1) & 1)) * m.bnd_len : nullptr;
+      ss.bnd_out = bnd ? bnd + (2 + (rho & 1)) * m.bnd_len : nullptr;
+      ss.stage = stage + kStage;
+      y_strip<R, DX, DY>(m, emit, g, ss, ring_y, diag_ring);
+    }
+    if (rho + 1 < rounds) {
+      // the boundary rows just stored must have landed (in L2) before the next round reads them
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
 }
 
 template <int R, typename Emit>
