@@ -112,8 +112,8 @@ def cpu_baseline(occ, src, seconds):
             break
     return {
         "value": round(done / wall, 2), "unit": "fields/s", "cores": cores, "kind": "port",
-        "sample": "oracle computeVisibility port (%s), %d sweeps of the same 1000x1000 workload on %d threads; "
-                  "single thread: %.1f fields/s (best sweep %.2f ms)" % (flags, done, cores, one, best1 * 1e3),
+        "sample": "oracle computeVisibility port (%s), %d sweeps of the same %dx%d workload on %d threads; "
+                  "single thread: %.1f fields/s (best sweep %.2f ms)" % (flags, done, occ.shape[1], occ.shape[0], cores, one, best1 * 1e3),
         "single_thread_value": round(one, 2),
     }
 

@@ -1,0 +1,38 @@
+"""Diagnostic build: cycle stamps around preamble / 8 steps / flush of the fast windows (X0, Y0)."""
+import os, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CS = os.path.join(ROOT, "visibility-heuristic-path-planner_amd", "csrc")
+B = "/tmp/expbuild"; os.makedirs(B, exist_ok=True)
+s = open(os.path.join(CS, "vhp_sweep.cuh")).read()
+def rep(old, new, cnt=1):
+    global s
+    assert old in s, old[:70]
+    s = s.replace(old, new, cnt)
+rep("struct UnitGeom {", "__device__ unsigned long long vhp_dbg[256];\nstruct UnitGeom {")
+rep("  auto fast_window = [&](int i, auto diag_tag, auto prod_tag, auto par_tag) {\n    constexpr bool DIAG = decltype(diag_tag)::value;  // the strip's diagonal may fall inside this window",
+    "  unsigned long long dacc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};\n  auto fast_window = [&](int i, auto diag_tag, auto prod_tag, auto par_tag) {\n    constexpr bool DIAG = decltype(diag_tag)::value;\n    unsigned long long ta0 = __builtin_amdgcn_s_memtime();")
+rep("    double* ring_w = ring_out + (xb & (kRing - 1));\n    double di = (double)i;\n", "    double* ring_w = ring_out + (xb & (kRing - 1));\n    double di = (double)i;\n    unsigned long long ta1 = __builtin_amdgcn_s_memtime();\n")
+rep("    // flush the whole window: S rows x 64 B\n", "    unsigned long long ta2 = __builtin_amdgcn_s_memtime();\n    // flush the whole window: S rows x 64 B\n")
+rep("    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n    __builtin_amdgcn_wave_barrier();\n  };\n\n  for (int T = 0; T <= tmax; ++T) {\n    const int n = T - ss.w + ss.nbase;",
+    "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n    __builtin_amdgcn_wave_barrier();\n    unsigned long long ta3 = __builtin_amdgcn_s_memtime();\n    const int o = DIAG ? 4 : 0;\n    dacc[o] += ta1 - ta0; dacc[o + 1] += ta2 - ta1; dacc[o + 2] += ta3 - ta2; dacc[o + 3] += 1;\n  };\n\n  for (int T = 0; T <= tmax; ++T) {\n    const int n = T - ss.w + ss.nbase;")
+rep("  auto fast_window = [&](int j, auto diag_tag, auto prod_tag) {\n    constexpr bool DIAG = decltype(diag_tag)::value;  // triangular start-up: seeding, ragged stores",
+    "  unsigned long long dacc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};\n  auto fast_window = [&](int j, auto diag_tag, auto prod_tag) {\n    constexpr bool DIAG = decltype(diag_tag)::value;\n    unsigned long long ta0 = __builtin_amdgcn_s_memtime();")
+rep("    double* ring_w = ring_out + (yb & (kRing - 1));\n    double dj = (double)j;\n", "    double* ring_w = ring_out + (yb & (kRing - 1));\n    double dj = (double)j;\n    unsigned long long ta1 = __builtin_amdgcn_s_memtime();\n")
+rep("      off += stride;\n      y += DY;\n    }\n  };", "      off += stride;\n      y += DY;\n    }\n    unsigned long long ta2 = __builtin_amdgcn_s_memtime();\n    const int o = DIAG ? 4 : 0;\n    dacc[o] += ta1 - ta0; dacc[o + 1] += ta2 - ta1; dacc[o + 3] += 1;\n  };")
+rep("    __syncthreads();\n  }\n}", "    __syncthreads();\n  }\n  if (blockIdx.x == 0 && lane == 0 && ss.w == 0) for (int k = 0; k < 8; ++k) vhp_dbg[k] += dacc[k];\n}")
+rep("    __syncthreads();\n  }\n}", "    __syncthreads();\n  }\n  if (blockIdx.x == 0 && lane == 0 && ss.w == 0) for (int k = 0; k < 8; ++k) vhp_dbg[16 + k] += dacc[k];\n}")
+open(os.path.join(B, "vhp_sweep.cuh"), "w").write(s)
+c = open(os.path.join(CS, "vhp_capi.hip")).read()
+c = c.replace('}  // extern "C"', '''int vhp_debug_fetch(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(vhp::vhp_dbg), 256 * 8);
+  if (reset) { unsigned long long z[256] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(vhp::vhp_dbg), z, 256 * 8); }
+  return 0;
+}
+}  // extern "C"''')
+open(os.path.join(B, "vhp_capi.hip"), "w").write(c)
+for f in ("vhp_planner.cuh", "vhp_queue.cuh"):
+    open(os.path.join(B, f), "w").write(open(os.path.join(CS, f)).read())
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "--offload-arch=gfx950",
+                       "-I" + os.path.join(ROOT, "include"), "-I.", "-shared", "-w", "-o", os.path.join(ROOT, "exp", "stamps_ph.so"), "vhp_capi.hip"], cwd=B)
+print("built exp/stamps_ph.so")

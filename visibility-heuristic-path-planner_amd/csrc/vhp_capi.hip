@@ -41,6 +41,8 @@ struct vhp_ctx {
   size_t d_out_cap = 0;
   double* d_bnd = nullptr;  // boundary rows of multi-round sweeps (sides above W*64*R)
   size_t d_bnd_cap = 0;
+  int* d_order = nullptr;   // launch order of the (source, quadrant) units, longest first
+  size_t d_order_cap = 0;
 
   vhp::PlannerState pl;  // device-resident planner state
   vhp::QueueScratch qs;  // scratch of the queue-variant sweep
@@ -121,8 +123,21 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   vhp::DevMap m = dev_map(c);
   hipError_t eb = vhp::attach_round_scratch(m, W * 64 * R, (size_t)n_src * vhp::kUnitsPerSource, &c->d_bnd, &c->d_bnd_cap);
   if (eb != hipSuccess) return eb;
-  hipLaunchKernelGGL(k, dim3((unsigned)n_src * vhp::kUnitsPerSource), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride,
-                     c->d_err);
+  const size_t n_units = (size_t)n_src * vhp::kUnitsPerSource;
+  const int* order = nullptr;
+  if (n_src >= 8) {  // worth a 1-workgroup pre-kernel once the batch spans many CUs
+    if (c->d_order_cap < n_units) {
+      if (c->d_order) (void)hipFree(c->d_order);
+      c->d_order = nullptr;
+      c->d_order_cap = 0;
+      hipError_t eo = hipMalloc(&c->d_order, n_units * sizeof(int));
+      if (eo != hipSuccess) return eo;
+      c->d_order_cap = n_units;
+    }
+    hipLaunchKernelGGL(vhp::vhp_order_units, dim3(1), dim3(1024), 0, c->stream, d_src, n_src, c->nx, c->ny, c->d_order);
+    order = c->d_order;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)n_units), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order);
   return hipGetLastError();
 }
 
@@ -206,6 +221,7 @@ int vhp_destroy(vhp_ctx* ctx) {
   if (ctx->d_src) hipFree(ctx->d_src);
   if (ctx->d_out) hipFree(ctx->d_out);
   if (ctx->d_bnd) hipFree(ctx->d_bnd);
+  if (ctx->d_order) hipFree(ctx->d_order);
   if (ctx->d_err) hipFree(ctx->d_err);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);

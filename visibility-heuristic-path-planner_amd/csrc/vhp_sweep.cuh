@@ -373,9 +373,10 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
   // ---- fast window: 8 steps i..i+7 covering one 8-aligned window of x, strip past its
   // diagonal (i >= j0 + S): every row active, every staged cell valid -------------------
   const int jbase = j0 + R * lane;  // row index of register 0, for the "am I this step's diagonal cell" test
-  auto fast_window = [&](int i, auto diag_tag, auto prod_tag) {
+  auto fast_window = [&](int i, auto diag_tag, auto prod_tag, auto par_tag) {
     constexpr bool DIAG = decltype(diag_tag)::value;  // the strip's diagonal may fall inside this window
     constexpr bool PROD = decltype(prod_tag)::value;  // a strip below feeds lane 0 (p > 0)
+    constexpr int PAR = decltype(par_tag)::value;     // R == 2: parity of (i - j0), i.e. which register holds step i's diagonal row
     const int x0 = g.sx + DX * i;             // x of the first step
     const int xb = x0 & ~(kTileCols - 1);     // lowest x of the window
     const int blk = x0 >> 6, t0 = x0 & 63;
@@ -414,19 +415,38 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
       if (DIAG) {
         // the diagonal cell (i,i) inherits the NEW value of the row below it times its own
         // occupancy; it is row ji[r] of the lane for which ji[r] == i
-        const double up = shift_up(v[R - 1], ringn);
-        bool hit_any = false;
-        double dval = 0.0;
+        if constexpr (R == 2) {
+          // which register holds the diagonal row of step i+k is known at compile time from the
+          // parity tag; the lane that holds it is wave-uniform
+          const int ld = (i + k - j0) >> 1;
+          if (((PAR + k) & 1) == 0) {  // folds after unrolling: register 0 holds the diagonal row
+            const double dcell = and_mask(shift_up(v[1], ringn), dmask[0]);
+            if (lane == ld) {
+              v[0] = dcell;
+              diag_ring[(i + k) & (kRing - 1)] = dcell;  // the y-major strips seed column i+k with it
+            }
+          } else {
+            const double dcell = and_mask(v[0], dmask[1]);
+            if (lane == ld) {
+              v[1] = dcell;
+              diag_ring[(i + k) & (kRing - 1)] = dcell;
+            }
+          }
+        } else {
+          const double up = shift_up(v[R - 1], ringn);
+          bool hit_any = false;
+          double dval = 0.0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const double below = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
-          const bool hit = jbase + r == i + k;
-          const double dcell = and_mask(below, dmask[r]);
-          v[r] = hit ? dcell : v[r];
-          dval = hit ? dcell : dval;
-          hit_any |= hit;
+          for (int r = 0; r < R; ++r) {
+            const double below = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
+            const bool hit = jbase + r == i + k;
+            const double dcell = and_mask(below, dmask[r]);
+            v[r] = hit ? dcell : v[r];
+            dval = hit ? dcell : dval;
+            hit_any |= hit;
+          }
+          if (hit_any) diag_ring[(i + k) & (kRing - 1)] = dval;  // the y-major strips seed column i+k with it
         }
-        if (hit_any) diag_ring[(i + k) & (kRing - 1)] = dval;  // the y-major strips seed column i+k with it
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -517,12 +537,17 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
         const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
         if (Emit::kFastPath && R >= 2 && aligned && i + 7 <= ihi) {
           const bool steady = i >= j0 + S;
+          using P0 = std::integral_constant<int, 0>;
+          using P1 = std::integral_constant<int, 1>;
+          const bool odd = ((i - j0) & 1) != 0;
           if (p > 0) {
-            if (steady) fast_window(i, std::false_type(), std::true_type());
-            else fast_window(i, std::true_type(), std::true_type());
+            if (steady) fast_window(i, std::false_type(), std::true_type(), P0());
+            else if (odd) fast_window(i, std::true_type(), std::true_type(), P1());
+            else fast_window(i, std::true_type(), std::true_type(), P0());
           } else {
-            if (steady) fast_window(i, std::false_type(), std::false_type());
-            else fast_window(i, std::true_type(), std::false_type());
+            if (steady) fast_window(i, std::false_type(), std::false_type(), P0());
+            else if (odd) fast_window(i, std::true_type(), std::false_type(), P1());
+            else fast_window(i, std::true_type(), std::false_type(), P0());
           }
           i += 8;
         } else {
@@ -702,27 +727,15 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
         // ragged stores.  For a pair of columns (ia, ia+1) with ia < jk either both are below the
         // diagonal, or ia+1 == jk: then the second cell is the diagonal cell (jk,jk) itself, which the
         // seeding has just put into v -- the x-major strip stores the same value there.  So away from
-        // the quadrant's right edge a pair is stored whole or not at all.
-        if (edge_free) {
+        // the quadrant's right edge (edge_free, a precondition of this window) a pair is stored whole or
+        // not at all.
 #pragma unroll
-          for (int r = 0; r + 1 < R; r += 2) {
-            if ((icol0 + r) < jk) {
-              if (DX > 0)
-                emit.pair_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1]);
-              else
-                emit.pair_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r]);
-            }
-          }
-        } else {
-          const int lim = min(jk, cols_total);
-#pragma unroll
-          for (int r = 0; r + 1 < R; r += 2) {
-            const bool okb = (icol0 + r + 1) < lim, oka = (icol0 + r) < lim;
-            const double va = ((icol0 + r) == jk) ? prev[r] : v[r];  // (never stored when seeded: oka is false then)
+        for (int r = 0; r + 1 < R; r += 2) {
+          if ((icol0 + r) < jk) {
             if (DX > 0)
-              emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, va, v[r + 1], okb, oka && !okb, 0, va);
+              emit.pair_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1]);
             else
-              emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], va, okb, oka && !okb, 1, va);
+              emit.pair_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r]);
           }
         }
       } else {
@@ -758,8 +771,8 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
       while (j <= jhi) {
         const int y = g.sy + DY * j;
         const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
-        if (Emit::kFastPath && R >= 2 && aligned && j + 7 <= jhi) {
-          const bool steady = all_cols && j >= i0 + S;
+        const bool steady = all_cols && j >= i0 + S;
+        if (Emit::kFastPath && R >= 2 && aligned && j + 7 <= jhi && (steady || edge_free)) {
           if (p > 0) {
             if (steady) fast_window(j, std::false_type(), std::true_type());
             else fast_window(j, std::true_type(), std::true_type());
@@ -883,10 +896,13 @@ __device__ __forceinline__ void sweep_quadrant(const DevMap& m, Emit& emit, int 
 template <int R, typename OutT>
 __global__ void __launch_bounds__(1024, R <= 2 ? 8 : 4)  // R <= 2: fit 64 VGPRs so two 16-wave workgroups share a CU
 vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
-                 int* __restrict__ err_flag) {
+                 int* __restrict__ err_flag, const int* __restrict__ order) {
   extern __shared__ double lds[];
-  const int s = blockIdx.x / kUnitsPerSource;
-  const int q = blockIdx.x - s * kUnitsPerSource;
+  // longest quadrants first (vhp_order_units): workgroups are handed out in blockIdx order, so
+  // this is longest-processing-time-first scheduling over the CUs
+  const int unit = order ? order[blockIdx.x] : (int)blockIdx.x;
+  const int s = unit / kUnitsPerSource;
+  const int q = unit - s * kUnitsPerSource;
   const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
   if (sx < 0 || sy < 0 || sx >= m.nx || sy >= m.ny) {
     if (threadIdx.x == 0 && q == 0) atomicOr(err_flag, 1);
@@ -894,6 +910,43 @@ vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict_
   }
   StoreEmit<OutT> emit(out + (size_t)s * field_stride, m.nx, m.ny);
   sweep_quadrant<R>(m, emit, sx, sy, q, lds);
+}
+
+// ---------------------------------------------------------------------------
+// Launch order of the (source, quadrant) units: a quadrant's sweep time grows with the length
+// of its longest front, max(ni, nj).  One workgroup counting-sorts the units by that length,
+// longest first.  order[k] = unit index; units of out-of-range sources sort last.
+// ---------------------------------------------------------------------------
+constexpr int kOrderBuckets = 1024;
+__global__ void __launch_bounds__(1024) vhp_order_units(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny,
+                                                        int* __restrict__ order) {
+  __shared__ int hist[kOrderBuckets];
+  __shared__ int start[kOrderBuckets];
+  const int n_units = n_src * kUnitsPerSource;
+  const int maxdim = max(nx, ny);
+  auto bucket_of = [&](int u) {
+    const int s = u / kUnitsPerSource, q = u - s * kUnitsPerSource;
+    const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
+    if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return kOrderBuckets - 1;
+    const int ni = (q == 0 || q == 3) ? nx - sx : sx;
+    const int nj = (q < 2) ? ny - sy : sy;
+    const int len = (ni <= 0 || nj <= 0) ? 0 : max(ni, nj);
+    // bucket 0 = longest
+    return (kOrderBuckets - 1) - (int)(((long long)len * (kOrderBuckets - 1)) / maxdim);
+  };
+  for (int b = threadIdx.x; b < kOrderBuckets; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  for (int u = threadIdx.x; u < n_units; u += blockDim.x) atomicAdd(&hist[bucket_of(u)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < kOrderBuckets; ++b) {
+      start[b] = acc;
+      acc += hist[b];
+    }
+  }
+  __syncthreads();
+  for (int u = threadIdx.x; u < n_units; u += blockDim.x) order[atomicAdd(&start[bucket_of(u)], 1)] = u;
 }
 
 // ---------------------------------------------------------------------------
