@@ -76,10 +76,10 @@ vhp::DevMap dev_map(const vhp_ctx* c) {
   return m;
 }
 
-// A workgroup sweeps one quadrant with 2*W wavefronts (W strips per octant) and R
-// rows/columns per lane: W*64*R must cover the longest front.  Overridable for tuning
-// with VHP_R / VHP_W.
-void pick_shape(int maxdim, int* R, int* W) {
+// A workgroup sweeps one quadrant with 2*W wavefronts (W strips per octant) and R rows/columns
+// per lane.  Fronts longer than W*64*R are swept in rounds (`multi`).  Overridable for tuning
+// with VHP_R / VHP_W / VHP_MULTI.
+void pick_shape(int maxdim, int* R, int* W, bool* multi) {
   if (maxdim <= 64) { *R = 1; *W = 1; }
   else if (maxdim <= 128) { *R = 1; *W = 2; }
   else if (maxdim <= 256) { *R = 1; *W = 4; }
@@ -88,13 +88,18 @@ void pick_shape(int maxdim, int* R, int* W) {
   else { *R = 4; *W = 8; }
   if (const char* e = getenv("VHP_R")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) *R = v; }
   if (const char* e = getenv("VHP_W")) { int v = atoi(e); if (v >= 1 && v <= 8) *W = v; }
-  while ((*W) * 64 * (*R) < maxdim && *W < 8) ++*W;
-  while ((*W) * 64 * (*R) < maxdim && *R < 4) *R *= 2;
+  if (*R == 1) {  // the one-row-per-lane shape has no multi-round build: grow it to cover the front
+    while ((*W) * 64 < maxdim && *W < 8) *W *= 2;
+    if ((*W) * 64 < maxdim) *R = 2;
+  }
+  *multi = (*W) * 64 * (*R) < maxdim;
+  if (const char* e = getenv("VHP_MULTI")) { if (atoi(e) == 1 && *R >= 2) *multi = true; }
+  if (*R == 2 && *multi && *W > 4) *W = 4;  // that build is compiled for 8-wavefront workgroups
 }
 
 }  // namespace
 namespace vhp {
-void pick_shape_for(int maxdim, int* R, int* W) { pick_shape(maxdim, R, W); }
+void pick_shape_for(int maxdim, int* R, int* W, bool* multi) { pick_shape(maxdim, R, W, multi); }
 }
 namespace {
 
@@ -109,10 +114,10 @@ void free_map(vhp_ctx* c) {
   c->nx = c->ny = 0;
 }
 
-template <int R, typename OutT>
+template <int R, bool MULTI, typename OutT>
 hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, int W) {
   const size_t lds = vhp::sweep_lds_bytes(R, W);
-  auto k = vhp::vhp_sweep_fronts<R, OutT>;
+  auto k = vhp::vhp_sweep_fronts<R, MULTI, OutT>;
   static size_t lds_allowed = 0;  // per instantiation: raise the dynamic-LDS limit once, not per launch
   if (lds > lds_allowed) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -144,11 +149,12 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
 template <typename OutT>
 hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
   int R, W;
-  pick_shape(std::max(c->nx, c->ny), &R, &W);
+  bool multi;
+  pick_shape(std::max(c->nx, c->ny), &R, &W, &multi);
   switch (R) {
-    case 1: return launch_sweep_t<1, OutT>(c, d_src, n_src, d_out, W);
-    case 2: return launch_sweep_t<2, OutT>(c, d_src, n_src, d_out, W);
-    default: return launch_sweep_t<4, OutT>(c, d_src, n_src, d_out, W);
+    case 1: return launch_sweep_t<1, false, OutT>(c, d_src, n_src, d_out, W);
+    case 2: return multi ? launch_sweep_t<2, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<2, false, OutT>(c, d_src, n_src, d_out, W);
+    default: return multi ? launch_sweep_t<4, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<4, false, OutT>(c, d_src, n_src, d_out, W);
   }
 }
 
@@ -369,7 +375,8 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
   vhp::DevMap pm = dev_map(ctx);
   {
     int R, W;
-    pick_shape(std::max(ctx->nx, ctx->ny), &R, &W);
+    bool multi;
+    pick_shape(std::max(ctx->nx, ctx->ny), &R, &W, &multi);
     hipError_t eb = vhp::attach_round_scratch(pm, W * 64 * R, 4, &ctx->d_bnd, &ctx->d_bnd_cap);
     if (eb != hipSuccess) return fail(ctx, VHP_ERR_HIP, std::string("scratch: ") + hipGetErrorString(eb));
   }

@@ -95,13 +95,13 @@ __device__ __forceinline__ PlannerKey key_shuffle_xor(const PlannerKey& k, int m
 
 // Step 1 of a planner iteration: the plain front sweep (vhp_sweep.cuh, fast path) from the
 // current pivot into vis_local -- the reference's visibility_ (solver.cpp:386-416).
-template <int R>
-__global__ void __launch_bounds__(1024, R <= 2 ? 8 : 4) vhp_planner_sweep(DevMap m, PlannerDev d) {
+template <int R, bool MULTI>
+__global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (MULTI ? 6 : 8)) vhp_planner_sweep(DevMap m, PlannerDev d) {
   extern __shared__ double lds[];
   if (d.ctl->done) return;
   const int nb = d.ctl->nb;
   const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
-  StoreEmit<double> emit(d.vis_local, m.nx, m.ny);
+  StoreEmit<double, MULTI> emit(d.vis_local, m.nx, m.ny);
   sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x, lds);
 }
 
@@ -229,7 +229,7 @@ inline void planner_free(PlannerState& s) {
   s = PlannerState();
 }
 
-void pick_shape_for(int maxdim, int* R, int* W);  // defined in vhp_capi.hip
+void pick_shape_for(int maxdim, int* R, int* W, bool* multi);  // defined in vhp_capi.hip
 
 #define VHP_PL_HIP(call)                                                      \
   do {                                                                        \
@@ -240,10 +240,10 @@ void pick_shape_for(int maxdim, int* R, int* W);  // defined in vhp_capi.hip
     }                                                                         \
   } while (0)
 
-template <int R>
+template <int R, bool MULTI>
 inline hipError_t launch_planner_fronts(const DevMap& m, const PlannerDev& d, int W, hipStream_t stream) {
   const size_t lds = sweep_lds_bytes(R, W);
-  auto k = vhp_planner_sweep<R>;
+  auto k = vhp_planner_sweep<R, MULTI>;
   static size_t lds_allowed = 0;
   if (lds > lds_allowed) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -312,7 +312,8 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   d.max_iter = max_iter;
 
   int R, W;
-  pick_shape_for(std::max(nx, ny), &R, &W);
+  bool multi;
+  pick_shape_for(std::max(nx, ny), &R, &W, &multi);
   VHP_PL_HIP(hipEventRecord(ev0, stream));
   hipLaunchKernelGGL(vhp_planner_init, dim3(1), dim3(64), 0, stream, d, nx, start_x, start_y);
   VHP_PL_HIP(hipGetLastError());
@@ -320,9 +321,9 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   const int batch = 4;  // iterations enqueued per host poll
   for (;;) {
     for (int b = 0; b < batch; ++b) {
-      hipError_t e = R == 1 ? launch_planner_fronts<1>(m, d, W, stream)
-                   : R == 2 ? launch_planner_fronts<2>(m, d, W, stream)
-                            : launch_planner_fronts<4>(m, d, W, stream);
+      hipError_t e = R == 1 ? launch_planner_fronts<1, false>(m, d, W, stream)
+                   : R == 2 ? (multi ? launch_planner_fronts<2, true>(m, d, W, stream) : launch_planner_fronts<2, false>(m, d, W, stream))
+                            : (multi ? launch_planner_fronts<4, true>(m, d, W, stream) : launch_planner_fronts<4, false>(m, d, W, stream));
       if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
       hipLaunchKernelGGL(vhp_planner_epilogue, dim3(kEpilogueBlocks), dim3(256), 0, stream, m, d);
       VHP_PL_HIP(hipGetLastError());

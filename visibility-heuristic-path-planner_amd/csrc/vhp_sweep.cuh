@@ -179,10 +179,11 @@ __device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
 // (Raw buffer stores with out-of-range offsets as predication were measured slower than
 // exec-masked global stores here: every store instruction costs the issuing wavefront
 // ~60-80 cycles whether or not its lanes are dropped.)
-template <typename OutT>
+template <typename OutT, bool MULTI = false>
 struct StoreEmit {
   static constexpr int kCellBytes = sizeof(OutT);
   static constexpr bool kFastPath = true;  // use the unrolled windows
+  static constexpr bool kMulti = MULTI;    // fronts may be longer than one round of W strips
   OutT* __restrict__ out;
   int nx;
   struct alignas(2 * sizeof(OutT)) Two { OutT a, b; };
@@ -229,7 +230,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
   double* ring_out = ring_base + ss.w * kRing;
   // lane 0's lower neighbour: the LDS ring of the wavefront below, or (first wavefront of a later
   // round) the staged copy of the boundary row the previous round left in global memory
-  constexpr bool kMulti = R >= 4;  // only the large-grid shape sweeps in rounds; keeps the small shapes lean
+  constexpr bool kMulti = Emit::kMulti;  // sweeping in rounds is compiled in only where the launch shape needs it
   const bool from_prev_round = kMulti && ss.w == 0 && p > 0;
   const double* ring_in = from_prev_round ? ss.stage : ring_base + (ss.w > 0 ? ss.w - 1 : 0) * kRing;
   const int rin_mask = from_prev_round ? kStage - 1 : kRing - 1;
@@ -578,7 +579,7 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
   const int nlast = chunk_seq<DY>(g.sy, g.nj - 1);
   const int nfirst = chunk_seq<DY>(g.sy, min(i0, g.nj - 1));
   double* ring_out = ring_base + ss.w * kRing;
-  constexpr bool kMulti = R >= 4;  // only the large-grid shape sweeps in rounds; keeps the small shapes lean
+  constexpr bool kMulti = Emit::kMulti;  // sweeping in rounds is compiled in only where the launch shape needs it
   const bool from_prev_round = kMulti && ss.w == 0 && p > 0;
   const double* ring_in = from_prev_round ? ss.stage : ring_base + (ss.w > 0 ? ss.w - 1 : 0) * kRing;
   const int rin_mask = from_prev_round ? kStage - 1 : kRing - 1;
@@ -838,7 +839,7 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
   double* tiles = stage + 2 * kStage;
   // Fronts longer than W strips are swept in rounds of W strips; the last strip of a round leaves
   // its boundary row in global memory for the first strip of the next round.
-  const int rounds = R >= 4 ? max((max(Px, Py) + W - 1) / W, 1) : 1;
+  const int rounds = Emit::kMulti ? max((max(Px, Py) + W - 1) / W, 1) : 1;
   double* bnd = m.bnd ? m.bnd + (size_t)blockIdx.x * 4 * m.bnd_len : nullptr;
   for (int rho = 0; rho < rounds; ++rho) {
     const int pg0 = rho * W;
@@ -893,8 +894,10 @@ __device__ __forceinline__ void sweep_quadrant(const DevMap& m, Emit& emit, int 
 }
 
 // grid = n_src * 4 workgroups of 128*W threads; dynamic LDS = sweep_lds_bytes(R, W)
-template <int R, typename OutT>
-__global__ void __launch_bounds__(1024, R <= 2 ? 8 : 4)  // R <= 2: fit 64 VGPRs so two 16-wave workgroups share a CU
+// Register budgets: R <= 2 single-round shapes fit 64 VGPRs so two 16-wavefront workgroups share a
+// CU; the R = 2 multi-round shape runs 8-wavefront workgroups, three per CU.
+template <int R, bool MULTI, typename OutT>
+__global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (MULTI ? 6 : 8))
 vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
                  int* __restrict__ err_flag, const int* __restrict__ order) {
   extern __shared__ double lds[];
@@ -908,7 +911,7 @@ vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict_
     if (threadIdx.x == 0 && q == 0) atomicOr(err_flag, 1);
     return;
   }
-  StoreEmit<OutT> emit(out + (size_t)s * field_stride, m.nx, m.ny);
+  StoreEmit<OutT, MULTI> emit(out + (size_t)s * field_stride, m.nx, m.ny);
   sweep_quadrant<R>(m, emit, sx, sy, q, lds);
 }
 
