@@ -166,23 +166,23 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ctx.timing(True)  # HIP events around every sweep kernel, recorded on the stream it is launched on
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)  # HIP events on the stream the kernel is launched on
+    for _ in range(args.steps):
         ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_out.data_ptr(), dtype=vdt)
-        b.record(stream)
         if gathered is not None:
             dist.all_gather_into_tensor(gathered, d_out)
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.sync()  # surfaces device-side validation errors
+    kern = ctx.timing_collect(args.steps)
+    ctx.timing(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    kern_ms = float(kern.mean())  # average duration of the dominant kernel inside the timed region
 
     if rank == 0:
         fields = world * n_src * args.steps

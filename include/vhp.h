@@ -118,6 +118,14 @@ int vhp_raycast_all(vhp_ctx* ctx, int src_x, int src_y, double* out_host);
  * stream.  Blocks until that work has finished. */
 int vhp_last_elapsed_ms(vhp_ctx* ctx, float* ms);
 
+/* Per-launch kernel timing for benchmarks.  vhp_timing(ctx, 1) makes every following
+ * vhp_sweep_batch_device call bracket its sweep kernel (only that kernel, not the unit-ordering
+ * pre-kernel) with a pair of hipEvents on the context stream; vhp_timing_collect waits for them,
+ * writes up to `cap` durations in milliseconds (oldest first), returns their count in *n and
+ * clears the list.  vhp_timing(ctx, 0) switches it off. */
+int vhp_timing(vhp_ctx* ctx, int enable);
+int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n);
+
 /* Library / build identification: "vhp-hip <version> gfx950". */
 const char* vhp_version(void);
 

@@ -38,7 +38,7 @@ UNLABELLED = 1000000000000000
 ABI_SYMBOLS = (
     "vhp_create", "vhp_destroy", "vhp_last_error", "vhp_set_stream", "vhp_set_map", "vhp_set_map_device",
     "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
-    "vhp_raycast_all",
+    "vhp_raycast_all", "vhp_timing", "vhp_timing_collect",
     "vhp_last_elapsed_ms", "vhp_version",
 )
 
@@ -83,6 +83,8 @@ def load_library():
     lib.vhp_planner_solve.argtypes = [vp, i32, i32, i32, i32, f64, u64, vp, vp, vp, vp, C.POINTER(u32)]
     lib.vhp_reconstruct_path.argtypes = [vp, vp, i32, i32, i32, i32, vp, u32, C.POINTER(u32), C.POINTER(f64)]
     lib.vhp_raycast_all.argtypes = [vp, i32, i32, vp]
+    lib.vhp_timing.argtypes = [vp, i32]
+    lib.vhp_timing_collect.argtypes = [vp, vp, i32, C.POINTER(i32)]
     lib.vhp_last_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.vhp_version.restype = C.c_char_p
     _lib = lib
@@ -142,6 +144,16 @@ class Context:
 
     def sync(self):
         self._check(self.lib.vhp_sync(self.h))
+
+    def timing(self, enable=True):
+        self._check(self.lib.vhp_timing(self.h, 1 if enable else 0))
+
+    def timing_collect(self, cap=4096):
+        """Durations (ms) of the sweep kernels launched since timing(True), oldest first."""
+        buf = np.zeros(cap, np.float32)
+        n = C.c_int(0)
+        self._check(self.lib.vhp_timing_collect(self.h, _ptr(buf), cap, C.byref(n)))
+        return buf[: n.value].copy()
 
     def last_elapsed_ms(self):
         ms = C.c_float(0)

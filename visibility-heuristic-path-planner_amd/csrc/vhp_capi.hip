@@ -43,6 +43,8 @@ struct vhp_ctx {
   size_t d_bnd_cap = 0;
   int* d_order = nullptr;   // launch order of the (source, quadrant) units, longest first
   size_t d_order_cap = 0;
+  bool timing = false;      // per-launch event pairs around the sweep kernel (vhp_timing)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_launches;
 
   vhp::PlannerState pl;  // device-resident planner state
   vhp::QueueScratch qs;  // scratch of the queue-variant sweep
@@ -142,8 +144,18 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     hipLaunchKernelGGL(vhp::vhp_order_units, dim3(1), dim3(1024), 0, c->stream, d_src, n_src, c->nx, c->ny, c->d_order);
     order = c->d_order;
   }
+  hipEvent_t ta = nullptr, tb = nullptr;
+  if (c->timing) {
+    if (hipEventCreate(&ta) != hipSuccess || hipEventCreate(&tb) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipEventRecord(ta, c->stream);
+  }
   hipLaunchKernelGGL(k, dim3((unsigned)n_units), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order);
-  return hipGetLastError();
+  const hipError_t el = hipGetLastError();
+  if (c->timing) {
+    (void)hipEventRecord(tb, c->stream);
+    c->timed_launches.push_back({ta, tb});
+  }
+  return el;
 }
 
 template <typename OutT>
@@ -228,6 +240,7 @@ int vhp_destroy(vhp_ctx* ctx) {
   if (ctx->d_out) hipFree(ctx->d_out);
   if (ctx->d_bnd) hipFree(ctx->d_bnd);
   if (ctx->d_order) hipFree(ctx->d_order);
+  for (auto& pr : ctx->timed_launches) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (ctx->d_err) hipFree(ctx->d_err);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -353,6 +366,30 @@ int vhp_raycast_all(vhp_ctx* ctx, int src_x, int src_y, double* out_host) {
   ctx->timed = true;
   VHP_HIP(hipMemcpyAsync(out_host, d, cells * 8, hipMemcpyDeviceToHost, ctx->stream));
   VHP_HIP(hipStreamSynchronize(ctx->stream));
+  return VHP_OK;
+}
+
+int vhp_timing(vhp_ctx* ctx, int enable) {
+  if (!ctx) return VHP_ERR_ARG;
+  ctx->timing = enable != 0;
+  return VHP_OK;
+}
+
+int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n) {
+  if (!ctx || !n || cap < 0 || (cap > 0 && !ms_out)) return VHP_ERR_ARG;
+  VHP_HIP(hipSetDevice(ctx->device));
+  int k = 0;
+  for (auto& pr : ctx->timed_launches) {
+    float ms = 0.f;
+    VHP_HIP(hipEventSynchronize(pr.second));
+    VHP_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+    if (k < cap) ms_out[k] = ms;
+    ++k;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  ctx->timed_launches.clear();
+  *n = std::min(k, cap);
   return VHP_OK;
 }
 
