@@ -30,8 +30,8 @@ __global__ void body(double* out, unsigned long long* cyc, int steps, uint64_t o
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   double s = 0; for (int r = 0; r < R; ++r) s += prev[r];
-  out[threadIdx.x] = s;
-  if (threadIdx.x == 0) cyc[0] = t1 - t0;
+  out[threadIdx.x & 63] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
 template <int MODE, int R> void run(const char* name, double* d, unsigned long long* c, int waves = 1) {
@@ -43,8 +43,21 @@ template <int MODE, int R> void run(const char* name, double* d, unsigned long l
          (double)h / steps, (double)h / steps / R, (double)h / steps / R / (waves > 4 ? waves / 4.0 : 1.0));
 }
 
+// every CU loaded: `blocks_per_cu` blocks of `waves` wavefronts on each of the 256 CUs
+template <int MODE, int R> void run_chip(const char* name, double* d, unsigned long long* c, int waves, int blocks_per_cu) {
+  const int steps = 4000, nb = 256 * blocks_per_cu;
+  for (int k = 0; k < 2; ++k) hipLaunchKernelGGL((body<MODE, R>), dim3(nb), dim3(64 * waves), 0, 0, d, c, steps, ~0ull);
+  hipDeviceSynchronize();
+  static unsigned long long h[4096];
+  hipMemcpy(h, c, 8 * nb, hipMemcpyDeviceToHost);
+  double avg = 0; for (int b = 0; b < nb; ++b) avg += (double)h[b] / nb;
+  const double wps = waves * blocks_per_cu / 4.0;
+  printf("%-28s R=%d waves/SIMD=%4.1f: %7.1f cycles/row-step per wave; SIMD cycles per row-step %.1f\n", name, R, wps, avg / steps / R,
+         avg / steps / R / wps);
+}
+
 int main() {
-  double* d; unsigned long long* c; hipMalloc(&d, 4096); hipMalloc(&c, 64);
+  double* d; unsigned long long* c; hipMalloc(&d, 4096); hipMalloc(&c, 8 * 4096);
   run<0, 1>("stencil only (3 dep fp64)", d, c);
   run<2, 1>("+ratio (3 more fp64, independent of chain)", d, c);
   run<1, 1>("stencil + dpp shift", d, c);
@@ -56,6 +69,7 @@ int main() {
   run<7, 2>("no readlane", d, c);
   run<7, 4>("no readlane", d, c);
   run<0, 4>("stencil only", d, c);
+  for (int w : {4, 8, 16}) for (int b : {1, 2}) { run_chip<7, 2>("chip: no readlane", d, c, w, b); run_chip<15, 2>("chip: all", d, c, w, b); }
   for (int w : {4, 8, 16}) { run<0, 4>("stencil only", d, c, w); run<7, 2>("no readlane", d, c, w); run<15, 2>("all", d, c, w); }
   return 0;
 }

@@ -41,7 +41,7 @@ struct vhp_ctx {
   size_t d_out_cap = 0;
   double* d_bnd = nullptr;  // boundary rows of multi-round sweeps (sides above W*64*R)
   size_t d_bnd_cap = 0;
-  int* d_order = nullptr;   // launch order of the (source, quadrant) units, longest first
+  int* d_order = nullptr;   // launch order of the (source, quadrant) units (+ one int4 descriptor per workgroup)
   size_t d_order_cap = 0;
   bool timing = false;      // per-launch event pairs around the sweep kernel (vhp_timing)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_launches;
@@ -118,7 +118,7 @@ void free_map(vhp_ctx* c) {
 
 template <int R, bool MULTI, typename OutT>
 hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, int W) {
-  const size_t lds = vhp::sweep_lds_bytes(R, W);
+  const size_t lds = vhp::sweep_lds_bytes(R, W, MULTI);
   auto k = vhp::vhp_sweep_fronts<R, MULTI, OutT>;
   static size_t lds_allowed = 0;  // per instantiation: raise the dynamic-LDS limit once, not per launch
   if (lds > lds_allowed) {
@@ -132,24 +132,33 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   if (eb != hipSuccess) return eb;
   const size_t n_units = (size_t)n_src * vhp::kUnitsPerSource;
   const int* order = nullptr;
+  const int4* desc = nullptr;
   if (n_src >= 8) {  // worth a 1-workgroup pre-kernel once the batch spans many CUs
     if (c->d_order_cap < n_units) {
       if (c->d_order) (void)hipFree(c->d_order);
       c->d_order = nullptr;
       c->d_order_cap = 0;
-      hipError_t eo = hipMalloc(&c->d_order, n_units * sizeof(int));
+      hipError_t eo = hipMalloc(&c->d_order, n_units * (sizeof(int) + sizeof(int4)) + 16);
       if (eo != hipSuccess) return eo;
       c->d_order_cap = n_units;
     }
-    hipLaunchKernelGGL(vhp::vhp_order_units, dim3(1), dim3(1024), 0, c->stream, d_src, n_src, c->nx, c->ny, c->d_order);
-    order = c->d_order;
+    int4* d_desc = reinterpret_cast<int4*>(c->d_order);                      // n_units descriptors first (16-byte aligned)
+    int* d_ord = reinterpret_cast<int*>(d_desc + n_units);                   // then the order list
+    // Packing short quadrants into one workgroup is implemented and parity-tested, but measured slower
+    // on MI355X: off unless VHP_PACK is set.
+    static const bool pack = getenv("VHP_PACK") != nullptr;
+    const int pack_w = (!MULTI && W == 8 && pack) ? W : 0;
+    hipLaunchKernelGGL(vhp::vhp_order_units, dim3(1), dim3(1024), 0, c->stream, d_src, n_src, c->nx, c->ny, 64 * R, pack_w, d_ord,
+                       d_desc);
+    order = d_ord;
+    desc = d_desc;
   }
   hipEvent_t ta = nullptr, tb = nullptr;
   if (c->timing) {
     if (hipEventCreate(&ta) != hipSuccess || hipEventCreate(&tb) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipEventRecord(ta, c->stream);
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)n_units), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order);
+  hipLaunchKernelGGL(k, dim3((unsigned)n_units), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order, desc);
   const hipError_t el = hipGetLastError();
   if (c->timing) {
     (void)hipEventRecord(tb, c->stream);

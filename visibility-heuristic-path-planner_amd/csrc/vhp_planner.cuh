@@ -102,7 +102,7 @@ __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (
   const int nb = d.ctl->nb;
   const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
   StoreEmit<double, MULTI> emit(d.vis_local, m.nx, m.ny);
-  sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x, lds);
+  sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x, lds, whole_workgroup());
 }
 
 // Step 2: the per-cell body of updateVisibility() that follows the store (solver.cpp:417-430)
@@ -242,7 +242,7 @@ void pick_shape_for(int maxdim, int* R, int* W, bool* multi);  // defined in vhp
 
 template <int R, bool MULTI>
 inline hipError_t launch_planner_fronts(const DevMap& m, const PlannerDev& d, int W, hipStream_t stream) {
-  const size_t lds = sweep_lds_bytes(R, W);
+  const size_t lds = sweep_lds_bytes(R, W, MULTI);
   auto k = vhp_planner_sweep<R, MULTI>;
   static size_t lds_allowed = 0;
   if (lds > lds_allowed) {

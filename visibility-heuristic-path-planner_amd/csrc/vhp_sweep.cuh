@@ -54,6 +54,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 namespace vhp {
@@ -149,6 +150,17 @@ struct UnitGeom {
   int sx, sy, ni, nj;
 };
 
+// A workgroup sweeps one quadrant with all its wavefronts, or -- packing -- several short
+// quadrants side by side, each with an equal share ("subgroup") of the wavefronts and of the LDS.
+// All subgroups execute the same number of barriers (`tmax_floor` = the longest partner's).
+struct SubGroup {
+  int W;           // strips per octant available to this subgroup
+  int wave;        // wavefront index inside the subgroup, 0 .. 2W-1
+  int tid;         // thread index inside the subgroup
+  int nthreads;    // threads of the subgroup
+  int tmax_floor;  // run at least this many + 1 pipeline slots
+};
+
 // Where a strip sits in the current round of a quadrant sweep.
 struct StripSlot {
   int pg;      // global strip index: rows/columns [pg*S, (pg+1)*S)
@@ -179,6 +191,13 @@ __device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
 // (Raw buffer stores with out-of-range offsets as predication were measured slower than
 // exec-masked global stores here: every store instruction costs the issuing wavefront
 // ~60-80 cycles whether or not its lanes are dropped.)
+#ifdef VHP_EXP_NOSTORE  // diagnostic builds only (tools/): all the work, none of the stores
+#define VHP_EXP_STORE_GUARD if (nx != 0x7fffffff) return;
+#elif defined(VHP_EXP_SMALLSTORE)  // all stores issued, into a 64 KB window per field: no HBM traffic
+#define VHP_EXP_STORE_GUARD off &= 0xffffu;
+#else
+#define VHP_EXP_STORE_GUARD
+#endif
 template <typename OutT, bool MULTI = false>
 struct StoreEmit {
   static constexpr int kCellBytes = sizeof(OutT);
@@ -190,12 +209,14 @@ struct StoreEmit {
   __device__ __forceinline__ StoreEmit(OutT* field, int nx_, int) : out(field), nx(nx_) {}
   // both cells valid; off = (y*nx + x) * kCellBytes, maintained incrementally by the caller
   __device__ __forceinline__ void pair_at(uint32_t off, int, int, double v0, double v1) {
+    VHP_EXP_STORE_GUARD
     *reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
   }
   // `both`: store the pair; else `one`: store only the cell at off + sel*kCellBytes (value vs)
   __device__ __forceinline__ void pair_or_single_at(uint32_t off, int, int, double v0, double v1, bool both, bool one,
                                                     int sel, double vs) {
     asm volatile("" : "+v"(vs));  // keep the compiler from splitting the 16-byte store to share a half with the single
+    VHP_EXP_STORE_GUARD
     if (both)
       *reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
     else if (one)
@@ -234,7 +255,6 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
   const bool from_prev_round = kMulti && ss.w == 0 && p > 0;
   const double* ring_in = from_prev_round ? ss.stage : ring_base + (ss.w > 0 ? ss.w - 1 : 0) * kRing;
   const int rin_mask = from_prev_round ? kStage - 1 : kRing - 1;
-  const crecip_p crecip = (crecip_p)m.recip;
   const int rows_here = max(min(S, rows_total - j0), 0);
 
   double prev[R], jd[R];
@@ -262,6 +282,9 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
   const uint32_t flush_pass_stride = (uint32_t)(16 * DY * m.nx * CB);
 
   auto refill = [&](int blk) {  // blocking: once per 64 steps
+#ifdef VHP_EXP_NOREFILL  // diagnostic builds only: wrong results, shows what the reloads cost
+    if (cur_blk != INT32_MIN) { cur_blk = blk; return; }
+#endif
     cur_blk = blk;
     const int xt = blk * 64 + lane;
     const int it = DX > 0 ? xt - g.sx : g.sx - xt;
@@ -382,11 +405,11 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
     const int xb = x0 & ~(kTileCols - 1);     // lowest x of the window
     const int blk = x0 >> 6, t0 = x0 & 63;
     if (blk != cur_blk) refill(blk);
-    // eight reciprocals: one scalar load (steady) or lane reads of the block's table (diagonal phase,
-    // where scalar registers are scarce)
+    // eight reciprocals: lane reads of the block's table (measured faster than one scalar load per
+    // window, whose latency sits exposed at the top of the window)
     double rr[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rr[k] = DIAG ? read_lane(rv, t0 + DX * k) : crecip[i + k];
+    for (int k = 0; k < 8; ++k) rr[k] = read_lane(rv, t0 + DX * k);
     // occupancy bits of the window, pre-shifted so that step k's bit sits at a fixed position
     int hs[R];
     const int sh = DX > 0 ? (t0 & 31) : (t0 & 31) - 7;
@@ -583,7 +606,6 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
   const bool from_prev_round = kMulti && ss.w == 0 && p > 0;
   const double* ring_in = from_prev_round ? ss.stage : ring_base + (ss.w > 0 ? ss.w - 1 : 0) * kRing;
   const int rin_mask = from_prev_round ? kStage - 1 : kRing - 1;
-  const crecip_p crecip = (crecip_p)m.recip;
   bool first_refill = true;
 
   double prev[R], id[R];
@@ -603,6 +625,9 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
     ow[r] = 0;
   }
   auto refill = [&](int blk) {
+#ifdef VHP_EXP_NOREFILL
+    if (cur_blk != INT32_MIN) { cur_blk = blk; return; }
+#endif
     cur_blk = blk;
     const int yt = blk * 64 + lane;
     const int jt = DY > 0 ? yt - g.sy : g.sy - yt;
@@ -690,7 +715,7 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
     if (blk != cur_blk) refill(blk);
     double rr[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rr[k] = DIAG ? read_lane(rv, t0 + DY * k) : crecip[j + k];
+    for (int k = 0; k < 8; ++k) rr[k] = read_lane(rv, t0 + DY * k);
     int hs[R];
     const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
 #pragma unroll
@@ -811,32 +836,43 @@ inline hipError_t attach_round_scratch(DevMap& m, int rows_per_round, size_t n_w
   return hipSuccess;
 }
 
-inline size_t sweep_lds_bytes(int R, int W) {
-  // x rings, y rings, the diagonal ring, two boundary staging areas, W staging tiles
-  return ((size_t)2 * W * kRing + kRing + 2 * kStage + (size_t)W * 64 * R * kTileStride) * sizeof(double);
+// LDS of one subgroup with W strips per octant: x rings, y rings, the diagonal ring, (multi-round
+// shapes) two boundary staging areas, W staging tiles.  In doubles.
+__host__ __device__ inline size_t sweep_lds_doubles(int R, int W, bool multi) {
+  return (size_t)2 * W * kRing + kRing + (multi ? 2 * kStage : 0) + (size_t)W * 64 * R * kTileStride;
+}
+// Dynamic LDS of a launch with W strips per octant per workgroup; packing (G subgroups of W/G
+// strips) must fit too.
+inline size_t sweep_lds_bytes(int R, int W, bool multi = false) {
+  size_t d = sweep_lds_doubles(R, W, multi);
+  for (int G = 2; G <= 4 && W / G >= 1; G *= 2) d = std::max(d, (size_t)G * sweep_lds_doubles(R, W / G, multi));
+  return d * sizeof(double);
 }
 
 // One quadrant of one source: called by all 2*W wavefronts of a workgroup.
 // Q1 (+,+) Q2 (-,+) Q3 (-,-) Q4 (+,-), reference solver.cpp:575-695.
 template <int R, int DX, int DY, typename Emit>
-__device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, int sx, int sy, double* lds) {
+__device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, int sx, int sy, double* lds, const SubGroup sg) {
   constexpr int S = 64 * R;
-  const int W = blockDim.x >> 7;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
+  const int W = sg.W;
+  const int wave = sg.wave;
   UnitGeom g;
   g.sx = sx;
   g.sy = sy;
   g.ni = DX > 0 ? m.nx - sx : sx;  // negative directions stop short of the border
   g.nj = DY > 0 ? m.ny - sy : sy;
-  if (g.ni <= 0 || g.nj <= 0) return;  // uniform for the workgroup
+  if (g.ni <= 0 || g.nj <= 0) {  // uniform for the subgroup: nothing to sweep, but keep the partners' barriers company
+    for (int t = 0; t <= sg.tmax_floor; ++t) __syncthreads();
+    return;
+  }
   const int rows_total = min(g.nj, g.ni);
   const int cols_total = max(min(g.ni, g.nj - 1), 0);
   const int Px = (rows_total + S - 1) / S, Py = (cols_total + S - 1) / S;
   double* ring_x = lds;
   double* ring_y = lds + (size_t)W * kRing;
   double* diag_ring = lds + (size_t)2 * W * kRing;
-  double* stage = diag_ring + kRing;  // 2 * kStage
-  double* tiles = stage + 2 * kStage;
+  double* stage = diag_ring + kRing;  // 2 * kStage, multi-round shapes only
+  double* tiles = stage + (Emit::kMulti ? 2 * kStage : 0);
   // Fronts longer than W strips are swept in rounds of W strips; the last strip of a round leaves
   // its boundary row in global memory for the first strip of the next round.
   const int rounds = Emit::kMulti ? max((max(Px, Py) + W - 1) / W, 1) : 1;
@@ -847,7 +883,8 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
     const int nbase_y = chunk_seq<DY>(sy, min(pg0 * S, g.nj - 1));
     const int wx = max(min(Px - pg0, W), 1), wy = max(min(Py - pg0, W), 1);
     StripSlot ss;
-    ss.tmax = max(chunk_seq<DX>(sx, g.ni - 1) - nbase_x + wx - 1, chunk_seq<DY>(sy, g.nj - 1) - nbase_y + wy - 1 + kYLag);
+    ss.tmax = max(max(chunk_seq<DX>(sx, g.ni - 1) - nbase_x + wx - 1, chunk_seq<DY>(sy, g.nj - 1) - nbase_y + wy - 1 + kYLag),
+                  sg.tmax_floor);
     if (wave < W) {
       ss.pg = pg0 + wave;
       ss.w = wave;
@@ -875,22 +912,47 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
   }
 }
 
+// Last pipeline slot of quadrant q of source (sx, sy) when swept in one round by W strips per octant
+// (-1: the quadrant is empty).  Must agree with sweep_quadrant_dir.
+template <int R>
+__device__ __forceinline__ int unit_tmax(const DevMap& m, int sx, int sy, int q, int W) {
+  constexpr int S = 64 * R;
+  const bool px = (q == 0 || q == 3), py = q < 2;
+  const int ni = px ? m.nx - sx : sx, nj = py ? m.ny - sy : sy;
+  if (ni <= 0 || nj <= 0) return -1;
+  const int Px = (min(nj, ni) + S - 1) / S, Py = (max(min(ni, nj - 1), 0) + S - 1) / S;
+  const int wx = max(min(Px, W), 1), wy = max(min(Py, W), 1);
+  const int nx_last = px ? chunk_seq<+1>(sx, ni - 1) : chunk_seq<-1>(sx, ni - 1);
+  const int ny_last = py ? chunk_seq<+1>(sy, nj - 1) : chunk_seq<-1>(sy, nj - 1);
+  return max(nx_last + wx - 1, ny_last + wy - 1 + kYLag);
+}
+
 template <int R, typename Emit>
-__device__ __forceinline__ void sweep_quadrant(const DevMap& m, Emit& emit, int sx, int sy, int q, double* lds) {
+__device__ __forceinline__ void sweep_quadrant(const DevMap& m, Emit& emit, int sx, int sy, int q, double* lds, const SubGroup sg) {
   if (q == 0) {
     // rows/columns no quadrant covers read as zero; quadrant 1 always exists
     if (sx > 0)
-      for (int y = threadIdx.x; y < m.ny; y += blockDim.x) emit.zero(0, y);
+      for (int y = sg.tid; y < m.ny; y += sg.nthreads) emit.zero(0, y);
     if (sy > 0)
-      for (int x = threadIdx.x; x < m.nx; x += blockDim.x) emit.zero(x, 0);
-    sweep_quadrant_dir<R, +1, +1>(m, emit, sx, sy, lds);
+      for (int x = sg.tid; x < m.nx; x += sg.nthreads) emit.zero(x, 0);
+    sweep_quadrant_dir<R, +1, +1>(m, emit, sx, sy, lds, sg);
   } else if (q == 1) {
-    sweep_quadrant_dir<R, -1, +1>(m, emit, sx, sy, lds);
+    sweep_quadrant_dir<R, -1, +1>(m, emit, sx, sy, lds, sg);
   } else if (q == 2) {
-    sweep_quadrant_dir<R, -1, -1>(m, emit, sx, sy, lds);
+    sweep_quadrant_dir<R, -1, -1>(m, emit, sx, sy, lds, sg);
   } else {
-    sweep_quadrant_dir<R, +1, -1>(m, emit, sx, sy, lds);
+    sweep_quadrant_dir<R, +1, -1>(m, emit, sx, sy, lds, sg);
   }
+}
+
+__device__ __forceinline__ SubGroup whole_workgroup() {
+  SubGroup sg;
+  sg.W = blockDim.x >> 7;
+  sg.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
+  sg.tid = threadIdx.x;
+  sg.nthreads = blockDim.x;
+  sg.tmax_floor = -1;
+  return sg;
 }
 
 // grid = n_src * 4 workgroups of 128*W threads; dynamic LDS = sweep_lds_bytes(R, W)
@@ -899,20 +961,56 @@ __device__ __forceinline__ void sweep_quadrant(const DevMap& m, Emit& emit, int 
 template <int R, bool MULTI, typename OutT>
 __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (MULTI ? 6 : 8))
 vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
-                 int* __restrict__ err_flag, const int* __restrict__ order) {
+                 int* __restrict__ err_flag, const int* __restrict__ order, const int4* __restrict__ wg_desc) {
   extern __shared__ double lds[];
-  // longest quadrants first (vhp_order_units): workgroups are handed out in blockIdx order, so
-  // this is longest-processing-time-first scheduling over the CUs
-  const int unit = order ? order[blockIdx.x] : (int)blockIdx.x;
-  const int s = unit / kUnitsPerSource;
-  const int q = unit - s * kUnitsPerSource;
-  const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
-  if (sx < 0 || sy < 0 || sx >= m.nx || sy >= m.ny) {
-    if (threadIdx.x == 0 && q == 0) atomicOr(err_flag, 1);
+  // Without descriptors: workgroup b sweeps unit b.  With (vhp_order_units): workgroup b sweeps
+  // `count` units order[first .. first+count) side by side, each with 1/G of the wavefronts; units
+  // are handed out longest first, which with in-order dispatch is LPT scheduling over the CUs.
+  int first = blockIdx.x, count = 1, G = 1;
+  if (wg_desc) {
+    const int4 d = wg_desc[blockIdx.x];
+    first = d.x;
+    count = d.y;
+    G = d.z;
+    if (count == 0) return;
+  }
+  // G and the wavefront count are powers of two: shifts only, and everything stays in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
+  const int wsub_shift = __builtin_amdgcn_readfirstlane(__builtin_ctz(blockDim.x >> 6) - __builtin_ctz(G));  // log2(wavefronts per subgroup)
+  const int sub = __builtin_amdgcn_readfirstlane(wave >> wsub_shift);
+  SubGroup sg;
+  sg.W = __builtin_amdgcn_readfirstlane((1 << wsub_shift) >> 1);
+  sg.wave = __builtin_amdgcn_readfirstlane(wave & ((1 << wsub_shift) - 1));
+  sg.tid = threadIdx.x & ((64 << wsub_shift) - 1);
+  sg.nthreads = 64 << wsub_shift;
+  sg.tmax_floor = -1;
+  if (G > 1) {
+    for (int u = 0; u < count; ++u) {
+      const int unit_u = order[first + u];
+      const int su = unit_u / kUnitsPerSource, qu = unit_u - su * kUnitsPerSource;
+      const int ux = src_xy[2 * su], uy = src_xy[2 * su + 1];
+      if (ux >= 0 && uy >= 0 && ux < m.nx && uy < m.ny) sg.tmax_floor = max(sg.tmax_floor, unit_tmax<R>(m, ux, uy, qu, sg.W));
+    }
+  }
+  bool live = sub < count;
+  int s = 0, q = 0, sx = 0, sy = 0;
+  if (live) {
+    const int unit = order ? order[first + sub] : first;
+    s = unit / kUnitsPerSource;
+    q = unit - s * kUnitsPerSource;
+    sx = src_xy[2 * s];
+    sy = src_xy[2 * s + 1];
+    if (sx < 0 || sy < 0 || sx >= m.nx || sy >= m.ny) {
+      if (sg.tid == 0 && q == 0) atomicOr(err_flag, 1);
+      live = false;
+    }
+  }
+  if (!live) {  // vacant subgroup or rejected source: only attend the partners' barriers
+    for (int t = 0; t <= sg.tmax_floor; ++t) __syncthreads();
     return;
   }
   StoreEmit<OutT, MULTI> emit(out + (size_t)s * field_stride, m.nx, m.ny);
-  sweep_quadrant<R>(m, emit, sx, sy, q, lds);
+  sweep_quadrant<R>(m, emit, sx, sy, q, lds + (size_t)sub * sweep_lds_doubles(R, sg.W, MULTI), sg);
 }
 
 // ---------------------------------------------------------------------------
@@ -921,35 +1019,61 @@ vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict_
 // longest first.  order[k] = unit index; units of out-of-range sources sort last.
 // ---------------------------------------------------------------------------
 constexpr int kOrderBuckets = 1024;
-__global__ void __launch_bounds__(1024) vhp_order_units(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny,
-                                                        int* __restrict__ order) {
-  __shared__ int hist[kOrderBuckets];
-  __shared__ int start[kOrderBuckets];
+constexpr int kOrderClasses = 3;  // G = 1, 2, 4 units per workgroup
+// `pack_w` = strips per octant a full workgroup offers (W) when packing is wanted, 0 = no packing.
+// Outputs: order[] (unit indices: class-major, longest first inside a class) and one descriptor
+// per workgroup slot {first, count, G} (count 0 = vacant slot).
+__global__ void __launch_bounds__(1024) vhp_order_units(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int rows_per_strip,
+                                                        int pack_w, int* __restrict__ order, int4* __restrict__ wg_desc) {
+  __shared__ int hist[kOrderClasses * kOrderBuckets];
+  __shared__ int start[kOrderClasses * kOrderBuckets];
+  __shared__ int cls_n[kOrderClasses], cls_off[kOrderClasses], wg_off[kOrderClasses + 1];
   const int n_units = n_src * kUnitsPerSource;
   const int maxdim = max(nx, ny);
   auto bucket_of = [&](int u) {
     const int s = u / kUnitsPerSource, q = u - s * kUnitsPerSource;
     const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
-    if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return kOrderBuckets - 1;
+    if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return kOrderClasses * kOrderBuckets - 1;
     const int ni = (q == 0 || q == 3) ? nx - sx : sx;
     const int nj = (q < 2) ? ny - sy : sy;
     const int len = (ni <= 0 || nj <= 0) ? 0 : max(ni, nj);
-    // bucket 0 = longest
-    return (kOrderBuckets - 1) - (int)(((long long)len * (kOrderBuckets - 1)) / maxdim);
+    const int strips = (ni <= 0 || nj <= 0) ? 0 : (min(ni, nj) + rows_per_strip - 1) / rows_per_strip;
+    int cls = 0;  // G = 1
+    if (pack_w >= 4 && strips <= pack_w / 4) cls = 2;       // four units per workgroup
+    else if (pack_w >= 2 && strips <= pack_w / 2) cls = 1;  // two
+    // bucket 0 of a class = longest
+    return cls * kOrderBuckets + (kOrderBuckets - 1) - (int)(((long long)len * (kOrderBuckets - 1)) / maxdim);
   };
-  for (int b = threadIdx.x; b < kOrderBuckets; b += blockDim.x) hist[b] = 0;
+  for (int b = threadIdx.x; b < kOrderClasses * kOrderBuckets; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   for (int u = threadIdx.x; u < n_units; u += blockDim.x) atomicAdd(&hist[bucket_of(u)], 1);
   __syncthreads();
   if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int b = 0; b < kOrderBuckets; ++b) {
-      start[b] = acc;
-      acc += hist[b];
+    int acc = 0, wacc = 0;
+    for (int c = 0; c < kOrderClasses; ++c) {
+      cls_off[c] = acc;
+      for (int b = 0; b < kOrderBuckets; ++b) {
+        start[c * kOrderBuckets + b] = acc;
+        acc += hist[c * kOrderBuckets + b];
+      }
+      cls_n[c] = acc - cls_off[c];
+      wg_off[c] = wacc;
+      wacc += (cls_n[c] + (1 << c) - 1) >> c;
     }
+    wg_off[kOrderClasses] = wacc;
   }
   __syncthreads();
   for (int u = threadIdx.x; u < n_units; u += blockDim.x) order[atomicAdd(&start[bucket_of(u)], 1)] = u;
+  for (int w = threadIdx.x; w < n_units; w += blockDim.x) {
+    int4 d = make_int4(0, 0, 1, 0);
+    for (int c = 0; c < kOrderClasses; ++c) {
+      if (w >= wg_off[c] && w < wg_off[c + 1]) {
+        const int k = (w - wg_off[c]) << c;
+        d = make_int4(cls_off[c] + k, min(1 << c, cls_n[c] - k), 1 << c, 0);
+      }
+    }
+    wg_desc[w] = d;
+  }
 }
 
 // ---------------------------------------------------------------------------
