@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5", "c1k-empty"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5", "c1k-empty", "c3-1024", "c3-1016", "c3-512"])
     ap.add_argument("--sources", type=int, default=0, help="sources per GPU (default: workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--gather", action="store_true", help="all-gather the fields over RCCL inside the timed region")
@@ -54,6 +54,12 @@ def make_workload(name, rank, n_src):
         occ = synth.random_rect_map(1000, 1000, 50, 20, 100, 20, 100, seed=1)
         src = synth.free_sources(occ, n, seed=7 + 1000 * rank)
         label = "C3: 1000x1000 random grid (50 rectangles 20..100, map seed 1), %d seeded sources per GPU" % n
+    elif name in ("c3-1024", "c3-1016", "c3-512"):  # diagnostic: C3 on a pitch that is a multiple of 128 B / of 64 B only
+        side = int(name.split("-")[1])
+        n = n_src or 256
+        occ = synth.random_rect_map(side, side, 50, 20, 100, 20, 100, seed=1)
+        src = synth.free_sources(occ, n, seed=7 + 1000 * rank)
+        label = "C3 variant: %dx%d random grid, %d seeded sources per GPU" % (side, side, n)
     elif name == "c5":
         n = n_src or 128
         occ = synth.random_rect_map(4096, 4096, 50, 80, 400, 80, 400, seed=1)

@@ -90,12 +90,8 @@ void pick_shape(int maxdim, int* R, int* W, bool* multi) {
   else { *R = 4; *W = 8; }
   if (const char* e = getenv("VHP_R")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) *R = v; }
   if (const char* e = getenv("VHP_W")) { int v = atoi(e); if (v >= 1 && v <= 8) *W = v; }
-  if (*R == 1) {  // the one-row-per-lane shape has no multi-round build: grow it to cover the front
-    while ((*W) * 64 < maxdim && *W < 8) *W *= 2;
-    if ((*W) * 64 < maxdim) *R = 2;
-  }
   *multi = (*W) * 64 * (*R) < maxdim;
-  if (const char* e = getenv("VHP_MULTI")) { if (atoi(e) == 1 && *R >= 2) *multi = true; }
+  if (const char* e = getenv("VHP_MULTI")) { if (atoi(e) == 1) *multi = true; }
   if (*R == 2 && *multi && *W > 4) *W = 4;  // that build is compiled for 8-wavefront workgroups
 }
 
@@ -173,7 +169,7 @@ hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out
   bool multi;
   pick_shape(std::max(c->nx, c->ny), &R, &W, &multi);
   switch (R) {
-    case 1: return launch_sweep_t<1, false, OutT>(c, d_src, n_src, d_out, W);
+    case 1: return multi ? launch_sweep_t<1, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<1, false, OutT>(c, d_src, n_src, d_out, W);
     case 2: return multi ? launch_sweep_t<2, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<2, false, OutT>(c, d_src, n_src, d_out, W);
     default: return multi ? launch_sweep_t<4, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<4, false, OutT>(c, d_src, n_src, d_out, W);
   }

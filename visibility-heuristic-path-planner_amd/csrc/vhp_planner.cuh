@@ -96,7 +96,7 @@ __device__ __forceinline__ PlannerKey key_shuffle_xor(const PlannerKey& k, int m
 // Step 1 of a planner iteration: the plain front sweep (vhp_sweep.cuh, fast path) from the
 // current pivot into vis_local -- the reference's visibility_ (solver.cpp:386-416).
 template <int R, bool MULTI>
-__global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (MULTI ? 6 : 8)) vhp_planner_sweep(DevMap m, PlannerDev d) {
+__global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : ((MULTI && R == 2) ? 6 : 8)) vhp_planner_sweep(DevMap m, PlannerDev d) {
   extern __shared__ double lds[];
   if (d.ctl->done) return;
   const int nb = d.ctl->nb;
@@ -321,7 +321,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   const int batch = 4;  // iterations enqueued per host poll
   for (;;) {
     for (int b = 0; b < batch; ++b) {
-      hipError_t e = R == 1 ? launch_planner_fronts<1, false>(m, d, W, stream)
+      hipError_t e = R == 1 ? (multi ? launch_planner_fronts<1, true>(m, d, W, stream) : launch_planner_fronts<1, false>(m, d, W, stream))
                    : R == 2 ? (multi ? launch_planner_fronts<2, true>(m, d, W, stream) : launch_planner_fronts<2, false>(m, d, W, stream))
                             : (multi ? launch_planner_fronts<4, true>(m, d, W, stream) : launch_planner_fronts<4, false>(m, d, W, stream));
       if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }

@@ -62,8 +62,13 @@ namespace vhp {
 constexpr int kChunk = 8;        // marching-coordinate cells per pipeline slot (aligned): one 8-step window
 constexpr int kRing = 32;        // entries of a boundary ring (>= 4*kChunk), indexed by marching coordinate & (kRing-1);
                                  // sized so that a 16-wavefront workgroup at 1000^2 needs < 80 KB of LDS (two per CU)
-constexpr int kTileCols = 8;     // columns staged per flush = 64 B of fp64
-constexpr int kTileStride = 9;   // doubles per staged row (odd: spreads column writes over banks)
+constexpr int kTileCols = 8;     // columns computed per window = 64 B of fp64
+// Staging tile of an x-major strip: the 8 columns of the current window, one row of `tile_stride(R)` doubles per
+// strip row (odd: spreads the column writes over the LDS banks).  (A 16-column ring that lets two windows leave
+// as one 128-byte line per row was tried for R == 1 -- the only shape whose LDS allows it -- and lost more in
+// instructions than it won in HBM efficiency: DESIGN.md section 10.)
+__host__ __device__ constexpr int tile_stride(int) { return 9; }
+__host__ __device__ constexpr int tile_cols(int) { return 8; }
 constexpr int kUnitsPerSource = 4;
 constexpr int kYLag = 2;         // y-major strips run this many slots behind the x-major ones (they consume diag(k))
 constexpr int kStage = 128;      // LDS staging of a boundary row that arrives from the previous round (per octant)
@@ -148,7 +153,18 @@ __device__ __forceinline__ double load_shared_f64(const double* p) {
 
 struct UnitGeom {
   int sx, sy, ni, nj;
+  int ya;  // y-major strips own columns [p*S - ya, (p+1)*S - ya): the grid is slid so that a strip's row
+           // segment starts on a 128-byte line of the output (partial 64-byte sectors cost a read-modify-write)
 };
+
+// Slide of the y-major column grid for a quadrant (0 .. 15), 0 if the slid grid would need one strip more
+// than `max_strips`.
+template <int DX>
+__device__ __forceinline__ int y_grid_slide(int sx, int cols_total, int S, int max_strips) {
+  // DX > 0: strip p starts at x = sx + p*S - ya;  DX < 0: its lowest x is sx - (p+1)*S + 1 + ya
+  const int a = DX > 0 ? (sx & 15) : ((-(sx + 1)) & 15);
+  return (cols_total + a + S - 1) / S <= max_strips ? a : 0;
+}
 
 // A workgroup sweeps one quadrant with all its wavefronts, or -- packing -- several short
 // quadrants side by side, each with an equal share ("subgroup") of the wavefronts and of the LDS.
@@ -193,6 +209,8 @@ __device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
 // ~60-80 cycles whether or not its lanes are dropped.)
 #ifdef VHP_EXP_NOSTORE  // diagnostic builds only (tools/): all the work, none of the stores
 #define VHP_EXP_STORE_GUARD if (nx != 0x7fffffff) return;
+#elif defined(VHP_EXP_NOSTORE_X) || defined(VHP_EXP_NOSTORE_Y)  // one octant's stores dropped
+#define VHP_EXP_STORE_GUARD if (nx == -12345) return;
 #elif defined(VHP_EXP_SMALLSTORE)  // all stores issued, into a 64 KB window per field: no HBM traffic
 #define VHP_EXP_STORE_GUARD off &= 0xffffu;
 #else
@@ -222,7 +240,13 @@ struct StoreEmit {
     else if (one)
       *reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off + (uint32_t)(sel * kCellBytes)) = static_cast<OutT>(vs);
   }
+  // one cell at byte offset off
+  __device__ __forceinline__ void single_at(uint32_t off, int, int, double v) {
+    VHP_EXP_STORE_GUARD
+    *reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off) = static_cast<OutT>(v);
+  }
   __device__ __forceinline__ void pair(int x, int y, double v0, double v1, bool ok0, bool ok1) {
+    VHP_EXP_STORE_GUARD
     OutT* p = out + (size_t)y * nx + x;
     if (ok0) p[0] = static_cast<OutT>(v0);
     if (ok1) p[1] = static_cast<OutT>(v1);
@@ -235,8 +259,14 @@ struct StoreEmit {
 // x = sx + DX*i, y = sy + DY*j.
 // ---------------------------------------------------------------------------
 template <int R, int DX, int DY, typename Emit>
-__device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitGeom g, const StripSlot ss, double* ring_base,
+__device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const UnitGeom g, const StripSlot ss, double* ring_base,
                                         double* tile, double* diag_ring) {
+#ifdef VHP_EXP_NOSTORE_X
+  Emit emit = emit_;
+  emit.nx = -12345;
+#else
+  Emit& emit = emit_;
+#endif
   const int p = ss.pg, tmax = ss.tmax;
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
@@ -275,6 +305,8 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
     dmask[r] = 0;
     if (strip_on) dmask[r] = ((m.rows[(size_t)y * m.wpr + 1 + (xd >> 6)] >> (xd & 63)) & 1ull) ? -1 : 0;
   }
+  constexpr int kTileStride = tile_stride(R);
+  constexpr int kRingCols = tile_cols(R);
   double* tile_lane = tile + R * lane * kTileStride;
   // flush geometry: lane <-> (row-in-group = lane>>2, column pair = lane&3), 16 rows x 64 B per pass
   const int cp = lane & 3, rsub = lane >> 2;
@@ -356,7 +388,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       prev[r] = v[r];
-      tile_lane[r * kTileStride + (x & (kTileCols - 1))] = v[r];
+      tile_lane[r * kTileStride + (x & (kRingCols - 1))] = v[r];
     }
     if (has_consumer && lane == 63) {
       ring_out[x & (kRing - 1)] = v[R - 1];
@@ -377,7 +409,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
         double ta[2], tb[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const double* q = tile + (rb + 16 * u + rsub) * kTileStride + 2 * cp;
+          const double* q = tile + (rb + 16 * u + rsub) * kTileStride + ((xbase + 2 * cp) & (kRingCols - 1));
           ta[u] = q[0];
           tb[u] = q[1];
         }
@@ -422,6 +454,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
     double ringv = 0.0;
     if (PROD) ringv = ring_in[(x0 - DX + DX * lane) & rin_mask];
     double* ring_w = ring_out + (xb & (kRing - 1));
+    double* tile_win = tile_lane + (xb & (kRingCols - 1));  // R == 1: the window's half of the 16-column ring
     double di = (double)i;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -475,7 +508,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         prev[r] = v[r];
-        tile_lane[r * kTileStride + col] = v[r];
+        tile_win[r * kTileStride + col] = v[r];
       }
       if (lane == 63) {
         ring_w[col] = v[R - 1];
@@ -490,7 +523,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
     const uint32_t off0 = flush_lane_off + (uint32_t)(xb * CB);
     const int xc = xb + 2 * cp;
     const int y0 = g.sy + DY * (j0 + rsub);
-    const double* q0 = tile + rsub * kTileStride + 2 * cp;
+    const double* q0 = tile + rsub * kTileStride + 2 * cp + (xb & (kRingCols - 1));
     if (DIAG) {
       // staged cell (column step ic, row j) is real iff j <= ic: below the diagonal both cells of
       // a pair are, on the diagonal only the later column's
@@ -559,7 +592,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
       while (i <= ihi) {
         const int x = g.sx + DX * i;
         const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
-        if (Emit::kFastPath && R >= 2 && aligned && i + 7 <= ihi) {
+        if (Emit::kFastPath && aligned && i + 7 <= ihi) {
           const bool steady = i >= j0 + S;
           using P0 = std::integral_constant<int, 0>;
           using P1 = std::integral_constant<int, 1>;
@@ -588,19 +621,26 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit, const UnitG
 // y-major strip: columns i = i0 + R*lane + r, steps j = i0 .. nj-1, cells (i, j), j > i.
 // ---------------------------------------------------------------------------
 template <int R, int DX, int DY, typename Emit>
-__device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitGeom g, const StripSlot ss, double* ring_base,
+__device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const UnitGeom g, const StripSlot ss, double* ring_base,
                                         const double* diag_ring) {
+#ifdef VHP_EXP_NOSTORE_Y
+  Emit emit = emit_;
+  emit.nx = -12345;
+#else
+  Emit& emit = emit_;
+#endif
   const int p = ss.pg, tmax = ss.tmax;
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
   const int lane = threadIdx.x & 63;
   const int cols_total = max(min(g.ni, g.nj - 1), 0);
-  const int P = (cols_total + S - 1) / S;
-  const int i0 = p * S;
+  const int P = (cols_total + g.ya + S - 1) / S;
+  const int i0 = p * S - g.ya;      // < 0 for strip 0 of a slid grid: its first ya columns do not exist
+  const int jstart = max(i0, 0);    // first step of the strip
   const bool strip_on = p < P;
   const bool has_consumer = p + 1 < P;
   const int nlast = chunk_seq<DY>(g.sy, g.nj - 1);
-  const int nfirst = chunk_seq<DY>(g.sy, min(i0, g.nj - 1));
+  const int nfirst = chunk_seq<DY>(g.sy, min(jstart, g.nj - 1));
   double* ring_out = ring_base + ss.w * kRing;
   constexpr bool kMulti = Emit::kMulti;  // sweeping in rounds is compiled in only where the launch shape needs it
   const bool from_prev_round = kMulti && ss.w == 0 && p > 0;
@@ -615,7 +655,8 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
   // the lane's R columns are x-consecutive; xlo = the lowest x among them
   const int icol0 = i0 + R * lane;
   const int xlo = DX > 0 ? g.sx + icol0 : g.sx - icol0 - (R - 1);
-  const bool all_cols = strip_on && i0 + S <= cols_total;  // every lane's every column is real
+  const bool all_cols = strip_on && i0 + S <= cols_total;  // every lane's every column < cols_total
+  const bool head = i0 < 0;                                 // ... but columns icol < 0 are not real
   const bool edge_free = strip_on && i0 + S <= g.ni && i0 + S <= g.nj;  // the diagonal cells (k,k) of all this strip's columns exist
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -635,7 +676,7 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = icol0 + r;
-      const int x = (strip_on && i < g.ni) ? g.sx + DX * i : g.sx;
+      const int x = (strip_on && i >= 0 && i < g.ni) ? g.sx + DX * i : g.sx;
       ow[r] = m.cols[(size_t)x * m.wpc + 1 + blk];
     }
     pin_loaded(rv);
@@ -679,10 +720,10 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
 #pragma unroll
     for (int r = 0; r < R; r += 2) {
       if (R == 1) {
-        emit.pair(xlo, y, v[0], 0.0, icol0 < j && icol0 < cols_total, false);
+        emit.pair(xlo, y, v[0], 0.0, icol0 >= 0 && icol0 < j && icol0 < cols_total, false);
       } else {
         const int ia = icol0 + r, ib = ia + 1;
-        const bool oka = ia < j && ia < cols_total, okb = ib < j && ib < cols_total;
+        const bool oka = ia >= 0 && ia < j && ia < cols_total, okb = ib >= 0 && ib < j && ib < cols_total;
         if (DX > 0)
           emit.pair(xlo + r, y, v[r], v[r + 1 < R ? r + 1 : r], oka, okb);
         else
@@ -706,9 +747,11 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
 
   // fast window: 8 steps j..j+7 inside one 8-aligned window of y, strip past its diagonal
   // (j >= i0 + S) and entirely inside the octant (all_cols): every lane stores every step
-  auto fast_window = [&](int j, auto diag_tag, auto prod_tag) {
+  auto fast_window = [&](int j, auto diag_tag, auto prod_tag, auto head_tag) {
     constexpr bool DIAG = decltype(diag_tag)::value;  // triangular start-up: seeding, ragged stores
     constexpr bool PROD = decltype(prod_tag)::value;  // a strip below feeds lane 0 (p > 0)
+    constexpr bool HEAD = decltype(head_tag)::value;  // strip 0 of a slid grid: columns icol < 0 are not stored
+    static_assert(!(HEAD && PROD), "only strip 0 has a head");
     const int y0 = g.sy + DY * j;
     const int yb = y0 & ~7;
     const int blk = y0 >> 6, t0 = y0 & 63;
@@ -750,6 +793,9 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
         const double dg = read_lane(dgv, k);
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = ((icol0 + r) == jk) ? dg : v[r];
+        if constexpr (R == 1) {
+          if (icol0 < jk && (!HEAD || icol0 >= 0)) emit.single_at(off, xlo, y, v[0]);
+        }
         // ragged stores.  For a pair of columns (ia, ia+1) with ia < jk either both are below the
         // diagonal, or ia+1 == jk: then the second cell is the diagonal cell (jk,jk) itself, which the
         // seeding has just put into v -- the x-major strip stores the same value there.  So away from
@@ -757,7 +803,14 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
         // not at all.
 #pragma unroll
         for (int r = 0; r + 1 < R; r += 2) {
-          if ((icol0 + r) < jk) {
+          const int ia = icol0 + r;
+          if (HEAD) {  // (ia, ia+1) = (-1, 0): only column 0 exists
+            if (DX > 0)
+              emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1], ia >= 0 && ia < jk, ia == -1 && 0 < jk, 1, v[r + 1]);
+            else
+              emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r], ia >= 0 && ia < jk,
+                                     ia == -1 && 0 < jk, 0, v[r + 1]);
+          } else if (ia < jk) {
             if (DX > 0)
               emit.pair_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1]);
             else
@@ -765,9 +818,18 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
           }
         }
       } else {
+        if constexpr (R == 1) {
+          if (!HEAD || icol0 >= 0) emit.single_at(off, xlo, y, v[0]);
+        }
 #pragma unroll
         for (int r = 0; r + 1 < R; r += 2) {
-          if (DX > 0)
+          if (HEAD) {
+            const int ia = icol0 + r;
+            if (DX > 0)
+              emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1], ia >= 0, ia == -1, 1, v[r + 1]);
+            else
+              emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r], ia >= 0, ia == -1, 0, v[r + 1]);
+          } else if (DX > 0)
             emit.pair_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1]);
           else
             emit.pair_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r]);
@@ -791,20 +853,23 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit, const UnitG
     if (strip_on && n >= nfirst && n <= nlast) {
       int jlo, jhi;
       chunk_steps<DY>(g.sy, n, &jlo, &jhi);
-      jlo = max(jlo, i0);
+      jlo = max(jlo, jstart);
       jhi = min(jhi, g.nj - 1);
       int j = jlo;
       while (j <= jhi) {
         const int y = g.sy + DY * j;
         const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
         const bool steady = all_cols && j >= i0 + S;
-        if (Emit::kFastPath && R >= 2 && aligned && j + 7 <= jhi && (steady || edge_free)) {
+        if (Emit::kFastPath && aligned && j + 7 <= jhi && (steady || edge_free)) {
           if (p > 0) {
-            if (steady) fast_window(j, std::false_type(), std::true_type());
-            else fast_window(j, std::true_type(), std::true_type());
+            if (steady) fast_window(j, std::false_type(), std::true_type(), std::false_type());
+            else fast_window(j, std::true_type(), std::true_type(), std::false_type());
+          } else if (head) {
+            if (steady) fast_window(j, std::false_type(), std::false_type(), std::true_type());
+            else fast_window(j, std::true_type(), std::false_type(), std::true_type());
           } else {
-            if (steady) fast_window(j, std::false_type(), std::false_type());
-            else fast_window(j, std::true_type(), std::false_type());
+            if (steady) fast_window(j, std::false_type(), std::false_type(), std::false_type());
+            else fast_window(j, std::true_type(), std::false_type(), std::false_type());
           }
           j += 8;
         } else {
@@ -839,7 +904,7 @@ inline hipError_t attach_round_scratch(DevMap& m, int rows_per_round, size_t n_w
 // LDS of one subgroup with W strips per octant: x rings, y rings, the diagonal ring, (multi-round
 // shapes) two boundary staging areas, W staging tiles.  In doubles.
 __host__ __device__ inline size_t sweep_lds_doubles(int R, int W, bool multi) {
-  return (size_t)2 * W * kRing + kRing + (multi ? 2 * kStage : 0) + (size_t)W * 64 * R * kTileStride;
+  return (size_t)2 * W * kRing + kRing + (multi ? 2 * kStage : 0) + (size_t)W * 64 * R * tile_stride(R);
 }
 // Dynamic LDS of a launch with W strips per octant per workgroup; packing (G subgroups of W/G
 // strips) must fit too.
@@ -867,7 +932,8 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
   }
   const int rows_total = min(g.nj, g.ni);
   const int cols_total = max(min(g.ni, g.nj - 1), 0);
-  const int Px = (rows_total + S - 1) / S, Py = (cols_total + S - 1) / S;
+  g.ya = y_grid_slide<DX>(sx, cols_total, S, Emit::kMulti ? INT32_MAX / S - 1 : W);
+  const int Px = (rows_total + S - 1) / S, Py = (cols_total + g.ya + S - 1) / S;
   double* ring_x = lds;
   double* ring_y = lds + (size_t)W * kRing;
   double* diag_ring = lds + (size_t)2 * W * kRing;
@@ -880,7 +946,7 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
   for (int rho = 0; rho < rounds; ++rho) {
     const int pg0 = rho * W;
     const int nbase_x = chunk_seq<DX>(sx, min(pg0 * S, g.ni - 1));
-    const int nbase_y = chunk_seq<DY>(sy, min(pg0 * S, g.nj - 1));
+    const int nbase_y = chunk_seq<DY>(sy, min(max(pg0 * S - g.ya, 0), g.nj - 1));
     const int wx = max(min(Px - pg0, W), 1), wy = max(min(Py - pg0, W), 1);
     StripSlot ss;
     ss.tmax = max(max(chunk_seq<DX>(sx, g.ni - 1) - nbase_x + wx - 1, chunk_seq<DY>(sy, g.nj - 1) - nbase_y + wy - 1 + kYLag),
@@ -893,7 +959,7 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
       ss.bnd_in = bnd ? bnd + ((rho + 1) & 1) * m.bnd_len : nullptr;
       ss.bnd_out = bnd ? bnd + (rho & 1) * m.bnd_len : nullptr;
       ss.stage = stage;
-      x_strip<R, DX, DY>(m, emit, g, ss, ring_x, tiles + (size_t)wave * S * kTileStride, diag_ring);
+      x_strip<R, DX, DY>(m, emit, g, ss, ring_x, tiles + (size_t)wave * S * tile_stride(R), diag_ring);
     } else {
       ss.pg = pg0 + wave - W;
       ss.w = wave - W;
@@ -920,7 +986,9 @@ __device__ __forceinline__ int unit_tmax(const DevMap& m, int sx, int sy, int q,
   const bool px = (q == 0 || q == 3), py = q < 2;
   const int ni = px ? m.nx - sx : sx, nj = py ? m.ny - sy : sy;
   if (ni <= 0 || nj <= 0) return -1;
-  const int Px = (min(nj, ni) + S - 1) / S, Py = (max(min(ni, nj - 1), 0) + S - 1) / S;
+  const int cols_total = max(min(ni, nj - 1), 0);
+  const int ya = px ? y_grid_slide<+1>(sx, cols_total, S, W) : y_grid_slide<-1>(sx, cols_total, S, W);
+  const int Px = (min(nj, ni) + S - 1) / S, Py = (cols_total + ya + S - 1) / S;
   const int wx = max(min(Px, W), 1), wy = max(min(Py, W), 1);
   const int nx_last = px ? chunk_seq<+1>(sx, ni - 1) : chunk_seq<-1>(sx, ni - 1);
   const int ny_last = py ? chunk_seq<+1>(sy, nj - 1) : chunk_seq<-1>(sy, nj - 1);
@@ -959,7 +1027,7 @@ __device__ __forceinline__ SubGroup whole_workgroup() {
 // Register budgets: R <= 2 single-round shapes fit 64 VGPRs so two 16-wavefront workgroups share a
 // CU; the R = 2 multi-round shape runs 8-wavefront workgroups, three per CU.
 template <int R, bool MULTI, typename OutT>
-__global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (MULTI ? 6 : 8))
+__global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : ((MULTI && R == 2) ? 6 : 8))
 vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
                  int* __restrict__ err_flag, const int* __restrict__ order, const int4* __restrict__ wg_desc) {
   extern __shared__ double lds[];
