@@ -155,6 +155,14 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     (void)hipEventRecord(ta, c->stream);
   }
   hipLaunchKernelGGL(k, dim3((unsigned)n_units), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order, desc);
+#ifdef VHP_EXP_WGTIME
+  if (n_units <= 4 * 4096) {
+    (void)hipStreamSynchronize(c->stream);
+    std::vector<unsigned long long> h(3 * n_units);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(vhp::g_wgtime), h.size() * 8);
+    if (FILE* f = fopen("gpurun_out/wgtime.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+  }
+#endif
   const hipError_t el = hipGetLastError();
   if (c->timing) {
     (void)hipEventRecord(tb, c->stream);

@@ -1023,6 +1023,9 @@ __device__ __forceinline__ SubGroup whole_workgroup() {
   return sg;
 }
 
+#ifdef VHP_EXP_WGTIME
+__device__ unsigned long long g_wgtime[3 * 4 * 4096];
+#endif
 // grid = n_src * 4 workgroups of 128*W threads; dynamic LDS = sweep_lds_bytes(R, W)
 // Register budgets: R <= 2 single-round shapes fit 64 VGPRs so two 16-wavefront workgroups share a
 // CU; the R = 2 multi-round shape runs 8-wavefront workgroups, three per CU.
@@ -1078,7 +1081,22 @@ vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict_
     return;
   }
   StoreEmit<OutT, MULTI> emit(out + (size_t)s * field_stride, m.nx, m.ny);
+#ifdef VHP_EXP_WGTIME  // diagnostic builds only: start/end time (100 MHz) and hardware id of each workgroup
+  const unsigned long long wg_t0 = wall_clock64();
+#endif
   sweep_quadrant<R>(m, emit, sx, sy, q, lds + (size_t)sub * sweep_lds_doubles(R, sg.W, MULTI), sg);
+#ifdef VHP_EXP_WGTIME
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long* w = g_wgtime + 3 * (size_t)(s * kUnitsPerSource + q);
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    w[0] = wg_t0;
+    w[1] = wall_clock64();
+    w[2] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1101,7 +1119,7 @@ __global__ void __launch_bounds__(1024) vhp_order_units(const int32_t* __restric
   auto bucket_of = [&](int u) {
     const int s = u / kUnitsPerSource, q = u - s * kUnitsPerSource;
     const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
-    if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return kOrderClasses * kOrderBuckets - 1;
+    if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return (pack_w ? kOrderClasses : 1) * kOrderBuckets - 1;  // rejected by the sweep kernel: last
     const int ni = (q == 0 || q == 3) ? nx - sx : sx;
     const int nj = (q < 2) ? ny - sy : sy;
     const int len = (ni <= 0 || nj <= 0) ? 0 : max(ni, nj);
@@ -1112,21 +1130,47 @@ __global__ void __launch_bounds__(1024) vhp_order_units(const int32_t* __restric
     // bucket 0 of a class = longest
     return cls * kOrderBuckets + (kOrderBuckets - 1) - (int)(((long long)len * (kOrderBuckets - 1)) / maxdim);
   };
-  for (int b = threadIdx.x; b < kOrderClasses * kOrderBuckets; b += blockDim.x) hist[b] = 0;
+  for (int b = threadIdx.x; b < (pack_w ? kOrderClasses : 1) * kOrderBuckets; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   for (int u = threadIdx.x; u < n_units; u += blockDim.x) atomicAdd(&hist[bucket_of(u)], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0, wacc = 0;
-    for (int c = 0; c < kOrderClasses; ++c) {
+  // exclusive prefix sums of the histogram, class after class: a wavefront scan by DPP-free shuffles, the 16
+  // wavefront totals by the first wavefront (blockDim.x == kOrderBuckets: thread t owns bucket t of every class)
+  __shared__ int wave_tot[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int acc = 0, wacc = 0;  // identical in every thread
+  for (int c = 0; c < (pack_w ? kOrderClasses : 1); ++c) {
+    const int v = hist[c * kOrderBuckets + threadIdx.x];
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int t = wave_tot[k];
+      before += k < wv ? t : 0;
+      total += t;
+    }
+    start[c * kOrderBuckets + threadIdx.x] = acc + before + inc - v;
+    if (threadIdx.x == 0) {
       cls_off[c] = acc;
-      for (int b = 0; b < kOrderBuckets; ++b) {
-        start[c * kOrderBuckets + b] = acc;
-        acc += hist[c * kOrderBuckets + b];
-      }
-      cls_n[c] = acc - cls_off[c];
+      cls_n[c] = total;
       wg_off[c] = wacc;
-      wacc += (cls_n[c] + (1 << c) - 1) >> c;
+    }
+    acc += total;
+    wacc += (total + (1 << c) - 1) >> c;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    for (int c = pack_w ? kOrderClasses : 1; c < kOrderClasses; ++c) {
+      cls_off[c] = acc;
+      cls_n[c] = 0;
+      wg_off[c] = wacc;
     }
     wg_off[kOrderClasses] = wacc;
   }
