@@ -155,6 +155,14 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     (void)hipEventRecord(ta, c->stream);
   }
   hipLaunchKernelGGL(k, dim3((unsigned)n_units), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order, desc);
+#ifdef VHP_EXP_SLOTTIME
+  {
+    (void)hipStreamSynchronize(c->stream);
+    std::vector<unsigned long long> h(4 * 16 * 160 * 2);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(vhp::g_slottime), h.size() * 8);
+    if (FILE* f = fopen("gpurun_out/slottime.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+  }
+#endif
 #ifdef VHP_EXP_WGTIME
   if (n_units <= 4 * 4096) {
     (void)hipStreamSynchronize(c->stream);

@@ -86,6 +86,9 @@ struct DevMap {
   int bnd_len;
 };
 
+#ifdef VHP_EXP_SLOTTIME
+__device__ unsigned long long g_slottime[4 * 16 * 160 * 2];
+#endif
 // the reciprocal table never changes during a launch: wave-uniform reads through the
 // constant address space become scalar loads
 typedef const __attribute__((address_space(4))) double* crecip_p;
@@ -613,7 +616,17 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
         }
       }
     }
+#ifdef VHP_EXP_SLOTTIME  // diagnostic builds only: when each wavefront reaches and leaves each slot's barrier
+    const unsigned long long st_a = wall_clock64();
     __syncthreads();
+    if ((threadIdx.x & 63) == 0 && T < 160) {
+      unsigned long long* w = g_slottime + ((size_t)(blockIdx.x & 3) * 16 + (threadIdx.x >> 6)) * 160 * 2 + 2 * T;
+      w[0] = st_a;
+      w[1] = wall_clock64();
+    }
+#else
+    __syncthreads();
+#endif
   }
 }
 
@@ -745,13 +758,15 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const Unit
     }
   };
 
-  // fast window: 8 steps j..j+7 inside one 8-aligned window of y, strip past its diagonal
-  // (j >= i0 + S) and entirely inside the octant (all_cols): every lane stores every step
-  auto fast_window = [&](int j, auto diag_tag, auto prod_tag, auto head_tag) {
+  // fast window: 8 steps j..j+7 covering one 8-aligned window of y
+  auto fast_window = [&](int j, auto diag_tag, auto prod_tag, auto edge_tag) {
     constexpr bool DIAG = decltype(diag_tag)::value;  // triangular start-up: seeding, ragged stores
     constexpr bool PROD = decltype(prod_tag)::value;  // a strip below feeds lane 0 (p > 0)
-    constexpr bool HEAD = decltype(head_tag)::value;  // strip 0 of a slid grid: columns icol < 0 are not stored
-    static_assert(!(HEAD && PROD), "only strip 0 has a head");
+    // EDGE: not every column of the strip is real -- strip 0 of a slid grid owns columns icol < 0, the last
+    // strip of an octant columns >= cols_total.  Those lanes compute on (nothing depends on them: a column
+    // only feeds higher ones, and the ragged strip has no consumer) but never store.
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    auto real = [&](int icol) { return icol >= 0 && icol < cols_total; };
     const int y0 = g.sy + DY * j;
     const int yb = y0 & ~7;
     const int blk = y0 >> 6, t0 = y0 & 63;
@@ -794,22 +809,23 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const Unit
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = ((icol0 + r) == jk) ? dg : v[r];
         if constexpr (R == 1) {
-          if (icol0 < jk && (!HEAD || icol0 >= 0)) emit.single_at(off, xlo, y, v[0]);
+          if (icol0 < jk && (!EDGE || real(icol0))) emit.single_at(off, xlo, y, v[0]);
         }
         // ragged stores.  For a pair of columns (ia, ia+1) with ia < jk either both are below the
         // diagonal, or ia+1 == jk: then the second cell is the diagonal cell (jk,jk) itself, which the
         // seeding has just put into v -- the x-major strip stores the same value there.  So away from
-        // the quadrant's right edge (edge_free, a precondition of this window) a pair is stored whole or
-        // not at all.
+        // the edges of the octant a pair is stored whole or not at all.
 #pragma unroll
         for (int r = 0; r + 1 < R; r += 2) {
           const int ia = icol0 + r;
-          if (HEAD) {  // (ia, ia+1) = (-1, 0): only column 0 exists
+          if (EDGE) {  // one cell of the pair may not exist
+            const bool oka = ia < jk && real(ia), okb = ia < jk && real(ia + 1);
+            const double vs = oka ? v[r] : v[r + 1];
             if (DX > 0)
-              emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1], ia >= 0 && ia < jk, ia == -1 && 0 < jk, 1, v[r + 1]);
+              emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1], oka && okb, oka != okb, oka ? 0 : 1, vs);
             else
-              emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r], ia >= 0 && ia < jk,
-                                     ia == -1 && 0 < jk, 0, v[r + 1]);
+              emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r], oka && okb, oka != okb,
+                                     oka ? 1 : 0, vs);
           } else if (ia < jk) {
             if (DX > 0)
               emit.pair_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1]);
@@ -819,16 +835,19 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const Unit
         }
       } else {
         if constexpr (R == 1) {
-          if (!HEAD || icol0 >= 0) emit.single_at(off, xlo, y, v[0]);
+          if (!EDGE || real(icol0)) emit.single_at(off, xlo, y, v[0]);
         }
 #pragma unroll
         for (int r = 0; r + 1 < R; r += 2) {
-          if (HEAD) {
+          if (EDGE) {
             const int ia = icol0 + r;
+            const bool oka = real(ia), okb = real(ia + 1);
+            const double vs = oka ? v[r] : v[r + 1];
             if (DX > 0)
-              emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1], ia >= 0, ia == -1, 1, v[r + 1]);
+              emit.pair_or_single_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1], oka && okb, oka != okb, oka ? 0 : 1, vs);
             else
-              emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r], ia >= 0, ia == -1, 0, v[r + 1]);
+              emit.pair_or_single_at(off + (uint32_t)((R - 2 - r) * CB), xlo + (R - 2 - r), y, v[r + 1], v[r], oka && okb, oka != okb,
+                                     oka ? 1 : 0, vs);
           } else if (DX > 0)
             emit.pair_at(off + (uint32_t)(r * CB), xlo + r, y, v[r], v[r + 1]);
           else
@@ -859,17 +878,27 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const Unit
       while (j <= jhi) {
         const int y = g.sy + DY * j;
         const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
-        const bool steady = all_cols && j >= i0 + S;
-        if (Emit::kFastPath && aligned && j + 7 <= jhi && (steady || edge_free)) {
+        if (Emit::kFastPath && aligned && j + 7 <= jhi) {
+          const bool steady = j >= i0 + S;                      // every column of the strip has started
+          const bool edge = head || !all_cols || !edge_free;    // some of its columns are not real
+          using T1 = std::true_type;
+          using T0 = std::false_type;
           if (p > 0) {
-            if (steady) fast_window(j, std::false_type(), std::true_type(), std::false_type());
-            else fast_window(j, std::true_type(), std::true_type(), std::false_type());
-          } else if (head) {
-            if (steady) fast_window(j, std::false_type(), std::false_type(), std::true_type());
-            else fast_window(j, std::true_type(), std::false_type(), std::true_type());
+            if (edge) {
+              if (steady) fast_window(j, T0(), T1(), T1());
+              else fast_window(j, T1(), T1(), T1());
+            } else {
+              if (steady) fast_window(j, T0(), T1(), T0());
+              else fast_window(j, T1(), T1(), T0());
+            }
           } else {
-            if (steady) fast_window(j, std::false_type(), std::false_type(), std::false_type());
-            else fast_window(j, std::true_type(), std::false_type(), std::false_type());
+            if (edge) {
+              if (steady) fast_window(j, T0(), T0(), T1());
+              else fast_window(j, T1(), T0(), T1());
+            } else {
+              if (steady) fast_window(j, T0(), T0(), T0());
+              else fast_window(j, T1(), T0(), T0());
+            }
           }
           j += 8;
         } else {
@@ -878,7 +907,17 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const Unit
         }
       }
     }
+#ifdef VHP_EXP_SLOTTIME  // diagnostic builds only: when each wavefront reaches and leaves each slot's barrier
+    const unsigned long long st_a = wall_clock64();
     __syncthreads();
+    if ((threadIdx.x & 63) == 0 && T < 160) {
+      unsigned long long* w = g_slottime + ((size_t)(blockIdx.x & 3) * 16 + (threadIdx.x >> 6)) * 160 * 2 + 2 * T;
+      w[0] = st_a;
+      w[1] = wall_clock64();
+    }
+#else
+    __syncthreads();
+#endif
   }
 }
 
