@@ -72,6 +72,19 @@ def test_multi_strip_sizes(vhp, oracle, side):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "side %d source %d" % (side, k))
 
 
+@pytest.mark.parametrize("nx,ny", [(101, 77), (300, 263), (1000, 1000), (1500, 1100)])
+def test_slid_column_grid_bit_exact(vhp, oracle, monkeypatch, nx, ny):
+    # large batches slide the y-major column grid onto 128-byte lines (strip 0 then owns columns that do
+    # not exist); force that path for a small batch and compare cell by cell
+    monkeypatch.setenv("VHP_SLIDE", "1")
+    occ = maps.random_rect_map(nx, ny, 30, 3, max(nx // 8, 4), 3, max(ny // 8, 4), nx + ny)
+    src = np.concatenate([maps.free_sources(occ, 5, nx), np.array([(0, 0), (nx - 1, ny - 1), (nx - 1, 0), (1, ny - 2)], np.int32)])
+    occ[src[:, 1], src[:, 0]] = 1
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d slid grid, source (%d,%d)" % (nx, ny, sx, sy))
+
+
 def test_config3_1000x1000_subset(vhp, oracle):
     occ, src = maps.config_c3(256)
     pick = src[[0, 17, 101, 255]]

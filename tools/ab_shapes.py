@@ -22,9 +22,11 @@ res = {c: [] for c in cfgs}
 for rep in range(6):
     for c in cfgs:
         parts = c.split()
-        for k in ("VHP_R", "VHP_W", "VHP_MULTI"):
+        for k in ("VHP_R", "VHP_W", "VHP_MULTI", "VHP_SLIDE"):
             os.environ.pop(k, None)
-        if parts[0] != "-":
+        if parts[0].startswith("slide"):
+            os.environ["VHP_SLIDE"] = parts[0][5:]
+        elif parts[0] != "-":
             os.environ["VHP_R"], os.environ["VHP_W"] = parts[0], parts[1]
             if len(parts) > 2:
                 os.environ["VHP_MULTI"] = parts[2]

@@ -75,6 +75,7 @@ vhp::DevMap dev_map(const vhp_ctx* c) {
   m.ny = c->ny;
   m.bnd = nullptr;
   m.bnd_len = 0;
+  m.slide = 0;  // set per launch (launch_sweep_t)
   return m;
 }
 
@@ -124,6 +125,11 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   }
   const long long stride = (long long)c->nx * c->ny;
   vhp::DevMap m = dev_map(c);
+  // Sliding the y-major column grid onto 128-byte lines pays in the store-bound regime (many quadrants in flight:
+  // +1 % at 1000^2, +3.5 % at 4096^2); a lone quadrant is latency-bound, and there the predicated stores of the
+  // slid strip 0 -- the busiest wavefront -- cost 9 %.
+  m.slide = n_src >= 96 ? 1 : 0;
+  if (const char* e = getenv("VHP_SLIDE")) m.slide = atoi(e);
   hipError_t eb = vhp::attach_round_scratch(m, W * 64 * R, (size_t)n_src * vhp::kUnitsPerSource, &c->d_bnd, &c->d_bnd_cap);
   if (eb != hipSuccess) return eb;
   const size_t n_units = (size_t)n_src * vhp::kUnitsPerSource;

@@ -84,6 +84,7 @@ struct DevMap {
   // 4 arrays of `bnd_len` doubles (x-major / y-major boundary rows, double-buffered by round)
   double* bnd;
   int bnd_len;
+  int slide;  // 1: slide the y-major column grid onto 128-byte lines (y_grid_slide)
 };
 
 #ifdef VHP_EXP_SLOTTIME
@@ -971,7 +972,7 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
   }
   const int rows_total = min(g.nj, g.ni);
   const int cols_total = max(min(g.ni, g.nj - 1), 0);
-  g.ya = y_grid_slide<DX>(sx, cols_total, S, Emit::kMulti ? INT32_MAX / S - 1 : W);
+  g.ya = m.slide ? y_grid_slide<DX>(sx, cols_total, S, Emit::kMulti ? INT32_MAX / S - 1 : W) : 0;
   const int Px = (rows_total + S - 1) / S, Py = (cols_total + g.ya + S - 1) / S;
   double* ring_x = lds;
   double* ring_y = lds + (size_t)W * kRing;
@@ -1026,7 +1027,7 @@ __device__ __forceinline__ int unit_tmax(const DevMap& m, int sx, int sy, int q,
   const int ni = px ? m.nx - sx : sx, nj = py ? m.ny - sy : sy;
   if (ni <= 0 || nj <= 0) return -1;
   const int cols_total = max(min(ni, nj - 1), 0);
-  const int ya = px ? y_grid_slide<+1>(sx, cols_total, S, W) : y_grid_slide<-1>(sx, cols_total, S, W);
+  const int ya = !m.slide ? 0 : px ? y_grid_slide<+1>(sx, cols_total, S, W) : y_grid_slide<-1>(sx, cols_total, S, W);
   const int Px = (min(nj, ni) + S - 1) / S, Py = (cols_total + ya + S - 1) / S;
   const int wx = max(min(Px, W), 1), wy = max(min(Py, W), 1);
   const int nx_last = px ? chunk_seq<+1>(sx, ni - 1) : chunk_seq<-1>(sx, ni - 1);
