@@ -85,6 +85,22 @@ def test_slid_column_grid_bit_exact(vhp, oracle, monkeypatch, nx, ny):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d slid grid, source (%d,%d)" % (nx, ny, sx, sy))
 
 
+@pytest.mark.parametrize("nx,ny", [(1000, 1000), (1024, 700), (640, 603), (1016, 520)])
+def test_line_mode_shape_bit_exact(vhp, oracle, monkeypatch, nx, ny):
+    # batches of 256+ sources on sides 513..1024 run in the one-row-per-lane shape, whose x-major strips hold rows
+    # back and flush whole 128-byte lines (rows alternate between the two line phases when nx/8 is odd); force
+    # that shape, and the slid column grid that goes with large batches, for a small batch
+    monkeypatch.setenv("VHP_R", "1")
+    monkeypatch.setenv("VHP_W", "8")
+    monkeypatch.setenv("VHP_SLIDE", "1")
+    occ = maps.random_rect_map(nx, ny, 40, 5, nx // 8, 5, ny // 8, nx * 3 + ny)
+    src = np.concatenate([maps.free_sources(occ, 4, ny), np.array([(0, 0), (nx - 1, ny - 1), (nx - 2, 1), (7, ny - 8)], np.int32)])
+    occ[src[:, 1], src[:, 0]] = 1
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d line mode, source (%d,%d)" % (nx, ny, sx, sy))
+
+
 def test_config3_1000x1000_subset(vhp, oracle):
     occ, src = maps.config_c3(256)
     pick = src[[0, 17, 101, 255]]

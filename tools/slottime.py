@@ -33,3 +33,7 @@ for q in range(4):
     print("  barrier exit - last arrival (ns):", " ".join("%d" % x for x in (b.max(axis=0) - a.max(axis=0))))
     busy = 1.0 - wait.sum(axis=1) / rel[-1]
     print("  busy fraction per wavefront:", " ".join("%.2f" % x for x in busy))
+    # work time of a wavefront in a slot = arrival at this slot's barrier - exit from the previous one
+    work = a - np.concatenate([np.zeros((16, 1)), b[:, :-1]], axis=1)
+    for wv in (0, 1, 3, 8, 9, 11):
+        print("  wavefront %2d work per slot (ns):" % wv, " ".join("%d" % x for x in work[wv]))

@@ -82,12 +82,19 @@ vhp::DevMap dev_map(const vhp_ctx* c) {
 // A workgroup sweeps one quadrant with 2*W wavefronts (W strips per octant) and R rows/columns
 // per lane.  Fronts longer than W*64*R are swept in rounds (`multi`).  Overridable for tuning
 // with VHP_R / VHP_W / VHP_MULTI.
-void pick_shape(int maxdim, int* R, int* W, bool* multi) {
+void pick_shape(int maxdim, int* R, int* W, bool* multi, int n_src = 1, bool f64 = true, bool pitch64 = false) {
   if (maxdim <= 64) { *R = 1; *W = 1; }
   else if (maxdim <= 128) { *R = 1; *W = 2; }
   else if (maxdim <= 256) { *R = 1; *W = 4; }
   else if (maxdim <= 512) { *R = 2; *W = 4; }
-  else if (maxdim <= 1024) { *R = 2; *W = 8; }
+  else if (maxdim <= 1024) {
+    *R = 2;
+    *W = 8;
+    // Store-bound batches (two or more workgroup rounds) do better in the one-row-per-lane shape, whose x-major
+    // strips flush whole 128-byte lines (vhp_sweep.cuh, line mode): +3 % at 1000^2 / 256 sources, +8 % at 512
+    // sources or on a 128-byte pitch; smaller batches are latency-bound and lose 10-15 % there.
+    if (n_src >= 256 && f64 && pitch64) *R = 1;
+  }
   else { *R = 4; *W = 8; }
   if (const char* e = getenv("VHP_R")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) *R = v; }
   if (const char* e = getenv("VHP_W")) { int v = atoi(e); if (v >= 1 && v <= 8) *W = v; }
@@ -115,7 +122,8 @@ void free_map(vhp_ctx* c) {
 
 template <int R, bool MULTI, typename OutT>
 hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, int W) {
-  const size_t lds = vhp::sweep_lds_bytes(R, W, MULTI);
+  static const bool pack = getenv("VHP_PACK") != nullptr;
+  const size_t lds = vhp::sweep_lds_bytes(R, W, MULTI, pack);
   auto k = vhp::vhp_sweep_fronts<R, MULTI, OutT>;
   static size_t lds_allowed = 0;  // per instantiation: raise the dynamic-LDS limit once, not per launch
   if (lds > lds_allowed) {
@@ -148,7 +156,6 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     int* d_ord = reinterpret_cast<int*>(d_desc + n_units);                   // then the order list
     // Packing short quadrants into one workgroup is implemented and parity-tested, but measured slower
     // on MI355X: off unless VHP_PACK is set.
-    static const bool pack = getenv("VHP_PACK") != nullptr;
     const int pack_w = (!MULTI && W == 8 && pack) ? W : 0;
     hipLaunchKernelGGL(vhp::vhp_order_units, dim3(1), dim3(1024), 0, c->stream, d_src, n_src, c->nx, c->ny, 64 * R, pack_w, d_ord,
                        d_desc);
@@ -189,7 +196,7 @@ template <typename OutT>
 hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
   int R, W;
   bool multi;
-  pick_shape(std::max(c->nx, c->ny), &R, &W, &multi);
+  pick_shape(std::max(c->nx, c->ny), &R, &W, &multi, n_src, sizeof(OutT) == 8, (c->nx & 7) == 0);
   switch (R) {
     case 1: return multi ? launch_sweep_t<1, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<1, false, OutT>(c, d_src, n_src, d_out, W);
     case 2: return multi ? launch_sweep_t<2, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<2, false, OutT>(c, d_src, n_src, d_out, W);

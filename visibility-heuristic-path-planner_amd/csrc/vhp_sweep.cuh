@@ -63,12 +63,13 @@ constexpr int kChunk = 8;        // marching-coordinate cells per pipeline slot 
 constexpr int kRing = 32;        // entries of a boundary ring (>= 4*kChunk), indexed by marching coordinate & (kRing-1);
                                  // sized so that a 16-wavefront workgroup at 1000^2 needs < 80 KB of LDS (two per CU)
 constexpr int kTileCols = 8;     // columns computed per window = 64 B of fp64
-// Staging tile of an x-major strip: the 8 columns of the current window, one row of `tile_stride(R)` doubles per
-// strip row (odd: spreads the column writes over the LDS banks).  (A 16-column ring that lets two windows leave
-// as one 128-byte line per row was tried for R == 1 -- the only shape whose LDS allows it -- and lost more in
-// instructions than it won in HBM efficiency: DESIGN.md section 10.)
-__host__ __device__ constexpr int tile_stride(int) { return 9; }
-__host__ __device__ constexpr int tile_cols(int) { return 8; }
+// Staging tile of an x-major strip: one row of `tile_stride(R)` doubles per strip row (odd: spreads the column
+// writes over the LDS banks).  R >= 2: the 8 columns of the current window.  R == 1: a ring of 16 columns
+// (x & 15), so that two consecutive windows can leave as one whole 128-byte line per row ("line mode", x_strip):
+// HBM takes whole lines at 5.8 TB/s but lone 64-byte halves at 3.5.  Only the one-row-per-lane shape has the LDS
+// for it: at R = 2 a 16-wavefront workgroup would need 139 KB.
+__host__ __device__ constexpr int tile_stride(int R) { return R == 1 ? 17 : 9; }
+__host__ __device__ constexpr int tile_cols(int R) { return R == 1 ? 16 : 8; }
 constexpr int kUnitsPerSource = 4;
 constexpr int kYLag = 2;         // y-major strips run this many slots behind the x-major ones (they consume diag(k))
 constexpr int kStage = 128;      // LDS staging of a boundary row that arrives from the previous round (per octant)
@@ -312,6 +313,13 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
   constexpr int kTileStride = tile_stride(R);
   constexpr int kRingCols = tile_cols(R);
   double* tile_lane = tile + R * lane * kTileStride;
+  // Line mode (R == 1, fp64 output, pitch a multiple of 64 B): in the steady windows the rows whose 128-byte line
+  // is only half computed are held back in the tile and leave one window later as a whole line.
+  // (y*nx + x)/8 even <=> chunk x>>3 is the lower half of its line.
+  constexpr bool kLineCapable = kRingCols == 16 && CB == 8;
+  const bool line_mode = kLineCapable && (m.nx & 7) == 0;
+  const bool rows_alternate = ((m.nx >> 3) & 1) != 0;  // consecutive rows start half a line apart
+  int held_chunk = INT32_MIN;                           // chunk whose hold-class rows are still in the tile
   // flush geometry: lane <-> (row-in-group = lane>>2, column pair = lane&3), 16 rows x 64 B per pass
   const int cp = lane & 3, rsub = lane >> 2;
   const uint32_t flush_lane_off = (uint32_t)(((g.sy + DY * (j0 + rsub)) * m.nx + 2 * cp) * CB);
@@ -352,8 +360,54 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
     }
   };
 
+  // ---- line mode helpers ---------------------------------------------------------------
+  // The rows of this strip for which chunk c (= x >> 3) is the half of their line that is computed first
+  // (`first_half`) or second: local rows rb, rb + rs, ...  Marching up in x the lower half comes first.
+  auto class_first_row = [&](int c, bool first_half) -> int {  // -1: no row of the strip is in the class
+    const int want = (first_half == (DX > 0)) ? 0 : 1;         // 0: c is the lower half of the row's line
+    if (rows_alternate) return (want ^ c ^ g.sy ^ j0) & 1;     // the parity of the row's y decides
+    return ((c & 1) == want) ? 0 : -1;
+  };
+  // bytes [64*h, 64*h + 64*nh) of the 128-byte line that starts at chunk clo, for the class rows rb, rb+rs, ...:
+  // 8 rows per store instruction, lanes outside the byte range idle
+  auto flush_rows = [&](int clo, int rb, int h, int nh) {
+    if (rb < 0) return;
+    int l = lane;
+    asm volatile("" : "+v"(l));  // keep this geometry out of the step loops' registers
+    const int q8 = l & 7, mloc = l >> 3;
+    const int rs = rows_alternate ? 2 : 1;
+    const int xl = 8 * clo + 2 * q8;
+    const bool on = (q8 >> 2) >= h && (q8 >> 2) < h + nh;
+    const int jr0 = rb + rs * mloc;
+    const double* q = tile + (xl & (kRingCols - 1)) + jr0 * kTileStride;
+    uint32_t off = (uint32_t)(((g.sy + DY * (j0 + jr0)) * m.nx + xl) * CB);
+    const uint32_t qstep = (uint32_t)(rs * 8 * kTileStride), ostep = (uint32_t)(rs * 8 * DY * m.nx * CB);
+    const int passes = rows_alternate ? 4 : 8;
+    for (int pass = 0; pass < passes; pass += 2) {
+      const double a0 = q[0], b0 = q[1], a1 = q[qstep], b1 = q[qstep + 1];
+      if (on) {
+        emit.pair_at(off, xl, 0, a0, b0);
+        emit.pair_at(off + ostep, xl, 0, a1, b1);
+      }
+      q += 2 * qstep;
+      off += 2 * ostep;
+    }
+  };
+  // leaving the steady windows: the rows still waiting for the second half of their line go out as they are
+  auto drain_held = [&]() {
+    if (kLineCapable && held_chunk != INT32_MIN) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      flush_rows(DX > 0 ? held_chunk : held_chunk - 1, class_first_row(held_chunk, true), DX > 0 ? 0 : 1, 1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      held_chunk = INT32_MIN;
+    }
+  };
+
   // ---- generic step: any i, diagonal handling, predicated flush ----------------
   auto slow_step = [&](int i) {
+    drain_held();
     const int x = g.sx + DX * i;
     const int blk = x >> 6, t = x & 63;
     if (blk != cur_blk) refill(blk);
@@ -562,6 +616,14 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
           }
         }
       }
+    } else if (rows_here == S && line_mode) {
+      // rows whose line this chunk completes leave whole; the others wait for the next window
+      const int c = xb >> 3;
+      const int rb = class_first_row(c, false);
+      const int clo = DX > 0 ? c - 1 : c;  // lower chunk of the line that c completes
+      if (held_chunk == c - DX) flush_rows(clo, rb, 0, 2);
+      else flush_rows(clo, rb, DX > 0 ? 1 : 0, 1);  // first steady window: their first half left on its own
+      held_chunk = c;
     } else if (rows_here == S) {
 #pragma unroll
       for (int pass = 0; pass < S / 16; pass += 2) {
@@ -629,6 +691,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
     __syncthreads();
 #endif
   }
+  drain_held();
 }
 
 // ---------------------------------------------------------------------------
@@ -946,11 +1009,12 @@ inline hipError_t attach_round_scratch(DevMap& m, int rows_per_round, size_t n_w
 __host__ __device__ inline size_t sweep_lds_doubles(int R, int W, bool multi) {
   return (size_t)2 * W * kRing + kRing + (multi ? 2 * kStage : 0) + (size_t)W * 64 * R * tile_stride(R);
 }
-// Dynamic LDS of a launch with W strips per octant per workgroup; packing (G subgroups of W/G
-// strips) must fit too.
-inline size_t sweep_lds_bytes(int R, int W, bool multi = false) {
+// Dynamic LDS of a launch with W strips per octant per workgroup; with packing, G subgroups of W/G strips must
+// fit too.
+inline size_t sweep_lds_bytes(int R, int W, bool multi = false, bool pack = false) {
   size_t d = sweep_lds_doubles(R, W, multi);
-  for (int G = 2; G <= 4 && W / G >= 1; G *= 2) d = std::max(d, (size_t)G * sweep_lds_doubles(R, W / G, multi));
+  if (pack)
+    for (int G = 2; G <= 4 && W / G >= 1; G *= 2) d = std::max(d, (size_t)G * sweep_lds_doubles(R, W / G, multi));
   return d * sizeof(double);
 }
 
