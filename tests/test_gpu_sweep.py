@@ -85,9 +85,9 @@ def test_slid_column_grid_bit_exact(vhp, oracle, monkeypatch, nx, ny):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d slid grid, source (%d,%d)" % (nx, ny, sx, sy))
 
 
-@pytest.mark.parametrize("nx,ny", [(1000, 1000), (1024, 700), (640, 603), (1016, 520)])
+@pytest.mark.parametrize("nx,ny", [(1000, 1000), (1024, 700), (640, 603), (1016, 520), (4096, 300), (300, 2048)])
 def test_line_mode_shape_bit_exact(vhp, oracle, monkeypatch, nx, ny):
-    # batches of 256+ sources on sides 513..1024 run in the one-row-per-lane shape, whose x-major strips hold rows
+    # batches of 256+ sources on sides above 256 run in the one-row-per-lane shape, whose x-major strips hold rows
     # back and flush whole 128-byte lines (rows alternate between the two line phases when nx/8 is odd); force
     # that shape, and the slid column grid that goes with large batches, for a small batch
     monkeypatch.setenv("VHP_R", "1")
