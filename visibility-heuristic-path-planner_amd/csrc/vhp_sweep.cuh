@@ -192,6 +192,7 @@ struct StripSlot {
   const double* bnd_in;  // boundary row from the previous round (w == 0, pg > 0), else unused
   double* bnd_out;       // boundary row for the next round (tail)
   double* stage;         // kStage doubles of LDS for bnd_in
+  double* dummy;         // 8 doubles of LDS per wavefront: where the lanes that are not the boundary lane "write" theirs
 };
 
 // Pipeline chunks are kChunk-aligned in the marching coordinate mc = s + DIR*step.
@@ -512,6 +513,9 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
     double ringv = 0.0;
     if (PROD) ringv = ring_in[(x0 - DX + DX * lane) & rin_mask];
     double* ring_w = ring_out + (xb & (kRing - 1));
+    // every lane writes "its boundary value" each step -- lane 63 into the ring, the others into a dummy slot:
+    // one ds_write instead of an exec-masked region per step
+    double* ring_wl = lane == 63 ? ring_w : ss.dummy;
     double* tile_win = tile_lane + (xb & (kRingCols - 1));  // R == 1: the window's half of the 16-column ring
     double di = (double)i;
 #pragma unroll
@@ -568,16 +572,16 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
         prev[r] = v[r];
         tile_win[r * kTileStride + col] = v[r];
       }
-      if (lane == 63) {
-        ring_w[col] = v[R - 1];
-        if (kMulti && ss.tail) ss.bnd_out[i + k] = v[R - 1];
-      }
+      ring_wl[col] = v[R - 1];
       if (PROD) ringv = ringn;
       di += 1.0;
     }
     // flush the whole window: S rows x 64 B
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (kMulti && ss.tail) {  // the next round's first strip reads this strip's boundary row from global memory
+      if (lane < 8) ss.bnd_out[i + lane] = ring_w[DX > 0 ? lane : 7 - lane];
+    }
     const uint32_t off0 = flush_lane_off + (uint32_t)(xb * CB);
     const int xc = xb + 2 * cp;
     const int y0 = g.sy + DY * (j0 + rsub);
@@ -850,6 +854,7 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const Unit
     double dgv = 0.0;  // lane t: diag(j + t), published by the x-major strips
     if (DIAG) dgv = diag_ring[(j + lane) & (kRing - 1)];
     double* ring_w = ring_out + (yb & (kRing - 1));
+    double* ring_wl = lane == 63 ? ring_w : ss.dummy;
     double dj = (double)j;
     uint32_t off = (uint32_t)((y0 * m.nx + xlo) * CB);
     const uint32_t stride = (uint32_t)(DY * m.nx * CB);
@@ -920,14 +925,18 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const Unit
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) prev[r] = v[r];
-      if (lane == 63) {
-        ring_w[bit] = v[R - 1];
-        if (kMulti && ss.tail) ss.bnd_out[j + k] = v[R - 1];
-      }
+      ring_wl[bit] = v[R - 1];
       if (PROD) ringv = rotate_down(ringv);
       dj += 1.0;
       off += stride;
       y += DY;
+    }
+    if (kMulti && ss.tail) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 8) ss.bnd_out[j + lane] = ring_w[DY > 0 ? lane : 7 - lane];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   };
 
@@ -1007,7 +1016,7 @@ inline hipError_t attach_round_scratch(DevMap& m, int rows_per_round, size_t n_w
 // LDS of one subgroup with W strips per octant: x rings, y rings, the diagonal ring, (multi-round
 // shapes) two boundary staging areas, W staging tiles.  In doubles.
 __host__ __device__ inline size_t sweep_lds_doubles(int R, int W, bool multi) {
-  return (size_t)2 * W * kRing + kRing + (multi ? 2 * kStage : 0) + (size_t)W * 64 * R * tile_stride(R);
+  return (size_t)2 * W * kRing + kRing + (multi ? 2 * kStage : 0) + (size_t)W * 64 * R * tile_stride(R) + (size_t)2 * W * 8;
 }
 // Dynamic LDS of a launch with W strips per octant per workgroup; with packing, G subgroups of W/G strips must
 // fit too.
@@ -1063,6 +1072,7 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
       ss.bnd_in = bnd ? bnd + ((rho + 1) & 1) * m.bnd_len : nullptr;
       ss.bnd_out = bnd ? bnd + (rho & 1) * m.bnd_len : nullptr;
       ss.stage = stage;
+      ss.dummy = tiles + (size_t)W * S * tile_stride(R) + (size_t)wave * 8;
       x_strip<R, DX, DY>(m, emit, g, ss, ring_x, tiles + (size_t)wave * S * tile_stride(R), diag_ring);
     } else {
       ss.pg = pg0 + wave - W;
@@ -1072,6 +1082,7 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
       ss.bnd_in = bnd ? bnd + (2 + ((rho + 1) & 1)) * m.bnd_len : nullptr;
       ss.bnd_out = bnd ? bnd + (2 + (rho & 1)) * m.bnd_len : nullptr;
       ss.stage = stage + kStage;
+      ss.dummy = tiles + (size_t)W * S * tile_stride(R) + (size_t)wave * 8;
       y_strip<R, DX, DY>(m, emit, g, ss, ring_y, diag_ring);
     }
     if (rho + 1 < rounds) {
