@@ -169,6 +169,10 @@ def test_device_resident_batch_and_full_size_properties(vhp):
     idx = torch.arange(len(src), device="cuda")
     assert bool((d_out[idx, sy, sx] == 1.0).all())                      # the source sees itself
     assert float(d_out[:, 0, :].abs().max()) == 0.0 and float(d_out[:, :, 0].abs().max()) == 0.0  # Q2
+    # the batch ran in the large-batch launch shape (one row per lane, whole-line flushes, slid column grid);
+    # the same sources as a small batch run in the small-batch shape: the fields must be the same bytes
+    small = c.sweep_batch(src[:24])
+    assert np.array_equal(d_out[:24].cpu().numpy(), small)
     # idempotence: a second launch into the same buffer gives the same bytes
     first = d_out.clone()
     c.sweep_batch_device(d_src.data_ptr(), len(src), d_out.data_ptr())
