@@ -151,6 +151,20 @@ def test_fp32_storage_is_rounded_fp64(vhp, oracle):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)).astype(np.float32), "fp32 source %d" % k)
 
 
+@pytest.mark.parametrize("nx,ny", [(640, 603), (1000, 520), (328, 300)])
+def test_fp32_large_batch_shape(vhp, oracle, monkeypatch, nx, ny):
+    # fp32 fields in the large-batch shape: the x-major strips hold rows back and flush whole 64-byte sectors
+    monkeypatch.setenv("VHP_R", "1")
+    monkeypatch.setenv("VHP_W", "8")
+    monkeypatch.setenv("VHP_SLIDE", "1")
+    occ = maps.random_rect_map(nx, ny, 30, 4, nx // 8, 4, ny // 8, nx + 7 * ny)
+    src = np.concatenate([maps.free_sources(occ, 4, nx), np.array([(0, 0), (nx - 1, ny - 1)], np.int32)])
+    occ[src[:, 1], src[:, 0]] = 1
+    got = _ctx(vhp, occ).sweep_batch(src, dtype=vhp.F32)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)).astype(np.float32), "%dx%d fp32 source (%d,%d)" % (nx, ny, sx, sy))
+
+
 def test_device_resident_batch_and_full_size_properties(vhp):
     import torch
     occ, src = maps.config_c3(256)

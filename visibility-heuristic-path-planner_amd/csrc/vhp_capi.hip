@@ -93,7 +93,8 @@ void pick_shape(int maxdim, int* R, int* W, bool* multi, int n_src = 1, bool f64
   // x-major strips flush whole 128-byte lines (vhp_sweep.cuh, line mode), swept in rounds of 512 rows: measured
   // against the shapes above at 256 sources, -3 % time at 1000^2, -8 % at 1024^2 and 2048^2, -17 % at 1536^2 and
   // 4096^2.  Smaller batches are latency-bound and lose 10-30 % there.
-  if (maxdim > 256 && n_src >= 256 && f64 && pitch64) { *R = 1; *W = 8; }
+  (void)f64;  // fp32 fields too: there the 16 staged columns are one whole 64-byte sector (-13 % time at 1000^2)
+  if (maxdim > 256 && n_src >= 256 && pitch64) { *R = 1; *W = 8; }
   if (const char* e = getenv("VHP_R")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) *R = v; }
   if (const char* e = getenv("VHP_W")) { int v = atoi(e); if (v >= 1 && v <= 8) *W = v; }
   *multi = (*W) * 64 * (*R) < maxdim;

@@ -317,7 +317,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
   // Line mode (R == 1, fp64 output, pitch a multiple of 64 B): in the steady windows the rows whose 128-byte line
   // is only half computed are held back in the tile and leave one window later as a whole line.
   // (y*nx + x)/8 even <=> chunk x>>3 is the lower half of its line.
-  constexpr bool kLineCapable = kRingCols == 16 && CB == 8;
+  constexpr bool kLineCapable = kRingCols == 16;  // fp32 output: the 16 columns are one whole 64-byte sector
   const bool line_mode = kLineCapable && (m.nx & 7) == 0;
   const bool rows_alternate = ((m.nx >> 3) & 1) != 0;  // consecutive rows start half a line apart
   int held_chunk = INT32_MIN;                           // chunk whose hold-class rows are still in the tile
