@@ -42,10 +42,12 @@ def parse():
     ap.add_argument("--sources", type=int, default=0, help="sources per GPU (default: workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--gather", action="store_true", help="all-gather the fields over RCCL inside the timed region")
-    ap.add_argument("--placements", type=int, default=6,
-                    help="output allocations to probe before the timed region, keeping the fastest (1 = take the first): the "
-                         "store rate of a multi-GB allocation on this pool depends on where it lands in HBM, by up to 25 %% "
-                         "(DESIGN.md section 10, tools/allocprobe6.py); the probe times are reported in config.output_placement")
+    ap.add_argument("--placements", type=int, default=1,
+                    help="diagnostic: allocate this many candidate outputs and time each with a few launches before the timed "
+                         "region.  The timed region ALWAYS runs on the first allocation; the probe times (and their median / "
+                         "best) are only reported, in config.output_placement")
+    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2],
+                    help="0 = the library's own choice, 1 = front sweep, 2 = streaming sweep (vhp_set_option \"kernel\")")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -158,14 +160,14 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
     ctx.set_map(occ)  # uploads + packs: the map is resident before the timed region
+    if args.kernel:
+        ctx.set_option("kernel", args.kernel)
     d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).to(dev)
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     vdt = vhp_amd.F64 if args.dtype == "f64" else vhp_amd.F32
-    # Where the output lands matters: allocations made one after the other in one process run the same launch in
-    # 0.55 or in 0.75 ms, each consistently (tools/allocprobe4.py, allocprobe6.py) -- zones of the physical address
-    # space, it seems.  A deployment allocates its result buffers once, so do what it would do: allocate a few
-    # candidates (all held, so that they are different memory; at most 24 GB), probe each with a few launches, keep
-    # the fastest and free the rest.  Every probe time is reported.
+    # The timed region runs on the FIRST allocation of the process, whatever its placement.  (Round 1 saw the same
+    # launch run 0.55 or 0.75 ms depending on the output allocation; --placements N > 1 times N candidates first and
+    # reports them, for diagnosis only.)
     out_bytes = n_src * ny * nx * (8 if args.dtype == "f64" else 4)
     n_cand = max(1, min(args.placements, int((24 << 30) // max(out_bytes, 1))))
     cands, probe_ms = [], []
@@ -176,14 +178,13 @@ def main():
             for _ in range(2):
                 ctx.sweep_batch_device(d_src.data_ptr(), n_src, buf.data_ptr(), dtype=vdt)
             torch.cuda.synchronize()
-            ctx.timing(True)
+            ctx.timing(True, prealloc=8)
             for _ in range(5):
                 ctx.sweep_batch_device(d_src.data_ptr(), n_src, buf.data_ptr(), dtype=vdt)
             torch.cuda.synchronize()
             probe_ms.append(round(float(np.median(ctx.timing_collect(5))), 4))
             ctx.timing(False)
-    chosen = int(np.argmin(probe_ms)) if probe_ms else 0
-    d_out = cands[chosen]
+    d_out = cands[0]
     cands = None
     torch.cuda.empty_cache()
     gathered = None
@@ -203,7 +204,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.timing(True)  # HIP events around every sweep kernel, recorded on the stream it is launched on
+    ctx.timing(True, prealloc=args.steps + 2)  # HIP events around every sweep kernel, on the stream it is launched on;
+    #                                              the event pairs exist before the timed region starts
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_out.data_ptr(), dtype=vdt)
@@ -225,11 +227,15 @@ def main():
         fields = world * n_src * args.steps
         alg_bytes = BYTES_PER_CELL[args.dtype] * nx * ny * n_src  # per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, args.dtype))
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this
+        # command): collected by tools/collect_profiles.sh into profiles/, not measured inside this run
+        traffic, traffic_src = None, None
+        kname = "vhp_stream_sweep" if (args.kernel == 2 or (args.kernel == 0 and n_src >= 128 and nx % 8 == 0)) else "vhp_sweep_fronts"
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s_%s.json" % (args.workload, args.dtype, kname))
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_src = "static: %s (rocprofv3 --pmc passes of this command, not measured in this run)" % os.path.relpath(tpath, ROOT)
             except Exception:
                 traffic = None
         out = {
@@ -246,12 +252,17 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": label, "grid": [nx, ny], "sources_per_gpu": n_src, "sharding": "sources/%d" % world,
-                       "output_placement": {"candidates": n_cand, "probe_kernel_ms": probe_ms, "chosen": chosen},
+                       "kernel_option": args.kernel,
+                       "output_placement": {"timed_on": "first allocation", "candidates": n_cand, "probe_kernel_ms": probe_ms,
+                                            "probe_median_ms": (round(float(np.median(probe_ms)), 4) if probe_ms else None),
+                                            "probe_best_ms": (min(probe_ms) if probe_ms else None)},
                        "collective": "rccl all_gather of fields" if gathered is not None else "none (independent sources)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "vhp_sweep_fronts", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname, "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         # the same rate counting only the field bytes written (the occupancy maps are read at 2 bits/cell)
+                         "frac_field_bytes": round((alg_bytes - nx * ny * n_src) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         if not args.no_cpu_baseline and world == 1:
             try:

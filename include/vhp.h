@@ -102,9 +102,13 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
 
 /* Replaces reconstructPath() (solver.cpp:1183-1213): walks came_from -> pivots from
  * `end` until the label repeats; writes the path start-first into path_xy (capacity
- * cap points), its point count into *n_path, the summed eval_d length into *length. */
-int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, int nx, int ny, int end_x,
-                         int end_y, int32_t* path_xy, uint32_t cap, uint32_t* n_path, double* length);
+ * cap points), its point count into *n_path, the summed eval_d length into *length.
+ * pivots_xy holds entries 0 .. n_pivots (vhp_planner_solve's *n_pivots).  A label above
+ * n_pivots (an unlabelled cell included) or a walk longer than n_pivots + 2 hops is
+ * VHP_ERR_ARG; a path longer than cap is VHP_ERR_TOO_LARGE with *n_path = the size
+ * needed and nothing written. */
+int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, uint32_t n_pivots, int nx, int ny,
+                         int end_x, int end_y, int32_t* path_xy, uint32_t cap, uint32_t* n_path, double* length);
 
 /* Replaces raycasting() driven over all targets as benchmark() does (solver.cpp:226-232,
  * 267-290): a Bresenham ray from the source to every cell; a blocked cell met on the way
@@ -123,8 +127,15 @@ int vhp_last_elapsed_ms(vhp_ctx* ctx, float* ms);
  * pre-kernel) with a pair of hipEvents on the context stream; vhp_timing_collect waits for them,
  * writes up to `cap` durations in milliseconds (oldest first), returns their count in *n and
  * clears the list.  vhp_timing(ctx, 0) switches it off. */
-int vhp_timing(vhp_ctx* ctx, int enable);
+int vhp_timing(vhp_ctx* ctx, int enable);  /* enable > 1: also pre-creates that many event pairs */
 int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n);
+
+/* Launch-shape overrides for tuning and for parity tests that must reach every compiled shape
+ * (0 / -1 = automatic, the default).  Keys: "rows_per_lane" (1, 2, 4), "strips" (1..8 wavefront
+ * strips per octant), "multi_round" (1 = force the multi-round build), "slide" (0 / 1: y-major
+ * column grid slid onto 128-byte lines), "pack" (1 = pack short quadrants), "kernel" (1 = front
+ * sweep, 2 = streaming sweep).  The results never depend on these; only the schedule does. */
+int vhp_set_option(vhp_ctx* ctx, const char* key, long long value);
 
 /* Library / build identification: "vhp-hip <version> gfx950". */
 const char* vhp_version(void);

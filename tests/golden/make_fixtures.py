@@ -8,6 +8,14 @@ maze_6.npz : images/maze_6.png reduced exactly as the reference's loadImage does
              pixel(x,y), y = 0 at the top), bit-packed.  Input of BASELINE config 4.
 benchmark_results.npz : Samples/benchmark_results.txt (the reference's only
              published numbers for this path), as a float array, for BASELINE.md checks.
+c1_rnd1_mask.npz : BASELINE config 1's 101x101 occupancy mask.  MATLAB_code/rnd_1.mat is DATA: a
+             MATLAB `rng` struct (Type 'twister', 625 x uint32 = the MT19937 state + position).
+             numpy's RandomState accepts that state, and random_sample() is the same 53-bit
+             construction as MATLAB's rand.  The obstacle recipe restated below is that of
+             MATLAB_code/f_comparison_to_a_star.m:54-78 (25 rectangles, sides 2..20, start/end
+             kept free), with randi(n) taken as floor(n*rand)+1 -- MATLAB itself is not
+             available here, so whether its randi draws exactly like that is unverified: the
+             committed MASK is the fixture, not the generator.
 """
 import os
 
@@ -26,6 +34,38 @@ def main():
     rows = np.loadtxt(os.path.join(REF, "Samples", "benchmark_results.txt"))
     np.savez_compressed(os.path.join(OUT, "benchmark_results.npz"), rows=rows.astype(np.float32))
     print("maze_6", occ.shape, "free cells", int(occ.sum()), "| benchmark rows", rows.shape)
+    c1 = c1_mask_from_rnd1()
+    np.savez_compressed(os.path.join(OUT, "c1_rnd1_mask.npz"), packed=np.packbits(c1, axis=1), nx=c1.shape[1], ny=c1.shape[0])
+    print("c1_rnd1_mask", c1.shape, "free cells", int(c1.sum()))
+
+
+def c1_mask_from_rnd1(n=101):
+    """occ[y, x] uint8 (1 = free) on an n x n grid from the twister state in rnd_1.mat."""
+    import scipy.io
+    st = scipy.io.loadmat(os.path.join(REF, "MATLAB_code", "rnd_1.mat"), squeeze_me=True, struct_as_record=False)["rngstate"]
+    assert st.Type == "twister" and st.State.shape == (625,)
+    rs = np.random.RandomState()
+    rs.set_state(("MT19937", st.State[:624].astype(np.uint32), int(st.State[624])))
+    randi = lambda k: int(np.floor(k * rs.random_sample())) + 1  # MATLAB randi(k): uniform on 1..k
+    nx = ny = n
+    sp, ep = (5, 5), (95, 95)                         # f_comparison_to_a_star.m:30-31 (1-based row, col)
+    obstacle = np.zeros((nx + 1, ny + 1), bool)        # 1-based indexing, row/col 0 unused
+    min_w, max_w, min_h, max_h = 2, 20, 2, 20          # :57-58
+    for _ in range(25):                                # :56,60
+        row_1 = 1 + randi(nx)
+        row_2 = row_1 + min_w + randi(max_w - min_w)
+        row_1, row_2 = min(row_1, nx - 1), min(row_2, nx - 1)
+        col_1 = 1 + randi(ny)
+        col_2 = col_1 + min_h + randi(max_h - min_h)
+        col_1, col_2 = min(col_1, ny - 1), min(col_2, ny - 1)
+        c1 = row_1 <= sp[0] <= row_2
+        c2 = col_1 <= sp[1] <= col_2
+        c3 = row_1 <= ep[0] <= row_2
+        c4 = col_1 <= ep[1] <= col_2
+        if not ((c1 and c2) or (c3 and c4)):
+            obstacle[row_1:row_2 + 1, col_1:col_2 + 1] = True   # MATLAB ranges are inclusive
+    # MATLAB (row, col) 1-based -> field (y, x) 0-based
+    return (~obstacle[1:, 1:]).astype(np.uint8)
 
 
 if __name__ == "__main__":

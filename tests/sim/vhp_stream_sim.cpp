@@ -1,0 +1,156 @@
+// vhp_stream_sim.cpp -- CPU simulator of the streaming sweep kernel.  TEST INFRASTRUCTURE ONLY.
+//
+// Compiles csrc/vhp_stream.hpp -- the very source hipcc builds for gfx950 -- with -DVHP_SIM, where a wavefront's
+// lane vector is an array of 64 values (csrc/vhp_lanes.hpp), and runs one workgroup at a time: slot after slot, and
+// inside a slot the wavefronts one after the other in a configurable order (forward, backward, shuffled).  Data that
+// crosses wavefronts only ever crosses a slot barrier, so every order must give the same bytes; an order-dependent
+// result is a missing barrier in the schedule.  LDS starts poisoned (NaN), so a read of a value that was never
+// produced shows up in the field.
+//
+// Only tests/ loads this library (tests/sim_lib.py).  It is not a CPU fallback of the product: libvhp_hip.so neither
+// links nor loads it, and it is three orders of magnitude slower than the oracle.
+#define VHP_SIM
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "../../visibility-heuristic-path-planner_amd/csrc/vhp_stream.hpp"
+
+using namespace vhp::stream;
+
+namespace {
+
+struct HostMap {
+  std::vector<uint64_t> rows, cols;
+  std::vector<double> recip;
+  Map m;
+};
+
+// the packed maps and the reciprocal table, as vhp_set_map builds them (vhp_capi.hip finish_set_map)
+void build_map(const uint8_t* occ, int nx, int ny, HostMap& h) {
+  const int wpr = (nx + 63) / 64 + 2, wpc = (ny + 63) / 64 + 2;
+  h.rows.assign((size_t)ny * wpr, 0);
+  h.cols.assign((size_t)nx * wpc, 0);
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x)
+      if (occ[(size_t)y * nx + x]) {
+        h.rows[(size_t)y * wpr + 1 + (x >> 6)] |= 1ull << (x & 63);
+        h.cols[(size_t)x * wpc + 1 + (y >> 6)] |= 1ull << (y & 63);
+      }
+  const int nrec = (nx > ny ? nx : ny) + 1 + 8;
+  h.recip.resize(nrec);
+  h.recip[0] = 0.0;
+  for (int k = 1; k < nrec; ++k) {
+    volatile double d = (double)k;
+    h.recip[k] = 1.0 / d;
+  }
+  h.m.rows = h.rows.data();
+  h.m.cols = h.cols.data();
+  h.m.recip = h.recip.data();
+  h.m.wpr = wpr;
+  h.m.wpc = wpc;
+  h.m.nx = nx;
+  h.m.ny = ny;
+}
+
+struct SimInfo {
+  long long slots = 0, max_slots = 0, lag_violations = 0;
+};
+
+uint32_t lcg(uint32_t& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
+
+template <int DX, int DY, typename OutT>
+void run_quadrant(const HostMap& h, OutT* field, int sx, int sy, int W, int order_mode, SimInfo& info, uint32_t& rng) {
+  Quad<DX, DY> g;
+  g.init(h.m.nx, h.m.ny, sx, sy);
+  if (g.empty()) return;
+  const Layout L = make_layout(W, h.m.nx, h.m.ny);
+  std::vector<double> lds(L.total, std::numeric_limits<double>::quiet_NaN());
+  int* sched = reinterpret_cast<int*>(lds.data() + L.sched);
+  compute_schedule(g, W, sched);
+  const int T_total = sched[0];
+  // the ring discipline the kernel relies on: inside a round a strip runs 1 (or 2) blocks behind its producer
+  for (int p = 1; p < g.Px; ++p)
+    if (p % W != 0) {
+      const int lag = (sched[1 + p] - g.nbx(kXRows * p)) - (sched[1 + p - 1] - g.nbx(kXRows * (p - 1)));
+      if (lag < 1 || lag > 2) info.lag_violations++;
+    }
+  for (int q = 1; q < g.Py; ++q)
+    if (q % W != 0) {
+      const int lag = (sched[1 + kMaxStrips + q] - g.nby(g.ystart(q))) - (sched[1 + kMaxStrips + q - 1] - g.nby(g.ystart(q - 1)));
+      if (lag < 1 || lag > 2) info.lag_violations++;
+    }
+  std::vector<XWave<DX, DY, OutT>> xs(W);
+  std::vector<YWave<DX, DY, OutT>> ys(W);
+  for (int w = 0; w < W; ++w) {
+    xs[w].init(h.m, g, field, w, W, lds.data(), L);
+    ys[w].init(h.m, g, field, w, W, lds.data(), L);
+  }
+  std::vector<int> order(2 * W);
+  for (int T = 0; T < T_total; ++T) {
+    for (int k = 0; k < 2 * W; ++k) order[k] = k;
+    if (order_mode == 1) for (int k = 0; k < 2 * W; ++k) order[k] = 2 * W - 1 - k;
+    if (order_mode == 2) for (int k = 2 * W - 1; k > 0; --k) { const int r = lcg(rng) % (k + 1); std::swap(order[k], order[r]); }
+    for (int k = 0; k < 2 * W; ++k) {
+      const int wv = order[k];
+      if (wv < W) xs[wv].slot(T); else ys[wv - W].slot(T);
+    }
+  }
+  // every wavefront must have finished all its strips inside the scheduled slots
+  for (int w = 0; w < W; ++w)
+    if (xs[w].active || ys[w].active) info.lag_violations += 1000000;
+  info.slots += T_total;
+  if (T_total > info.max_slots) info.max_slots = T_total;
+}
+
+template <typename OutT>
+int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int order_mode, long long* stats) {
+  HostMap h;
+  build_map(occ, nx, ny, h);
+  SimInfo info;
+  uint32_t rng = 12345u;
+  vhp::lanes::store_stats() = vhp::lanes::StoreStats();
+  for (int s = 0; s < n_src; ++s) {
+    const int sx = src[2 * s], sy = src[2 * s + 1];
+    if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return 2;
+    OutT* field = out + (size_t)s * nx * ny;
+    // rows / columns no quadrant covers read as zero: the workgroup of quadrant 1 stores them
+    if (sx > 0) for (int y = 0; y < ny; ++y) field[(size_t)y * nx] = OutT(0);
+    if (sy > 0) for (int x = 0; x < nx; ++x) field[x] = OutT(0);
+    run_quadrant<+1, +1>(h, field, sx, sy, W, order_mode, info, rng);
+    run_quadrant<-1, +1>(h, field, sx, sy, W, order_mode, info, rng);
+    run_quadrant<-1, -1>(h, field, sx, sy, W, order_mode, info, rng);
+    run_quadrant<+1, -1>(h, field, sx, sy, W, order_mode, info, rng);
+  }
+  if (stats) {
+    stats[0] = info.slots;
+    stats[1] = info.max_slots;
+    stats[2] = info.lag_violations;
+    stats[3] = vhp::lanes::store_stats().n16;
+    stats[4] = vhp::lanes::store_stats().n8;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// out: n_src fields of nx*ny elements (dtype 0 = double, 1 = float), pre-filled by the caller (e.g. with NaN, to prove
+// that every cell is written).  W: strips per octant and round (>= 3).  order_mode: 0 forward, 1 backward, 2 shuffled.
+// stats (5 entries, may be null): total slots, longest workgroup in slots, schedule violations, 16-byte / 8-byte store
+// instructions.
+int vhp_sim_stream_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W,
+                         int order_mode, long long* stats) {
+  if (!occ || !src || !out || nx <= 0 || ny <= 0 || (nx & 7) != 0 || W < 3 || W > 8) return 1;
+  if (dtype == 0) return run_batch<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), W, order_mode, stats);
+  return run_batch<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), W, order_mode, stats);
+}
+
+int vhp_sim_lds_bytes(int nx, int ny, int W) { return make_layout(W, nx, ny).total * 8; }
+
+}  // extern "C"

@@ -58,6 +58,30 @@ def test_config4_maze6(vhp, oracle):
     assert "%.6g" % d == "1529.55"
 
 
+def test_config1_rnd1_mask_planner(vhp, oracle):
+    # BASELINE config 1's grid (tests/golden/c1_rnd1_mask.npz, from MATLAB_code/rnd_1.mat), start (5,5) -> end (95,95)
+    # as in f_comparison_to_a_star.m:30-31, at the paper's threshold and at the script's
+    occ = maps.c1_rnd1_mask()
+    for thr in (0.5, 0.2):
+        c, got, want = _solve_both(vhp, oracle, occ, (5, 5), (95, 95), thr, 120)
+        _assert_same_solution(got, want, "C1 rnd_1 mask thr %g" % thr)
+        if got["status"] == vhp.VHP_OK:
+            d, path = c.reconstruct_path(got["came_from"], got["pivots"], (95, 95))
+            dw, pathw = oracle.reconstruct_path(want["came_from"], want["pivots"], (95, 95))
+            assert d == dw and path.tolist() == pathw.tolist()
+
+
+def test_negative_threshold_skips_the_loop(vhp, oracle):
+    # while (visibility_global_(end) <= threshold) with an all-zero field: a negative threshold never enters the
+    # loop (solver.cpp:127), lightSources_[0] becomes `end` (:141), nothing is swept
+    occ = maps.random_rect_map(64, 48, 6, 3, 9, 3, 9, 3)
+    pts = maps.free_sources(occ, 2, 1)
+    start, end = tuple(int(v) for v in pts[0]), tuple(int(v) for v in pts[1])
+    _, got, want = _solve_both(vhp, oracle, occ, start, end, -0.5, 10)
+    _assert_same_solution(got, want, "negative threshold")
+    assert got["n_pivots"] == 0 and got["pivots"].tolist() == [list(end)] and not got["vis_global"].any()
+
+
 def test_1000_shipped_config_seed1(vhp, oracle):
     # the shipped settings.config with seedValue 1: pivots (50,50),(273,350),(525,675), path 1346.71
     import platform

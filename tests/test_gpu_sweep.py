@@ -15,10 +15,17 @@ def vhp():
     return vhp_amd
 
 
-def _ctx(vhp, occ):
+def _ctx(vhp, occ, **options):
+    """options: launch-shape overrides through the ABI (vhp_set_option), e.g. rows_per_lane=1, strips=8, slide=1."""
     c = vhp.Context(0)
     c.set_map(occ)
+    for k, v in options.items():
+        c.set_option(k, v)
     return c
+
+
+# the front sweep's shape for batches of 256+ sources (vhp_capi.hip pick_shape)
+LINE_SHAPE = dict(rows_per_lane=1, strips=8, slide=1)
 
 
 def _assert_same(got, want, what):
@@ -39,11 +46,19 @@ def test_small_random_maps_bit_exact(vhp, oracle, seed):
 
 
 def test_config1_101x101(vhp, oracle):
-    # BASELINE config 1: 101x101 random grid, single source (5,5)
+    # BASELINE config 1: the 101x101 grid derived from MATLAB_code/rnd_1.mat (tests/golden/c1_rnd1_mask.npz),
+    # single source (5,5); plus the other corner region and an LCG map of the same size
+    occ = maps.c1_rnd1_mask()
+    assert occ.shape == (101, 101) and occ[5, 5] == 1
+    src = np.array([[5, 5], [95, 95], [4, 4], [50, 50]], np.int32)
+    src = src[[bool(occ[y, x]) for x, y in src]]
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "config 1 (rnd_1 mask) source (%d,%d)" % (sx, sy))
     occ = maps.random_rect_map(101, 101, 25, 2, 20, 2, 20, 1)
     occ[5, 5] = 1
     got = _ctx(vhp, occ).sweep_batch(np.array([[5, 5]], np.int32))
-    _assert_same(got[0], oracle.sweep_full(occ, 5, 5), "config 1")
+    _assert_same(got[0], oracle.sweep_full(occ, 5, 5), "config 1 (LCG map)")
 
 
 def test_border_blocked_and_thin(vhp, oracle):
@@ -73,30 +88,26 @@ def test_multi_strip_sizes(vhp, oracle, side):
 
 
 @pytest.mark.parametrize("nx,ny", [(101, 77), (300, 263), (1000, 1000), (1500, 1100)])
-def test_slid_column_grid_bit_exact(vhp, oracle, monkeypatch, nx, ny):
+def test_slid_column_grid_bit_exact(vhp, oracle, nx, ny):
     # large batches slide the y-major column grid onto 128-byte lines (strip 0 then owns columns that do
     # not exist); force that path for a small batch and compare cell by cell
-    monkeypatch.setenv("VHP_SLIDE", "1")
     occ = maps.random_rect_map(nx, ny, 30, 3, max(nx // 8, 4), 3, max(ny // 8, 4), nx + ny)
     src = np.concatenate([maps.free_sources(occ, 5, nx), np.array([(0, 0), (nx - 1, ny - 1), (nx - 1, 0), (1, ny - 2)], np.int32)])
     occ[src[:, 1], src[:, 0]] = 1
-    got = _ctx(vhp, occ).sweep_batch(src)
+    got = _ctx(vhp, occ, slide=1).sweep_batch(src)
     for k, (sx, sy) in enumerate(src):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d slid grid, source (%d,%d)" % (nx, ny, sx, sy))
 
 
 @pytest.mark.parametrize("nx,ny", [(1000, 1000), (1024, 700), (640, 603), (1016, 520), (4096, 300), (300, 2048)])
-def test_line_mode_shape_bit_exact(vhp, oracle, monkeypatch, nx, ny):
+def test_line_mode_shape_bit_exact(vhp, oracle, nx, ny):
     # batches of 256+ sources on sides above 256 run in the one-row-per-lane shape, whose x-major strips hold rows
     # back and flush whole 128-byte lines (rows alternate between the two line phases when nx/8 is odd); force
     # that shape, and the slid column grid that goes with large batches, for a small batch
-    monkeypatch.setenv("VHP_R", "1")
-    monkeypatch.setenv("VHP_W", "8")
-    monkeypatch.setenv("VHP_SLIDE", "1")
     occ = maps.random_rect_map(nx, ny, 40, 5, nx // 8, 5, ny // 8, nx * 3 + ny)
     src = np.concatenate([maps.free_sources(occ, 4, ny), np.array([(0, 0), (nx - 1, ny - 1), (nx - 2, 1), (7, ny - 8)], np.int32)])
     occ[src[:, 1], src[:, 0]] = 1
-    got = _ctx(vhp, occ).sweep_batch(src)
+    got = _ctx(vhp, occ, **LINE_SHAPE).sweep_batch(src)
     for k, (sx, sy) in enumerate(src):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d line mode, source (%d,%d)" % (nx, ny, sx, sy))
 
@@ -152,15 +163,12 @@ def test_fp32_storage_is_rounded_fp64(vhp, oracle):
 
 
 @pytest.mark.parametrize("nx,ny", [(640, 603), (1000, 520), (328, 300)])
-def test_fp32_large_batch_shape(vhp, oracle, monkeypatch, nx, ny):
+def test_fp32_large_batch_shape(vhp, oracle, nx, ny):
     # fp32 fields in the large-batch shape: the x-major strips hold rows back and flush whole 64-byte sectors
-    monkeypatch.setenv("VHP_R", "1")
-    monkeypatch.setenv("VHP_W", "8")
-    monkeypatch.setenv("VHP_SLIDE", "1")
     occ = maps.random_rect_map(nx, ny, 30, 4, nx // 8, 4, ny // 8, nx + 7 * ny)
     src = np.concatenate([maps.free_sources(occ, 4, nx), np.array([(0, 0), (nx - 1, ny - 1)], np.int32)])
     occ[src[:, 1], src[:, 0]] = 1
-    got = _ctx(vhp, occ).sweep_batch(src, dtype=vhp.F32)
+    got = _ctx(vhp, occ, **LINE_SHAPE).sweep_batch(src, dtype=vhp.F32)
     for k, (sx, sy) in enumerate(src):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)).astype(np.float32), "%dx%d fp32 source (%d,%d)" % (nx, ny, sx, sy))
 
@@ -194,6 +202,88 @@ def test_device_resident_batch_and_full_size_properties(vhp):
     assert torch.equal(first, d_out)
 
 
+def _device_launch(vhp, c, src, shape, dtype_t, dtype_v):
+    import torch
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
+    d_out = torch.full((len(src),) + shape, -1.0, dtype=dtype_t, device="cuda")
+    c.sweep_batch_device(d_src.data_ptr(), len(src), d_out.data_ptr(), dtype=dtype_v)
+    c.sync()
+    return d_out
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_config3_all_256_fields_of_the_bench_launch(vhp, oracle, dtype, kernel):
+    # the launch bench.py times (256 C3 sources, device-resident, default shape selection): EVERY field against
+    # the oracle, cell by cell.  kernel 0 = what the library picks by itself (the streaming sweep for a batch this
+    # size), 1 = the front sweep in its large-batch shape (one row per lane, line mode, slid grid), 2 = streaming sweep
+    import torch
+    occ, src = maps.config_c3(256)
+    c = _ctx(vhp, occ, kernel=kernel)
+    d_out = _device_launch(vhp, c, src, occ.shape, torch.float64 if dtype == "f64" else torch.float32,
+                           vhp.F64 if dtype == "f64" else vhp.F32)
+    for lo in range(0, 256, 32):
+        got = d_out[lo: lo + 32].cpu().numpy()
+        for k in range(32):
+            sx, sy = int(src[lo + k][0]), int(src[lo + k][1])
+            want = oracle.sweep_full(occ, sx, sy)
+            _assert_same(got[k], want if dtype == "f64" else want.astype(np.float32), "C3 %s bench launch, source %d (%d,%d)" % (dtype, lo + k, sx, sy))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_4096_large_batch_shape_eight_rounds(vhp, oracle, dtype):
+    # what 256+ sources run in at 4096^2: one row per lane, 8 strips per round => 8 rounds per octant, whole-line
+    # flushes, slid column grid.  Forced through the ABI options for a handful of sources incl. the corners.
+    occ, src = maps.config_c5(128)
+    pick = np.concatenate([src[[3, 64]], np.array([[0, 0], [4095, 4095], [4095, 0], [1, 4094]], np.int32)])
+    pick = pick[[bool(occ[y, x]) for x, y in pick]]
+    got = _ctx(vhp, occ, kernel=1, **LINE_SHAPE).sweep_batch(pick, dtype=vhp.F64 if dtype == "f64" else vhp.F32)
+    for k, (sx, sy) in enumerate(pick):
+        want = oracle.sweep_full(occ, int(sx), int(sy))
+        _assert_same(got[k], want if dtype == "f64" else want.astype(np.float32), "4096^2 %s 8-round shape, source (%d,%d)" % (dtype, sx, sy))
+
+
+def test_config5_sixteen_bench_sources(vhp, oracle):
+    # 16 of the exact 128 sources bench.py --workload c5 sweeps on rank 0, in the shape and grid slide that launch uses
+    import torch
+    occ, src = maps.config_c5(128)
+    pick = src[::8]
+    assert len(pick) == 16
+    c = _ctx(vhp, occ, slide=1)  # 128 sources => slid grid; 16 would not slide by themselves
+    d_out = _device_launch(vhp, c, pick, occ.shape, torch.float64, vhp.F64)
+    for k, (sx, sy) in enumerate(pick):
+        _assert_same(d_out[k].cpu().numpy(), oracle.sweep_full(occ, int(sx), int(sy)), "C5 bench source %d (%d,%d)" % (8 * k, sx, sy))
+
+
+@pytest.mark.parametrize("nx,ny", [(1500, 1100), (2500, 2300)])
+@pytest.mark.parametrize("shape", [dict(rows_per_lane=2, strips=4, multi_round=1), dict(rows_per_lane=4, strips=8),
+                                   dict(rows_per_lane=4, strips=4, multi_round=1), dict(rows_per_lane=2, strips=8, multi_round=1, slide=1)])
+def test_fp32_forced_shapes_above_1024(vhp, oracle, nx, ny, shape):
+    # fp32 fields in the two- and four-rows-per-lane instantiations, single- and multi-round, on sides above 1024
+    occ = maps.random_rect_map(nx, ny, 40, 10, nx // 6, 10, ny // 6, nx + 1)
+    src = np.concatenate([maps.free_sources(occ, 3, ny + 1), np.array([(0, 0), (nx - 1, ny - 1)], np.int32)])
+    occ[src[:, 1], src[:, 0]] = 1
+    got = _ctx(vhp, occ, **shape).sweep_batch(src, dtype=vhp.F32)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)).astype(np.float32), "%dx%d fp32 %r source (%d,%d)" % (nx, ny, shape, sx, sy))
+
+
+def test_two_contexts_and_caller_device_untouched(vhp, oracle):
+    # the dynamic-LDS limit is raised per context (per device), and no entry point changes the caller's device
+    import torch
+    before = torch.cuda.current_device()
+    occ = maps.random_rect_map(300, 263, 20, 3, 40, 3, 40, 4)
+    src = maps.free_sources(occ, 3, 4)
+    a, b = _ctx(vhp, occ), _ctx(vhp, occ)
+    ga, gb = a.sweep_batch(src), b.sweep_batch(src)
+    assert torch.cuda.current_device() == before
+    for k, (sx, sy) in enumerate(src):
+        want = oracle.sweep_full(occ, int(sx), int(sy))
+        _assert_same(ga[k], want, "context a")
+        _assert_same(gb[k], want, "context b")
+
+
 def test_errors(vhp):
     c = vhp.Context(0)
     with pytest.raises(vhp.VhpError) as e:
@@ -204,3 +294,8 @@ def test_errors(vhp):
         c.sweep_batch(np.array([[8, 0]], np.int32))
     assert e.value.code == vhp.VHP_ERR_SOURCE_OOB
     assert c.sweep_batch(np.zeros((0, 2), np.int32)).shape == (0, 8, 8)
+    with pytest.raises(vhp.VhpError) as e:
+        c.set_option("no_such_option", 1)
+    assert e.value.code == vhp.VHP_ERR_ARG
+    with pytest.raises(vhp.VhpError):
+        c.set_option("rows_per_lane", 3)

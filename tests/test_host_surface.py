@@ -134,3 +134,32 @@ def test_abi_exports():
             vhp_amd.Context(0)
     nm = subprocess.run(["nm", "-D", vhp_amd.LIB_PATH], capture_output=True, text=True).stdout
     assert "vhp_oracle" not in nm  # the product never links the oracle
+
+
+def test_reconstruct_path_rejects_inconsistent_tables(oracle):
+    """vhp_reconstruct_path is host code: it runs here.  A planner result of the oracle walks to the same path and
+    length; labels outside the pivot list, unlabelled cells and label cycles are errors, never out-of-bounds reads."""
+    import vhp_amd
+    import maps
+    vhp_amd.build_library()
+    occ = maps.random_rect_map(60, 50, 10, 3, 12, 3, 12, 2)
+    pts = maps.free_sources(occ, 2, 9)
+    start, end = tuple(int(v) for v in pts[0]), tuple(int(v) for v in pts[1])
+    r = oracle.solve(occ, start, end, 0.3, 40)
+    assert r["status"] == 0
+    d, path = vhp_amd.reconstruct_path(r["came_from"], r["pivots"], end)
+    dw, pathw = oracle.reconstruct_path(r["came_from"], r["pivots"], end)
+    assert d == dw and path.tolist() == pathw.tolist()
+    bad = r["came_from"].copy()
+    bad[end[1], end[0]] = r["n_pivots"] + 5          # label beyond the pivot list
+    with pytest.raises(vhp_amd.VhpError):
+        vhp_amd.reconstruct_path(bad, r["pivots"], end)
+    bad[end[1], end[0]] = vhp_amd.UNLABELLED         # unlabelled end cell
+    with pytest.raises(vhp_amd.VhpError):
+        vhp_amd.reconstruct_path(bad, r["pivots"], end)
+    # a 2-cycle between two pivots' cells: the walk is bounded by the pivot count
+    came = np.full((8, 8), vhp_amd.UNLABELLED, np.uint64)
+    piv = np.array([[1, 1], [5, 5], [7, 7]], np.int32)
+    came[1, 1], came[5, 5], came[7, 7] = 1, 0, 1
+    with pytest.raises(vhp_amd.VhpError):
+        vhp_amd.reconstruct_path(came, piv, (7, 7))

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "visibility-heuristic-path-planner_amd", "csrc")
 B = "/tmp/expbuild"
 os.makedirs(B, exist_ok=True)
-s = open(os.path.join(CS, "vhp_sweep.cuh")).read()
+s = open(os.path.join(CS, "vhp_sweep.hip.h")).read()
 s = s.replace("struct UnitGeom {", "__device__ unsigned long long vhp_dbg[256];\nstruct UnitGeom {", 1)
 def rep(old, new, count=1):
     global s
@@ -47,7 +47,7 @@ rep("  for (int T = 0; T <= tmax; ++T) {\n    const int n = T - p - kYLag;\n    
     "  unsigned long long dacc[8] = {0,0,0,0,0,0,0,0};\n  const int dbg_slot = 8 + p;\n  for (int T = 0; T <= tmax; ++T) {\n    const int n = T - p - kYLag;\n    if (strip_on && n >= nfirst && n <= nlast) {\n      int jlo, jhi;")
 rep("    __syncthreads();\n  }\n}",
     "    { unsigned long long tb = __builtin_amdgcn_s_memtime(); __syncthreads(); dacc[6] += __builtin_amdgcn_s_memtime() - tb; dacc[7] += 1; }\n  }\n  if (blockIdx.x == 0 && lane == 0) for (int k = 0; k < 8; ++k) vhp_dbg[dbg_slot * 8 + k] += dacc[k];\n}", 2)
-open(os.path.join(B, "vhp_sweep.cuh"), "w").write(s)
+open(os.path.join(B, "vhp_sweep.hip.h"), "w").write(s)
 c = open(os.path.join(CS, "vhp_capi.hip")).read()
 c = c.replace('}  // extern "C"', '''int vhp_debug_fetch(unsigned long long* out, int reset) {
   hipDeviceSynchronize();
@@ -57,7 +57,7 @@ c = c.replace('}  // extern "C"', '''int vhp_debug_fetch(unsigned long long* out
 }
 }  // extern "C"''')
 open(os.path.join(B, "vhp_capi.hip"), "w").write(c)
-for f in ("vhp_planner.cuh", "vhp_queue.cuh"):
+for f in ("vhp_planner.hip.h", "vhp_queue.hip.h"):
     open(os.path.join(B, f), "w").write(open(os.path.join(CS, f)).read())
 os.makedirs(os.path.join(ROOT, "exp"), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "--offload-arch=gfx950",

@@ -3,7 +3,7 @@ import os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "visibility-heuristic-path-planner_amd", "csrc")
 B = "/tmp/expbuild"; os.makedirs(B, exist_ok=True)
-s = open(os.path.join(CS, "vhp_sweep.cuh")).read()
+s = open(os.path.join(CS, "vhp_sweep.hip.h")).read()
 def rep(old, new, cnt=1):
     global s
     assert old in s, old[:70]
@@ -21,7 +21,7 @@ rep("    double* ring_w = ring_out + (yb & (kRing - 1));\n    double dj = (doubl
 rep("      off += stride;\n      y += DY;\n    }\n  };", "      off += stride;\n      y += DY;\n    }\n    unsigned long long ta2 = __builtin_amdgcn_s_memtime();\n    const int o = DIAG ? 4 : 0;\n    dacc[o] += ta1 - ta0; dacc[o + 1] += ta2 - ta1; dacc[o + 3] += 1;\n  };")
 rep("    __syncthreads();\n  }\n}", "    __syncthreads();\n  }\n  if (blockIdx.x == 0 && lane == 0 && ss.w == 0) for (int k = 0; k < 8; ++k) vhp_dbg[k] += dacc[k];\n}")
 rep("    __syncthreads();\n  }\n}", "    __syncthreads();\n  }\n  if (blockIdx.x == 0 && lane == 0 && ss.w == 0) for (int k = 0; k < 8; ++k) vhp_dbg[16 + k] += dacc[k];\n}")
-open(os.path.join(B, "vhp_sweep.cuh"), "w").write(s)
+open(os.path.join(B, "vhp_sweep.hip.h"), "w").write(s)
 c = open(os.path.join(CS, "vhp_capi.hip")).read()
 c = c.replace('}  // extern "C"', '''int vhp_debug_fetch(unsigned long long* out, int reset) {
   hipDeviceSynchronize();
@@ -31,7 +31,7 @@ c = c.replace('}  // extern "C"', '''int vhp_debug_fetch(unsigned long long* out
 }
 }  // extern "C"''')
 open(os.path.join(B, "vhp_capi.hip"), "w").write(c)
-for f in ("vhp_planner.cuh", "vhp_queue.cuh"):
+for f in ("vhp_planner.hip.h", "vhp_queue.hip.h"):
     open(os.path.join(B, f), "w").write(open(os.path.join(CS, f)).read())
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "--offload-arch=gfx950",
                        "-I" + os.path.join(ROOT, "include"), "-I.", "-shared", "-w", "-o", os.path.join(ROOT, "exp", "stamps_ph.so"), "vhp_capi.hip"], cwd=B)

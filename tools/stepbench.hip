@@ -2,7 +2,7 @@
 // variants of the dependent chain.  Diagnostic only.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../visibility-heuristic-path-planner_amd/csrc/vhp_sweep.cuh"
+#include "../visibility-heuristic-path-planner_amd/csrc/vhp_sweep.hip.h"
 using namespace vhp;
 
 template <int MODE, int R>

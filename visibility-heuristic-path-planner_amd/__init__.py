@@ -38,7 +38,7 @@ UNLABELLED = 1000000000000000
 ABI_SYMBOLS = (
     "vhp_create", "vhp_destroy", "vhp_last_error", "vhp_set_stream", "vhp_set_map", "vhp_set_map_device",
     "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
-    "vhp_raycast_all", "vhp_timing", "vhp_timing_collect",
+    "vhp_raycast_all", "vhp_timing", "vhp_timing_collect", "vhp_set_option",
     "vhp_last_elapsed_ms", "vhp_version",
 )
 
@@ -53,7 +53,7 @@ def build_library(force=False):
     """Compile libvhp_hip.so in-tree with hipcc (cross-compiles gfx950 without a GPU)."""
     if force and os.path.exists(LIB_PATH):
         os.remove(LIB_PATH)
-    subprocess.check_call(["make", "-s", "-C", CSRC])
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
     return LIB_PATH
 
 
@@ -81,7 +81,8 @@ def load_library():
     lib.vhp_sweep_batch_device.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.vhp_sync.argtypes = [vp]
     lib.vhp_planner_solve.argtypes = [vp, i32, i32, i32, i32, f64, u64, vp, vp, vp, vp, C.POINTER(u32)]
-    lib.vhp_reconstruct_path.argtypes = [vp, vp, i32, i32, i32, i32, vp, u32, C.POINTER(u32), C.POINTER(f64)]
+    lib.vhp_reconstruct_path.argtypes = [vp, vp, u32, i32, i32, i32, i32, vp, u32, C.POINTER(u32), C.POINTER(f64)]
+    lib.vhp_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
     lib.vhp_raycast_all.argtypes = [vp, i32, i32, vp]
     lib.vhp_timing.argtypes = [vp, i32]
     lib.vhp_timing_collect.argtypes = [vp, vp, i32, C.POINTER(i32)]
@@ -145,8 +146,13 @@ class Context:
     def sync(self):
         self._check(self.lib.vhp_sync(self.h))
 
-    def timing(self, enable=True):
-        self._check(self.lib.vhp_timing(self.h, 1 if enable else 0))
+    def set_option(self, key, value):
+        """Launch-shape override (include/vhp.h vhp_set_option); 0 / -1 = automatic."""
+        self._check(self.lib.vhp_set_option(self.h, key.encode(), int(value)))
+
+    def timing(self, enable=True, prealloc=0):
+        """prealloc > 1: event pairs created now, so that launches inside a timed loop create none."""
+        self._check(self.lib.vhp_timing(self.h, max(int(prealloc), 1) if enable else 0))
 
     def timing_collect(self, cap=4096):
         """Durations (ms) of the sweep kernels launched since timing(True), oldest first."""
@@ -180,17 +186,27 @@ class Context:
         return out
 
     def reconstruct_path(self, came_from, pivots, end):
-        ny, nx = came_from.shape
-        cap = 1 << 16
-        path = np.zeros((cap, 2), np.int32)
-        n = C.c_uint32(0)
-        d = C.c_double(0)
-        came = np.ascontiguousarray(came_from, np.uint64)
-        piv = np.ascontiguousarray(pivots, np.int32)
-        rc = self.lib.vhp_reconstruct_path(_ptr(came), _ptr(piv), nx, ny, end[0], end[1], _ptr(path), cap,
-                                           C.byref(n), C.byref(d))
-        self._check(rc)
-        return d.value, path[: n.value].copy()
+        return reconstruct_path(came_from, pivots, end)
+
+
+def reconstruct_path(came_from, pivots, end):
+    """vhp_reconstruct_path (host-only: needs no context and no GPU).
+
+    pivots: [n_pivots + 1, 2] as planner_solve returns them (the last entry is `end`).  Returns (length, path)."""
+    lib = load_library()
+    ny, nx = came_from.shape
+    piv = np.ascontiguousarray(pivots, np.int32).reshape(-1, 2)
+    n_pivots = len(piv) - 1
+    cap = n_pivots + 3
+    path = np.zeros((cap, 2), np.int32)
+    n = C.c_uint32(0)
+    d = C.c_double(0)
+    came = np.ascontiguousarray(came_from, np.uint64)
+    rc = lib.vhp_reconstruct_path(_ptr(came), _ptr(piv), n_pivots, nx, ny, end[0], end[1], _ptr(path), cap,
+                                  C.byref(n), C.byref(d))
+    if rc != VHP_OK:
+        raise VhpError(rc, "vhp_reconstruct_path: inconsistent came_from / pivots (or a path longer than %d points)" % cap)
+    return d.value, path[: n.value].copy()
 
 
 def version():

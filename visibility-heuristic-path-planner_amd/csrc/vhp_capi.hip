@@ -14,9 +14,10 @@
 #include <string>
 #include <vector>
 
-#include "vhp_sweep.cuh"
-#include "vhp_planner.cuh"
-#include "vhp_queue.cuh"
+#include "vhp_stream_launch.h"
+#include "vhp_sweep.hip.h"
+#include "vhp_planner.hip.h"
+#include "vhp_queue.hip.h"
 
 struct vhp_ctx {
   int device = 0;
@@ -45,12 +46,51 @@ struct vhp_ctx {
   size_t d_order_cap = 0;
   bool timing = false;      // per-launch event pairs around the sweep kernel (vhp_timing)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_launches;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;  // recycled pairs: no hipEventCreate inside a timed loop
+
+  // launch-shape overrides (vhp_set_option); 0 / -1 = automatic
+  int opt_rows_per_lane = 0;  // R: 1, 2 or 4
+  int opt_strips = 0;         // W: 1..8
+  int opt_multi = 0;          // 1: force the multi-round build
+  int opt_slide = -1;         // 0 / 1: y-major column grid slid onto 128-byte lines
+  int opt_pack = 0;           // 1: pack short quadrants into one workgroup
+  int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream)
+  // dynamic-LDS limit already raised on THIS context's device, per kernel function
+  std::vector<std::pair<const void*, size_t>> lds_raised;
 
   vhp::PlannerState pl;  // device-resident planner state
   vhp::QueueScratch qs;  // scratch of the queue-variant sweep
 };
 
 namespace {
+
+// Every entry point runs on the context's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: remember it per context.
+hipError_t raise_lds_limit(vhp_ctx* c, const void* fn, size_t bytes) {
+  for (auto& e : c->lds_raised)
+    if (e.first == fn) {
+      if (e.second >= bytes) return hipSuccess;
+      hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (r == hipSuccess) e.second = bytes;
+      return r;
+    }
+  hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (r == hipSuccess) c->lds_raised.push_back({fn, bytes});
+  return r;
+}
 
 int fail(vhp_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -63,6 +103,10 @@ int fail(vhp_ctx* c, int code, const std::string& msg) {
     if (e_ != hipSuccess)                                                                   \
       return fail(ctx, VHP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
   } while (0)
+
+#define VHP_ON_DEVICE(ctx)                   \
+  DeviceGuard device_guard_((ctx)->device); \
+  if (!device_guard_.ok) return fail((ctx), VHP_ERR_HIP, "hipSetDevice failed")
 
 vhp::DevMap dev_map(const vhp_ctx* c) {
   vhp::DevMap m;
@@ -82,7 +126,7 @@ vhp::DevMap dev_map(const vhp_ctx* c) {
 // A workgroup sweeps one quadrant with 2*W wavefronts (W strips per octant) and R rows/columns
 // per lane.  Fronts longer than W*64*R are swept in rounds (`multi`).  Overridable for tuning
 // with VHP_R / VHP_W / VHP_MULTI.
-void pick_shape(int maxdim, int* R, int* W, bool* multi, int n_src = 1, bool f64 = true, bool pitch64 = false) {
+void pick_shape(const vhp_ctx* c, int maxdim, int* R, int* W, bool* multi, int n_src = 1, bool f64 = true, bool pitch64 = false) {
   if (maxdim <= 64) { *R = 1; *W = 1; }
   else if (maxdim <= 128) { *R = 1; *W = 2; }
   else if (maxdim <= 256) { *R = 1; *W = 4; }
@@ -90,22 +134,20 @@ void pick_shape(int maxdim, int* R, int* W, bool* multi, int n_src = 1, bool f64
   else if (maxdim <= 1024) { *R = 2; *W = 8; }
   else { *R = 4; *W = 8; }
   // Store-bound batches (256+ sources: two or more workgroup rounds) do better in the one-row-per-lane shape, whose
-  // x-major strips flush whole 128-byte lines (vhp_sweep.cuh, line mode), swept in rounds of 512 rows: measured
+  // x-major strips flush whole 128-byte lines (vhp_sweep.hip.h, line mode), swept in rounds of 512 rows: measured
   // against the shapes above at 256 sources, -3 % time at 1000^2, -8 % at 1024^2 and 2048^2, -17 % at 1536^2 and
   // 4096^2.  Smaller batches are latency-bound and lose 10-30 % there.
   (void)f64;  // fp32 fields too: there the 16 staged columns are one whole 64-byte sector (-13 % time at 1000^2)
   if (maxdim > 256 && n_src >= 256 && pitch64) { *R = 1; *W = 8; }
-  if (const char* e = getenv("VHP_R")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) *R = v; }
-  if (const char* e = getenv("VHP_W")) { int v = atoi(e); if (v >= 1 && v <= 8) *W = v; }
+  if (c && c->opt_rows_per_lane) *R = c->opt_rows_per_lane;
+  if (c && c->opt_strips) *W = c->opt_strips;
   *multi = (*W) * 64 * (*R) < maxdim;
-  if (const char* e = getenv("VHP_MULTI")) { if (atoi(e) == 1) *multi = true; }
+  if (c && c->opt_multi) *multi = true;
   if (*R == 2 && *multi && *W > 4) *W = 4;  // that build is compiled for 8-wavefront workgroups
 }
 
 }  // namespace
-namespace vhp {
-void pick_shape_for(int maxdim, int* R, int* W, bool* multi) { pick_shape(maxdim, R, W, multi); }
-}
+
 namespace {
 
 void free_map(vhp_ctx* c) {
@@ -121,14 +163,12 @@ void free_map(vhp_ctx* c) {
 
 template <int R, bool MULTI, typename OutT>
 hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, int W) {
-  static const bool pack = getenv("VHP_PACK") != nullptr;
+  const bool pack = c->opt_pack != 0;
   const size_t lds = vhp::sweep_lds_bytes(R, W, MULTI, pack);
   auto k = vhp::vhp_sweep_fronts<R, MULTI, OutT>;
-  static size_t lds_allowed = 0;  // per instantiation: raise the dynamic-LDS limit once, not per launch
-  if (lds > lds_allowed) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = raise_lds_limit(c, reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return e;
-    lds_allowed = lds;
   }
   const long long stride = (long long)c->nx * c->ny;
   vhp::DevMap m = dev_map(c);
@@ -136,7 +176,7 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   // +1 % at 1000^2, +3.5 % at 4096^2); a lone quadrant is latency-bound, and there the predicated stores of the
   // slid strip 0 -- the busiest wavefront -- cost 9 %.
   m.slide = n_src >= 96 ? 1 : 0;
-  if (const char* e = getenv("VHP_SLIDE")) m.slide = atoi(e);
+  if (c->opt_slide >= 0) m.slide = c->opt_slide;
   hipError_t eb = vhp::attach_round_scratch(m, W * 64 * R, (size_t)n_src * vhp::kUnitsPerSource, &c->d_bnd, &c->d_bnd_cap);
   if (eb != hipSuccess) return eb;
   const size_t n_units = (size_t)n_src * vhp::kUnitsPerSource;
@@ -163,7 +203,13 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   }
   hipEvent_t ta = nullptr, tb = nullptr;
   if (c->timing) {
-    if (hipEventCreate(&ta) != hipSuccess || hipEventCreate(&tb) != hipSuccess) return hipErrorOutOfMemory;
+    if (!c->event_pool.empty()) {
+      ta = c->event_pool.back().first;
+      tb = c->event_pool.back().second;
+      c->event_pool.pop_back();
+    } else if (hipEventCreate(&ta) != hipSuccess || hipEventCreate(&tb) != hipSuccess) {
+      return hipErrorOutOfMemory;
+    }
     (void)hipEventRecord(ta, c->stream);
   }
   hipLaunchKernelGGL(k, dim3((unsigned)n_units), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order, desc);
@@ -191,11 +237,57 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   return el;
 }
 
+// Which kernel sweeps a batch: the streaming sweep (vhp_stream.hpp) is built for throughput -- many quadrants in
+// flight, whole-line stores, one barrier per 64 steps -- the front sweep (vhp_sweep.hip.h) for the latency of a few.
+bool use_stream_kernel(const vhp_ctx* c, int n_src) {
+  if (c->opt_kernel == 1) return false;
+  if (!vhp::stream_supported(c->nx, c->ny)) return false;
+  if (c->opt_kernel == 2) return true;
+  return n_src >= 128;
+}
+
+template <typename OutT>
+hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
+  const size_t n_units = (size_t)n_src * vhp::kUnitsPerSource;
+  if (c->d_order_cap < n_units) {
+    if (c->d_order) (void)hipFree(c->d_order);
+    c->d_order = nullptr;
+    c->d_order_cap = 0;
+    hipError_t eo = hipMalloc(&c->d_order, n_units * (sizeof(int) + sizeof(int4)) + 16);
+    if (eo != hipSuccess) return eo;
+    c->d_order_cap = n_units;
+  }
+  vhp::StreamArgs a;
+  a.rows = c->d_rows; a.cols = c->d_cols; a.recip = c->d_recip;
+  a.wpr = c->wpr; a.wpc = c->wpc; a.nx = c->nx; a.ny = c->ny;
+  a.d_src = d_src; a.n_src = n_src; a.d_out = d_out;
+  a.dtype = sizeof(OutT) == 8 ? VHP_F64 : VHP_F32;
+  a.field_stride = (long long)c->nx * c->ny;
+  a.d_err = c->d_err;
+  a.d_order = c->d_order;
+  a.stream = c->stream;
+  a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
+  a.ev_begin = a.ev_end = nullptr;
+  if (c->timing) {
+    if (!c->event_pool.empty()) {
+      a.ev_begin = c->event_pool.back().first;
+      a.ev_end = c->event_pool.back().second;
+      c->event_pool.pop_back();
+    } else if (hipEventCreate(&a.ev_begin) != hipSuccess || hipEventCreate(&a.ev_end) != hipSuccess) {
+      return hipErrorOutOfMemory;
+    }
+  }
+  const hipError_t e = vhp::launch_stream(a);
+  if (c->timing) c->timed_launches.push_back({a.ev_begin, a.ev_end});
+  return e;
+}
+
 template <typename OutT>
 hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
+  if (use_stream_kernel(c, n_src)) return launch_stream_sweep<OutT>(c, d_src, n_src, d_out);
   int R, W;
   bool multi;
-  pick_shape(std::max(c->nx, c->ny), &R, &W, &multi, n_src, sizeof(OutT) == 8, (c->nx & 7) == 0);
+  pick_shape(c, std::max(c->nx, c->ny), &R, &W, &multi, n_src, sizeof(OutT) == 8, (c->nx & 7) == 0);
   switch (R) {
     case 1: return multi ? launch_sweep_t<1, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<1, false, OutT>(c, d_src, n_src, d_out, W);
     case 2: return multi ? launch_sweep_t<2, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<2, false, OutT>(c, d_src, n_src, d_out, W);
@@ -253,7 +345,8 @@ int vhp_create(int device_ordinal, vhp_ctx** out) {
   if (device_ordinal < 0 || device_ordinal >= n) return VHP_ERR_ARG;
   vhp_ctx* ctx = new vhp_ctx();
   ctx->device = device_ordinal;
-  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess ||
+  DeviceGuard guard(device_ordinal);
+  if (!guard.ok || hipStreamCreate(&ctx->own_stream) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipMalloc(&ctx->d_err, sizeof(int)) != hipSuccess || hipMemset(ctx->d_err, 0, sizeof(int)) != hipSuccess) {
     delete ctx;
@@ -266,7 +359,7 @@ int vhp_create(int device_ordinal, vhp_ctx** out) {
 
 int vhp_destroy(vhp_ctx* ctx) {
   if (!ctx) return VHP_ERR_ARG;
-  hipSetDevice(ctx->device);
+  DeviceGuard guard(ctx->device);
   hipStreamSynchronize(ctx->stream);
   free_map(ctx);
   if (ctx->d_src) hipFree(ctx->d_src);
@@ -274,6 +367,7 @@ int vhp_destroy(vhp_ctx* ctx) {
   if (ctx->d_bnd) hipFree(ctx->d_bnd);
   if (ctx->d_order) hipFree(ctx->d_order);
   for (auto& pr : ctx->timed_launches) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& pr : ctx->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (ctx->d_err) hipFree(ctx->d_err);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -293,7 +387,7 @@ int vhp_set_stream(vhp_ctx* ctx, void* hip_stream) {
 static int set_map_common(vhp_ctx* ctx, const uint8_t* src, int nx, int ny, bool from_device) {
   if (!ctx || !src || nx <= 0 || ny <= 0) return fail(ctx, VHP_ERR_ARG, "vhp_set_map: bad argument");
   if (nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return fail(ctx, VHP_ERR_TOO_LARGE, "vhp_set_map: grid side exceeds VHP_MAX_SIDE");
-  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_ON_DEVICE(ctx);
   VHP_HIP(hipStreamSynchronize(ctx->stream));
   free_map(ctx);
   const size_t n = (size_t)nx * ny;
@@ -311,7 +405,7 @@ int vhp_sweep_batch_device(vhp_ctx* ctx, const int32_t* d_src_xy, int n_src, int
   if (dtype != VHP_F64 && dtype != VHP_F32) return fail(ctx, VHP_ERR_ARG, "bad dtype");
   if (variant != VHP_SWEEP_FULL && variant != VHP_SWEEP_QUEUE) return fail(ctx, VHP_ERR_ARG, "bad variant");
   if (n_src == 0) return VHP_OK;
-  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_ON_DEVICE(ctx);
   VHP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   hipError_t e;
   if (variant == VHP_SWEEP_QUEUE) {
@@ -329,7 +423,7 @@ int vhp_sweep_batch_device(vhp_ctx* ctx, const int32_t* d_src_xy, int n_src, int
 
 int vhp_sync(vhp_ctx* ctx) {
   if (!ctx) return VHP_ERR_ARG;
-  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_ON_DEVICE(ctx);
   VHP_HIP(hipStreamSynchronize(ctx->stream));
   int flag = 0;
   VHP_HIP(hipMemcpy(&flag, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost));
@@ -348,7 +442,7 @@ int vhp_sweep_batch(vhp_ctx* ctx, const int32_t* src_xy, int n_src, int variant,
     if (src_xy[2 * s] < 0 || src_xy[2 * s + 1] < 0 || src_xy[2 * s] >= ctx->nx || src_xy[2 * s + 1] >= ctx->ny)
       return fail(ctx, VHP_ERR_SOURCE_OOB, "a sweep source lies outside the grid");
   if (n_src == 0) return VHP_OK;
-  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_ON_DEVICE(ctx);
   const size_t esz = dtype == VHP_F64 ? 8 : 4;
   const size_t cells = (size_t)ctx->nx * ctx->ny;
   // bound device scratch: process the batch in slices of at most ~1 GiB of output
@@ -381,7 +475,7 @@ int vhp_raycast_all(vhp_ctx* ctx, int src_x, int src_y, double* out_host) {
   if (!ctx || !out_host) return fail(ctx, VHP_ERR_ARG, "vhp_raycast_all: bad argument");
   if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_raycast_all: no map set");
   if (src_x < 0 || src_y < 0 || src_x >= ctx->nx || src_y >= ctx->ny) return fail(ctx, VHP_ERR_SOURCE_OOB, "source outside the grid");
-  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_ON_DEVICE(ctx);
   const size_t cells = (size_t)ctx->nx * ctx->ny;
   if (ctx->d_out_cap < cells * 8) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
@@ -405,12 +499,35 @@ int vhp_raycast_all(vhp_ctx* ctx, int src_x, int src_y, double* out_host) {
 int vhp_timing(vhp_ctx* ctx, int enable) {
   if (!ctx) return VHP_ERR_ARG;
   ctx->timing = enable != 0;
+  if (enable > 1) {  // pre-create `enable` event pairs so that no launch inside a timed loop has to
+    VHP_ON_DEVICE(ctx);
+    while ((int)ctx->event_pool.size() < enable) {
+      hipEvent_t a = nullptr, b = nullptr;
+      VHP_HIP(hipEventCreate(&a));
+      VHP_HIP(hipEventCreate(&b));
+      ctx->event_pool.push_back({a, b});
+    }
+  }
+  return VHP_OK;
+}
+
+int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
+  if (!ctx || !key) return VHP_ERR_ARG;
+  const std::string k(key);
+  const int v = (int)value;
+  if (k == "rows_per_lane") { if (v != 0 && v != 1 && v != 2 && v != 4) return fail(ctx, VHP_ERR_ARG, "rows_per_lane: 0, 1, 2 or 4"); ctx->opt_rows_per_lane = v; }
+  else if (k == "strips") { if (v < 0 || v > 8) return fail(ctx, VHP_ERR_ARG, "strips: 0..8"); ctx->opt_strips = v; }
+  else if (k == "multi_round") { ctx->opt_multi = v != 0; }
+  else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
+  else if (k == "pack") { ctx->opt_pack = v != 0; }
+  else if (k == "kernel") { if (v < 0 || v > 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream"); ctx->opt_kernel = v; }
+  else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;
 }
 
 int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n) {
   if (!ctx || !n || cap < 0 || (cap > 0 && !ms_out)) return VHP_ERR_ARG;
-  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_ON_DEVICE(ctx);
   int k = 0;
   for (auto& pr : ctx->timed_launches) {
     float ms = 0.f;
@@ -418,8 +535,7 @@ int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n) {
     VHP_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
     if (k < cap) ms_out[k] = ms;
     ++k;
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+    ctx->event_pool.push_back(pr);  // recycled by the next timed launches
   }
   ctx->timed_launches.clear();
   *n = std::min(k, cap);
@@ -429,7 +545,7 @@ int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n) {
 int vhp_last_elapsed_ms(vhp_ctx* ctx, float* ms) {
   if (!ctx || !ms) return VHP_ERR_ARG;
   if (!ctx->timed) return fail(ctx, VHP_ERR_ARG, "nothing timed yet");
-  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_ON_DEVICE(ctx);
   VHP_HIP(hipEventSynchronize(ctx->ev1));
   VHP_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
   return VHP_OK;
@@ -440,15 +556,19 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
                       int32_t* pivots_xy, uint32_t* n_pivots) {
   if (!ctx) return VHP_ERR_ARG;
   if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_planner_solve: no map set");
-  VHP_HIP(hipSetDevice(ctx->device));
+  VHP_ON_DEVICE(ctx);
   std::string msg;
   vhp::DevMap pm = dev_map(ctx);
   {
     int R, W;
     bool multi;
-    pick_shape(std::max(ctx->nx, ctx->ny), &R, &W, &multi);
+    pick_shape(ctx, std::max(ctx->nx, ctx->ny), &R, &W, &multi);
     hipError_t eb = vhp::attach_round_scratch(pm, W * 64 * R, 4, &ctx->d_bnd, &ctx->d_bnd_cap);
     if (eb != hipSuccess) return fail(ctx, VHP_ERR_HIP, std::string("scratch: ") + hipGetErrorString(eb));
+    ctx->pl.R = R;
+    ctx->pl.W = W;
+    ctx->pl.multi = multi;
+    ctx->pl.raise_lds = [ctx](const void* fn, size_t bytes) { return raise_lds_limit(ctx, fn, bytes); };
   }
   int rc = vhp::planner_solve(ctx->pl, pm, ctx->d_occ, ctx->stream, ctx->ev0, ctx->ev1, start_x, start_y, end_x,
                               end_y, threshold, max_iter, came_from, vis_global, vis_local, pivots_xy, n_pivots, &msg);
@@ -462,12 +582,13 @@ static inline double eval_d_host(int ax, int ay, int bx, int by) {
   return std::sqrt((double)(ax - bx) * (ax - bx) + (ay - by) * (ay - by));
 }
 
-int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, int nx, int ny, int end_x, int end_y,
-                         int32_t* path_xy, uint32_t cap, uint32_t* n_path, double* length) {
+int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, uint32_t n_pivots, int nx, int ny, int end_x,
+                         int end_y, int32_t* path_xy, uint32_t cap, uint32_t* n_path, double* length) {
   if (!came_from || !pivots_xy || nx <= 0 || ny <= 0) return VHP_ERR_ARG;
   if (end_x < 0 || end_y < 0 || end_x >= nx || end_y >= ny) return VHP_ERR_END_OOB;
   // walk labels back to the start: the label of a pivot's own cell is the pivot that
-  // lit it, the start labels itself, so the walk stops when the label repeats
+  // lit it, the start labels itself, so the walk stops when the label repeats.  Labels index
+  // pivots_xy[0 .. n_pivots]; a consistent table needs at most n_pivots + 1 hops.
   std::vector<std::pair<int, int>> rev;
   int x = end_x, y = end_y;
   uint64_t t = came_from[(size_t)x + (size_t)y * nx];
@@ -475,7 +596,8 @@ int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, in
   while (t != t_old) {
     rev.push_back({x, y});
     t_old = t;
-    if (t >= VHP_UNLABELLED) return VHP_ERR_ARG;  // unlabelled cell on the path: nothing to follow
+    if (t > n_pivots) return VHP_ERR_ARG;  // unlabelled cell (VHP_UNLABELLED) or a label outside the pivot list
+    if (rev.size() > (size_t)n_pivots + 2) return VHP_ERR_ARG;  // the labels form a cycle: not a planner result
     x = pivots_xy[2 * t];
     y = pivots_xy[2 * t + 1];
     if (x < 0 || y < 0 || x >= nx || y >= ny) return VHP_ERR_ARG;
@@ -486,13 +608,15 @@ int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, in
   double total = 0.0;
   for (size_t k = 0; k + 1 < rev.size(); ++k)
     total += eval_d_host(rev[k].first, rev[k].second, rev[k + 1].first, rev[k + 1].second);
-  if (n_path) *n_path = (uint32_t)rev.size();
+  if (n_path) *n_path = (uint32_t)rev.size();  // the size needed, also when it exceeds cap
   if (length) *length = total;
-  if (path_xy)
-    for (size_t k = 0; k < rev.size() && k < cap; ++k) {
+  if (path_xy) {
+    if (rev.size() > cap) return VHP_ERR_TOO_LARGE;  // nothing written; *n_path says how many points there are
+    for (size_t k = 0; k < rev.size(); ++k) {
       path_xy[2 * k] = rev[k].first;
       path_xy[2 * k + 1] = rev[k].second;
     }
+  }
   return VHP_OK;
 }
 

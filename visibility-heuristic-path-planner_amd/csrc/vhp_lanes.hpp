@@ -1,0 +1,234 @@
+// vhp_lanes.hpp -- the wavefront as a value type.
+//
+// The streaming sweep kernel (vhp_stream.hpp) is written once against the few operations below and compiled twice:
+//
+//   * by hipcc for gfx950 (the product): a "lane vector" is the plain per-thread scalar of the SIMT model, every
+//     operation is the instruction it names (DPP wave shifts, v_readlane, v_bfe_i32, ds_read/ds_write, global
+//     stores with a 32-bit byte offset on a scalar base) and all of it inlines away;
+//   * by g++ with -DVHP_SIM (tests/sim only): a lane vector is an array of 64 values and every operation is a loop
+//     over lanes, so that the kernel's schedule, index arithmetic, predicates and data flow can be checked against
+//     the oracle on a machine without a GPU, cell for cell, over thousands of geometries.  That build is TEST
+//     INFRASTRUCTURE: nothing in the product loads it, and it is not a CPU fallback (it runs one workgroup at a
+//     time, wavefront by wavefront, and is ~1000x slower than the oracle itself).
+//
+// The discipline this buys: control flow in the kernel is wavefront-uniform by construction -- an `if` on a lane
+// vector does not compile in the simulator build -- and everything lane-dependent is a select or a predicated store.
+#pragma once
+#include <stdint.h>
+
+#ifdef VHP_SIM
+#include <cmath>
+#include <cstring>
+#define VHP_LANE_FN inline
+#else
+#include <hip/hip_runtime.h>
+#define VHP_LANE_FN __device__ __forceinline__
+#endif
+
+namespace vhp {
+namespace lanes {
+
+constexpr int kLanes = 64;
+
+#ifdef VHP_SIM
+// ------------------------------------------------------------------------------------------------------------
+// simulator build: 64 explicit lanes
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct V {
+  T v[kLanes];
+  V() = default;
+  V(T s) {  // broadcast (implicit on purpose: uniform values mix freely with lane vectors)
+    for (int l = 0; l < kLanes; ++l) v[l] = s;
+  }
+};
+using vd = V<double>;
+using vi = V<int>;
+using vu32 = V<uint32_t>;
+using vu64 = V<uint64_t>;
+using vb = V<bool>;
+
+#define VHP_SIM_BINOP(OP, RT)                                                                        \
+  template <typename T> inline V<RT> operator OP(const V<T>& a, const V<T>& b) {                       \
+    V<RT> r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] OP b.v[l]; return r; }                   \
+  template <typename T> inline V<RT> operator OP(const V<T>& a, T b) {                                 \
+    V<RT> r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] OP b; return r; }                        \
+  template <typename T> inline V<RT> operator OP(T a, const V<T>& b) {                                 \
+    V<RT> r; for (int l = 0; l < kLanes; ++l) r.v[l] = a OP b.v[l]; return r; }
+#define VHP_SIM_ARITH(OP) VHP_SIM_BINOP(OP, T)
+#define VHP_SIM_CMP(OP) VHP_SIM_BINOP(OP, bool)
+VHP_SIM_ARITH(+) VHP_SIM_ARITH(-) VHP_SIM_ARITH(*) VHP_SIM_ARITH(&) VHP_SIM_ARITH(|) VHP_SIM_ARITH(^)
+VHP_SIM_ARITH(>>) VHP_SIM_ARITH(<<)
+VHP_SIM_CMP(==) VHP_SIM_CMP(!=) VHP_SIM_CMP(<) VHP_SIM_CMP(<=) VHP_SIM_CMP(>) VHP_SIM_CMP(>=)
+#undef VHP_SIM_ARITH
+#undef VHP_SIM_CMP
+#undef VHP_SIM_BINOP
+inline vb operator&&(const vb& a, const vb& b) { vb r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] && b.v[l]; return r; }
+inline vb operator&&(const vb& a, bool b) { vb r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] && b; return r; }
+inline vb operator&&(bool a, const vb& b) { return b && a; }
+inline vb operator||(const vb& a, const vb& b) { vb r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] || b.v[l]; return r; }
+inline vb operator!(const vb& a) { vb r; for (int l = 0; l < kLanes; ++l) r.v[l] = !a.v[l]; return r; }
+template <typename T> inline V<T> operator-(const V<T>& a) { V<T> r; for (int l = 0; l < kLanes; ++l) r.v[l] = -a.v[l]; return r; }
+
+inline vi lane_id() { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = l; return r; }
+inline vd to_f64(const vi& a) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = (double)a.v[l]; return r; }
+inline vu32 to_u32(const vi& a) { vu32 r; for (int l = 0; l < kLanes; ++l) r.v[l] = (uint32_t)a.v[l]; return r; }
+template <typename T> inline V<T> select(const vb& c, const V<T>& a, const V<T>& b) {
+  V<T> r; for (int l = 0; l < kLanes; ++l) r.v[l] = c.v[l] ? a.v[l] : b.v[l]; return r; }
+inline vi vmin(const vi& a, int b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] < b ? a.v[l] : b; return r; }
+inline vi vmax(const vi& a, int b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] > b ? a.v[l] : b; return r; }
+inline vd vfma(const vd& a, const vd& b, const vd& c) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = std::fma(a.v[l], b.v[l], c.v[l]); return r; }
+
+// lane l <- lane l-1; lane 0 <- fill's lane 0
+inline vd shift_up(const vd& v, const vd& fill) { vd r; r.v[0] = fill.v[0]; for (int l = 1; l < kLanes; ++l) r.v[l] = v.v[l - 1]; return r; }
+// lane l <- lane l+1; lane 63 <- lane 0
+inline vd rotate_down(const vd& v) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = v.v[(l + 1) & 63]; return r; }
+inline double read_lane(const vd& v, int l) { return v.v[l & 63]; }
+// v * occ for occ in {0,1}: AND with 0 / ~0
+inline vd and_mask(const vd& v, const vi& m) {
+  vd r;
+  for (int l = 0; l < kLanes; ++l) { uint64_t u; std::memcpy(&u, &v.v[l], 8); u &= m.v[l] ? ~0ull : 0ull; std::memcpy(&r.v[l], &u, 8); }
+  return r;
+}
+// bit b (uniform, 0..63) of a lane-private word as 0 / ~0
+inline vi bit_mask(const vu64& w, int b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = ((w.v[l] >> (b & 63)) & 1ull) ? -1 : 0; return r; }
+// the 32-bit half of w that holds bit t (uniform), shifted right by sh (uniform, 0..31)
+inline vu32 half_shifted(const vu64& w, int t, int sh) {
+  vu32 r; for (int l = 0; l < kLanes; ++l) r.v[l] = (uint32_t)((t & 32) ? (w.v[l] >> 32) : w.v[l]) >> sh; return r; }
+// bit `b` (compile time in the kernel) of hs as 0 / ~0: v_bfe_i32
+inline vi sbfe1(const vu32& hs, int b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = ((hs.v[l] >> b) & 1u) ? -1 : 0; return r; }
+
+inline vd lds_load(const double* base, const vi& idx) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = base[idx.v[l]]; return r; }
+inline void lds_store(double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) base[idx.v[l]] = v.v[l]; }
+inline void lds_store_if(const vb& p, double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v.v[l]; }
+inline vu64 g_load_u64(const uint64_t* base, const vi& idx) { vu64 r; for (int l = 0; l < kLanes; ++l) r.v[l] = base[idx.v[l]]; return r; }
+inline vd g_load_f64(const double* base, const vi& idx) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = base[idx.v[l]]; return r; }
+
+// The simulator records every global store (how many, how wide, which 64-byte sectors) for the tests' coverage
+// and store-shape checks.
+struct StoreStats { long long n16 = 0, n8 = 0, n4 = 0; };
+inline StoreStats& store_stats() { static StoreStats s; return s; }
+
+// two adjacent cells at byte offset off (16-byte aligned for double, 8 for float)
+template <typename OutT> inline void g_store2(OutT* base, const vu32& off, const vd& a, const vd& b) {
+  for (int l = 0; l < kLanes; ++l) {
+    OutT* p = reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]);
+    p[0] = (OutT)a.v[l]; p[1] = (OutT)b.v[l];
+  }
+  store_stats().n16 += 1;
+}
+template <typename OutT> inline void g_store2_if(const vb& p2, const vb& p_lo, const vb& p_hi, OutT* base, const vu32& off, const vd& a, const vd& b) {
+  // p2: both cells; else p_lo: only the first; else p_hi: only the second
+  for (int l = 0; l < kLanes; ++l) {
+    OutT* p = reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]);
+    if (p2.v[l]) { p[0] = (OutT)a.v[l]; p[1] = (OutT)b.v[l]; }
+    else if (p_lo.v[l]) p[0] = (OutT)a.v[l];
+    else if (p_hi.v[l]) p[1] = (OutT)b.v[l];
+  }
+  store_stats().n16 += 1;
+}
+template <typename OutT> inline void g_store1_if(const vb& p1, OutT* base, const vu32& off, const vd& a) {
+  for (int l = 0; l < kLanes; ++l) if (p1.v[l]) *reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]) = (OutT)a.v[l];
+  store_stats().n8 += 1;
+}
+inline void wave_sync() {}
+template <typename T> inline void pin(T&) {}
+inline int uniform(int x) { return x; }
+
+#else
+// ------------------------------------------------------------------------------------------------------------
+// device build (gfx950): a lane vector is the per-thread scalar
+// ------------------------------------------------------------------------------------------------------------
+using vd = double;
+using vi = int;
+using vu32 = uint32_t;
+using vu64 = uint64_t;
+using vb = bool;
+
+VHP_LANE_FN vi lane_id() { return (int)(threadIdx.x & 63u); }
+VHP_LANE_FN vd to_f64(vi a) { return (double)a; }
+VHP_LANE_FN vu32 to_u32(vi a) { return (uint32_t)a; }
+template <typename T> VHP_LANE_FN T select(bool c, T a, T b) { return c ? a : b; }
+VHP_LANE_FN vi vmin(vi a, int b) { return a < b ? a : b; }
+VHP_LANE_FN vi vmax(vi a, int b) { return a > b ? a : b; }
+VHP_LANE_FN vd vfma(vd a, vd b, vd c) { return __builtin_fma(a, b, c); }
+
+// lane l <- lane l-1, lane 0 keeps `fill`'s lane 0.  DPP wave_shr:1 (gfx9 encoding 0x138); with bound_ctrl off the
+// lane without a source keeps `old`.
+VHP_LANE_FN vd shift_up(vd v, vd fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  const int flo = __double2loint(fill), fhi = __double2hiint(fill);
+  lo = __builtin_amdgcn_update_dpp(flo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// lane l <- lane l+1 (lane 63 <- lane 0): DPP wave_rol:1 (0x134)
+VHP_LANE_FN vd rotate_down(vd v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// wave-uniform read of lane l (l uniform): v_readlane_b32 x 2
+VHP_LANE_FN double read_lane(vd v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+VHP_LANE_FN vd and_mask(vd v, vi m) { return __hiloint2double(__double2hiint(v) & m, __double2loint(v) & m); }
+VHP_LANE_FN vi bit_mask(vu64 w, int b) {
+  const uint32_t half = (b & 32) ? (uint32_t)(w >> 32) : (uint32_t)w;
+  return __builtin_amdgcn_sbfe(half, b & 31, 1);
+}
+VHP_LANE_FN vu32 half_shifted(vu64 w, int t, int sh) { return ((t & 32) ? (uint32_t)(w >> 32) : (uint32_t)w) >> sh; }
+VHP_LANE_FN vi sbfe1(vu32 hs, int b) { return __builtin_amdgcn_sbfe(hs, b, 1); }
+
+VHP_LANE_FN vd lds_load(const double* base, vi idx) { return base[idx]; }
+VHP_LANE_FN void lds_store(double* base, vi idx, vd v) { base[idx] = v; }
+VHP_LANE_FN void lds_store_if(bool p, double* base, vi idx, vd v) { if (p) base[idx] = v; }
+VHP_LANE_FN vu64 g_load_u64(const uint64_t* base, vi idx) { return base[idx]; }
+VHP_LANE_FN vd g_load_f64(const double* base, vi idx) { return base[idx]; }
+
+template <typename OutT> struct alignas(2 * sizeof(OutT)) Pair { OutT a, b; };
+template <typename OutT> VHP_LANE_FN void g_store2(OutT* base, vu32 off, vd a, vd b) {
+  *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
+}
+template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p_hi, OutT* base, vu32 off, vd a, vd b) {
+  vd single = p_lo ? a : b;
+  asm volatile("" : "+v"(single));  // keep the compiler from splitting the 16-byte store to share a half with the single
+  if (p2) *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
+  else if (p_lo || p_hi)
+    *reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off + (p_lo ? 0u : (uint32_t)sizeof(OutT))) = static_cast<OutT>(single);
+}
+template <typename OutT> VHP_LANE_FN void g_store1_if(bool p1, OutT* base, vu32 off, vd a) {
+  if (p1) *reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off) = static_cast<OutT>(a);
+}
+// orders this wavefront's LDS writes before its later LDS reads of other lanes' data
+VHP_LANE_FN void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Makes a just-loaded value count as "used here": the compiler then waits for the load at this point instead of at
+// the first real use (where the s_waitcnt vmcnt would also drain every store issued in between).
+VHP_LANE_FN void pin(double& v) { asm volatile("" : "+v"(v)); }
+VHP_LANE_FN void pin(uint64_t& v) { asm volatile("" : "+v"(v)); }
+VHP_LANE_FN int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+#endif
+
+// RN(num/den) for integers 0 <= num < den <= 16384, given rden = RN(1/den): Markstein's correction, proved
+// bit-identical to the division by oracle/markstein_check.c.  num is a lane vector, den and rden are uniform.
+VHP_LANE_FN vd ratio(vd num, double den, double rden) {
+  const vd q = num * vd(rden);
+  const vd r = vfma(vd(-den), q, num);
+  return vfma(r, vd(rden), q);
+}
+// the reference's update (solver.cpp:592-594 / 598-600): a - c*(a - b), no contraction
+VHP_LANE_FN vd stencil(vd a, vd b, vd c) {
+  const vd t = a - b;
+  const vd u = c * t;
+  return a - u;
+}
+
+}  // namespace lanes
+}  // namespace vhp

@@ -1,4 +1,4 @@
-// vhp_planner.cuh -- the visibility-heuristic planner loop on the GPU.
+// vhp_planner.hip.h -- the visibility-heuristic planner loop on the GPU.
 //
 // Replaces solve() (reference src/visibilityBasedSolver.cpp:76-160), updateVisibility()
 // (:379-565) and the std::priority_queue / top() arg-min
@@ -7,7 +7,7 @@
 // All planner state lives in HBM for the whole solve: vis_global, vis_local, labels
 // (cameFrom_ as uint32), the pivot list (lightSources_) and a small control block.
 // One iteration = three kernels on one stream, no host round trip:
-//   vhp_planner_sweep    : the front sweep of vhp_sweep.cuh (its fast path) from the current
+//   vhp_planner_sweep    : the front sweep of vhp_sweep.hip.h (its fast path) from the current
 //                          pivot into vis_local;
 //   vhp_planner_epilogue : per visited cell max-union into vis_global, first-lit labelling,
 //                          heuristic h of every lit cell, block arg-min of (h, push rank);
@@ -25,11 +25,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
 #include "vhp.h"
-#include "vhp_sweep.cuh"
+#include "vhp_sweep.hip.h"
 
 namespace vhp {
 
@@ -93,7 +94,7 @@ __device__ __forceinline__ PlannerKey key_shuffle_xor(const PlannerKey& k, int m
   return o;
 }
 
-// Step 1 of a planner iteration: the plain front sweep (vhp_sweep.cuh, fast path) from the
+// Step 1 of a planner iteration: the plain front sweep (vhp_sweep.hip.h, fast path) from the
 // current pivot into vis_local -- the reference's visibility_ (solver.cpp:386-416).
 template <int R, bool MULTI>
 __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : ((MULTI && R == 2) ? 6 : 8)) vhp_planner_sweep(DevMap m, PlannerDev d) {
@@ -197,6 +198,13 @@ __global__ void vhp_planner_init(PlannerDev d, int nx, int start_x, int start_y)
     d.pivots[0] = start_x;  // lightSources_[0] = start; cameFrom_(start) = 0   (solver.cpp:121-122)
     d.pivots[1] = start_y;
     d.label[(size_t)start_y * nx + start_x] = 0;
+    // while (visibility_global_(end) <= threshold), solver.cpp:127: visibility_global_ is all zero here, so a
+    // negative threshold skips the loop altogether; lightSources_[0] = end then (:141)
+    if (0.0 > d.threshold) {
+      d.pivots[0] = d.end_x;
+      d.pivots[1] = d.end_y;
+      d.ctl->done = 1;
+    }
   }
 }
 
@@ -216,6 +224,10 @@ struct PlannerState {
   int32_t* pivots = nullptr;
   PlannerCtl* ctl = nullptr;
   PlannerKey* partial = nullptr;
+  // launch shape of the front sweep and the per-device dynamic-LDS bookkeeping, set by the caller (vhp_capi.hip)
+  int R = 2, W = 8;
+  bool multi = false;
+  std::function<hipError_t(const void*, size_t)> raise_lds;
 };
 
 inline void planner_free(PlannerState& s) {
@@ -226,10 +238,15 @@ inline void planner_free(PlannerState& s) {
   if (s.pivots) (void)hipFree(s.pivots);
   if (s.ctl) (void)hipFree(s.ctl);
   if (s.partial) (void)hipFree(s.partial);
-  s = PlannerState();
+  s.cells = 0;
+  s.pivot_cap = 0;
+  s.vis_global = s.vis_local = nullptr;
+  s.label = nullptr;
+  s.came64 = nullptr;
+  s.pivots = nullptr;
+  s.ctl = nullptr;
+  s.partial = nullptr;
 }
-
-void pick_shape_for(int maxdim, int* R, int* W, bool* multi);  // defined in vhp_capi.hip
 
 #define VHP_PL_HIP(call)                                                      \
   do {                                                                        \
@@ -241,14 +258,13 @@ void pick_shape_for(int maxdim, int* R, int* W, bool* multi);  // defined in vhp
   } while (0)
 
 template <int R, bool MULTI>
-inline hipError_t launch_planner_fronts(const DevMap& m, const PlannerDev& d, int W, hipStream_t stream) {
+inline hipError_t launch_planner_fronts(PlannerState& s, const DevMap& m, const PlannerDev& d, int W, hipStream_t stream) {
   const size_t lds = sweep_lds_bytes(R, W, MULTI);
   auto k = vhp_planner_sweep<R, MULTI>;
-  static size_t lds_allowed = 0;
-  if (lds > lds_allowed) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = s.raise_lds ? s.raise_lds(reinterpret_cast<const void*>(k), lds)
+                               : hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    lds_allowed = lds;
   }
   hipLaunchKernelGGL(k, dim3(4), dim3(128 * W), lds, stream, m, d);
   return hipGetLastError();
@@ -311,9 +327,8 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   d.end_y = end_y;
   d.max_iter = max_iter;
 
-  int R, W;
-  bool multi;
-  pick_shape_for(std::max(nx, ny), &R, &W, &multi);
+  const int R = s.R, W = s.W;
+  const bool multi = s.multi;
   VHP_PL_HIP(hipEventRecord(ev0, stream));
   hipLaunchKernelGGL(vhp_planner_init, dim3(1), dim3(64), 0, stream, d, nx, start_x, start_y);
   VHP_PL_HIP(hipGetLastError());
@@ -321,9 +336,9 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   const int batch = 4;  // iterations enqueued per host poll
   for (;;) {
     for (int b = 0; b < batch; ++b) {
-      hipError_t e = R == 1 ? (multi ? launch_planner_fronts<1, true>(m, d, W, stream) : launch_planner_fronts<1, false>(m, d, W, stream))
-                   : R == 2 ? (multi ? launch_planner_fronts<2, true>(m, d, W, stream) : launch_planner_fronts<2, false>(m, d, W, stream))
-                            : (multi ? launch_planner_fronts<4, true>(m, d, W, stream) : launch_planner_fronts<4, false>(m, d, W, stream));
+      hipError_t e = R == 1 ? (multi ? launch_planner_fronts<1, true>(s, m, d, W, stream) : launch_planner_fronts<1, false>(s, m, d, W, stream))
+                   : R == 2 ? (multi ? launch_planner_fronts<2, true>(s, m, d, W, stream) : launch_planner_fronts<2, false>(s, m, d, W, stream))
+                            : (multi ? launch_planner_fronts<4, true>(s, m, d, W, stream) : launch_planner_fronts<4, false>(s, m, d, W, stream));
       if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
       hipLaunchKernelGGL(vhp_planner_epilogue, dim3(kEpilogueBlocks), dim3(256), 0, stream, m, d);
       VHP_PL_HIP(hipGetLastError());

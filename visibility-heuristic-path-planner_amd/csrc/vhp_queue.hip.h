@@ -1,4 +1,4 @@
-// vhp_queue.cuh -- computeVisibilityUsingQueue() on the device.
+// vhp_queue.hip.h -- computeVisibilityUsingQueue() on the device.
 //
 // Replaces reference src/visibilityBasedSolver.cpp:701-893.  That routine is a FIFO
 // flood whose result depends on the exact pop order (a cell is computed at
@@ -15,7 +15,7 @@
 #include <stdint.h>
 
 #include "vhp.h"
-#include "vhp_sweep.cuh"
+#include "vhp_sweep.hip.h"
 
 namespace vhp {
 

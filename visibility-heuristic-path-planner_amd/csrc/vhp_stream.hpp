@@ -1,0 +1,616 @@
+// vhp_stream.hpp -- the streaming visibility sweep: the throughput shape of computeVisibility()
+// (reference src/visibilityBasedSolver.cpp:570-696) for large batches of sources.
+//
+// Same mathematics as the front sweep of vhp_sweep.hip.h (tests/schedule_model.py states it: a quadrant is an
+// x-major octant whose fronts are columns and a y-major octant whose fronts are rows; a cell needs only the
+// previous front: itself and its neighbour one row / column below), organised for a store-bound launch of a
+// thousand quadrants instead of for the latency of one:
+//
+//   * one workgroup per (source, quadrant), 2*W wavefronts: W sweep strips of the x-major octant (64 rows each,
+//     one row per lane), W sweep strips of the y-major octant (128 columns each, two adjacent columns per lane, so
+//     that a lane stores 16 bytes per row and a wavefront 1 KB);
+//   * time is cut into SLOTS of one 64-cell block of the marching coordinate -- exactly one word of the bit-packed
+//     occupancy maps, so a lane loads one word per owned row/column and slot -- with one workgroup barrier per slot
+//     (an eighth of the front sweep's barriers).  A wavefront takes the strips w, w+W, w+2W, ... one after the other;
+//     inside a round strip p runs one slot behind strip p-1 and receives its boundary row through a two-block LDS
+//     ring, and the last strip of a round leaves its boundary row in a full-length LDS row for the first strip of the
+//     next round.  The whole schedule is static (compute_schedule): every wavefront knows in which slot it sweeps
+//     which block of which strip, and the only synchronisation is the slot barrier;
+//   * x-major strips stage 16 columns in a wave-private LDS tile and emit every row as whole, aligned 128-byte lines
+//     (8 rows per store instruction).  With a row pitch that is an odd multiple of 64 bytes (1000 columns!) odd and even
+//     rows are half a line apart, so the two row classes flush alternately, each every 16 steps;
+//   * the stale diagonal of the reference (cell (k,k) = cell (k,k-1) * occ) is produced by the x-major strip
+//     that owns row k and handed to the y-major octant, which seeds column k with it, through an LDS array.
+//
+// The code is written against vhp_lanes.hpp and is compiled for gfx950 (vhp_stream.hip) and, unchanged, for the CPU
+// simulator of tests/sim (parity against the oracle without a GPU).  Requires nx % 8 == 0 (whole 64-byte sectors per
+// row piece); vhp_capi.hip falls back to the front sweep otherwise.
+#pragma once
+#include "vhp_lanes.hpp"
+
+namespace vhp {
+namespace stream {
+
+using namespace vhp::lanes;
+
+#ifdef VHP_SIM
+#define VHP_FN inline
+#define VHP_HD inline
+#else
+#define VHP_FN __device__ __forceinline__
+#define VHP_HD __host__ __device__ __forceinline__
+#endif
+
+constexpr int kBlock = 64;       // steps per slot: one word of the packed occupancy maps
+constexpr int kRing = 256;       // entries of a strip-to-strip boundary ring: four blocks, indexed by the absolute marching coordinate
+                                 // (the reader of block n also needs the last entry of block n-1 while the writer is in block n+1)
+constexpr int kTileStride = 17;  // doubles per tile row: 16 staged columns + 1 (spreads the column writes over the LDS banks)
+constexpr int kXRows = 64;       // rows per x-major strip (one per lane)
+constexpr int kYCols = 128;      // columns per y-major strip (two per lane)
+constexpr int kMaxStrips = 136;  // 8192 / 64 + slack
+
+struct Map {
+  const uint64_t* rows;  // bit x&63 of rows[y*wpr + 1 + (x>>6)] = occ(x,y)
+  const uint64_t* cols;  // bit y&63 of cols[x*wpc + 1 + (y>>6)] = occ(x,y)
+  const double* recip;   // recip[k] = RN(1/k), recip[0] = 0, readable up to max(nx,ny)+8
+  int wpr, wpc, nx, ny;
+};
+
+VHP_HD int imin(int a, int b) { return a < b ? a : b; }
+VHP_HD int imax(int a, int b) { return a > b ? a : b; }
+VHP_HD int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// LDS of one workgroup, in doubles.
+struct Layout {
+  int ring_x, ring_y;    // W rings of kRing each (ring w = output of wavefront w of the octant)
+  int round_x, round_y;  // boundary row from the last strip of a round to the first strip of the next, indexed by absolute x / y
+  int diag;              // diag(k), k = quadrant-local index
+  int dummy;             // 8 doubles per wavefront: where lanes that are not the boundary lane "write" theirs
+  int tiles;             // W staging tiles of kXRows * kTileStride
+  int sched;             // ints: [0] = number of slots, then sched_x[kMaxStrips], sched_y[kMaxStrips]
+  int total;
+  int round_x_mask, round_y_mask;
+};
+VHP_HD Layout make_layout(int W, int nx, int ny) {
+  Layout L;
+  const int rx = next_pow2(nx), ry = next_pow2(ny);
+  int o = 0;
+  L.ring_x = o; o += W * kRing;
+  L.ring_y = o; o += W * kRing;
+  L.round_x = o; o += rx;
+  L.round_y = o; o += ry;
+  L.diag = o; o += imax(nx, ny) + 72;
+  L.dummy = o; o += 2 * W * 8;
+  L.tiles = o; o += W * kXRows * kTileStride;
+  L.sched = o; o += (1 + 2 * kMaxStrips + 1) / 2 + 1;
+  L.total = o;
+  L.round_x_mask = rx - 1;
+  L.round_y_mask = ry - 1;
+  return L;
+}
+
+// Geometry of one quadrant.  x = sx + DX*i, y = sy + DY*j; negative directions stop one cell short of the border
+// (solver.cpp:607-610,638-642).
+template <int DX, int DY>
+struct Quad {
+  int sx, sy, ni, nj;
+  int rows_total;  // x-major rows j in [0, rows_total)
+  int cols_total;  // y-major columns i in [0, cols_total) have computed cells (j > i)
+  int ya;          // y-major strips own columns [128q - ya, 128q - ya + 128): slid so that a strip starts on a 128-byte line
+  int Px, Py;      // strips per octant
+  int bx0, by0;    // block (>> 6) of the source
+  int Nbx, Nby;    // blocks per march
+
+  VHP_FN void init(int nx, int ny, int sx_, int sy_) {
+    sx = sx_; sy = sy_;
+    ni = DX > 0 ? nx - sx : sx;
+    nj = DY > 0 ? ny - sy : sy;
+    rows_total = imin(ni, nj);
+    cols_total = imax(imin(ni, nj - 1), 0);
+    ya = DX > 0 ? (sx & 15) : ((-(sx + 1)) & 15);
+    Px = (rows_total + kXRows - 1) / kXRows;
+    Py = cols_total > 0 ? (cols_total + ya + kYCols - 1) / kYCols : 0;
+    bx0 = sx >> 6; by0 = sy >> 6;
+    Nbx = ni > 0 ? nbx(ni - 1) + 1 : 0;
+    Nby = nj > 0 ? nby(nj - 1) + 1 : 0;
+  }
+  VHP_FN bool empty() const { return ni <= 0 || nj <= 0; }
+  VHP_FN int X(int i) const { return sx + DX * i; }
+  VHP_FN int Y(int j) const { return sy + DY * j; }
+  // block sequence number of a step
+  VHP_FN int nbx(int i) const { const int b = X(i) >> 6; return DX > 0 ? b - bx0 : bx0 - b; }
+  VHP_FN int nby(int j) const { const int b = Y(j) >> 6; return DY > 0 ? b - by0 : by0 - b; }
+  // steps of block n, clipped to the march
+  VHP_FN void xsteps(int n, int& lo, int& hi) const {
+    const int b = DX > 0 ? bx0 + n : bx0 - n;
+    if (DX > 0) { lo = 64 * b - sx; hi = 64 * b + 63 - sx; } else { lo = sx - (64 * b + 63); hi = sx - 64 * b; }
+    lo = imax(lo, 0); hi = imin(hi, ni - 1);
+  }
+  VHP_FN void ysteps(int n, int& lo, int& hi) const {
+    const int b = DY > 0 ? by0 + n : by0 - n;
+    if (DY > 0) { lo = 64 * b - sy; hi = 64 * b + 63 - sy; } else { lo = sy - (64 * b + 63); hi = sy - 64 * b; }
+    lo = imax(lo, 0); hi = imin(hi, nj - 1);
+  }
+  VHP_FN int ycol0(int q) const { return kYCols * q - ya; }           // first column of y-major strip q (may be < 0)
+  VHP_FN int ystart(int q) const { return imax(ycol0(q), 0); }        // its first step
+};
+
+// The static schedule: sched_x[p] / sched_y[q] = the slot in which the strip sweeps its FIRST block; block n of the
+// strip follows in slot sched + (n - first block).  Rules:
+//   (1) a wavefront takes its strips one after the other (strip p after strip p-W has swept its last block);
+//   (2) strip p sweeps block n at least one slot after strip p-1 did (boundary ring);
+//   (3) the y-major octant as a whole is delayed by Y0 slots so that every y-major strip starts after the x-major
+//       strips have published the diagonal cells of all its columns;
+//   (4) a wavefront reuses its output ring for its next strip only after the reader of the previous one has finished.
+// Inside a round rule (2) binds with equality (the reader is one block behind the writer), so a four-block ring is
+// enough between neighbours (the simulator asserts a lag of 1 or 2); the round-to-round hand-over goes through a
+// full-length row, whose writer (the last wavefront) runs W-1 >= 2 blocks behind its reader (the first).
+template <int DX, int DY>
+VHP_FN void compute_schedule(const Quad<DX, DY>& g, int W, int* sched) {
+  int* sx_ = sched + 1;
+  int* sy_ = sched + 1 + kMaxStrips;
+  int tx = 0, ty = 0;
+  for (int p = 0; p < g.Px; ++p) {
+    int s = 0;
+    if (p > 0) s = sx_[p - 1] + (g.nbx(kXRows * p) - g.nbx(kXRows * (p - 1))) + 1;
+    if (p >= W) s = imax(s, sx_[p - W] + (g.Nbx - g.nbx(kXRows * (p - W))));
+    if (p >= W && (p - W + 1) % W != 0) s = imax(s, sx_[p - W + 1] + (g.Nbx - g.nbx(kXRows * (p - W + 1))));
+    sx_[p] = s;
+    tx = imax(tx, s + g.Nbx - g.nbx(kXRows * p));
+  }
+  int y0 = 0;
+  for (int q = 0; q < g.Py; ++q) {
+    int s = 0;
+    if (q > 0) s = sy_[q - 1] + (g.nby(g.ystart(q)) - g.nby(g.ystart(q - 1))) + 1;
+    if (q >= W) s = imax(s, sy_[q - W] + (g.Nby - g.nby(g.ystart(q - W))));
+    if (q >= W && (q - W + 1) % W != 0) s = imax(s, sy_[q - W + 1] + (g.Nby - g.nby(g.ystart(q - W + 1))));
+    sy_[q] = s;
+    // the last diagonal cell this strip is seeded with, and the slot in which its x-major strip publishes it
+    const int klast = imin(g.ycol0(q) + kYCols - 1, g.rows_total - 1);
+    if (klast >= g.ystart(q)) {
+      const int px = klast / kXRows;
+      const int need = sx_[px] + (g.nbx(klast) - g.nbx(kXRows * px)) + 1;
+      y0 = imax(y0, need - s);
+    }
+  }
+  for (int q = 0; q < g.Py; ++q) {
+    sy_[q] += y0;
+    ty = imax(ty, sy_[q] + g.Nby - g.nby(g.ystart(q)));
+  }
+  sched[0] = imax(tx, ty);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// x-major wavefront: strips p = w, w+W, ...; rows j = 64p + lane; steps i = 64p .. ni-1; cells (i, j), j <= i.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY, typename OutT>
+struct XWave {
+  static constexpr int CB = sizeof(OutT);
+  // uniform
+  Map m;
+  Quad<DX, DY> g;
+  OutT* out;
+  int w, W;
+  double* tile;
+  double* ring_base;
+  double* round;
+  int round_mask;
+  double* diag;
+  const int* sched;  // sched_x
+  bool rows_alternate;  // row pitch is an odd multiple of 64 bytes: odd and even rows are half a line apart
+  int p, j0, rows_here, nf, s0;
+  bool active, has_consumer;
+  const double* rin;
+  int rin_mask;
+  double* rout;
+  int rout_mask;
+  int i_pub;  // first step whose boundary value has not been copied to rout yet
+  // lanes
+  vi lane;
+  vd prev, jd;
+  vu64 ow;
+  vd rv;
+
+  VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
+    m = m_; g = g_; out = out_; w = w_; W = W_;
+    tile = lds + L.tiles + w * kXRows * kTileStride;
+    ring_base = lds + L.ring_x;
+    round = lds + L.round_x;
+    round_mask = L.round_x_mask;
+    diag = lds + L.diag;
+    sched = reinterpret_cast<const int*>(lds + L.sched) + 1;
+    rows_alternate = ((m.nx >> 3) & 1) != 0;
+    lane = lane_id();
+    active = true;
+    load_strip(w);
+  }
+
+  VHP_FN void load_strip(int pn) {
+    p = pn;
+    if (p >= g.Px) { active = false; return; }
+    j0 = kXRows * p;
+    rows_here = imin(kXRows, g.rows_total - j0);
+    has_consumer = p + 1 < g.Px;
+    nf = g.nbx(j0);
+    s0 = sched[p];
+    prev = vd(0.0);
+    jd = to_f64(lane + j0);
+    if (p % W == 0) { rin = round; rin_mask = round_mask; } else { rin = ring_base + (w - 1) * kRing; rin_mask = kRing - 1; }
+    if ((p + 1) % W == 0) { rout = round; rout_mask = round_mask; } else { rout = ring_base + w * kRing; rout_mask = kRing - 1; }
+    i_pub = j0;
+  }
+
+  // one slot of the workgroup's schedule
+  VHP_FN void slot(int T) {
+    if (!active) return;
+    const int n = nf + (T - s0);
+    if (n < nf) return;  // this strip has not started yet
+    sweep_block(n);
+    if (n == g.Nbx - 1) {
+      end_of_march();
+      load_strip(p + W);
+    }
+  }
+
+  // boundary row for the strip above: row 63 of the tile, steps i_pub .. i_last (at most 8), copied into the ring
+  VHP_FN void publish(int i_last) {
+    if (has_consumer) {
+      wave_sync();
+      const vi ie = lane + i_pub;                // lanes 0..7
+      const vi xe = ie * DX + g.sx;
+      const vb on = (lane < 8) && (ie <= i_last);
+      const vd v = lds_load(tile, select(on, (xe & 15) + 63 * kTileStride, vi(63 * kTileStride)));
+      lds_store_if(on, rout, xe & rout_mask, v);
+    }
+    i_pub = i_last + 1;
+  }
+
+  // Emits one 128-byte line (16 cells from xa on; for fp32 fields that is one 64-byte sector) of the rows
+  // r = r_first, r_first + r_stride, ... of this strip from the tile.  8 rows per store instruction: lane -> (row
+  // slot = lane >> 3, piece = lane & 7 = cells xa + 2*piece, +1).  PRED: only the cells the march has reached and that
+  // belong to the octant (step index i' with j <= i' <= i_now) are stored.
+  template <bool PRED>
+  VHP_FN void flush(int xa, int r_first, int r_stride, int i_now) {
+    wave_sync();
+    const vi rslot = lane >> 3, pc = lane & 7;
+    const vi xc = pc * 2 + xa;  // x of the pair's first cell
+    for (int u = 0; r_first + r_stride * 8 * u < rows_here; ++u) {
+      const vi r = (rslot + 8 * u) * r_stride + r_first;
+      const vb row_ok = r < rows_here;
+      const vi rr = select(row_ok, r, vi(0));
+      const vi tidx = rr * kTileStride + (xc & 15);
+      const vd a = lds_load(tile, tidx);
+      const vd b = lds_load(tile, tidx + 1);
+      const vi yr = (rr + j0) * DY + g.sy;
+      const vu32 off = to_u32((yr * m.nx + xc) * CB);
+      if (!PRED) {
+        if (rows_here == kXRows) g_store2(out, off, a, b);
+        else g_store2_if(row_ok, vb(false), vb(false), out, off, a, b);
+      } else {
+        const vi i0c = (xc - g.sx) * DX, i1c = (xc + 1 - g.sx) * DX;  // step indices of the two cells
+        const vi jr = rr + j0;
+        const vb ok0 = row_ok && (i0c >= jr) && (i0c <= i_now);
+        const vb ok1 = row_ok && (i1c >= jr) && (i1c <= i_now);
+        g_store2_if(ok0 && ok1, ok0, ok1, out, off, a, b);
+      }
+    }
+    wave_sync();
+  }
+
+  // After the step at x_b, which ends an 8-cell window of x: the rows whose 128-byte line this completes leave.
+  // (y*nx + x) % 16 == 0 marks a line start; with nx = 8*m that is x % 16 == 8 * ((y*m) & 1).
+  VHP_FN void flush_completed(int x_b, int i_now) {
+    const int edge = DX > 0 ? x_b + 1 : x_b;  // marching up, the line ends below `edge`; marching down it starts at `edge`
+    const int hbit = (edge >> 3) & 1;
+    const int xa = DX > 0 ? x_b - 15 : x_b;
+    const int i_first = i_now - 15;  // step of the line's first-marched cell
+    const bool steady = i_first >= j0 + kXRows - 1;
+    if (!rows_alternate) {
+      if (hbit != 0) return;
+      if (steady) flush<false>(xa, 0, 1, i_now); else flush<true>(xa, 0, 1, i_now);
+    } else {
+      const int rpar = (hbit ^ g.sy ^ j0) & 1;  // rows with (y & 1) == hbit
+      if (steady) flush<false>(xa, rpar, 2, i_now); else flush<true>(xa, rpar, 2, i_now);
+    }
+  }
+
+  // the march of this strip is over: what is still in the tile leaves as partial lines
+  VHP_FN void end_of_march() {
+    const int i_now = g.ni - 1;
+    const int xe = g.X(i_now);
+    if (i_pub <= i_now) publish(i_now);
+    if (!rows_alternate) {
+      flush<true>(xe & ~15, 0, 1, i_now);
+    } else {
+      for (int ph = 0; ph < 2; ++ph) {  // rows whose lines start at x % 16 == 8*ph
+        const int xa = 8 * ph + (((xe - 8 * ph) >> 4) << 4);
+        flush<true>(xa, (ph ^ g.sy ^ j0) & 1, 2, i_now);
+      }
+    }
+  }
+
+  // one generic step
+  VHP_FN void step1(int i) {
+    const int x = g.X(i);
+    const int t = x & 63;
+    const double ri = read_lane(rv, t);
+    const double di = (double)i;
+    double fill = 0.0, dsrc = 1.0;  // OLD / NEW value of the row just below lane 0's (1.0 = light strength at the origin)
+    if (p > 0) { fill = rin[(x - DX) & rin_mask]; dsrc = rin[x & rin_mask]; }
+    const vd b = shift_up(prev, vd(fill));
+    const vi mk = bit_mask(ow, t);
+    vd v = and_mask(stencil(prev, b, ratio(jd, di, ri)), mk);
+    if (i < j0 + kXRows) {
+      // the diagonal cell (i,i) inherits the NEW value of the row below it times its own occupancy
+      const vd up = shift_up(v, vd(dsrc));
+      const vb isd = lane == (i - j0);
+      const vd dcell = and_mask(up, mk);
+      v = select(isd, dcell, v);
+      lds_store_if(isd, diag, vi(i), dcell);
+    }
+    prev = v;
+    lds_store(tile, lane * kTileStride + (x & 15), v);
+  }
+
+  // eight steps covering one aligned window of x; DIAG: the strip's diagonal may fall into it
+  template <bool DIAG>
+  VHP_FN void window8(int i0) {
+    const int x0 = g.X(i0);
+    const int t0 = x0 & 63;
+    const int xw = x0 & ~7;  // lowest x of the window
+    double rr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rr[k] = read_lane(rv, t0 + DX * k);
+    const vu32 hs = half_shifted(ow, t0, DX > 0 ? (t0 & 31) : (t0 & 31) - 7);  // step k's bit at position (x & 7)
+    vd ringv = vd(0.0);  // lane l: OLD boundary value for step k = l, rotated down by one lane per step
+    if (p > 0) ringv = lds_load(rin, (lane * DX + (x0 - DX)) & rin_mask);
+    const vi tidx = lane * kTileStride + (xw & 15);
+    double di = (double)i0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int col = DX > 0 ? k : 7 - k;
+      const vd b = shift_up(prev, ringv);
+      const vi mk = sbfe1(hs, col);
+      vd v = and_mask(stencil(prev, b, ratio(jd, di, rr[k])), mk);
+      vd ringn = vd(1.0);
+      if (p > 0) ringn = rotate_down(ringv);  // lane 0: NEW value of the row below this strip
+      if (DIAG) {
+        const vd up = shift_up(v, ringn);
+        const vb isd = lane == (i0 + k - j0);
+        const vd dcell = and_mask(up, mk);
+        v = select(isd, dcell, v);
+        lds_store_if(isd, diag, vi(i0 + k), dcell);
+      }
+      prev = v;
+      lds_store(tile, tidx + col, v);
+      if (p > 0) ringv = ringn;
+      di += 1.0;
+    }
+  }
+
+  VHP_FN void sweep_block(int n) {
+    int lo, hi;
+    g.xsteps(n, lo, hi);
+    lo = imax(lo, j0);
+    if (lo > hi) return;
+    const int blk = g.X(lo) >> 6;
+    {
+      const vi yl = (vmin(lane + j0, g.rows_total - 1)) * DY + g.sy;
+      ow = g_load_u64(m.rows, yl * m.wpr + (1 + blk));
+      const vi it = (lane + (blk * 64 - g.sx)) * DX;
+      const vb ok = (it >= 0) && (it < g.ni);
+      rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
+      pin(ow);
+      pin(rv);
+    }
+    int i = lo;
+    while (i <= hi) {
+      const int x = g.X(i);
+      const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
+      int i_last;
+      if (aligned && i + 7 <= hi) {
+        if (i < j0 + kXRows) window8<true>(i); else window8<false>(i);
+        i_last = i + 7;
+      } else {
+        step1(i);
+        i_last = i;
+      }
+      i = i_last + 1;
+      const int xl = g.X(i_last);
+      const bool boundary = DX > 0 ? (xl & 7) == 7 : (xl & 7) == 0;
+      if (boundary && i_last != g.ni - 1) {  // (the last step of the march is end_of_march's)
+        publish(i_last);
+        flush_completed(xl, i_last);
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// y-major wavefront: strips q = w, w+W, ...; columns i = 128q - ya + 2*lane + {0,1}; steps j = max(i0,0) .. nj-1;
+// cells (i, j), i <= j (the diagonal cell is the seed diag(j), stored again with its neighbour).
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY, typename OutT>
+struct YWave {
+  static constexpr int CB = sizeof(OutT);
+  Map m;
+  Quad<DX, DY> g;
+  OutT* out;
+  int w, W;
+  double* ring_base;
+  double* round;
+  int round_mask;
+  const double* diag;
+  double* dummy;
+  const int* sched;  // sched_y
+  int q, i0, jstart, nf, s0;
+  bool active, has_consumer, interior;
+  const double* rin;
+  int rin_mask;
+  double* rout;
+  int rout_mask;
+  vi lane, ia, ib;
+  vd prev0, prev1, id0, id1;
+  vu64 ow0, ow1;
+  vd rv;
+  vu32 xoff;  // byte offset of the lane's pair inside a row
+
+  VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
+    m = m_; g = g_; out = out_; w = w_; W = W_;
+    ring_base = lds + L.ring_y;
+    round = lds + L.round_y;
+    round_mask = L.round_y_mask;
+    diag = lds + L.diag;
+    dummy = lds + L.dummy + (W + w) * 8;
+    sched = reinterpret_cast<const int*>(lds + L.sched) + 1 + kMaxStrips;
+    lane = lane_id();
+    active = true;
+    load_strip(w);
+  }
+
+  VHP_FN void load_strip(int qn) {
+    q = qn;
+    if (q >= g.Py) { active = false; return; }
+    i0 = g.ycol0(q);
+    jstart = g.ystart(q);
+    has_consumer = q + 1 < g.Py;
+    interior = i0 >= 0 && i0 + kYCols - 1 < g.ni;  // every column of the strip is a column of the grid
+    nf = g.nby(jstart);
+    s0 = sched[q];
+    ia = lane * 2 + i0;
+    ib = ia + 1;
+    prev0 = vd(0.0);
+    prev1 = vd(0.0);
+    id0 = to_f64(ia);
+    id1 = to_f64(ib);
+    // the pair's lower x: x(ia) marching up, x(ib) marching down
+    const vi xlo = DX > 0 ? ia + g.sx : (-ib) + g.sx;
+    xoff = to_u32(xlo * CB);
+    if (q % W == 0) { rin = round; rin_mask = round_mask; } else { rin = ring_base + (w - 1) * kRing; rin_mask = kRing - 1; }
+    if ((q + 1) % W == 0) { rout = round; rout_mask = round_mask; } else { rout = ring_base + w * kRing; rout_mask = kRing - 1; }
+  }
+
+  VHP_FN void slot(int T) {
+    if (!active) return;
+    const int n = nf + (T - s0);
+    if (n < nf) return;
+    sweep_block(n);
+    if (n == g.Nby - 1) load_strip(q + W);
+  }
+
+  // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below
+  // the diagonal
+  VHP_FN void store_pred(uint32_t rowoff, int j, vd v0, vd v1) {
+    const vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
+    const vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
+    if (DX > 0) g_store2_if(ok0 && ok1, ok0, ok1, out, xoff + rowoff, v0, v1);
+    else g_store2_if(ok0 && ok1, ok1, ok0, out, xoff + rowoff, v1, v0);
+  }
+
+  VHP_FN void step1(int j) {
+    const int y = g.Y(j);
+    const int t = y & 63;
+    const double rj = read_lane(rv, t);
+    const double dj = (double)j;
+    double fill = 0.0;
+    if (q > 0) fill = rin[(y - DY) & rin_mask];
+    const vd b0 = shift_up(prev1, vd(fill));
+    vd v0 = and_mask(stencil(prev0, b0, ratio(id0, dj, rj)), bit_mask(ow0, t));
+    vd v1 = and_mask(stencil(prev1, prev0, ratio(id1, dj, rj)), bit_mask(ow1, t));
+    if (j <= i0 + kYCols - 1) {  // column j (if this strip owns it) is seeded with diag(j)
+      const double dg = diag[j];
+      v0 = select(ia == j, vd(dg), v0);
+      v1 = select(ib == j, vd(dg), v1);
+    }
+    store_pred((uint32_t)(y * m.nx * CB), j, v0, v1);
+    prev0 = v0;
+    prev1 = v1;
+    if (has_consumer) lds_store_if(lane == 63, rout, vi(y & rout_mask), v1);
+  }
+
+  // eight steps covering one aligned window of y.  DIAG: seeding may happen (implies PRED); PRED: predicated stores
+  template <bool DIAG, bool PRED>
+  VHP_FN void window8(int j0w) {
+    const int y0 = g.Y(j0w);
+    const int t0 = y0 & 63;
+    const int yb = y0 & ~7;
+    double rr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rr[k] = read_lane(rv, t0 + DY * k);
+    const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
+    const vu32 hs0 = half_shifted(ow0, t0, sh), hs1 = half_shifted(ow1, t0, sh);
+    vd ringv = vd(0.0);
+    if (q > 0) ringv = lds_load(rin, (lane * DY + (y0 - DY)) & rin_mask);
+    vd dgv = vd(0.0);  // lane t < 8: diag(j0w + t)
+    if (DIAG) dgv = lds_load(diag, (lane & 7) + j0w);
+    // every lane writes "its boundary value" each step -- lane 63 into the ring, the others into a dummy slot: one
+    // ds_write instead of an exec-masked region per step
+    double* rbase = has_consumer ? rout + (yb & rout_mask) : dummy;
+    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - rbase)));
+    double dj = (double)j0w;
+    uint32_t rowoff = (uint32_t)(y0 * m.nx * CB);
+    const uint32_t rowstep = (uint32_t)(DY * m.nx * CB);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bit = DY > 0 ? k : 7 - k;
+      const vd b0 = shift_up(prev1, ringv);
+      vd v0 = and_mask(stencil(prev0, b0, ratio(id0, dj, rr[k])), sbfe1(hs0, bit));
+      vd v1 = and_mask(stencil(prev1, prev0, ratio(id1, dj, rr[k])), sbfe1(hs1, bit));
+      if (DIAG) {
+        const double dg = read_lane(dgv, k);
+        v0 = select(ia == j0w + k, vd(dg), v0);
+        v1 = select(ib == j0w + k, vd(dg), v1);
+      }
+      if (PRED) store_pred(rowoff, j0w + k, v0, v1);
+      else if (DX > 0) g_store2(out, xoff + rowoff, v0, v1);
+      else g_store2(out, xoff + rowoff, v1, v0);
+      prev0 = v0;
+      prev1 = v1;
+      lds_store(rbase, widx + bit, v1);
+      if (q > 0) ringv = rotate_down(ringv);
+      dj += 1.0;
+      rowoff += rowstep;
+    }
+  }
+
+  VHP_FN void sweep_block(int n) {
+    int lo, hi;
+    g.ysteps(n, lo, hi);
+    lo = imax(lo, jstart);
+    if (lo > hi) return;
+    const int blk = g.Y(lo) >> 6;
+    {
+      const vi xa = vmin(vmax(ia, 0), g.ni - 1) * DX + g.sx;
+      const vi xb = vmin(vmax(ib, 0), g.ni - 1) * DX + g.sx;
+      ow0 = g_load_u64(m.cols, xa * m.wpc + (1 + blk));
+      ow1 = g_load_u64(m.cols, xb * m.wpc + (1 + blk));
+      const vi jt = (lane + (blk * 64 - g.sy)) * DY;
+      const vb ok = (jt >= 0) && (jt < g.nj);
+      rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
+      pin(ow0);
+      pin(ow1);
+      pin(rv);
+    }
+    int j = lo;
+    while (j <= hi) {
+      const int y = g.Y(j);
+      const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
+      if (aligned && j + 7 <= hi) {
+        if (j <= i0 + kYCols - 1) window8<true, true>(j);
+        else if (!interior) window8<false, true>(j);
+        else window8<false, false>(j);
+        j += 8;
+      } else {
+        step1(j);
+        j += 1;
+      }
+    }
+  }
+};
+
+// rows / columns no quadrant covers read as zero: done by the workgroup of quadrant 1
+template <typename OutT>
+VHP_FN void zero_fill_cell(OutT* out, size_t idx) { out[idx] = OutT(0); }
+
+}  // namespace stream
+}  // namespace vhp

@@ -1,0 +1,36 @@
+// vhp_stream_launch.h -- host-side interface of the streaming sweep kernel (vhp_stream.hip), used by vhp_capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <functional>
+
+namespace vhp {
+
+struct StreamArgs {
+  const uint64_t* rows;   // packed maps and reciprocal table of the context (vhp_set_map)
+  const uint64_t* cols;
+  const double* recip;
+  int wpr, wpc, nx, ny;
+  const int32_t* d_src;   // n_src (x, y) pairs, device
+  int n_src;
+  void* d_out;            // n_src fields
+  int dtype;              // VHP_F64 / VHP_F32
+  long long field_stride; // elements
+  int* d_err;             // device flag: a source outside the grid
+  int* d_order;           // scratch: 4 * n_src ints (launch order of the (source, quadrant) units)
+  hipStream_t stream;
+  // called with (kernel, bytes) before a launch that needs more than the default dynamic LDS: the per-device
+  // bookkeeping lives with the context
+  std::function<hipError_t(const void*, size_t)> raise_lds;
+  // optional per-launch timing events, recorded around the sweep kernel only
+  hipEvent_t ev_begin, ev_end;
+};
+
+// true if the streaming kernel can sweep this grid (pitch a multiple of 8 cells, LDS of a workgroup fits)
+bool stream_supported(int nx, int ny);
+// strips per octant and round the launch will use for this grid (4 or 8), 0 if unsupported
+int stream_strips(int nx, int ny);
+hipError_t launch_stream(const StreamArgs& a);
+
+}  // namespace vhp

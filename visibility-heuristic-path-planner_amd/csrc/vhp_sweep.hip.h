@@ -1,4 +1,4 @@
-// vhp_sweep.cuh -- CDNA4 (gfx950) device code of the visibility-transport sweep.
+// vhp_sweep.hip.h -- CDNA4 (gfx950) device code of the visibility-transport sweep.
 //
 // Replaces the four loop nests of computeVisibility()
 // (reference src/visibilityBasedSolver.cpp:570-696) for a batch of sources, and --

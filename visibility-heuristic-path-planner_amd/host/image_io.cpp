@@ -2,12 +2,15 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 
 namespace vbs {
 namespace {
+
+constexpr uint32_t kMaxImageSide = 8192;  // VHP_MAX_SIDE: nothing larger can become a grid
 
 uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 void put32(std::vector<uint8_t>& v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s)); }
@@ -27,9 +30,12 @@ bool decodePng(const std::vector<uint8_t>& f, Image& out, std::string* err) {
     const uint32_t len = be32(&f[p]);
     const char* tag = reinterpret_cast<const char*>(&f[p + 4]);
     const uint8_t* body = &f[p + 8];
-    if (p + 12 + len > f.size()) { *err = "truncated PNG chunk"; return false; }
+    if ((size_t)len > f.size() || p + 12 + (size_t)len > f.size()) { *err = "truncated PNG chunk"; return false; }
+    if (be32(body + len) != (uint32_t)crc32(0, &f[p + 4], (uInt)(len + 4))) { *err = "PNG chunk CRC mismatch"; return false; }
     if (!std::memcmp(tag, "IHDR", 4)) {
+      if (len != 13) { *err = "bad PNG header"; return false; }
       w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+      if (w > kMaxImageSide || h > kMaxImageSide) { *err = "PNG larger than the solver's maximum grid side"; return false; }
     } else if (!std::memcmp(tag, "PLTE", 4)) {
       plte.assign(body, body + len);
     } else if (!std::memcmp(tag, "IDAT", 4)) {
@@ -86,11 +92,14 @@ bool decodePng(const std::vector<uint8_t>& f, Image& out, std::string* err) {
 bool decodePgm(const std::vector<uint8_t>& f, Image& out, std::string* err) {
   unsigned w = 0, h = 0, maxv = 0;
   int used = 0;
-  if (std::sscanf(reinterpret_cast<const char*>(f.data()), "P5 %u %u %u%n", &w, &h, &maxv, &used) != 3 || maxv > 255) {
+  // the header is text: parse a NUL-terminated copy of (at most) its first bytes, never the raw buffer
+  const std::string head(reinterpret_cast<const char*>(f.data()), std::min<size_t>(f.size(), 64));
+  if (std::sscanf(head.c_str(), "P5 %u %u %u%n", &w, &h, &maxv, &used) != 3 || maxv > 255 || !w || !h ||
+      w > kMaxImageSide || h > kMaxImageSide) {
     *err = "unsupported PGM";
     return false;
   }
-  const size_t off = used + 1;
+  const size_t off = (size_t)used + 1;
   if (f.size() < off + (size_t)w * h) { *err = "truncated PGM"; return false; }
   out.create(w, h, Rgba{});
   for (size_t k = 0; k < (size_t)w * h; ++k) out.px[k] = {f[off + k], f[off + k], f[off + k], 255};

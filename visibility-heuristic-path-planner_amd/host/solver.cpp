@@ -233,7 +233,7 @@ void visibilityBasedSolver::reconstructPath() {
   std::vector<int32_t> pts(2 * (std::size_t)(nb_of_sources_ + 3));
   uint32_t n = 0;
   double length = 0;
-  const int rc = vhp_reconstruct_path(cameFrom_.data(), lightSources_.data(), (int)nx_, (int)ny_, end_.first, end_.second,
+  const int rc = vhp_reconstruct_path(cameFrom_.data(), lightSources_.data(), nb_of_sources_, (int)nx_, (int)ny_, end_.first, end_.second,
                                       pts.data(), (uint32_t)(pts.size() / 2), &n, &length);
   if (rc != VHP_OK) { std::cerr << "vhp_reconstruct_path failed (" << rc << ")" << std::endl; return; }
   if (!config_->silent) std::cout << "Path length: " << length << std::endl;

@@ -64,6 +64,13 @@ def config_c5(n_sources=128):
     return occ, free_sources(occ, n_sources, seed=11)
 
 
+def c1_rnd1_mask():
+    """BASELINE config 1: the 101x101 mask derived from MATLAB_code/rnd_1.mat (tests/golden/make_fixtures.py)."""
+    z = np.load(os.path.join(GOLDEN, "c1_rnd1_mask.npz"))
+    nx, ny = int(z["nx"]), int(z["ny"])
+    return np.unpackbits(z["packed"], axis=1)[:, :nx].astype(np.uint8).reshape(ny, nx)
+
+
 def maze_6():
     z = np.load(os.path.join(GOLDEN, "maze_6.npz"))
     nx, ny = int(z["nx"]), int(z["ny"])
