@@ -1,7 +1,7 @@
 """A/B of library builds inside one process (same box, same clocks): loads several libvhp_hip.so builds side by
 side, alternates blocks of launches between them and prints the median kernel time per build.  Diagnostic only.
-usage: ab_libs.py <side> <n sources> <lib>[@R,W] <lib>[@R,W] ...      ("-" = the in-tree build; @R,W sets VHP_R / VHP_W for
-that build's launches)"""
+usage: ab_libs.py <side> <n sources> <lib>[@key=value,...] ...      ("-" = the in-tree build; the keys are vhp_set_option
+keys, e.g. -@kernel=1 exp/libvhp_NOSTORE.so@kernel=2)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,20 +25,18 @@ ctxs = []
 shapes = {}
 for lib in libs:
     path, _, shape = lib.partition("@")
-    shapes[lib] = shape.split(",") if shape else None
+    shapes[lib] = [kv.split("=") for kv in shape.split(",")] if shape else []
     mod._lib = None
     mod.LIB_PATH = os.path.join(mod._HERE, "libvhp_hip.so") if path == "-" else os.path.join(ROOT, path)
     c = mod.Context(0)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     c.set_map(occ)
+    for k, v in shapes[lib]:
+        c.set_option(k, int(v))
     ctxs.append(c)
 res = {l: [] for l in libs}
 for rep in range(6):
     for lib, ctx in zip(libs, ctxs):
-        for k in ("VHP_R", "VHP_W"):
-            os.environ.pop(k, None)
-        if shapes[lib]:
-            os.environ["VHP_R"], os.environ["VHP_W"] = shapes[lib]
         for _ in range(3):
             ctx.sweep_batch_device(d_src.data_ptr(), n, out.data_ptr(), dtype=mod.F64)
         torch.cuda.synchronize()

@@ -1,0 +1,59 @@
+"""Per-workgroup timeline of one streaming-sweep launch (a -DVHP_EXP_WGTIME build): when each workgroup ran, on which
+CU, how many slots it had and how busy each of its wavefronts was.  Diagnostic only.
+usage: stream_timeline.py <lib built with -DVHP_EXP_WGTIME> [side] [n sources]"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from importlib import import_module
+mod = import_module("visibility-heuristic-path-planner_amd")
+synth = import_module("visibility-heuristic-path-planner_amd.synth")
+lib = sys.argv[1]
+side = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+mod.LIB_PATH = os.path.join(ROOT, lib)
+lo, hi = (20, 100) if side <= 1024 else (80, 400)
+occ = synth.random_rect_map(side, side, 50, lo, hi, lo, hi, seed=1)
+src = synth.free_sources(occ, n, seed=7)
+c = mod.Context(0)
+c.set_stream(torch.cuda.current_stream().cuda_stream)
+c.set_map(occ)
+c.set_option("kernel", 2)
+d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
+out = torch.empty((n, side, side), dtype=torch.float64, device="cuda")
+for _ in range(5):
+    c.sweep_batch_device(d_src.data_ptr(), n, out.data_ptr())
+torch.cuda.synchronize()
+c.timing(True)
+c.sweep_batch_device(d_src.data_ptr(), n, out.data_ptr())
+torch.cuda.synchronize()
+print("kernel ms", c.timing_collect(4))
+nu = 4 * n
+buf = np.zeros(nu * 16, np.uint64)
+rc = mod._lib.vhp_debug_read_wgtime(C.c_void_p(buf.ctypes.data), nu * 16)
+assert rc == 0
+w = buf.reshape(nu, 16)
+t0, t1 = w[:, 0].astype(np.int64), w[:, 1].astype(np.int64)
+live = t1 > 0
+base = t0[live].min()
+start, end = (t0 - base) / 100.0, (t1 - base) / 100.0  # us (100 MHz)
+slots = (w[:, 2] & 0xffff).astype(int); ni = ((w[:, 2] >> 16) & 0xffff).astype(int); nj = ((w[:, 2] >> 32) & 0xffff).astype(int)
+cyc = w[:, 4].astype(np.float64)
+busy = w[:, 8:16].astype(np.float64)
+print("workgroups live %d of %d; launch span %.1f us" % (live.sum(), nu, end[live].max()))
+dur = end - start
+print("start-time percentiles us:", np.percentile(start[live], [0, 25, 50, 75, 100]).round(1))
+print("duration percentiles us  :", np.percentile(dur[live], [0, 25, 50, 75, 100]).round(1))
+sel = live & (slots >= 10)
+print("us per slot (median over WGs with >= 10 slots):", np.median((dur / np.maximum(slots, 1))[sel]).round(2))
+frac = busy / np.maximum(cyc[:, None], 1)
+print("busy fraction per wavefront (mean over WGs with >= 10 slots): x", frac[sel][:, :4].mean(0).round(2), " y", frac[sel][:, 4:8].mean(0).round(2))
+print("cycles per slot (median):", np.median((cyc / np.maximum(slots, 1))[sel]).round(0), " clock MHz ~", np.median((cyc / np.maximum(dur, 1e-3))[sel]).round(0))
+ts = np.linspace(0, end[live].max(), 41)
+conc = [(int(((start <= t) & (end > t) & live).sum())) for t in ts]
+print("resident workgroups over time:", conc)
+print("sum of slots", slots[live].sum(), " sum of WG-us", dur[live].sum().round(0))
+big = np.argsort(-dur)[:8]
+for b in big:
+    print("  long WG %4d: start %.1f dur %.1f us slots %d ni %d nj %d busy x %s y %s" % (b, start[b], dur[b], slots[b], ni[b], nj[b], frac[b, :4].round(2), frac[b, 4:8].round(2)))
+np.save(os.path.join(ROOT, "gpurun_out", "stream_timeline.npy"), w)

@@ -133,12 +133,9 @@ void pick_shape(const vhp_ctx* c, int maxdim, int* R, int* W, bool* multi, int n
   else if (maxdim <= 512) { *R = 2; *W = 4; }
   else if (maxdim <= 1024) { *R = 2; *W = 8; }
   else { *R = 4; *W = 8; }
-  // Store-bound batches (256+ sources: two or more workgroup rounds) do better in the one-row-per-lane shape, whose
-  // x-major strips flush whole 128-byte lines (vhp_sweep.hip.h, line mode), swept in rounds of 512 rows: measured
-  // against the shapes above at 256 sources, -3 % time at 1000^2, -8 % at 1024^2 and 2048^2, -17 % at 1536^2 and
-  // 4096^2.  Smaller batches are latency-bound and lose 10-30 % there.
-  (void)f64;  // fp32 fields too: there the 16 staged columns are one whole 64-byte sector (-13 % time at 1000^2)
-  if (maxdim > 256 && n_src >= 256 && pitch64) { *R = 1; *W = 8; }
+  // (Round 1 sent batches of 256+ sources to the one-row-per-lane shape with whole-line flushes; those batches now
+  // take the streaming sweep, vhp_stream.hpp, which is built for them.)
+  (void)n_src; (void)f64; (void)pitch64;
   if (c && c->opt_rows_per_lane) *R = c->opt_rows_per_lane;
   if (c && c->opt_strips) *W = c->opt_strips;
   *multi = (*W) * 64 * (*R) < maxdim;

@@ -162,11 +162,12 @@ VHP_LANE_FN vd shift_up(vd v, vd fill) {
   hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-// lane l <- lane l+1 (lane 63 <- lane 0): DPP wave_rol:1 (0x134)
+// lane l <- lane l+1 (lane 63 <- lane 0): DPP wave_rol:1 (0x134).  Every lane has a source, so the destination needs
+// no previous value: mov_dpp leaves `old` undefined and the compiler is free to write a fresh register (update_dpp ties
+// the destination to `old` and costs two v_mov per use when the source is still live).
 VHP_LANE_FN vd rotate_down(vd v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 // wave-uniform read of lane l (l uniform): v_readlane_b32 x 2
@@ -186,14 +187,28 @@ VHP_LANE_FN vi sbfe1(vu32 hs, int b) { return __builtin_amdgcn_sbfe(hs, b, 1); }
 VHP_LANE_FN vd lds_load(const double* base, vi idx) { return base[idx]; }
 VHP_LANE_FN void lds_store(double* base, vi idx, vd v) { base[idx] = v; }
 VHP_LANE_FN void lds_store_if(bool p, double* base, vi idx, vd v) { if (p) base[idx] = v; }
+#ifdef VHP_EXP_NOLOAD  // diagnostic builds only: no vector loads, so no s_waitcnt vmcnt ever drains the stores (wrong results)
+VHP_LANE_FN vu64 g_load_u64(const uint64_t*, vi idx) { return ~0ull - (uint64_t)(idx & 1); }
+VHP_LANE_FN vd g_load_f64(const double*, vi idx) { return 1.0 / (double)(idx + 1); }
+#else
 VHP_LANE_FN vu64 g_load_u64(const uint64_t* base, vi idx) { return base[idx]; }
 VHP_LANE_FN vd g_load_f64(const double* base, vi idx) { return base[idx]; }
+#endif
 
 template <typename OutT> struct alignas(2 * sizeof(OutT)) Pair { OutT a, b; };
+#ifdef VHP_EXP_NOSTORE  // diagnostic builds only (tools/): all the work, none of the stores
+#define VHP_EXP_STORE_GUARD(a, b, off) { asm volatile("" :: "v"(a), "v"(b), "v"(off)); return; }
+#elif defined(VHP_EXP_SMALLSTORE)  // all stores issued, into a 64 KB window: no HBM traffic
+#define VHP_EXP_STORE_GUARD(a, b, off) off &= 0xfff0u; base = reinterpret_cast<OutT*>(reinterpret_cast<uintptr_t>(base) & ~(uintptr_t)0xffff);
+#else
+#define VHP_EXP_STORE_GUARD(a, b, off)
+#endif
 template <typename OutT> VHP_LANE_FN void g_store2(OutT* base, vu32 off, vd a, vd b) {
+  VHP_EXP_STORE_GUARD(a, b, off)
   *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
 }
 template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p_hi, OutT* base, vu32 off, vd a, vd b) {
+  VHP_EXP_STORE_GUARD(a, b, off)
   vd single = p_lo ? a : b;
   asm volatile("" : "+v"(single));  // keep the compiler from splitting the 16-byte store to share a half with the single
   if (p2) *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};

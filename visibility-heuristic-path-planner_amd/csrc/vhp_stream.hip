@@ -11,6 +11,13 @@ namespace stream {
 
 constexpr int kUnits = 4;  // quadrants per source
 
+#ifdef VHP_EXP_WGTIME  // diagnostic builds only (tools/stream_timeline.py): when each workgroup ran and how busy its wavefronts were
+__device__ unsigned long long g_wgtime[8 * 16384];
+#define VHP_WG_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define VHP_WG_STAMP(var)
+#endif
+
 template <int DX, int DY, typename OutT>
 __device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, int sy, int W, double* lds) {
   Quad<DX, DY> g;
@@ -22,21 +29,49 @@ __device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, 
   __syncthreads();
   const int T_total = uniform(sched[0]);
   const int wave = uniform((int)(threadIdx.x >> 6));
+#ifdef VHP_EXP_WGTIME
+  unsigned long long busy = 0;
+  const unsigned long long wg_t0 = wall_clock64(), c_begin = __builtin_readcyclecounter();
+#endif
   if (wave < W) {
     XWave<DX, DY, OutT> xw;
     xw.init(m, g, field, wave, W, lds, L);
     for (int T = 0; T < T_total; ++T) {
+      VHP_WG_STAMP(c0);
       xw.slot(T);
+#ifdef VHP_EXP_WGTIME
+      busy += __builtin_readcyclecounter() - c0;
+#endif
       __syncthreads();
     }
   } else {
     YWave<DX, DY, OutT> yw;
     yw.init(m, g, field, wave - W, W, lds, L);
     for (int T = 0; T < T_total; ++T) {
+      VHP_WG_STAMP(c0);
       yw.slot(T);
+#ifdef VHP_EXP_WGTIME
+      busy += __builtin_readcyclecounter() - c0;
+#endif
       __syncthreads();
     }
   }
+#ifdef VHP_EXP_WGTIME
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 16384 / 2) {
+    unsigned long long* wv = g_wgtime + (size_t)blockIdx.x * 16;
+    if (wave == 0) {
+      unsigned hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      wv[0] = wg_t0;
+      wv[1] = wall_clock64();
+      wv[2] = (unsigned long long)T_total | ((unsigned long long)g.ni << 16) | ((unsigned long long)g.nj << 32);
+      wv[3] = ((unsigned long long)xcc << 32) | hwid;
+      wv[4] = __builtin_readcyclecounter() - c_begin;
+    }
+    if (wave < 8) wv[8 + wave] = busy;   // waves 0..W-1: x-major, W..2W-1: y-major
+  }
+#endif
 }
 
 // grid = 4 * n_src workgroups of 128*W threads; dynamic LDS = make_layout(W, nx, ny).total doubles.
@@ -141,6 +176,12 @@ hipError_t launch_t(const StreamArgs& a) {
   return e;
 }
 }  // namespace
+
+#ifdef VHP_EXP_WGTIME
+extern "C" int vhp_debug_read_wgtime(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(stream::g_wgtime), (size_t)n_words * 8);
+}
+#endif
 
 int stream_strips(int nx, int ny) {
   if (nx <= 0 || ny <= 0 || (nx & 7) != 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return 0;

@@ -273,25 +273,44 @@ struct XWave {
   VHP_FN void flush(int xa, int r_first, int r_stride, int i_now) {
     wave_sync();
     const vi rslot = lane >> 3, pc = lane & 7;
-    const vi xc = pc * 2 + xa;  // x of the pair's first cell
-    for (int u = 0; r_first + r_stride * 8 * u < rows_here; ++u) {
-      const vi r = (rslot + 8 * u) * r_stride + r_first;
-      const vb row_ok = r < rows_here;
-      const vi rr = select(row_ok, r, vi(0));
-      const vi tidx = rr * kTileStride + (xc & 15);
-      const vd a = lds_load(tile, tidx);
-      const vd b = lds_load(tile, tidx + 1);
-      const vi yr = (rr + j0) * DY + g.sy;
-      const vu32 off = to_u32((yr * m.nx + xc) * CB);
-      if (!PRED) {
-        if (rows_here == kXRows) g_store2(out, off, a, b);
-        else g_store2_if(row_ok, vb(false), vb(false), out, off, a, b);
-      } else {
-        const vi i0c = (xc - g.sx) * DX, i1c = (xc + 1 - g.sx) * DX;  // step indices of the two cells
-        const vi jr = rr + j0;
-        const vb ok0 = row_ok && (i0c >= jr) && (i0c <= i_now);
-        const vb ok1 = row_ok && (i1c >= jr) && (i1c <= i_now);
-        g_store2_if(ok0 && ok1, ok0, ok1, out, off, a, b);
+    const vi xc = pc * 2 + xa;                      // x of the pair's first cell
+    const vi r0 = rslot * r_stride + r_first;       // the lane's row in the first store instruction
+    const vi t0 = r0 * kTileStride + (xc & 15);     // ... its tile index
+    // ... and its byte offset from the LOWEST row (in y) of the store instruction: offsets are unsigned 32-bit on a
+    // uniform 64-bit base, so they must not be negative
+    const vi rs = DY > 0 ? rslot : 7 - rslot;
+    const vu32 off = to_u32((rs * (r_stride * m.nx) + xc) * CB);
+    const int t_step = 8 * r_stride * kTileStride;  // per store instruction: 8 row slots further
+    const long y_low = DY > 0 ? g.Y(j0 + r_first) : g.Y(j0 + r_first + 7 * r_stride);
+    OutT* base = out + y_low * (long)m.nx;          // uniform: the row term lives in scalar registers
+    const long base_step = (long)(8 * r_stride * DY) * m.nx;
+    if (!PRED && rows_here == kXRows) {
+      const int n_inst = kXRows / 8 / r_stride;
+#pragma unroll 4
+      for (int u = 0; u < n_inst; ++u) {
+        const vd a = lds_load(tile, t0 + u * t_step);
+        const vd b = lds_load(tile, t0 + (u * t_step + 1));
+        g_store2(base, off, a, b);
+        base += base_step;
+      }
+    } else {
+      const vi i0c = (xc - g.sx) * DX, i1c = (xc + 1 - g.sx) * DX;  // step indices of the two cells
+      for (int u = 0; r_first + r_stride * 8 * u < rows_here; ++u) {
+        const vi r = r0 + 8 * r_stride * u;
+        const vb row_ok = r < rows_here;
+        const vi tix = select(row_ok, t0 + u * t_step, vi(0));
+        const vd a = lds_load(tile, tix);
+        const vd b = lds_load(tile, tix + 1);
+        if (!PRED) {
+          g_store2_if(row_ok, vb(false), vb(false), base, off, a, b);
+        } else {
+          // only the cells the march has reached and that belong to the octant: j <= i' <= i_now
+          const vi jr = r + j0;
+          const vb ok0 = row_ok && (i0c >= jr) && (i0c <= i_now);
+          const vb ok1 = row_ok && (i1c >= jr) && (i1c <= i_now);
+          g_store2_if(ok0 && ok1, ok0, ok1, base, off, a, b);
+        }
+        base += base_step;
       }
     }
     wave_sync();
@@ -372,10 +391,9 @@ struct XWave {
       const vd b = shift_up(prev, ringv);
       const vi mk = sbfe1(hs, col);
       vd v = and_mask(stencil(prev, b, ratio(jd, di, rr[k])), mk);
-      vd ringn = vd(1.0);
-      if (p > 0) ringn = rotate_down(ringv);  // lane 0: NEW value of the row below this strip
+      const vd ringn = rotate_down(ringv);  // lane 0: NEW value of the row below this strip (all zeros for strip 0)
       if (DIAG) {
-        const vd up = shift_up(v, ringn);
+        const vd up = shift_up(v, p > 0 ? ringn : vd(1.0));  // strip 0: 1.0 = light strength at the origin
         const vb isd = lane == (i0 + k - j0);
         const vd dcell = and_mask(up, mk);
         v = select(isd, dcell, v);
@@ -383,7 +401,7 @@ struct XWave {
       }
       prev = v;
       lds_store(tile, tidx + col, v);
-      if (p > 0) ringv = ringn;
+      ringv = ringn;
       di += 1.0;
     }
   }
@@ -500,12 +518,14 @@ struct YWave {
 
   // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below
   // the diagonal
-  VHP_FN void store_pred(uint32_t rowoff, int j, vd v0, vd v1) {
+  VHP_FN void store_pred(OutT* row, int j, vd v0, vd v1) {
     const vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
     const vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
-    if (DX > 0) g_store2_if(ok0 && ok1, ok0, ok1, out, xoff + rowoff, v0, v1);
-    else g_store2_if(ok0 && ok1, ok1, ok0, out, xoff + rowoff, v1, v0);
+    if (DX > 0) g_store2_if(ok0 && ok1, ok0, ok1, row, xoff, v0, v1);
+    else g_store2_if(ok0 && ok1, ok1, ok0, row, xoff, v1, v0);
   }
+  // the row of the field as a uniform pointer: the row term stays in scalar registers, the lane term (xoff) in one VGPR
+  VHP_FN OutT* row_ptr(int y) const { return out + (size_t)y * (size_t)m.nx; }
 
   VHP_FN void step1(int j) {
     const int y = g.Y(j);
@@ -522,7 +542,7 @@ struct YWave {
       v0 = select(ia == j, vd(dg), v0);
       v1 = select(ib == j, vd(dg), v1);
     }
-    store_pred((uint32_t)(y * m.nx * CB), j, v0, v1);
+    store_pred(row_ptr(y), j, v0, v1);
     prev0 = v0;
     prev1 = v1;
     if (has_consumer) lds_store_if(lane == 63, rout, vi(y & rout_mask), v1);
@@ -548,8 +568,8 @@ struct YWave {
     double* rbase = has_consumer ? rout + (yb & rout_mask) : dummy;
     const vi widx = select(lane == 63, vi(0), vi((int)(dummy - rbase)));
     double dj = (double)j0w;
-    uint32_t rowoff = (uint32_t)(y0 * m.nx * CB);
-    const uint32_t rowstep = (uint32_t)(DY * m.nx * CB);
+    OutT* row = row_ptr(y0);
+    const long rowstep = (long)DY * m.nx;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int bit = DY > 0 ? k : 7 - k;
@@ -561,15 +581,15 @@ struct YWave {
         v0 = select(ia == j0w + k, vd(dg), v0);
         v1 = select(ib == j0w + k, vd(dg), v1);
       }
-      if (PRED) store_pred(rowoff, j0w + k, v0, v1);
-      else if (DX > 0) g_store2(out, xoff + rowoff, v0, v1);
-      else g_store2(out, xoff + rowoff, v1, v0);
+      if (PRED) store_pred(row, j0w + k, v0, v1);
+      else if (DX > 0) g_store2(row, xoff, v0, v1);
+      else g_store2(row, xoff, v1, v0);
       prev0 = v0;
       prev1 = v1;
       lds_store(rbase, widx + bit, v1);
-      if (q > 0) ringv = rotate_down(ringv);
+      ringv = rotate_down(ringv);
       dj += 1.0;
-      rowoff += rowstep;
+      row += rowstep;
     }
   }
 

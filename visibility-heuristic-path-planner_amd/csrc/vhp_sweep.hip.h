@@ -1045,7 +1045,10 @@ __device__ __forceinline__ void sweep_quadrant_dir(const DevMap& m, Emit& emit, 
   }
   const int rows_total = min(g.nj, g.ni);
   const int cols_total = max(min(g.ni, g.nj - 1), 0);
-  g.ya = m.slide ? y_grid_slide<DX>(sx, cols_total, S, Emit::kMulti ? INT32_MAX / S - 1 : W) : 0;
+  // Multi-round sweeps keep the plain grid: slid, a round's first y-major strip would own columns whose diagonal cells
+  // the PREVIOUS round published, and the 32-entry diagonal ring has been overwritten by then (found by the 4096^2
+  // eight-round parity test of round 2: last-bit differences next to a round boundary).
+  g.ya = (m.slide && !Emit::kMulti) ? y_grid_slide<DX>(sx, cols_total, S, W) : 0;
   const int Px = (rows_total + S - 1) / S, Py = (cols_total + g.ya + S - 1) / S;
   double* ring_x = lds;
   double* ring_y = lds + (size_t)W * kRing;
