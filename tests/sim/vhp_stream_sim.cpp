@@ -1,11 +1,13 @@
 // vhp_stream_sim.cpp -- CPU simulator of the streaming sweep kernel.  TEST INFRASTRUCTURE ONLY.
 //
 // Compiles csrc/vhp_stream.hpp -- the very source hipcc builds for gfx950 -- with -DVHP_SIM, where a wavefront's
-// lane vector is an array of 64 values (csrc/vhp_lanes.hpp), and runs one workgroup at a time: slot after slot, and
-// inside a slot the wavefronts one after the other in a configurable order (forward, backward, shuffled).  Data that
-// crosses wavefronts only ever crosses a slot barrier, so every order must give the same bytes; an order-dependent
-// result is a missing barrier in the schedule.  LDS starts poisoned (NaN), so a read of a value that was never
-// produced shows up in the field.
+// lane vector is an array of 64 values (csrc/vhp_lanes.hpp), and runs one workgroup at a time.  The workgroup is a
+// dataflow machine: a wavefront may sweep its next unit (one 64-step block of one strip) whenever its ready() says so.
+// The simulator interleaves the wavefronts unit by unit under several policies -- round robin forward / backward,
+// shuffled, and "greedy" (one wavefront runs for as long as it is ready: maximally ahead of everyone else, which is what
+// stresses the ring-capacity and buffer-reuse conditions).  Every interleaving must give the same bytes; a result that
+// depends on the policy is a missing dependency in ready().  A state in which no wavefront is ready is a deadlock and
+// is reported.  LDS starts poisoned (NaN), so a read of a value that was never produced shows up in the field.
 //
 // Only tests/ loads this library (tests/sim_lib.py).  It is not a CPU fallback of the product: libvhp_hip.so neither
 // links nor loads it, and it is three orders of magnitude slower than the oracle.
@@ -70,41 +72,42 @@ void run_quadrant(const HostMap& h, OutT* field, int sx, int sy, int W, int orde
   if (g.empty()) return;
   const Layout L = make_layout(W, h.m.nx, h.m.ny);
   std::vector<double> lds(L.total, std::numeric_limits<double>::quiet_NaN());
-  int* sched = reinterpret_cast<int*>(lds.data() + L.sched);
-  compute_schedule(g, W, sched);
-  const int T_total = sched[0];
-  // the ring discipline the kernel relies on: inside a round a strip runs 1 (or 2) blocks behind its producer
-  for (int p = 1; p < g.Px; ++p)
-    if (p % W != 0) {
-      const int lag = (sched[1 + p] - g.nbx(kXRows * p)) - (sched[1 + p - 1] - g.nbx(kXRows * (p - 1)));
-      if (lag < 1 || lag > 2) info.lag_violations++;
-    }
-  for (int q = 1; q < g.Py; ++q)
-    if (q % W != 0) {
-      const int lag = (sched[1 + kMaxStrips + q] - g.nby(g.ystart(q))) - (sched[1 + kMaxStrips + q - 1] - g.nby(g.ystart(q - 1)));
-      if (lag < 1 || lag > 2) info.lag_violations++;
-    }
+  Progress<DX, DY> prog;
+  prog.bind(lds.data(), L, W);
+  prog.setup(g);
   std::vector<XWave<DX, DY, OutT>> xs(W);
   std::vector<YWave<DX, DY, OutT>> ys(W);
   for (int w = 0; w < W; ++w) {
     xs[w].init(h.m, g, field, w, W, lds.data(), L);
     ys[w].init(h.m, g, field, w, W, lds.data(), L);
   }
+  auto active = [&](int wv) { return wv < W ? xs[wv].active : ys[wv - W].active; };
+  auto ready = [&](int wv) { return wv < W ? xs[wv].ready() : ys[wv - W].ready(); };
+  auto run = [&](int wv) { if (wv < W) xs[wv].run_unit(); else ys[wv - W].run_unit(); };
   std::vector<int> order(2 * W);
-  for (int T = 0; T < T_total; ++T) {
+  long long passes = 0;
+  for (;;) {
+    bool any_active = false, progress = false;
     for (int k = 0; k < 2 * W; ++k) order[k] = k;
     if (order_mode == 1) for (int k = 0; k < 2 * W; ++k) order[k] = 2 * W - 1 - k;
-    if (order_mode == 2) for (int k = 2 * W - 1; k > 0; --k) { const int r = lcg(rng) % (k + 1); std::swap(order[k], order[r]); }
+    if (order_mode >= 2) for (int k = 2 * W - 1; k > 0; --k) { const int r = lcg(rng) % (k + 1); std::swap(order[k], order[r]); }
     for (int k = 0; k < 2 * W; ++k) {
       const int wv = order[k];
-      if (wv < W) xs[wv].slot(T); else ys[wv - W].slot(T);
+      if (!active(wv)) continue;
+      any_active = true;
+      // policies 0-2: one unit per visit; 3 (greedy): as many as it can; 4: a random few
+      int budget = order_mode == 3 ? (1 << 30) : order_mode == 4 ? 1 + (int)(lcg(rng) % 5) : 1;
+      while (budget-- > 0 && active(wv) && ready(wv)) {
+        run(wv);
+        progress = true;
+      }
     }
+    ++passes;
+    if (!any_active) break;
+    if (!progress) { info.lag_violations += 1000000; break; }  // deadlock
   }
-  // every wavefront must have finished all its strips inside the scheduled slots
-  for (int w = 0; w < W; ++w)
-    if (xs[w].active || ys[w].active) info.lag_violations += 1000000;
-  info.slots += T_total;
-  if (T_total > info.max_slots) info.max_slots = T_total;
+  info.slots += passes;
+  if (passes > info.max_slots) info.max_slots = passes;
 }
 
 template <typename OutT>
@@ -141,9 +144,10 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
 extern "C" {
 
 // out: n_src fields of nx*ny elements (dtype 0 = double, 1 = float), pre-filled by the caller (e.g. with NaN, to prove
-// that every cell is written).  W: strips per octant and round (>= 3).  order_mode: 0 forward, 1 backward, 2 shuffled.
-// stats (5 entries, may be null): total slots, longest workgroup in slots, schedule violations, 16-byte / 8-byte store
-// instructions.
+// that every cell is written).  W: strips per octant and round (>= 3).  order_mode: 0 round robin forward, 1 backward,
+// 2 shuffled, 3 greedy (a wavefront runs while it is ready), 4 shuffled with random bursts.
+// stats (5 entries, may be null): scheduler passes in total, most passes of one workgroup, violations (deadlocks),
+// 16-byte / 8-byte store instructions.
 int vhp_sim_stream_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W,
                          int order_mode, long long* stats) {
   if (!occ || !src || !out || nx <= 0 || ny <= 0 || (nx & 7) != 0 || W < 3 || W > 8) return 1;

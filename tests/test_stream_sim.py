@@ -44,7 +44,7 @@ def test_sim_small_and_ragged_grids(oracle, nx, ny):
     nb = max(3, min(40, nx * ny // 400))
     occ = maps.random_rect_map(nx, ny, nb, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 7 + ny)
     src = _sources(occ, 6, nx + ny)
-    for W, order, dtype in [(4, 0, np.float64), (4, 1, np.float64), (4, 2, np.float32), (8, 2, np.float64), (3, 2, np.float64)]:
+    for W, order, dtype in [(4, 0, np.float64), (4, 1, np.float64), (4, 2, np.float32), (8, 3, np.float64), (3, 4, np.float64), (4, 3, np.float64)]:
         _check(oracle, occ, src, W, order, dtype, "%dx%d W=%d order=%d %s" % (nx, ny, W, order, dtype.__name__))
 
 
@@ -53,7 +53,11 @@ def test_sim_multi_round_grids(oracle, nx, ny, W):
     # several rounds of W strips per octant: the round-to-round boundary rows and the diagonal hand-over at full size
     occ = maps.random_rect_map(nx, ny, 40, 5, nx // 8, 5, ny // 8, nx * 3 + ny)
     src = _sources(occ, 2, ny)[:6]
-    _check(oracle, occ, src, W, 2, np.float64, "%dx%d W=%d" % (nx, ny, W))
+    # greedy (a wavefront runs ahead for as long as it may) and bursty interleavings: these are what an unguarded
+    # buffer reuse fails under
+    _check(oracle, occ, src, W, 3, np.float64, "%dx%d W=%d greedy" % (nx, ny, W))
+    _check(oracle, occ, src[:3], W, 4, np.float64, "%dx%d W=%d bursts" % (nx, ny, W))
+    _check(oracle, occ, src[:3], 3, 3, np.float64, "%dx%d W=3 greedy" % (nx, ny))
 
 
 def test_sim_config3_sources(oracle):

@@ -134,6 +134,9 @@ template <typename OutT> inline void g_store1_if(const vb& p1, OutT* base, const
 inline void wave_sync() {}
 template <typename T> inline void pin(T&) {}
 inline int uniform(int x) { return x; }
+// release: everything this wavefront has written to LDS becomes visible, then the progress word
+inline void lds_publish(volatile int* word, int value) { *word = value; }
+inline void lds_acquire() {}
 
 #else
 // ------------------------------------------------------------------------------------------------------------
@@ -229,6 +232,13 @@ VHP_LANE_FN void wave_sync() {
 VHP_LANE_FN void pin(double& v) { asm volatile("" : "+v"(v)); }
 VHP_LANE_FN void pin(uint64_t& v) { asm volatile("" : "+v"(v)); }
 VHP_LANE_FN int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// release: everything this wavefront has written to LDS has landed (s_waitcnt lgkmcnt(0)), then the progress word
+VHP_LANE_FN void lds_publish(volatile int* word, int value) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63u) == 0) *word = value;
+}
+// acquire: LDS reads issued after a successful poll are not satisfied by anything older
+VHP_LANE_FN void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #endif
 
 // RN(num/den) for integers 0 <= num < den <= 16384, given rden = RN(1/den): Markstein's correction, proved

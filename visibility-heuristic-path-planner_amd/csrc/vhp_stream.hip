@@ -24,36 +24,54 @@ __device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, 
   g.init(m.nx, m.ny, sx, sy);
   if (g.empty()) return;  // uniform for the workgroup
   const Layout L = make_layout(W, m.nx, m.ny);
-  int* sched = reinterpret_cast<int*>(lds + L.sched);
-  if (threadIdx.x == 0) compute_schedule(g, W, sched);
-  __syncthreads();
-  const int T_total = uniform(sched[0]);
+  {
+    Progress<DX, DY> prog;
+    prog.bind(lds, L, W);
+    if (threadIdx.x == 0) prog.setup(g);
+  }
+  __syncthreads();  // the only workgroup barrier: from here on the wavefronts synchronise through their progress words
   const int wave = uniform((int)(threadIdx.x >> 6));
+#ifndef VHP_EXP_NOPRIO
+  // The launch is as long as its largest quadrants (a full-size one is 1/256 of a 256-source batch: a CU's fair
+  // share all by itself), and two workgroups share a CU: the larger the quadrant, the higher the issue priority of its
+  // wavefronts, so that it runs as if alone and the smaller neighbour fills the gaps.
+  {
+    const long area = (long)g.ni * g.nj, full = (long)m.nx * m.ny;
+    if (4 * area >= 3 * full) __builtin_amdgcn_s_setprio(3);
+    else if (2 * area >= full) __builtin_amdgcn_s_setprio(2);
+    else if (4 * area >= full) __builtin_amdgcn_s_setprio(1);
+  }
+#endif
 #ifdef VHP_EXP_WGTIME
   unsigned long long busy = 0;
+  int units = 0;
   const unsigned long long wg_t0 = wall_clock64(), c_begin = __builtin_readcyclecounter();
 #endif
   if (wave < W) {
     XWave<DX, DY, OutT> xw;
     xw.init(m, g, field, wave, W, lds, L);
-    for (int T = 0; T < T_total; ++T) {
+    while (xw.active) {
+      while (!xw.ready()) __builtin_amdgcn_s_sleep(4);
+      lds_acquire();
       VHP_WG_STAMP(c0);
-      xw.slot(T);
+      xw.run_unit();
 #ifdef VHP_EXP_WGTIME
       busy += __builtin_readcyclecounter() - c0;
+      ++units;
 #endif
-      __syncthreads();
     }
   } else {
     YWave<DX, DY, OutT> yw;
     yw.init(m, g, field, wave - W, W, lds, L);
-    for (int T = 0; T < T_total; ++T) {
+    while (yw.active) {
+      while (!yw.ready()) __builtin_amdgcn_s_sleep(4);
+      lds_acquire();
       VHP_WG_STAMP(c0);
-      yw.slot(T);
+      yw.run_unit();
 #ifdef VHP_EXP_WGTIME
       busy += __builtin_readcyclecounter() - c0;
+      ++units;
 #endif
-      __syncthreads();
     }
   }
 #ifdef VHP_EXP_WGTIME
@@ -65,7 +83,7 @@ __device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, 
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       wv[0] = wg_t0;
       wv[1] = wall_clock64();
-      wv[2] = (unsigned long long)T_total | ((unsigned long long)g.ni << 16) | ((unsigned long long)g.nj << 32);
+      wv[2] = (unsigned long long)units | ((unsigned long long)g.ni << 16) | ((unsigned long long)g.nj << 32);
       wv[3] = ((unsigned long long)xcc << 32) | hwid;
       wv[4] = __builtin_readcyclecounter() - c_begin;
     }

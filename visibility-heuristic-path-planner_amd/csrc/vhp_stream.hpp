@@ -9,13 +9,16 @@
 //   * one workgroup per (source, quadrant), 2*W wavefronts: W sweep strips of the x-major octant (64 rows each,
 //     one row per lane), W sweep strips of the y-major octant (128 columns each, two adjacent columns per lane, so
 //     that a lane stores 16 bytes per row and a wavefront 1 KB);
-//   * time is cut into SLOTS of one 64-cell block of the marching coordinate -- exactly one word of the bit-packed
-//     occupancy maps, so a lane loads one word per owned row/column and slot -- with one workgroup barrier per slot
-//     (an eighth of the front sweep's barriers).  A wavefront takes the strips w, w+W, w+2W, ... one after the other;
-//     inside a round strip p runs one slot behind strip p-1 and receives its boundary row through a two-block LDS
-//     ring, and the last strip of a round leaves its boundary row in a full-length LDS row for the first strip of the
-//     next round.  The whole schedule is static (compute_schedule): every wavefront knows in which slot it sweeps
-//     which block of which strip, and the only synchronisation is the slot barrier;
+//   * the unit of work is one 64-cell BLOCK of the marching coordinate of one strip -- exactly one word of the
+//     bit-packed occupancy maps, so a lane loads one word per owned row/column and unit.  A wavefront takes the strips
+//     w, w+W, w+2W, ... one after the other, block by block.  There is no workgroup barrier: the workgroup is a small
+//     dataflow machine.  Every wavefront counts the units it has finished in an LDS word, and before a unit it polls
+//     (once per 64 steps) the counters of the few wavefronts it depends on: the strip below must have swept the same
+//     block (boundary row, through a four-block LDS ring, or through a full-length LDS row from the last strip of a
+//     round to the first strip of the next), the reader of its output ring must not lag more than the ring holds, and
+//     a y-major strip needs the diagonal cells of its columns.  A wavefront that is ahead simply runs ahead, and one
+//     that has nothing to do costs nothing (the barrier-per-slot form of this kernel left 70 % of its wavefront
+//     slots idle and was bound by its largest quadrants: profiles/r02_*);
 //   * x-major strips stage 16 columns in a wave-private LDS tile and emit every row as whole, aligned 128-byte lines
 //     (8 rows per store instruction).  With a row pitch that is an odd multiple of 64 bytes (1000 columns!) odd and even
 //     rows are half a line apart, so the two row classes flush alternately, each every 16 steps;
@@ -67,7 +70,7 @@ struct Layout {
   int diag;              // diag(k), k = quadrant-local index
   int dummy;             // 8 doubles per wavefront: where lanes that are not the boundary lane "write" theirs
   int tiles;             // W staging tiles of kXRows * kTileStride
-  int sched;             // ints: [0] = number of slots, then sched_x[kMaxStrips], sched_y[kMaxStrips]
+  int sched;             // ints: done[16] (units finished per wavefront), then base_x[kMaxStrips], base_y[kMaxStrips]
   int total;
   int round_x_mask, round_y_mask;
 };
@@ -82,7 +85,7 @@ VHP_HD Layout make_layout(int W, int nx, int ny) {
   L.diag = o; o += imax(nx, ny) + 72;
   L.dummy = o; o += 2 * W * 8;
   L.tiles = o; o += W * kXRows * kTileStride;
-  L.sched = o; o += (1 + 2 * kMaxStrips + 1) / 2 + 1;
+  L.sched = o; o += (16 + 2 * kMaxStrips) / 2 + 1;
   L.total = o;
   L.round_x_mask = rx - 1;
   L.round_y_mask = ry - 1;
@@ -135,50 +138,45 @@ struct Quad {
   VHP_FN int ystart(int q) const { return imax(ycol0(q), 0); }        // its first step
 };
 
-// The static schedule: sched_x[p] / sched_y[q] = the slot in which the strip sweeps its FIRST block; block n of the
-// strip follows in slot sched + (n - first block).  Rules:
-//   (1) a wavefront takes its strips one after the other (strip p after strip p-W has swept its last block);
-//   (2) strip p sweeps block n at least one slot after strip p-1 did (boundary ring);
-//   (3) the y-major octant as a whole is delayed by Y0 slots so that every y-major strip starts after the x-major
-//       strips have published the diagonal cells of all its columns;
-//   (4) a wavefront reuses its output ring for its next strip only after the reader of the previous one has finished.
-// Inside a round rule (2) binds with equality (the reader is one block behind the writer), so a four-block ring is
-// enough between neighbours (the simulator asserts a lag of 1 or 2); the round-to-round hand-over goes through a
-// full-length row, whose writer (the last wavefront) runs W-1 >= 2 blocks behind its reader (the first).
+// Progress bookkeeping of a workgroup (ints in LDS at Layout::sched):
+//   done[0..W-1]   units (strip, block) the x-major wavefronts have finished, done[W..2W-1] the y-major ones;
+//   base_x[p]      index of strip p's first block in the unit sequence of its wavefront (p % W): the wavefront has
+//                  finished block n of strip p once done >= base_x[p] + (n - first block of p) + 1;
+//   base_y[q]      the same for the y-major strips.
+constexpr int kDoneSlots = 16;
 template <int DX, int DY>
-VHP_FN void compute_schedule(const Quad<DX, DY>& g, int W, int* sched) {
-  int* sx_ = sched + 1;
-  int* sy_ = sched + 1 + kMaxStrips;
-  int tx = 0, ty = 0;
-  for (int p = 0; p < g.Px; ++p) {
-    int s = 0;
-    if (p > 0) s = sx_[p - 1] + (g.nbx(kXRows * p) - g.nbx(kXRows * (p - 1))) + 1;
-    if (p >= W) s = imax(s, sx_[p - W] + (g.Nbx - g.nbx(kXRows * (p - W))));
-    if (p >= W && (p - W + 1) % W != 0) s = imax(s, sx_[p - W + 1] + (g.Nbx - g.nbx(kXRows * (p - W + 1))));
-    sx_[p] = s;
-    tx = imax(tx, s + g.Nbx - g.nbx(kXRows * p));
+struct Progress {
+  volatile int* done;
+  int* base_x;
+  int* base_y;
+  int W;
+
+  VHP_FN void bind(double* lds, const Layout& L, int W_) {
+    int* p = reinterpret_cast<int*>(lds + L.sched);
+    done = p;
+    base_x = p + kDoneSlots;
+    base_y = p + kDoneSlots + kMaxStrips;
+    W = W_;
   }
-  int y0 = 0;
-  for (int q = 0; q < g.Py; ++q) {
-    int s = 0;
-    if (q > 0) s = sy_[q - 1] + (g.nby(g.ystart(q)) - g.nby(g.ystart(q - 1))) + 1;
-    if (q >= W) s = imax(s, sy_[q - W] + (g.Nby - g.nby(g.ystart(q - W))));
-    if (q >= W && (q - W + 1) % W != 0) s = imax(s, sy_[q - W + 1] + (g.Nby - g.nby(g.ystart(q - W + 1))));
-    sy_[q] = s;
-    // the last diagonal cell this strip is seeded with, and the slot in which its x-major strip publishes it
-    const int klast = imin(g.ycol0(q) + kYCols - 1, g.rows_total - 1);
-    if (klast >= g.ystart(q)) {
-      const int px = klast / kXRows;
-      const int need = sx_[px] + (g.nbx(klast) - g.nbx(kXRows * px)) + 1;
-      y0 = imax(y0, need - s);
-    }
+  // run by one thread before any wavefront starts
+  VHP_FN void setup(const Quad<DX, DY>& g) {
+    for (int k = 0; k < kDoneSlots; ++k) done[k] = 0;
+    for (int p = 0; p < g.Px; ++p) base_x[p] = p >= W ? base_x[p - W] + (g.Nbx - g.nbx(kXRows * (p - W))) : 0;
+    for (int q = 0; q < g.Py; ++q) base_y[q] = q >= W ? base_y[q - W] + (g.Nby - g.nby(g.ystart(q - W))) : 0;
   }
-  for (int q = 0; q < g.Py; ++q) {
-    sy_[q] += y0;
-    ty = imax(ty, sy_[q] + g.Nby - g.nby(g.ystart(q)));
+  // has x-major strip p swept block n?  (blocks before the strip's first are nothing to wait for, blocks past the
+  // march mean "the whole strip")
+  VHP_FN bool x_done(const Quad<DX, DY>& g, int p, int n) const {
+    const int nf = g.nbx(kXRows * p);
+    if (n < nf) return true;
+    return uniform(done[p % W]) >= base_x[p] + (imin(n, g.Nbx - 1) - nf) + 1;
   }
-  sched[0] = imax(tx, ty);
-}
+  VHP_FN bool y_done(const Quad<DX, DY>& g, int q, int n) const {
+    const int nf = g.nby(g.ystart(q));
+    if (n < nf) return true;
+    return uniform(done[W + q % W]) >= base_y[q] + (imin(n, g.Nby - 1) - nf) + 1;
+  }
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // x-major wavefront: strips p = w, w+W, ...; rows j = 64p + lane; steps i = 64p .. ni-1; cells (i, j), j <= i.
@@ -196,9 +194,11 @@ struct XWave {
   double* round;
   int round_mask;
   double* diag;
-  const int* sched;  // sched_x
+  Progress<DX, DY> prog;
   bool rows_alternate;  // row pitch is an odd multiple of 64 bytes: odd and even rows are half a line apart
-  int p, j0, rows_here, nf, s0;
+  int p, j0, rows_here, nf;
+  int n;        // the block to sweep next
+  int my_done;  // units finished
   bool active, has_consumer;
   const double* rin;
   int rin_mask;
@@ -218,10 +218,11 @@ struct XWave {
     round = lds + L.round_x;
     round_mask = L.round_x_mask;
     diag = lds + L.diag;
-    sched = reinterpret_cast<const int*>(lds + L.sched) + 1;
+    prog.bind(lds, L, W);
     rows_alternate = ((m.nx >> 3) & 1) != 0;
     lane = lane_id();
     active = true;
+    my_done = 0;
     load_strip(w);
   }
 
@@ -232,7 +233,7 @@ struct XWave {
     rows_here = imin(kXRows, g.rows_total - j0);
     has_consumer = p + 1 < g.Px;
     nf = g.nbx(j0);
-    s0 = sched[p];
+    n = nf;
     prev = vd(0.0);
     jd = to_f64(lane + j0);
     if (p % W == 0) { rin = round; rin_mask = round_mask; } else { rin = ring_base + (w - 1) * kRing; rin_mask = kRing - 1; }
@@ -240,16 +241,35 @@ struct XWave {
     i_pub = j0;
   }
 
-  // one slot of the workgroup's schedule
-  VHP_FN void slot(int T) {
-    if (!active) return;
-    const int n = nf + (T - s0);
-    if (n < nf) return;  // this strip has not started yet
-    sweep_block(n);
-    if (n == g.Nbx - 1) {
-      end_of_march();
-      load_strip(p + W);
+  // May the next unit (strip p, block n) run?  Everything it reads from other wavefronts has been produced, and
+  // nothing it overwrites is still needed.
+  VHP_FN bool ready() const {
+    // the boundary row: strip p-1 has swept this block
+    if (p > 0 && !prog.x_done(g, p - 1, n)) return false;
+    if (has_consumer) {
+      if ((p + 1) % W != 0) {
+        // my output ring holds four blocks; writing block n overwrites block n-4, whose last entry the reader needs
+        // while it sweeps block n-3
+        if (!prog.x_done(g, p + 1, n - 3)) return false;
+      } else if (p >= 2 * W - 1) {
+        // I write the round-to-round row: the strip that still reads the previous round's entries from it (strip
+        // p-W+1, the first of my round) needs the last entry of block n while it sweeps block n+1
+        if (!prog.x_done(g, p - W + 1, n + 1)) return false;
+      }
     }
+    // a new strip reuses my output ring: the reader of my previous strip must be through with it
+    if (n == nf && p >= W && (p - W + 1) % W != 0 && !prog.x_done(g, p - W + 1, g.Nbx - 1)) return false;
+    return true;
+  }
+
+  // sweeps the next unit and publishes it
+  VHP_FN void run_unit() {
+    sweep_block(n);
+    const bool last = n == g.Nbx - 1;
+    if (last) end_of_march();
+    ++my_done;
+    lds_publish(prog.done + w, my_done);
+    if (last) load_strip(p + W); else ++n;
   }
 
   // boundary row for the strip above: row 63 of the tile, steps i_pub .. i_last (at most 8), copied into the ring
@@ -460,8 +480,10 @@ struct YWave {
   int round_mask;
   const double* diag;
   double* dummy;
-  const int* sched;  // sched_y
-  int q, i0, jstart, nf, s0;
+  Progress<DX, DY> prog;
+  int q, i0, jstart, nf;
+  int n;        // the block to sweep next
+  int my_done;  // units finished
   bool active, has_consumer, interior;
   const double* rin;
   int rin_mask;
@@ -480,9 +502,10 @@ struct YWave {
     round_mask = L.round_y_mask;
     diag = lds + L.diag;
     dummy = lds + L.dummy + (W + w) * 8;
-    sched = reinterpret_cast<const int*>(lds + L.sched) + 1 + kMaxStrips;
+    prog.bind(lds, L, W);
     lane = lane_id();
     active = true;
+    my_done = 0;
     load_strip(w);
   }
 
@@ -494,7 +517,7 @@ struct YWave {
     has_consumer = q + 1 < g.Py;
     interior = i0 >= 0 && i0 + kYCols - 1 < g.ni;  // every column of the strip is a column of the grid
     nf = g.nby(jstart);
-    s0 = sched[q];
+    n = nf;
     ia = lane * 2 + i0;
     ib = ia + 1;
     prev0 = vd(0.0);
@@ -508,12 +531,31 @@ struct YWave {
     if ((q + 1) % W == 0) { rout = round; rout_mask = round_mask; } else { rout = ring_base + w * kRing; rout_mask = kRing - 1; }
   }
 
-  VHP_FN void slot(int T) {
-    if (!active) return;
-    const int n = nf + (T - s0);
-    if (n < nf) return;
+  VHP_FN bool ready() const {
+    if (q > 0 && !prog.y_done(g, q - 1, n)) return false;
+    if (has_consumer) {
+      if ((q + 1) % W != 0) {
+        if (!prog.y_done(g, q + 1, n - 3)) return false;
+      } else if (q >= 2 * W - 1) {
+        if (!prog.y_done(g, q - W + 1, n + 1)) return false;
+      }
+    }
+    if (n == nf && q >= W && (q - W + 1) % W != 0 && !prog.y_done(g, q - W + 1, g.Nby - 1)) return false;
+    // the seeds of this block: diag(k) for the strip's columns k among the block's steps, published by the x-major
+    // strip that owns row k when it swept the block that holds step k
+    int lo, hi;
+    g.ysteps(n, lo, hi);
+    const int kmax = imin(imin(hi, i0 + kYCols - 1), g.rows_total - 1);
+    if (kmax >= imax(lo, jstart) && !prog.x_done(g, kmax / kXRows, g.nbx(kmax))) return false;
+    return true;
+  }
+
+  VHP_FN void run_unit() {
     sweep_block(n);
-    if (n == g.Nby - 1) load_strip(q + W);
+    const bool last = n == g.Nby - 1;
+    ++my_done;
+    lds_publish(prog.done + W + w, my_done);
+    if (last) load_strip(q + W); else ++n;
   }
 
   // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below
