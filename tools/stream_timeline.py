@@ -15,6 +15,9 @@ mod.LIB_PATH = os.path.join(ROOT, lib)
 lo, hi = (20, 100) if side <= 1024 else (80, 400)
 occ = synth.random_rect_map(side, side, 50, lo, hi, lo, hi, seed=1)
 src = synth.free_sources(occ, n, seed=7)
+if n == 1:  # the lone large quadrant
+    occ[5, 5] = 1
+    src = np.array([[5, 5]], np.int32)
 c = mod.Context(0)
 c.set_stream(torch.cuda.current_stream().cuda_stream)
 c.set_map(occ)
@@ -57,3 +60,11 @@ big = np.argsort(-dur)[:8]
 for b in big:
     print("  long WG %4d: start %.1f dur %.1f us slots %d ni %d nj %d busy x %s y %s" % (b, start[b], dur[b], slots[b], ni[b], nj[b], frac[b, :4].round(2), frac[b, 4:8].round(2)))
 np.save(os.path.join(ROOT, "gpurun_out", "stream_timeline.npy"), w)
+# where the cycles of workgroup 0's wavefronts went (XWave / YWave prof[] of the diagnostic build)
+pr = np.zeros(64, np.uint64)
+if mod._lib.vhp_debug_read_prof(C.c_void_p(pr.ctypes.data)) == 0:
+    pr = pr.reshape(8, 8).astype(np.float64)
+    for wv in range(8):
+        r = pr[wv]
+        print("  WG0 wave %d (%s): loads %.0f  steady windows %.0f  diag/pred windows %.0f  single steps %.0f  flushes %.0f  kcycles; %d windows -> %.0f cycles per window" % (
+            wv, "x" if wv < 4 else "y", r[0] / 1e3, r[1] / 1e3, r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5], (r[1] + r[2]) / max(r[5], 1)))

@@ -27,6 +27,7 @@ struct vhp_ctx {
   bool timed = false;
   std::string err;
 
+  int n_cus = 256;
   int nx = 0, ny = 0;
   uint8_t* d_occ = nullptr;    // uint8 map (kept for the planner's validation and packing)
   uint64_t* d_rows = nullptr;  // packed along x
@@ -44,6 +45,8 @@ struct vhp_ctx {
   size_t d_bnd_cap = 0;
   int* d_order = nullptr;   // launch order of the (source, quadrant) units (+ one int4 descriptor per workgroup)
   size_t d_order_cap = 0;
+  int* d_queue = nullptr;   // streaming sweep: unit queue, per-CU counters, launch order
+  size_t d_queue_cap = 0;
   bool timing = false;      // per-launch event pairs around the sweep kernel (vhp_timing)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_launches;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;  // recycled pairs: no hipEventCreate inside a timed loop
@@ -55,6 +58,7 @@ struct vhp_ctx {
   int opt_slide = -1;         // 0 / 1: y-major column grid slid onto 128-byte lines
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream)
+  int opt_stream_strips = 0;  // streaming sweep: 0 auto, 4 or 8 strips per octant and round
   // dynamic-LDS limit already raised on THIS context's device, per kernel function
   std::vector<std::pair<const void*, size_t>> lds_raised;
 
@@ -240,19 +244,24 @@ bool use_stream_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel == 1) return false;
   if (!vhp::stream_supported(c->nx, c->ny)) return false;
   if (c->opt_kernel == 2) return true;
-  return n_src >= 128;
+  // measured on MI355X, one process (tools/ab_libs.py, profiles/r02_*): the streaming sweep wins by 17-20 % on sides of
+  // 2048 and 4096, is level with the front sweep at 1000^2 from ~200 sources up (-4 % at 256) and loses below that
+  // (a lone large quadrant takes 0.39 ms in it against 0.28 ms: the front sweep's pipeline is 8 steps deep, not 64)
+  const int maxdim = std::max(c->nx, c->ny);
+  if (maxdim > 1024) return n_src >= 32;
+  return maxdim > 512 && n_src >= 192;
 }
 
 template <typename OutT>
 hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
-  const size_t n_units = (size_t)n_src * vhp::kUnitsPerSource;
-  if (c->d_order_cap < n_units) {
-    if (c->d_order) (void)hipFree(c->d_order);
-    c->d_order = nullptr;
-    c->d_order_cap = 0;
-    hipError_t eo = hipMalloc(&c->d_order, n_units * (sizeof(int) + sizeof(int4)) + 16);
+  const size_t qbytes = vhp::stream_queue_bytes(n_src);
+  if (c->d_queue_cap < qbytes) {
+    if (c->d_queue) (void)hipFree(c->d_queue);
+    c->d_queue = nullptr;
+    c->d_queue_cap = 0;
+    hipError_t eo = hipMalloc(&c->d_queue, qbytes);
     if (eo != hipSuccess) return eo;
-    c->d_order_cap = n_units;
+    c->d_queue_cap = qbytes;
   }
   vhp::StreamArgs a;
   a.rows = c->d_rows; a.cols = c->d_cols; a.recip = c->d_recip;
@@ -261,10 +270,12 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.dtype = sizeof(OutT) == 8 ? VHP_F64 : VHP_F32;
   a.field_stride = (long long)c->nx * c->ny;
   a.d_err = c->d_err;
-  a.d_order = c->d_order;
+  a.d_queue = c->d_queue;
+  a.n_cus = c->n_cus;
   a.stream = c->stream;
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
   a.ev_begin = a.ev_end = nullptr;
+  a.force_strips = c->opt_stream_strips;
   if (c->timing) {
     if (!c->event_pool.empty()) {
       a.ev_begin = c->event_pool.back().first;
@@ -350,6 +361,10 @@ int vhp_create(int device_ordinal, vhp_ctx** out) {
     return VHP_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount;
+  }
   *out = ctx;
   return VHP_OK;
 }
@@ -363,6 +378,7 @@ int vhp_destroy(vhp_ctx* ctx) {
   if (ctx->d_out) hipFree(ctx->d_out);
   if (ctx->d_bnd) hipFree(ctx->d_bnd);
   if (ctx->d_order) hipFree(ctx->d_order);
+  if (ctx->d_queue) hipFree(ctx->d_queue);
   for (auto& pr : ctx->timed_launches) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (ctx->d_err) hipFree(ctx->d_err);
@@ -517,6 +533,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "multi_round") { ctx->opt_multi = v != 0; }
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
+  else if (k == "stream_strips") { if (v != 0 && v != 4 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_strips: 0, 4 or 8"); ctx->opt_stream_strips = v; }
   else if (k == "kernel") { if (v < 0 || v > 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream"); ctx->opt_kernel = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;

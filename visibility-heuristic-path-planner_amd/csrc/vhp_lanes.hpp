@@ -99,6 +99,8 @@ inline vu32 half_shifted(const vu64& w, int t, int sh) {
 inline vi sbfe1(const vu32& hs, int b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = ((hs.v[l] >> b) & 1u) ? -1 : 0; return r; }
 
 inline vd lds_load(const double* base, const vi& idx) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = base[idx.v[l]]; return r; }
+// every lane reads the same (uniform) entry
+inline vd lds_bcast(const double* base, int idx) { return vd(base[idx]); }
 inline void lds_store(double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) base[idx.v[l]] = v.v[l]; }
 inline void lds_store_if(const vb& p, double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v.v[l]; }
 inline vu64 g_load_u64(const uint64_t* base, const vi& idx) { vu64 r; for (int l = 0; l < kLanes; ++l) r.v[l] = base[idx.v[l]]; return r; }
@@ -188,6 +190,8 @@ VHP_LANE_FN vu32 half_shifted(vu64 w, int t, int sh) { return ((t & 32) ? (uint3
 VHP_LANE_FN vi sbfe1(vu32 hs, int b) { return __builtin_amdgcn_sbfe(hs, b, 1); }
 
 VHP_LANE_FN vd lds_load(const double* base, vi idx) { return base[idx]; }
+// every lane reads the same (uniform) entry: an LDS broadcast read, the value arrives in a VGPR
+VHP_LANE_FN vd lds_bcast(const double* base, int idx) { return base[idx]; }
 VHP_LANE_FN void lds_store(double* base, vi idx, vd v) { base[idx] = v; }
 VHP_LANE_FN void lds_store_if(bool p, double* base, vi idx, vd v) { if (p) base[idx] = v; }
 #ifdef VHP_EXP_NOLOAD  // diagnostic builds only: no vector loads, so no s_waitcnt vmcnt ever drains the stores (wrong results)
@@ -221,11 +225,17 @@ template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p
 template <typename OutT> VHP_LANE_FN void g_store1_if(bool p1, OutT* base, vu32 off, vd a) {
   if (p1) *reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off) = static_cast<OutT>(a);
 }
-// orders this wavefront's LDS writes before its later LDS reads of other lanes' data
+// Orders this wavefront's LDS writes before its later LDS reads of other lanes' data.  The LDS executes the DS
+// instructions of one wavefront in issue order, so a read issued after a write sees it without an s_waitcnt in between:
+// only the compiler must be kept from moving the read up (wave_barrier is a scheduling barrier, it emits no code).
 VHP_LANE_FN void wave_sync() {
+#ifdef VHP_EXP_HEAVYSYNC  // the conservative form: fences make the compiler wait for lgkmcnt(0) on both sides
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+  __builtin_amdgcn_wave_barrier();
+#endif
 }
 // Makes a just-loaded value count as "used here": the compiler then waits for the load at this point instead of at
 // the first real use (where the s_waitcnt vmcnt would also drain every store issued in between).
@@ -243,13 +253,20 @@ VHP_LANE_FN void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workg
 
 // RN(num/den) for integers 0 <= num < den <= 16384, given rden = RN(1/den): Markstein's correction, proved
 // bit-identical to the division by oracle/markstein_check.c.  num is a lane vector, den and rden are uniform.
-VHP_LANE_FN vd ratio(vd num, double den, double rden) {
+template <typename D, typename R>
+VHP_LANE_FN vd ratio(vd num, D den, R rden) {
+#ifdef VHP_EXP_NOMATH  // diagnostic builds only: the memory traffic of the sweep without its arithmetic (wrong results)
+  return num;
+#endif
   const vd q = num * vd(rden);
-  const vd r = vfma(vd(-den), q, num);
+  const vd r = vfma(-vd(den), q, num);
   return vfma(r, vd(rden), q);
 }
 // the reference's update (solver.cpp:592-594 / 598-600): a - c*(a - b), no contraction
 VHP_LANE_FN vd stencil(vd a, vd b, vd c) {
+#ifdef VHP_EXP_NOMATH
+  return a;
+#endif
   const vd t = a - b;
   const vd u = c * t;
   return a - u;

@@ -10,16 +10,19 @@ namespace vhp {
 namespace stream {
 
 constexpr int kUnits = 4;  // quadrants per source
+constexpr int kCuSlots = 2048;  // per-CU arrival counters (XCC, SE, SH, CU packed into 11 bits)
 
 #ifdef VHP_EXP_WGTIME  // diagnostic builds only (tools/stream_timeline.py): when each workgroup ran and how busy its wavefronts were
 __device__ unsigned long long g_wgtime[8 * 16384];
+__device__ unsigned long long g_prof[8 * 8];  // per wavefront of workgroup 0: the XWave / YWave prof[] words
 #define VHP_WG_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
 #else
 #define VHP_WG_STAMP(var)
 #endif
 
 template <int DX, int DY, typename OutT>
-__device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, int sy, int W, double* lds) {
+__device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, int sy, int W, double* lds, int slot) {
+  (void)slot;
   Quad<DX, DY> g;
   g.init(m.nx, m.ny, sx, sy);
   if (g.empty()) return;  // uniform for the workgroup
@@ -60,9 +63,15 @@ __device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, 
       ++units;
 #endif
     }
+#ifdef VHP_EXP_WGTIME
+    if (slot == 0 && (threadIdx.x & 63) == 0)
+      for (int k = 0; k < 6; ++k) g_prof[wave * 8 + k] = xw.prof[k];
+#endif
   } else {
+    // wavefronts k and k + W share a SIMD: the x-major wavefront with the longest strips is paired with the y-major
+    // one with the shortest
     YWave<DX, DY, OutT> yw;
-    yw.init(m, g, field, wave - W, W, lds, L);
+    yw.init(m, g, field, W - 1 - (wave - W), W, lds, L);
     while (yw.active) {
       while (!yw.ready()) __builtin_amdgcn_s_sleep(4);
       lds_acquire();
@@ -73,10 +82,14 @@ __device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, 
       ++units;
 #endif
     }
+#ifdef VHP_EXP_WGTIME
+    if (slot == 0 && (threadIdx.x & 63) == 0)
+      for (int k = 0; k < 6; ++k) g_prof[wave * 8 + k] = yw.prof[k];
+#endif
   }
 #ifdef VHP_EXP_WGTIME
-  if ((threadIdx.x & 63) == 0 && blockIdx.x < 16384 / 2) {
-    unsigned long long* wv = g_wgtime + (size_t)blockIdx.x * 16;
+  if ((threadIdx.x & 63) == 0 && slot < 16384 / 2) {
+    unsigned long long* wv = g_wgtime + (size_t)slot * 16;
     if (wave == 0) {
       unsigned hwid, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -92,41 +105,90 @@ __device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, 
 #endif
 }
 
-// grid = 4 * n_src workgroups of 128*W threads; dynamic LDS = make_layout(W, nx, ny).total doubles.
-// Workgroup b sweeps unit order[b] (largest quadrants first: with in-order dispatch that is LPT scheduling).
+// Persistent workgroups: the grid is as many workgroups as the chip holds at once (LDS-limited: two 8-wavefront ones per
+// CU at 1000^2), and each takes the next unit -- one quadrant of one source, largest first -- from a global queue until
+// the queue is empty.  A CU's store path moves only ~8-10 bytes per clock, and a full-size quadrant is 8 MB = 1/256 of a
+// 256-source batch, i.e. a CU's whole fair share: with one workgroup per unit, dealt out in launch order, the CUs that
+// happened to get two large quadrants set the length of the launch.  Pulling balances the bytes per CU by itself: a
+// workgroup busy with a large quadrant simply pulls nothing else.
+// dynamic LDS = make_layout(W, nx, ny).total doubles.
 template <typename OutT, int W>
 __global__ void __launch_bounds__(128 * W, W == 4 ? 4 : 4)
 vhp_stream_sweep(Map m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride, int* __restrict__ err_flag,
-                 const int* __restrict__ order) {
+                 const int* __restrict__ order, unsigned long long* __restrict__ queue, int* __restrict__ cu_slots, int n_units) {
   extern __shared__ double lds[];
-  const int unit = order ? order[blockIdx.x] : (int)blockIdx.x;
-  const int s = unit / kUnits, q = unit - s * kUnits;
-  const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
-  if (sx < 0 || sy < 0 || sx >= m.nx || sy >= m.ny) {
-    if (threadIdx.x == 0 && q == 0) atomicOr(err_flag, 1);
-    return;
+  __shared__ int next_unit;
+  // Two workgroups share a CU.  The first to arrive on a CU pulls from the head of the queue (largest quadrants first),
+  // the second from its tail (smallest first), until the two ends meet: every CU then carries one stream of large
+  // quadrants and one of small ones, instead of some CUs starting with two of the largest.  `queue` packs both ends in
+  // one word (low half: units taken from the head, high half: from the tail) so that a pull sees both consistently.
+  __shared__ int from_tail;
+  __shared__ int cu_key;
+  if (threadIdx.x == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned key = (((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu)) & (kCuSlots - 1);  // XCC | SE, SH, CU of this workgroup
+    cu_key = (int)key;
+    from_tail = atomicAdd(&cu_slots[key], 1) & 1;
   }
-  OutT* field = out + (size_t)s * field_stride;
-  if (q == 0) {
-    // rows/columns no quadrant covers read as zero; quadrant 1 always exists
-    if (sx > 0)
-      for (int y = threadIdx.x; y < m.ny; y += blockDim.x) field[(size_t)y * m.nx] = OutT(0);
-    if (sy > 0)
-      for (int x = threadIdx.x; x < m.nx; x += blockDim.x) field[x] = OutT(0);
-    run_quadrant<+1, +1>(m, field, sx, sy, W, lds);
-  } else if (q == 1) {
-    run_quadrant<-1, +1>(m, field, sx, sy, W, lds);
-  } else if (q == 2) {
-    run_quadrant<-1, -1>(m, field, sx, sy, W, lds);
-  } else {
-    run_quadrant<+1, -1>(m, field, sx, sy, W, lds);
+  __syncthreads();
+  const bool tail = from_tail != 0;
+  // cu_slots[kCuSlots + key]: the head workgroup of this CU is sweeping a very large quadrant.  Such a quadrant sets the
+  // length of the launch, and it runs 1.6x slower with a neighbour on its CU (they share the CU's store path): the tail
+  // workgroup of that CU waits it out instead of pulling.
+  int* big_flag = cu_slots + kCuSlots + cu_key;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      if (tail) {
+        int spins = 0;
+        while (__hip_atomic_load(big_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(32);
+      }
+      const unsigned long long old = atomicAdd(queue, tail ? (1ull << 32) : 1ull);
+      const unsigned h = (unsigned)old, t = (unsigned)(old >> 32);
+      next_unit = (h + t >= (unsigned)n_units) ? n_units : (tail ? n_units - 1 - (int)t : (int)h);
+    }
+    __syncthreads();
+    const int slot = uniform(next_unit);
+    if (slot >= n_units) return;
+    const int unit = order ? order[slot] : slot;
+    const int s = unit / kUnits, q = unit - s * kUnits;
+    const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
+    if (sx < 0 || sy < 0 || sx >= m.nx || sy >= m.ny) {
+      if (threadIdx.x == 0 && q == 0) atomicOr(err_flag, 1);
+    } else {
+      OutT* field = out + (size_t)s * field_stride;
+      const long ni_ = (q == 0 || q == 3) ? m.nx - sx : sx, nj_ = q < 2 ? m.ny - sy : sy;
+      const bool very_large = !tail && 20 * ni_ * nj_ >= 13 * (long)m.nx * m.ny;  // >= 0.65 of the grid
+      if (very_large && threadIdx.x == 0) __hip_atomic_store(big_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (q == 0) {
+        // rows/columns no quadrant covers read as zero; quadrant 1 always exists
+        if (sx > 0)
+          for (int y = threadIdx.x; y < m.ny; y += blockDim.x) field[(size_t)y * m.nx] = OutT(0);
+        if (sy > 0)
+          for (int x = threadIdx.x; x < m.nx; x += blockDim.x) field[x] = OutT(0);
+        run_quadrant<+1, +1>(m, field, sx, sy, W, lds, slot);
+      } else if (q == 1) {
+        run_quadrant<-1, +1>(m, field, sx, sy, W, lds, slot);
+      } else if (q == 2) {
+        run_quadrant<-1, -1>(m, field, sx, sy, W, lds, slot);
+      } else {
+        run_quadrant<+1, -1>(m, field, sx, sy, W, lds, slot);
+      }
+      if (very_large && threadIdx.x == 0) __hip_atomic_store(big_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // every wavefront is through with this unit's LDS before the next unit's setup
   }
 }
 
 // Launch order of the units: a quadrant's work grows with its area.  One workgroup counting-sorts the units by
 // area, largest first.  Units of out-of-range sources sort last.
 constexpr int kBuckets = 1024;
-__global__ void __launch_bounds__(1024) vhp_stream_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order) {
+__global__ void __launch_bounds__(1024) vhp_stream_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order,
+                                                         unsigned long long* __restrict__ queue, int* __restrict__ cu_slots) {
+  if (threadIdx.x == 0) *queue = 0ull;
+  for (int k = threadIdx.x; k < 2 * kCuSlots; k += blockDim.x) cu_slots[k] = 0;
+  if (!order) return;
   __shared__ int hist[kBuckets];
   __shared__ int start[kBuckets];
   __shared__ int wave_tot[16];
@@ -181,14 +243,20 @@ hipError_t launch_t(const StreamArgs& a) {
   Map m;
   m.rows = a.rows; m.cols = a.cols; m.recip = a.recip;
   m.wpr = a.wpr; m.wpc = a.wpc; m.nx = a.nx; m.ny = a.ny;
-  const int* order = nullptr;
-  if (a.d_order && a.n_src >= 8) {
-    hipLaunchKernelGGL(vhp_stream_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, a.d_order);
-    order = a.d_order;
-  }
+  // scratch: the queue word, the per-CU arrival counters, the launch order of the units
+  unsigned long long* queue = reinterpret_cast<unsigned long long*>(a.d_queue);
+  int* cu_slots = a.d_queue + 2;
+  int* ord = a.n_src >= 8 ? a.d_queue + 2 + 2 * kCuSlots : nullptr;
+  hipLaunchKernelGGL(vhp_stream_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, ord, queue, cu_slots);
+  const int n_units = a.n_src * kUnits;
+  int per_cu = (int)(kLdsLimit / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu * 2 * W > 32) per_cu = 32 / (2 * W);  // 32 wavefronts per CU
+  const int resident = per_cu * a.n_cus;
+  const int grid = n_units < resident ? n_units : resident;
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);
-  hipLaunchKernelGGL(k, dim3((unsigned)(a.n_src * kUnits)), dim3(128 * W), lds, a.stream, m, a.d_src, static_cast<OutT*>(a.d_out),
-                     a.field_stride, a.d_err, order);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(128 * W), lds, a.stream, m, a.d_src, static_cast<OutT*>(a.d_out), a.field_stride,
+                     a.d_err, (const int*)ord, queue, cu_slots, n_units);
   const hipError_t e = hipGetLastError();
   if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
   return e;
@@ -199,7 +267,12 @@ hipError_t launch_t(const StreamArgs& a) {
 extern "C" int vhp_debug_read_wgtime(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(stream::g_wgtime), (size_t)n_words * 8);
 }
+extern "C" int vhp_debug_read_prof(unsigned long long* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(stream::g_prof), 64 * 8);
+}
 #endif
+
+size_t stream_queue_bytes(int n_src) { return (size_t)(2 + 2 * stream::kCuSlots + 4 * (size_t)n_src) * sizeof(int); }
 
 int stream_strips(int nx, int ny) {
   if (nx <= 0 || ny <= 0 || (nx & 7) != 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return 0;
@@ -211,8 +284,9 @@ int stream_strips(int nx, int ny) {
 bool stream_supported(int nx, int ny) { return stream_strips(nx, ny) != 0; }
 
 hipError_t launch_stream(const StreamArgs& a) {
-  const int W = stream_strips(a.nx, a.ny);
+  int W = stream_strips(a.nx, a.ny);
   if (W == 0) return hipErrorInvalidValue;
+  if ((a.force_strips == 4 || a.force_strips == 8) && lds_bytes(a.nx, a.ny, a.force_strips) <= kLdsLimit) W = a.force_strips;
   if (a.dtype == VHP_F64) return W == 4 ? launch_t<double, 4>(a) : launch_t<double, 8>(a);
   return W == 4 ? launch_t<float, 4>(a) : launch_t<float, 8>(a);
 }

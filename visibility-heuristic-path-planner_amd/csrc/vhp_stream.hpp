@@ -36,6 +36,17 @@ namespace stream {
 
 using namespace vhp::lanes;
 
+#if defined(VHP_EXP_WGTIME) && !defined(VHP_SIM)  // diagnostic builds only: where a wavefront's cycles go
+#define VHP_PROF_DECL unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
+#define VHP_PROF_T0(var) const unsigned long long var = __builtin_readcyclecounter()
+#define VHP_PROF_ADD(slot, var) prof[slot] += __builtin_readcyclecounter() - var
+#define VHP_PROF_COUNT(slot) prof[slot] += 1
+#else
+#define VHP_PROF_DECL
+#define VHP_PROF_T0(var)
+#define VHP_PROF_ADD(slot, var)
+#define VHP_PROF_COUNT(slot)
+#endif
 #ifdef VHP_SIM
 #define VHP_FN inline
 #define VHP_HD inline
@@ -69,8 +80,10 @@ struct Layout {
   int round_x, round_y;  // boundary row from the last strip of a round to the first strip of the next, indexed by absolute x / y
   int diag;              // diag(k), k = quadrant-local index
   int dummy;             // 8 doubles per wavefront: where lanes that are not the boundary lane "write" theirs
+  int slab;              // 64 doubles per wavefront: the reciprocals of the block it sweeps
   int tiles;             // W staging tiles of kXRows * kTileStride
-  int sched;             // ints: done[16] (units finished per wavefront), then base_x[kMaxStrips], base_y[kMaxStrips]
+  int sched;             // ints: done[16] (units finished per wavefront), then base_x[strips_x], base_y[strips_y]
+  int strips_x, strips_y;  // capacity of the two base arrays: the most strips an octant of this grid can have
   int total;
   int round_x_mask, round_y_mask;
 };
@@ -84,8 +97,11 @@ VHP_HD Layout make_layout(int W, int nx, int ny) {
   L.round_y = o; o += ry;
   L.diag = o; o += imax(nx, ny) + 72;
   L.dummy = o; o += 2 * W * 8;
+  L.slab = o; o += 2 * W * kBlock;
   L.tiles = o; o += W * kXRows * kTileStride;
-  L.sched = o; o += (16 + 2 * kMaxStrips) / 2 + 1;
+  L.strips_x = (imin(nx, ny) + kXRows - 1) / kXRows + 1;
+  L.strips_y = (imin(nx, ny) + 15 + kYCols - 1) / kYCols + 1;
+  L.sched = o; o += (16 + L.strips_x + L.strips_y) / 2 + 1;
   L.total = o;
   L.round_x_mask = rx - 1;
   L.round_y_mask = ry - 1;
@@ -155,7 +171,7 @@ struct Progress {
     int* p = reinterpret_cast<int*>(lds + L.sched);
     done = p;
     base_x = p + kDoneSlots;
-    base_y = p + kDoneSlots + kMaxStrips;
+    base_y = p + kDoneSlots + L.strips_x;
     W = W_;
   }
   // run by one thread before any wavefront starts
@@ -179,6 +195,14 @@ struct Progress {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
+// Both kinds of wavefront keep every VALU instruction they can off the step: on gfx950 a wave64 vector instruction
+// occupies its SIMD for 4 cycles whatever its width, so the count of vector instructions per step IS the speed of a
+// strip.  Wave-uniform operands of a step (the reciprocal of the step index, the boundary value of the strip below,
+// the seed of a column) are therefore not moved between lanes by v_readlane / DPP rotates but fetched by LDS broadcast
+// reads (every lane reads the same address: an LDS-queue instruction, no vector ALU slot), a window of 8 steps ahead.
+// ---------------------------------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------------------------------
 // x-major wavefront: strips p = w, w+W, ...; rows j = 64p + lane; steps i = 64p .. ni-1; cells (i, j), j <= i.
 // ---------------------------------------------------------------------------------------------------------------
 template <int DX, int DY, typename OutT>
@@ -194,8 +218,10 @@ struct XWave {
   double* round;
   int round_mask;
   double* diag;
+  double* slab;   // reciprocals of the current block's 64 steps, indexed by x & 63
+  double* dummy;  // where the lanes that are not the boundary lane "write" theirs
   Progress<DX, DY> prog;
-  bool rows_alternate;  // row pitch is an odd multiple of 64 bytes: odd and even rows are half a line apart
+  int r_stride;   // 2: the row pitch is an odd multiple of 64 bytes, odd and even rows are half a line apart; else 1
   int p, j0, rows_here, nf;
   int n;        // the block to sweep next
   int my_done;  // units finished
@@ -204,12 +230,15 @@ struct XWave {
   int rin_mask;
   double* rout;
   int rout_mask;
-  int i_pub;  // first step whose boundary value has not been copied to rout yet
   // lanes
   vi lane;
+  VHP_PROF_DECL     // [0] block-start loads, [1] steady windows, [2] diagonal windows, [3] single steps, [4] flushes, [5] windows
+  vi tile_l;        // lane * kTileStride
+  vi fl_t0, fl_d8;  // flush: tile index of the lane's piece for a line that starts at x % 16 == 0 (row slot 0 .. 7), and what
+                    // a line that starts at x % 16 == 8 adds to it
+  vu32 fl_off;      // flush: byte offset of the lane's piece from the lowest row of a store instruction, for xa = 0
   vd prev, jd;
   vu64 ow;
-  vd rv;
 
   VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
     m = m_; g = g_; out = out_; w = w_; W = W_;
@@ -218,9 +247,21 @@ struct XWave {
     round = lds + L.round_x;
     round_mask = L.round_x_mask;
     diag = lds + L.diag;
+    slab = lds + L.slab + w * kBlock;
+    dummy = lds + L.dummy + w * 8;
     prog.bind(lds, L, W);
-    rows_alternate = ((m.nx >> 3) & 1) != 0;
+    r_stride = ((m.nx >> 3) & 1) ? 2 : 1;
     lane = lane_id();
+    tile_l = lane * kTileStride;
+    {
+      // flush geometry: lane -> (row slot = lane >> 3, piece = lane & 7 = cells xa + 2*piece, +1); the row slots of a
+      // store instruction are counted upward in y, so that byte offsets from its lowest row are never negative
+      const vi rslot = lane >> 3, pc = lane & 7;
+      const vi rs = DY > 0 ? rslot : 7 - rslot;
+      fl_t0 = rslot * (r_stride * kTileStride) + pc * 2;
+      fl_d8 = ((pc * 2) ^ 8) - pc * 2;
+      fl_off = to_u32((rs * (r_stride * m.nx) + pc * 2) * CB);
+    }
     active = true;
     my_done = 0;
     load_strip(w);
@@ -238,7 +279,6 @@ struct XWave {
     jd = to_f64(lane + j0);
     if (p % W == 0) { rin = round; rin_mask = round_mask; } else { rin = ring_base + (w - 1) * kRing; rin_mask = kRing - 1; }
     if ((p + 1) % W == 0) { rout = round; rout_mask = round_mask; } else { rout = ring_base + w * kRing; rout_mask = kRing - 1; }
-    i_pub = j0;
   }
 
   // May the next unit (strip p, block n) run?  Everything it reads from other wavefronts has been produced, and
@@ -272,34 +312,16 @@ struct XWave {
     if (last) load_strip(p + W); else ++n;
   }
 
-  // boundary row for the strip above: row 63 of the tile, steps i_pub .. i_last (at most 8), copied into the ring
-  VHP_FN void publish(int i_last) {
-    if (has_consumer) {
-      wave_sync();
-      const vi ie = lane + i_pub;                // lanes 0..7
-      const vi xe = ie * DX + g.sx;
-      const vb on = (lane < 8) && (ie <= i_last);
-      const vd v = lds_load(tile, select(on, (xe & 15) + 63 * kTileStride, vi(63 * kTileStride)));
-      lds_store_if(on, rout, xe & rout_mask, v);
-    }
-    i_pub = i_last + 1;
-  }
-
   // Emits one 128-byte line (16 cells from xa on; for fp32 fields that is one 64-byte sector) of the rows
-  // r = r_first, r_first + r_stride, ... of this strip from the tile.  8 rows per store instruction: lane -> (row
-  // slot = lane >> 3, piece = lane & 7 = cells xa + 2*piece, +1).  PRED: only the cells the march has reached and that
-  // belong to the octant (step index i' with j <= i' <= i_now) are stored.
+  // r = r_first, r_first + r_stride, ... of this strip from the tile, 8 rows per store instruction.  PRED: only the
+  // cells the march has reached and that belong to the octant (step index i' with j <= i' <= i_now) are stored.
   template <bool PRED>
-  VHP_FN void flush(int xa, int r_first, int r_stride, int i_now) {
+  VHP_FN void flush(int xa, int r_first, int i_now) {
     wave_sync();
-    const vi rslot = lane >> 3, pc = lane & 7;
-    const vi xc = pc * 2 + xa;                      // x of the pair's first cell
-    const vi r0 = rslot * r_stride + r_first;       // the lane's row in the first store instruction
-    const vi t0 = r0 * kTileStride + (xc & 15);     // ... its tile index
-    // ... and its byte offset from the LOWEST row (in y) of the store instruction: offsets are unsigned 32-bit on a
-    // uniform 64-bit base, so they must not be negative
-    const vi rs = DY > 0 ? rslot : 7 - rslot;
-    const vu32 off = to_u32((rs * (r_stride * m.nx) + xc) * CB);
+    // (arithmetic, not a select between the two members: a select of two loads becomes a load through a selected
+    // address, which keeps the whole wavefront object in scratch memory)
+    const vi t0 = fl_t0 + fl_d8 * ((xa >> 3) & 1) + r_first * kTileStride;
+    const vu32 off = fl_off + (uint32_t)(xa * CB);
     const int t_step = 8 * r_stride * kTileStride;  // per store instruction: 8 row slots further
     const long y_low = DY > 0 ? g.Y(j0 + r_first) : g.Y(j0 + r_first + 7 * r_stride);
     OutT* base = out + y_low * (long)m.nx;          // uniform: the row term lives in scalar registers
@@ -314,7 +336,9 @@ struct XWave {
         base += base_step;
       }
     } else {
+      const vi xc = (lane & 7) * 2 + xa;                             // x of the pair's first cell
       const vi i0c = (xc - g.sx) * DX, i1c = (xc + 1 - g.sx) * DX;  // step indices of the two cells
+      const vi r0 = (lane >> 3) * r_stride + r_first;
       for (int u = 0; r_first + r_stride * 8 * u < rows_here; ++u) {
         const vi r = r0 + 8 * r_stride * u;
         const vb row_ok = r < rows_here;
@@ -324,7 +348,6 @@ struct XWave {
         if (!PRED) {
           g_store2_if(row_ok, vb(false), vb(false), base, off, a, b);
         } else {
-          // only the cells the march has reached and that belong to the octant: j <= i' <= i_now
           const vi jr = r + j0;
           const vb ok0 = row_ok && (i0c >= jr) && (i0c <= i_now);
           const vb ok1 = row_ok && (i1c >= jr) && (i1c <= i_now);
@@ -342,28 +365,26 @@ struct XWave {
     const int edge = DX > 0 ? x_b + 1 : x_b;  // marching up, the line ends below `edge`; marching down it starts at `edge`
     const int hbit = (edge >> 3) & 1;
     const int xa = DX > 0 ? x_b - 15 : x_b;
-    const int i_first = i_now - 15;  // step of the line's first-marched cell
-    const bool steady = i_first >= j0 + kXRows - 1;
-    if (!rows_alternate) {
+    const bool steady = i_now - 15 >= j0 + kXRows - 1;  // the line's first-marched cell is past every row's diagonal
+    int r_first = 0;
+    if (r_stride == 1) {
       if (hbit != 0) return;
-      if (steady) flush<false>(xa, 0, 1, i_now); else flush<true>(xa, 0, 1, i_now);
     } else {
-      const int rpar = (hbit ^ g.sy ^ j0) & 1;  // rows with (y & 1) == hbit
-      if (steady) flush<false>(xa, rpar, 2, i_now); else flush<true>(xa, rpar, 2, i_now);
+      r_first = (hbit ^ g.sy ^ j0) & 1;  // rows with (y & 1) == hbit
     }
+    if (steady) flush<false>(xa, r_first, i_now); else flush<true>(xa, r_first, i_now);
   }
 
   // the march of this strip is over: what is still in the tile leaves as partial lines
   VHP_FN void end_of_march() {
     const int i_now = g.ni - 1;
     const int xe = g.X(i_now);
-    if (i_pub <= i_now) publish(i_now);
-    if (!rows_alternate) {
-      flush<true>(xe & ~15, 0, 1, i_now);
+    if (r_stride == 1) {
+      flush<true>(xe & ~15, 0, i_now);
     } else {
       for (int ph = 0; ph < 2; ++ph) {  // rows whose lines start at x % 16 == 8*ph
         const int xa = 8 * ph + (((xe - 8 * ph) >> 4) << 4);
-        flush<true>(xa, (ph ^ g.sy ^ j0) & 1, 2, i_now);
+        flush<true>(xa, (ph ^ g.sy ^ j0) & 1, i_now);
       }
     }
   }
@@ -372,7 +393,7 @@ struct XWave {
   VHP_FN void step1(int i) {
     const int x = g.X(i);
     const int t = x & 63;
-    const double ri = read_lane(rv, t);
+    const double ri = slab[t];
     const double di = (double)i;
     double fill = 0.0, dsrc = 1.0;  // OLD / NEW value of the row just below lane 0's (1.0 = light strength at the origin)
     if (p > 0) { fill = rin[(x - DX) & rin_mask]; dsrc = rin[x & rin_mask]; }
@@ -388,7 +409,8 @@ struct XWave {
       lds_store_if(isd, diag, vi(i), dcell);
     }
     prev = v;
-    lds_store(tile, lane * kTileStride + (x & 15), v);
+    lds_store(tile, tile_l + (x & 15), v);
+    if (has_consumer) lds_store_if(lane == 63, rout, vi(x & rout_mask), v);
   }
 
   // eight steps covering one aligned window of x; DIAG: the strip's diagonal may fall into it
@@ -397,23 +419,36 @@ struct XWave {
     const int x0 = g.X(i0);
     const int t0 = x0 & 63;
     const int xw = x0 & ~7;  // lowest x of the window
-    double rr[8];
+    // uniform operands by LDS broadcast: the reciprocals of the 8 step indices ...
+    vd rr[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rr[k] = read_lane(rv, t0 + DX * k);
+    for (int k = 0; k < 8; ++k) rr[k] = lds_bcast(slab, (xw & 63) + (DX > 0 ? k : 7 - k));
+    // ... and the boundary row of the strip below: rb[k] = its value at x(i0 + k) - DX, the OLD neighbour of lane 0 at
+    // step k (and rb[k + 1] the NEW one, which the diagonal cell of row j0 takes)
+    vd rb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rb[k] = vd(0.0);
+    if (p > 0) {
+      rb[0] = lds_bcast(rin, (x0 - DX) & rin_mask);
+      const int xb = xw & rin_mask;  // the window itself never wraps in the ring
+#pragma unroll
+      for (int k = 1; k < 9; ++k) rb[k] = lds_bcast(rin, xb + (DX > 0 ? k - 1 : 8 - k));
+    }
     const vu32 hs = half_shifted(ow, t0, DX > 0 ? (t0 & 31) : (t0 & 31) - 7);  // step k's bit at position (x & 7)
-    vd ringv = vd(0.0);  // lane l: OLD boundary value for step k = l, rotated down by one lane per step
-    if (p > 0) ringv = lds_load(rin, (lane * DX + (x0 - DX)) & rin_mask);
-    const vi tidx = lane * kTileStride + (xw & 15);
-    double di = (double)i0;
+    const vi tidx = tile_l + (xw & 15);
+    // every lane writes "its boundary value" each step -- lane 63 into the ring, the others into a dummy slot: one
+    // ds_write instead of an exec-masked region per step
+    double* wbase = has_consumer ? rout + (xw & rout_mask) : dummy;
+    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
+    vd di = vd((double)i0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int col = DX > 0 ? k : 7 - k;
-      const vd b = shift_up(prev, ringv);
+      const vd b = shift_up(prev, rb[k]);
       const vi mk = sbfe1(hs, col);
       vd v = and_mask(stencil(prev, b, ratio(jd, di, rr[k])), mk);
-      const vd ringn = rotate_down(ringv);  // lane 0: NEW value of the row below this strip (all zeros for strip 0)
       if (DIAG) {
-        const vd up = shift_up(v, p > 0 ? ringn : vd(1.0));  // strip 0: 1.0 = light strength at the origin
+        const vd up = shift_up(v, p > 0 ? rb[k + 1] : vd(1.0));  // strip 0: 1.0 = light strength at the origin
         const vb isd = lane == (i0 + k - j0);
         const vd dcell = and_mask(up, mk);
         v = select(isd, dcell, v);
@@ -421,45 +456,51 @@ struct XWave {
       }
       prev = v;
       lds_store(tile, tidx + col, v);
-      ringv = ringn;
-      di += 1.0;
+      lds_store(wbase, widx + col, v);
+      di = di + 1.0;
     }
   }
 
-  VHP_FN void sweep_block(int n) {
+  VHP_FN void sweep_block(int nb) {
     int lo, hi;
-    g.xsteps(n, lo, hi);
+    g.xsteps(nb, lo, hi);
     lo = imax(lo, j0);
     if (lo > hi) return;
     const int blk = g.X(lo) >> 6;
+    VHP_PROF_T0(tl0);
     {
       const vi yl = (vmin(lane + j0, g.rows_total - 1)) * DY + g.sy;
       ow = g_load_u64(m.rows, yl * m.wpr + (1 + blk));
       const vi it = (lane + (blk * 64 - g.sx)) * DX;
       const vb ok = (it >= 0) && (it < g.ni);
-      rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
+      vd rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
       pin(ow);
       pin(rv);
+      lds_store(slab, lane, rv);
+      wave_sync();
     }
+    VHP_PROF_ADD(0, tl0);
     int i = lo;
     while (i <= hi) {
       const int x = g.X(i);
       const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
       int i_last;
+      VHP_PROF_T0(tw0);
       if (aligned && i + 7 <= hi) {
-        if (i < j0 + kXRows) window8<true>(i); else window8<false>(i);
+        if (i < j0 + kXRows) { window8<true>(i); VHP_PROF_ADD(2, tw0); } else { window8<false>(i); VHP_PROF_ADD(1, tw0); }
+        VHP_PROF_COUNT(5);
         i_last = i + 7;
       } else {
         step1(i);
+        VHP_PROF_ADD(3, tw0);
         i_last = i;
       }
       i = i_last + 1;
       const int xl = g.X(i_last);
       const bool boundary = DX > 0 ? (xl & 7) == 7 : (xl & 7) == 0;
-      if (boundary && i_last != g.ni - 1) {  // (the last step of the march is end_of_march's)
-        publish(i_last);
-        flush_completed(xl, i_last);
-      }
+      VHP_PROF_T0(tf0);
+      if (boundary && i_last != g.ni - 1) flush_completed(xl, i_last);  // (the last step of the march is end_of_march's)
+      VHP_PROF_ADD(4, tf0);
     }
   }
 };
@@ -479,6 +520,7 @@ struct YWave {
   double* round;
   int round_mask;
   const double* diag;
+  double* slab;   // reciprocals of the current block's 64 steps, indexed by y & 63
   double* dummy;
   Progress<DX, DY> prog;
   int q, i0, jstart, nf;
@@ -492,8 +534,8 @@ struct YWave {
   vi lane, ia, ib;
   vd prev0, prev1, id0, id1;
   vu64 ow0, ow1;
-  vd rv;
   vu32 xoff;  // byte offset of the lane's pair inside a row
+  VHP_PROF_DECL  // [0] block-start loads, [1] steady windows, [2] diagonal / predicated windows, [3] single steps, [5] windows
 
   VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
     m = m_; g = g_; out = out_; w = w_; W = W_;
@@ -501,6 +543,7 @@ struct YWave {
     round = lds + L.round_y;
     round_mask = L.round_y_mask;
     diag = lds + L.diag;
+    slab = lds + L.slab + (W + w) * kBlock;
     dummy = lds + L.dummy + (W + w) * 8;
     prog.bind(lds, L, W);
     lane = lane_id();
@@ -572,7 +615,7 @@ struct YWave {
   VHP_FN void step1(int j) {
     const int y = g.Y(j);
     const int t = y & 63;
-    const double rj = read_lane(rv, t);
+    const double rj = slab[t];
     const double dj = (double)j;
     double fill = 0.0;
     if (q > 0) fill = rin[(y - DY) & rin_mask];
@@ -596,51 +639,60 @@ struct YWave {
     const int y0 = g.Y(j0w);
     const int t0 = y0 & 63;
     const int yb = y0 & ~7;
-    double rr[8];
+    vd rr[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rr[k] = read_lane(rv, t0 + DY * k);
+    for (int k = 0; k < 8; ++k) rr[k] = lds_bcast(slab, (yb & 63) + (DY > 0 ? k : 7 - k));
+    vd rb[8];  // the boundary column of the strip below at y(j0w + k) - DY
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rb[k] = vd(0.0);
+    if (q > 0) {
+      rb[0] = lds_bcast(rin, (y0 - DY) & rin_mask);
+      const int yq = yb & rin_mask;
+#pragma unroll
+      for (int k = 1; k < 8; ++k) rb[k] = lds_bcast(rin, yq + (DY > 0 ? k - 1 : 8 - k));
+    }
+    vd dg[8];  // diag(j0w + k)
+    if (DIAG) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dg[k] = lds_bcast(diag, j0w + k);
+    }
     const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
     const vu32 hs0 = half_shifted(ow0, t0, sh), hs1 = half_shifted(ow1, t0, sh);
-    vd ringv = vd(0.0);
-    if (q > 0) ringv = lds_load(rin, (lane * DY + (y0 - DY)) & rin_mask);
-    vd dgv = vd(0.0);  // lane t < 8: diag(j0w + t)
-    if (DIAG) dgv = lds_load(diag, (lane & 7) + j0w);
     // every lane writes "its boundary value" each step -- lane 63 into the ring, the others into a dummy slot: one
     // ds_write instead of an exec-masked region per step
-    double* rbase = has_consumer ? rout + (yb & rout_mask) : dummy;
-    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - rbase)));
-    double dj = (double)j0w;
+    double* wbase = has_consumer ? rout + (yb & rout_mask) : dummy;
+    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
+    vd dj = vd((double)j0w);
     OutT* row = row_ptr(y0);
     const long rowstep = (long)DY * m.nx;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int bit = DY > 0 ? k : 7 - k;
-      const vd b0 = shift_up(prev1, ringv);
+      const vd b0 = shift_up(prev1, rb[k]);
       vd v0 = and_mask(stencil(prev0, b0, ratio(id0, dj, rr[k])), sbfe1(hs0, bit));
       vd v1 = and_mask(stencil(prev1, prev0, ratio(id1, dj, rr[k])), sbfe1(hs1, bit));
       if (DIAG) {
-        const double dg = read_lane(dgv, k);
-        v0 = select(ia == j0w + k, vd(dg), v0);
-        v1 = select(ib == j0w + k, vd(dg), v1);
+        v0 = select(ia == j0w + k, dg[k], v0);
+        v1 = select(ib == j0w + k, dg[k], v1);
       }
       if (PRED) store_pred(row, j0w + k, v0, v1);
       else if (DX > 0) g_store2(row, xoff, v0, v1);
       else g_store2(row, xoff, v1, v0);
       prev0 = v0;
       prev1 = v1;
-      lds_store(rbase, widx + bit, v1);
-      ringv = rotate_down(ringv);
-      dj += 1.0;
+      lds_store(wbase, widx + bit, v1);
+      dj = dj + 1.0;
       row += rowstep;
     }
   }
 
-  VHP_FN void sweep_block(int n) {
+  VHP_FN void sweep_block(int nb) {
     int lo, hi;
-    g.ysteps(n, lo, hi);
+    g.ysteps(nb, lo, hi);
     lo = imax(lo, jstart);
     if (lo > hi) return;
     const int blk = g.Y(lo) >> 6;
+    VHP_PROF_T0(tl0);
     {
       const vi xa = vmin(vmax(ia, 0), g.ni - 1) * DX + g.sx;
       const vi xb = vmin(vmax(ib, 0), g.ni - 1) * DX + g.sx;
@@ -648,22 +700,28 @@ struct YWave {
       ow1 = g_load_u64(m.cols, xb * m.wpc + (1 + blk));
       const vi jt = (lane + (blk * 64 - g.sy)) * DY;
       const vb ok = (jt >= 0) && (jt < g.nj);
-      rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
+      vd rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
       pin(ow0);
       pin(ow1);
       pin(rv);
+      lds_store(slab, lane, rv);
+      wave_sync();
     }
+    VHP_PROF_ADD(0, tl0);
     int j = lo;
     while (j <= hi) {
       const int y = g.Y(j);
       const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
+      VHP_PROF_T0(tw0);
       if (aligned && j + 7 <= hi) {
-        if (j <= i0 + kYCols - 1) window8<true, true>(j);
-        else if (!interior) window8<false, true>(j);
-        else window8<false, false>(j);
+        if (j <= i0 + kYCols - 1) { window8<true, true>(j); VHP_PROF_ADD(2, tw0); }
+        else if (!interior) { window8<false, true>(j); VHP_PROF_ADD(2, tw0); }
+        else { window8<false, false>(j); VHP_PROF_ADD(1, tw0); }
+        VHP_PROF_COUNT(5);
         j += 8;
       } else {
         step1(j);
+        VHP_PROF_ADD(3, tw0);
         j += 1;
       }
     }
