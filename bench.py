@@ -42,6 +42,13 @@ def parse():
     ap.add_argument("--sources", type=int, default=0, help="sources per GPU (default: workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--gather", action="store_true", help="all-gather the fields over RCCL inside the timed region")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank sweeps the workload's sources-per-GPU (no collective: the default, BASELINE's metric); "
+                         "strong: --sources-total sources are block-partitioned over the ranks (SURVEY 8e: 1024 at config 5)")
+    ap.add_argument("--sources-total", type=int, default=1024, help="strong scaling: sources of the whole job")
+    ap.add_argument("--gather-mode", default="blocking", choices=["blocking", "overlapped"],
+                    help="with --gather: one all-gather after the sweeps, or chunked all-gathers overlapped with the next chunk's sweeps")
+    ap.add_argument("--chunks", type=int, default=4, help="pieces per shard for --gather-mode overlapped")
     ap.add_argument("--placements", type=int, default=1,
                     help="diagnostic: allocate this many candidate outputs and time each with a few launches before the timed "
                          "region.  The timed region ALWAYS runs on the first allocation; the probe times (and their median / "
@@ -153,13 +160,32 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    occ, src, label = make_workload(args.workload, rank, args.sources)
+    from importlib import import_module
+    vdist = import_module("visibility-heuristic-path-planner_amd.dist")
+    if args.scaling == "strong":
+        # the whole job's sources, block-partitioned over the ranks (dist.shard_bounds)
+        total = args.sources_total
+        if args.gather and args.gather_mode == "overlapped":
+            total -= total % (world * args.chunks)
+        occ, src_all, label = make_workload(args.workload, 0, total)
+        lo, hi = vdist.shard_bounds(total, rank, world)
+        src = src_all[lo:hi]
+        label = label.replace("per GPU", "in total, %d per GPU" % (hi - lo))
+    else:
+        occ, src, label = make_workload(args.workload, rank, args.sources)
     ny, nx = occ.shape
     n_src = len(src)
     ctx = vhp_amd.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
-    ctx.set_map(occ)  # uploads + packs: the map is resident before the timed region
+    if world > 1:
+        # the occupancy map is broadcast from rank 0 over RCCL and stays on the device
+        d_occ = torch.from_numpy(occ).to(dev) if rank == 0 else torch.zeros((ny, nx), dtype=torch.uint8, device=dev)
+        vdist.broadcast_map(d_occ, 0)
+        torch.cuda.synchronize()
+        ctx.set_map_device(d_occ.data_ptr(), nx, ny)
+    else:
+        ctx.set_map(occ)  # uploads + packs: the map is resident before the timed region
     if args.kernel:
         ctx.set_option("kernel", args.kernel)
     d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).to(dev)
@@ -188,10 +214,18 @@ def main():
     cands = None
     torch.cuda.empty_cache()
     gathered = None
-    if args.gather and world > 1:
+    overlapped = args.gather and args.gather_mode == "overlapped" and world >= 1 and n_src % args.chunks == 0 and dist.is_initialized()
+    if args.gather and (world > 1 or overlapped):
         gathered = torch.empty((world * n_src, ny, nx), dtype=tdt, device=dev)
 
+    def launch_piece(a, b, dst):
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.sweep_batch_device(d_src[a:b].data_ptr(), b - a, dst.data_ptr(), dtype=vdt)
+
     def step():
+        if overlapped:
+            vdist.sweep_gather_overlapped(launch_piece, range(world * n_src), gathered, args.chunks)
+            return
         ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_out.data_ptr(), dtype=vdt)
         if gathered is not None:
             dist.all_gather_into_tensor(gathered, d_out)
@@ -204,24 +238,23 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.timing(True, prealloc=args.steps + 2)  # HIP events around every sweep kernel, on the stream it is launched on;
+    launches_per_step = args.chunks if overlapped else 1
+    ctx.timing(True, prealloc=args.steps * launches_per_step + 2)  # HIP events around every sweep kernel, on the stream it is launched on;
     #                                              the event pairs exist before the timed region starts
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_out.data_ptr(), dtype=vdt)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, d_out)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.sync()  # surfaces device-side validation errors
-    kern = ctx.timing_collect(args.steps)
+    kern = ctx.timing_collect(args.steps * launches_per_step)
     ctx.timing(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kern_ms = float(kern.mean())  # average duration of the dominant kernel inside the timed region
+    kern_ms = float(kern.sum()) / args.steps  # sweep-kernel time per step (one launch, or the pieces of an overlapped step)
 
     if rank == 0:
         fields = world * n_src * args.steps
@@ -247,7 +280,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
@@ -256,7 +289,9 @@ def main():
                        "output_placement": {"timed_on": "first allocation", "candidates": n_cand, "probe_kernel_ms": probe_ms,
                                             "probe_median_ms": (round(float(np.median(probe_ms)), 4) if probe_ms else None),
                                             "probe_best_ms": (min(probe_ms) if probe_ms else None)},
-                       "collective": "rccl all_gather of fields" if gathered is not None else "none (independent sources)"},
+                       "collective": ("rccl all_gather of fields (%s%s)" % (args.gather_mode if gathered is not None else "", ", %d chunks per shard" % args.chunks if overlapped else "")
+                                      if gathered is not None else "none (independent sources)"),
+                       "map": "rccl broadcast from rank 0" if world > 1 else "uploaded by the only rank"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": round(kern_ms, 4),

@@ -1,0 +1,75 @@
+"""The multi-GPU source sharding with the HIP sweep as the per-rank compute, under torch.distributed's RCCL backend
+("nccl") with a single rank: every code path of dist.py that the 8-GPU bench uses (map broadcast, block partition,
+all-gather of fields, max-union + arg-source, chunked all-gather overlapped with the next chunk's sweeps) runs on one
+MI355X, on device tensors, against the oracle.  World sizes 2 and 3 run on CPU with gloo (tests/test_dist_gloo.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import maps
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_hip_sweep_under_rccl_single_rank(oracle):
+    import torch
+    import torch.distributed as dist
+    import vhp_amd
+    from importlib import import_module
+    vd = import_module("visibility-heuristic-path-planner_amd.dist")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        occ = maps.random_rect_map(328, 300, 30, 3, 40, 3, 40, 5)
+        n = 16
+        src = maps.free_sources(occ, n, 8)
+        full = np.stack([oracle.sweep_full(occ, int(x), int(y)) for x, y in src])
+        # the map is broadcast as a device tensor and handed to the library without a host round trip
+        d_occ = vd.broadcast_map(torch.from_numpy(occ).cuda(), 0)
+        ctx = vhp_amd.Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_map_device(d_occ.data_ptr(), occ.shape[1], occ.shape[0])
+
+        def compute(shard):
+            d_src = torch.from_numpy(np.ascontiguousarray(shard, np.int32)).cuda()
+            out = torch.empty((len(shard),) + occ.shape, dtype=torch.float64, device="cuda")
+            if len(shard):
+                ctx.sweep_batch_device(d_src.data_ptr(), len(shard), out.data_ptr())
+            ctx.sync()
+            return out
+
+        local, lo = vd.sweep_sharded(compute, src, "none")
+        assert lo == 0 and np.array_equal(local.cpu().numpy(), full)
+        allf = vd.sweep_sharded(compute, src, "gather")
+        assert np.array_equal(allf.cpu().numpy(), full)
+        best, arg = vd.sweep_sharded(compute, src, "union")
+        assert np.array_equal(best.cpu().numpy(), full.max(0))
+        assert np.array_equal(arg.cpu().numpy(), (full == full.max(0)[None]).argmax(0))
+        # chunked all-gather overlapped with the sweeps of the next chunk, on two streams
+        d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
+        out = torch.full((n,) + occ.shape, -1.0, dtype=torch.float64, device="cuda")
+
+        def launch(a, b, dst):
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.sweep_batch_device(d_src[a:b].data_ptr(), b - a, dst.data_ptr())
+
+        vd.sweep_gather_overlapped(launch, src, out, chunks=4)
+        torch.cuda.synchronize()
+        ctx.sync()
+        rows = [vd.gathered_index(i, n, 1, 4) for i in range(n)]
+        assert np.array_equal(out.cpu().numpy()[rows], full)
+    finally:
+        dist.destroy_process_group()

@@ -34,9 +34,26 @@ def shard_sources(sources, rank=None, world=None):
     return sources[lo:hi], lo
 
 
-def gather_fields(local_fields, n_sources):
-    """local_fields [n_local, ny, nx] on this rank's device -> [n_sources, ny, nx] on every rank."""
+def broadcast_map(occ, src=0):
+    """The occupancy map (uint8 [ny, nx] tensor on this rank's device) from rank `src` to every rank: one RCCL
+    broadcast of nx*ny bytes (16.8 MB at 4096^2), SURVEY 8(e).  Returns the tensor (filled in place)."""
+    dist.broadcast(occ, src=src)
+    return occ
+
+
+def gather_fields(local_fields, n_sources, out=None):
+    """local_fields [n_local, ny, nx] on this rank's device -> [n_sources, ny, nx] on every rank.
+
+    Equal shards (n_sources % world == 0, the BASELINE configurations): ONE all-gather straight into `out` (allocated
+    here if not given) -- no padding, no concatenation, no second copy of the result (at config 5 in fp64 the result
+    alone is 137 GB of the 288 GB).  Ragged shards are padded to the largest and trimmed."""
     world, rank = dist.get_world_size(), dist.get_rank()
+    if n_sources % world == 0:
+        assert local_fields.shape[0] == n_sources // world
+        if out is None:
+            out = local_fields.new_empty((n_sources,) + tuple(local_fields.shape[1:]))
+        dist.all_gather_into_tensor(out, local_fields.contiguous())
+        return out
     cap = (n_sources + world - 1) // world  # all_gather_into_tensor needs equal shards: pad to the largest
     pad = local_fields.new_zeros((cap,) + tuple(local_fields.shape[1:]))
     pad[: local_fields.shape[0]] = local_fields
@@ -74,6 +91,53 @@ def union_fields(local_fields, first_index, n_sources):
     gbest, _ = all_best.max(dim=0)
     cand = torch.where(all_best == gbest.unsqueeze(0), all_arg, torch.full_like(all_arg, n_sources))
     return gbest, cand.min(dim=0).values
+
+
+def sweep_gather_overlapped(launch, sources, out, chunks=4):
+    """Strong-scaling form of "sweep my shard, all-gather the fields": the shard is cut into `chunks` pieces; while the
+    sweeps of piece k+1 run on the compute stream, the all-gather of piece k runs on a second stream (RCCL over xGMI is
+    per-link bound and far slower than the sweeps, SURVEY 8(e): overlapping hides the compute, not the wire time).
+
+    launch(lo, hi, dst) must enqueue the sweeps of this rank's shard sources [lo, hi) into dst ([hi-lo, ny, nx], a
+    view of this rank's block of `out`) on the CURRENT stream and return without synchronising.
+    out: [n_sources, ny, nx], n_sources % (world * chunks) == 0; on return (after the final synchronisation by the
+    caller) piece k of rank r sits at out[k * world * m + r * m : ... + m], m = n_sources / (world * chunks) -- the
+    layout an all-gather of equal pieces gives; `gathered_index` maps a source index to its row."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = len(sources)
+    assert n % (world * chunks) == 0
+    per_rank = n // world
+    m = per_rank // chunks
+    cuda = out.is_cuda
+    comm = torch.cuda.Stream() if cuda else None
+    works = []
+    for k in range(chunks):
+        block = out[k * world * m: (k + 1) * world * m]
+        mine = block[rank * m: (rank + 1) * m]
+        launch(k * m, (k + 1) * m, mine)
+        if cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev)
+                works.append(dist.all_gather_into_tensor(block, mine, async_op=True))
+        else:
+            works.append(dist.all_gather_into_tensor(block, mine.clone(), async_op=True))
+    for w in works:
+        w.wait()
+    if cuda:
+        torch.cuda.current_stream().wait_stream(comm)
+    return out
+
+
+def gathered_index(source_index, n_sources, world, chunks):
+    """Row of `out` (sweep_gather_overlapped) that holds the field of global source `source_index`, sources being
+    block-partitioned over ranks (shard_bounds) and each shard cut into `chunks` pieces."""
+    per_rank = n_sources // world
+    m = per_rank // chunks
+    r, local = divmod(source_index, per_rank)
+    k, j = divmod(local, m)
+    return k * world * m + r * m + j
 
 
 def sweep_sharded(compute, sources, mode="none"):
