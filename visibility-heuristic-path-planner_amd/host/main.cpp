@@ -12,9 +12,11 @@ int main(int argc, char** argv) {
   std::string config_path = "config/settings.config";
   int device = 0;
   bool series = false, standalone = false;
+  int series_points = 60;  // the reference's 60 log-spaced sizes 50..5000 (solver.cpp:298-315); fewer for a quick run
   for (int k = 1; k < argc; ++k) {
     if (!std::strcmp(argv[k], "--device") && k + 1 < argc) device = std::atoi(argv[++k]);
     else if (!std::strcmp(argv[k], "--benchmark-series")) series = true;
+    else if (!std::strcmp(argv[k], "--series-points") && k + 1 < argc) series_points = std::atoi(argv[++k]);
     else if (!std::strcmp(argv[k], "--standalone")) standalone = true;
     else config_path = argv[k];
   }
@@ -37,6 +39,6 @@ int main(int argc, char** argv) {
   solver.solve();
   if (standalone) solver.standAloneVisibility();
   solver.benchmark();
-  if (series) solver.benchmarkSeries();
+  if (series) solver.benchmarkSeries(series_points);
   return 0;
 }

@@ -152,10 +152,10 @@ void visibilityBasedSolver::benchmark() {
   std::cout << "Density of the occupancy grid: " << (double)blocked / (double)(nx_ * ny_) * 100 << "%" << std::endl;
 }
 
-void visibilityBasedSolver::benchmarkSeries() {
+void visibilityBasedSolver::benchmarkSeries(int num_points) {
   if (!ctx_) { std::cerr << error_ << std::endl; return; }
-  // 60 log-spaced sizes 50..5000 on an empty grid, source at the centre (solver.cpp:298-324)
-  const int num_points = 60;
+  // log-spaced sizes 50..5000 (60 of them in the reference) on an empty grid, source at the centre (solver.cpp:298-324)
+  if (num_points < 2) num_points = 2;
   const double first = 50, last = 5000;
   std::vector<int> sizes;
   for (int k = 0; k < num_points; ++k) sizes.push_back((int)std::round(first * std::exp(std::log(last / first) * k / (num_points - 1))));

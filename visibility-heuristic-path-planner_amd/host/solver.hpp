@@ -21,7 +21,7 @@ class visibilityBasedSolver {
   void solve();                 // solver.cpp:76-160
   void standAloneVisibility();  // :165-189
   void benchmark();             // :194-262
-  void benchmarkSeries();       // :295-374
+  void benchmarkSeries(int num_points = 60);       // :295-374
   int getGlobalIter() const { return 0; }  // the reference never increments its counter (.h:35,150)
 
   bool ok() const { return ctx_ != nullptr; }
