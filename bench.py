@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5", "c1k-empty", "c3-1024", "c3-1016", "c3-512"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "c1k-empty", "c3-1024", "c3-1016", "c3-512"])
     ap.add_argument("--sources", type=int, default=0, help="sources per GPU (default: workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--gather", action="store_true", help="all-gather the fields over RCCL inside the timed region")
@@ -140,8 +140,66 @@ def cpu_baseline(occ, src, seconds):
     }
 
 
+def bench_planner(args):
+    """--workload c4: BASELINE config 4, the full visibility-heuristic planner on maze_6 (690x402, threshold 0.1, 64 pivots,
+    results left on the device).  A step = one whole solve.  The planner does not shard (pivot k+1 needs the union after
+    pivot k): one GPU; with --gpus N every rank solves its own replica."""
+    import numpy as np
+    import torch
+    import vhp_amd
+    from importlib import import_module
+    synth = import_module("visibility-heuristic-path-planner_amd.synth")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    occ = synth.maze_6()
+    ny, nx = occ.shape
+    start, end = (345, ny - 1 - 391), (341, ny - 1 - 10)
+    ctx = vhp_amd.Context(local_rank)
+    ctx.set_map(occ)
+    n_piv = 0
+    for _ in range(max(args.warmup, 1)):
+        rc, n_piv, _ = ctx.planner_solve_device(start, end, 0.1, 250)
+        assert rc == 0
+    torch.cuda.synchronize()
+    dev_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.planner_solve_device(start, end, 0.1, 250)
+        dev_ms.append(ctx.last_elapsed_ms())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    loop_ms = float(np.mean(dev_ms))
+    bytes_per_pivot = 32 * nx * ny  # vis_local 8 W + 8 R, vis_global 8 R + 8 W, labels 4 R + 4 W (DESIGN.md section 5)
+    achieved = bytes_per_pivot * n_piv / (loop_ms * 1e-3) / 1e9
+    out = {
+        "metric": "planner pivots/sec on maze_6 (690x402)", "value": round(n_piv * args.steps / elapsed, 1), "unit": "pivots/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "reference fixture (images/maze_6.png as tests/golden/maze_6.npz)",
+        "config": {"workload": "C4: maze_6, start {345,391}, end {341,10}, visibilityThreshold 0.1: %d pivots per solve, results device-resident" % n_piv,
+                   "us_per_pivot_device_loop": round(loop_ms * 1e3 / n_piv, 2), "us_per_pivot_wall": round(elapsed / args.steps * 1e6 / n_piv, 2)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": None, "kernel": "vhp_planner_sweep + vhp_planner_epilogue", "kernel_ms": round(loop_ms, 4),
+                     "note": "latency case by construction: one source per pivot, pivots are sequential (SURVEY 8d expectation management)"},
+    }
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        ts = []
+        t_end = time.time() + min(args.cpu_seconds, 10.0)
+        while time.time() < t_end or len(ts) < 3:
+            t = time.perf_counter()
+            w = orc.solve(occ, start, end, 0.1, 250)
+            ts.append(time.perf_counter() - t)
+        out["cpu_baseline"] = {"value": round(w["n_pivots"] / min(ts), 1), "unit": "pivots/s", "cores": 1, "kind": "port",
+                               "sample": "oracle port of solve() (strict IEEE build), best of %d solves of the same maze" % len(ts)}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "c4":
+        return bench_planner(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

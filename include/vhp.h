@@ -100,6 +100,16 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
                       uint64_t max_iter, uint64_t* came_from, double* vis_global, double* vis_local,
                       int32_t* pivots_xy, uint32_t* n_pivots);
 
+/* The same solve with every result left in device memory (a batched or multi-GPU planner consumes labels and union on
+ * the GPU; the host copy of vhp_planner_solve costs 10x the device loop at 1000^2).  *n_pivots = nb_of_sources_.
+ * vhp_planner_results_device then hands out the device arrays of the most recent solve on this context, valid until the
+ * next solve or vhp_set_map: labels nx*ny uint32 (0xFFFFFFFF where the reference holds (size_t)1e15), vis_global and
+ * vis_local nx*ny doubles, pivots_xy int32 pairs 0 .. n_pivots.  Any output pointer may be NULL. */
+int vhp_planner_solve_device(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold, uint64_t max_iter,
+                             uint32_t* n_pivots);
+int vhp_planner_results_device(vhp_ctx* ctx, const uint32_t** labels, const double** vis_global, const double** vis_local,
+                               const int32_t** pivots_xy);
+
 /* Replaces reconstructPath() (solver.cpp:1183-1213): walks came_from -> pivots from
  * `end` until the label repeats; writes the path start-first into path_xy (capacity
  * cap points), its point count into *n_path, the summed eval_d length into *length.
@@ -116,6 +126,22 @@ int vhp_reconstruct_path(const uint64_t* came_from, const int32_t* pivots_xy, ui
  * initialised to 1, solver.cpp:45).  Every write is a zero, so the union does not depend
  * on the order the rays are cast in and one thread per ray reproduces the reference. */
 int vhp_raycast_all(vhp_ctx* ctx, int src_x, int src_y, double* out_host);
+
+/* MATLAB-flavoured variants.  The reference's MATLAB demos are a different algorithm from its C++ program:
+ * MATLAB_code/visibility/getAccessibilityMap.m has an explicit diagonal rule (cell (i,i*1/fac) = alpha * its diagonal
+ * predecessor), a decay `alpha` on every update, a curve factor `fac`, and sweeps every row and column.
+ * vhp_sweep_batch_variant replaces getAccessibilityMap(alpha, 1, lightPos, 1-obstacle, ., fac) for a batch of sources
+ * (fp64 fields, host buffers).  vhp_planner_solve_variant replaces the exploration loop of
+ * MATLAB_code/c_sample_planner_solving_random_environments.m:100-171 over getAccessibilityMapPlanner.m (fac = 1):
+ * first-lit labels at v >= threshold (0-based waypoint index, UINT64_MAX where none), min-max-scaled heuristic, stop when
+ * the newest waypoint's own field sees the target; waypoints_xy holds 2*(max_iter+3) ints, waypoints_xy[0..1] = start.
+ * Returns VHP_OK, VHP_ERR_MAX_ITER (the script itself has no bound) or VHP_ERR_NOTHING_LIT.
+ * Parity: against a line-by-line CPU restatement of the .m files (oracle/vhp_oracle_matlab.cpp); MATLAB itself is not
+ * available to the build, so these modes are unpinned against it.  Grid sides up to 4096. */
+int vhp_sweep_batch_variant(vhp_ctx* ctx, const int32_t* src_xy, int n_src, double alpha, double fac, double* out_host);
+int vhp_planner_solve_variant(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold, double alpha,
+                              uint64_t max_iter, uint64_t* label, double* map_builder, double* local, int32_t* waypoints_xy,
+                              uint32_t* n_waypoints);
 
 /* Elapsed milliseconds between the first and last kernel of the most recent
  * vhp_sweep_batch_device / planner call, from hipEvents recorded on the context

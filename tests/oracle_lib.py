@@ -43,6 +43,9 @@ def load(path=None):
     lib.vhp_oracle_generate_env.argtypes = [
         C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _u8p]
     lib.vhp_oracle_raycast_all.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f64p]
+    lib.vhp_oracle_sweep_matlab.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f64p]
+    lib.vhp_oracle_planner_matlab.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                              C.c_uint64, _u64p, _f64p, _f64p, _i32p, C.POINTER(C.c_uint32)]
     lib.vhp_oracle_time_sweeps.restype = C.c_double
     lib.vhp_oracle_time_sweeps.argtypes = [_u8p, C.c_int, C.c_int, _i32p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     return lib
@@ -67,6 +70,25 @@ class Oracle:
         rc = self.lib.vhp_oracle_sweep_queue(np.ascontiguousarray(occ, np.uint8), nx, ny, sx, sy, vis)
         assert rc == 0, rc
         return vis
+
+    def sweep_matlab(self, occ, sx, sy, alpha=1.0, fac=1.0):
+        """getAccessibilityMap.m restated (oracle/vhp_oracle_matlab.cpp; unpinned against MATLAB itself)."""
+        ny, nx = occ.shape
+        vis = np.full((ny, nx), np.nan)
+        rc = self.lib.vhp_oracle_sweep_matlab(np.ascontiguousarray(occ, np.uint8), nx, ny, sx, sy, float(alpha), float(fac), vis)
+        assert rc == 0, rc
+        return vis
+
+    def solve_matlab(self, occ, start, end, threshold, alpha, max_iter):
+        ny, nx = occ.shape
+        lab = np.zeros((ny, nx), np.uint64)
+        uni = np.zeros((ny, nx), np.float64)
+        loc = np.zeros((ny, nx), np.float64)
+        way = np.zeros((max_iter + 3, 2), np.int32)
+        n = C.c_uint32(0)
+        rc = self.lib.vhp_oracle_planner_matlab(np.ascontiguousarray(occ, np.uint8), nx, ny, start[0], start[1], end[0], end[1],
+                                                float(threshold), float(alpha), int(max_iter), lab, uni, loc, way, C.byref(n))
+        return dict(status=rc, label=lab, map_builder=uni, local=loc, waypoints=way[: n.value].copy())
 
     def solve(self, occ, start, end, threshold, max_iter):
         ny, nx = occ.shape

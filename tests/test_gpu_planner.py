@@ -82,6 +82,35 @@ def test_negative_threshold_skips_the_loop(vhp, oracle):
     assert got["n_pivots"] == 0 and got["pivots"].tolist() == [list(end)] and not got["vis_global"].any()
 
 
+def test_device_resident_results(vhp, oracle):
+    # vhp_planner_solve_device + vhp_planner_results_device: labels, union, local field and pivots read back from the
+    # device arrays equal the oracle's (and the host-copy entry point's)
+    import ctypes as C
+    import torch
+    occ = maps.maze_6()
+    ny, nx = occ.shape
+    start, end = (345, ny - 1 - 391), (341, ny - 1 - 10)
+    c = vhp.Context(0)
+    c.set_map(occ)
+    rc, n_piv, ptr = c.planner_solve_device(start, end, 0.1, 250)
+    want = oracle.solve(occ, start, end, 0.1, 250)
+    assert rc == want["status"] == 0 and n_piv == want["n_pivots"] == 64
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def fetch(p, shape, dtype):
+        a = np.empty(shape, dtype)
+        assert hip.hipMemcpy(a.ctypes.data, p, a.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return a
+
+    lab = fetch(ptr["labels"], (ny, nx), np.uint32).astype(np.uint64)
+    lab[lab == 0xFFFFFFFF] = vhp.UNLABELLED
+    assert np.array_equal(lab, want["came_from"])
+    assert fetch(ptr["vis_global"], (ny, nx), np.float64).tobytes() == want["vis_global"].tobytes()
+    assert fetch(ptr["vis_local"], (ny, nx), np.float64).tobytes() == want["vis_local"].tobytes()
+    assert fetch(ptr["pivots"], (n_piv + 1, 2), np.int32).tolist() == want["pivots"].tolist()
+
+
 def test_1000_shipped_config_seed1(vhp, oracle):
     # the shipped settings.config with seedValue 1: pivots (50,50),(273,350),(525,675), path 1346.71
     import platform

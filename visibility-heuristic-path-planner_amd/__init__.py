@@ -38,7 +38,8 @@ UNLABELLED = 1000000000000000
 ABI_SYMBOLS = (
     "vhp_create", "vhp_destroy", "vhp_last_error", "vhp_set_stream", "vhp_set_map", "vhp_set_map_device",
     "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
-    "vhp_raycast_all", "vhp_timing", "vhp_timing_collect", "vhp_set_option",
+    "vhp_raycast_all", "vhp_timing", "vhp_timing_collect", "vhp_set_option", "vhp_sweep_batch_variant", "vhp_planner_solve_variant",
+    "vhp_planner_solve_device", "vhp_planner_results_device",
     "vhp_last_elapsed_ms", "vhp_version",
 )
 
@@ -83,6 +84,10 @@ def load_library():
     lib.vhp_planner_solve.argtypes = [vp, i32, i32, i32, i32, f64, u64, vp, vp, vp, vp, C.POINTER(u32)]
     lib.vhp_reconstruct_path.argtypes = [vp, vp, u32, i32, i32, i32, i32, vp, u32, C.POINTER(u32), C.POINTER(f64)]
     lib.vhp_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+    lib.vhp_planner_solve_device.argtypes = [vp, i32, i32, i32, i32, f64, u64, C.POINTER(u32)]
+    lib.vhp_planner_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.vhp_sweep_batch_variant.argtypes = [vp, vp, i32, f64, f64, vp]
+    lib.vhp_planner_solve_variant.argtypes = [vp, i32, i32, i32, i32, f64, f64, u64, vp, vp, vp, vp, C.POINTER(u32)]
     lib.vhp_raycast_all.argtypes = [vp, i32, i32, vp]
     lib.vhp_timing.argtypes = [vp, i32]
     lib.vhp_timing_collect.argtypes = [vp, vp, i32, C.POINTER(i32)]
@@ -179,6 +184,39 @@ class Context:
             self._check(rc)
         return dict(status=rc, came_from=came, vis_global=vg, vis_local=vl, pivots=piv[: npiv.value + 1].copy(),
                     n_pivots=npiv.value)
+
+    def planner_solve_device(self, start, end, threshold, max_iter):
+        """Planner solve with the results left on the device.  Returns (status, n_pivots, dict of raw device pointers:
+        labels uint32 [ny, nx] (0xFFFFFFFF = unlabelled), vis_global / vis_local float64 [ny, nx], pivots int32 [n_pivots+1, 2])."""
+        npiv = C.c_uint32(0)
+        rc = self.lib.vhp_planner_solve_device(self.h, start[0], start[1], end[0], end[1], float(threshold), int(max_iter), C.byref(npiv))
+        if rc in (VHP_ERR_HIP, VHP_ERR_NO_MAP, VHP_ERR_ARG, VHP_ERR_TOO_LARGE):
+            self._check(rc)
+        ptrs = {}
+        if rc in (VHP_OK, VHP_ERR_MAX_ITER):
+            p = [C.c_void_p() for _ in range(4)]
+            self._check(self.lib.vhp_planner_results_device(self.h, *[C.byref(q) for q in p]))
+            ptrs = dict(labels=p[0].value, vis_global=p[1].value, vis_local=p[2].value, pivots=p[3].value)
+        return rc, npiv.value, ptrs
+
+    def sweep_batch_variant(self, sources, alpha=1.0, fac=1.0):
+        """MATLAB-flavoured sweep (getAccessibilityMap.m): fields [n, ny, nx] float64."""
+        src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
+        out = np.empty((len(src), self.ny, self.nx), np.float64)
+        self._check(self.lib.vhp_sweep_batch_variant(self.h, _ptr(src), len(src), float(alpha), float(fac), _ptr(out)))
+        return out
+
+    def planner_solve_variant(self, start, end, threshold, alpha, max_iter):
+        lab = np.empty((self.ny, self.nx), np.uint64)
+        uni = np.empty((self.ny, self.nx), np.float64)
+        loc = np.empty((self.ny, self.nx), np.float64)
+        way = np.zeros((int(max_iter) + 3, 2), np.int32)
+        n = C.c_uint32(0)
+        rc = self.lib.vhp_planner_solve_variant(self.h, start[0], start[1], end[0], end[1], float(threshold), float(alpha), int(max_iter),
+                                                _ptr(lab), _ptr(uni), _ptr(loc), _ptr(way), C.byref(n))
+        if rc in (VHP_ERR_HIP, VHP_ERR_NO_MAP, VHP_ERR_ARG, VHP_ERR_TOO_LARGE):
+            self._check(rc)
+        return dict(status=rc, label=lab, map_builder=uni, local=loc, waypoints=way[: n.value].copy())
 
     def raycast_all(self, sx, sy):
         out = np.empty((self.ny, self.nx), np.float64)

@@ -18,6 +18,7 @@
 #include "vhp_sweep.hip.h"
 #include "vhp_planner.hip.h"
 #include "vhp_queue.hip.h"
+#include "vhp_variant.hip.h"
 
 struct vhp_ctx {
   int device = 0;
@@ -509,6 +510,124 @@ int vhp_raycast_all(vhp_ctx* ctx, int src_x, int src_y, double* out_host) {
   return VHP_OK;
 }
 
+// ---- MATLAB-flavoured variants (vhp_variant.hip.h) -------------------------------------------------------------------
+static int variant_launch_sweep(vhp_ctx* ctx, const int32_t* d_src, int n_src, double alpha, double fac, double* d_out) {
+  const size_t lds = (size_t)3 * (std::max(ctx->nx, ctx->ny) + 1) * sizeof(double);
+  auto k = vhp::variant::vhp_variant_sweep;
+  hipError_t e = raise_lds_limit(ctx, reinterpret_cast<const void*>(k), lds);
+  if (e != hipSuccess) return fail(ctx, VHP_ERR_HIP, std::string("variant sweep: ") + hipGetErrorString(e));
+  hipLaunchKernelGGL(k, dim3((unsigned)(4 * n_src)), dim3(1024), lds, ctx->stream, ctx->nx, ctx->ny, ctx->d_occ, d_src, d_out,
+                     (long long)ctx->nx * ctx->ny, alpha, fac, ctx->d_err);
+  VHP_HIP(hipGetLastError());
+  return VHP_OK;
+}
+
+int vhp_sweep_batch_variant(vhp_ctx* ctx, const int32_t* src_xy, int n_src, double alpha, double fac, double* out_host) {
+  if (!ctx || !src_xy || !out_host || n_src < 0 || !(fac > 0)) return fail(ctx, VHP_ERR_ARG, "vhp_sweep_batch_variant: bad argument");
+  if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_sweep_batch_variant: no map set");
+  if (std::max(ctx->nx, ctx->ny) > 4096) return fail(ctx, VHP_ERR_TOO_LARGE, "variant sweeps: grid side above 4096");
+  for (int s = 0; s < n_src; ++s)
+    if (src_xy[2 * s] < 0 || src_xy[2 * s + 1] < 0 || src_xy[2 * s] >= ctx->nx || src_xy[2 * s + 1] >= ctx->ny)
+      return fail(ctx, VHP_ERR_SOURCE_OOB, "a sweep source lies outside the grid");
+  if (n_src == 0) return VHP_OK;
+  VHP_ON_DEVICE(ctx);
+  const size_t cells = (size_t)ctx->nx * ctx->ny;
+  const int slice = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_src, ((size_t)1 << 30) / (cells * 8)));
+  if (ctx->d_src_cap < (size_t)slice) {
+    if (ctx->d_src) hipFree(ctx->d_src);
+    ctx->d_src = nullptr;
+    VHP_HIP(hipMalloc(&ctx->d_src, (size_t)slice * 2 * sizeof(int32_t)));
+    ctx->d_src_cap = slice;
+  }
+  if (ctx->d_out_cap < (size_t)slice * cells * 8) {
+    if (ctx->d_out) hipFree(ctx->d_out);
+    ctx->d_out = nullptr;
+    VHP_HIP(hipMalloc(&ctx->d_out, (size_t)slice * cells * 8));
+    ctx->d_out_cap = (size_t)slice * cells * 8;
+  }
+  for (int s0 = 0; s0 < n_src; s0 += slice) {
+    const int n = std::min(slice, n_src - s0);
+    VHP_HIP(hipMemcpyAsync(ctx->d_src, src_xy + 2 * (size_t)s0, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    const int rc = variant_launch_sweep(ctx, ctx->d_src, n, alpha, fac, static_cast<double*>(ctx->d_out));
+    if (rc != VHP_OK) return rc;
+    VHP_HIP(hipMemcpyAsync(out_host + (size_t)s0 * cells, ctx->d_out, (size_t)n * cells * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VHP_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return VHP_OK;
+}
+
+int vhp_planner_solve_variant(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold, double alpha,
+                              uint64_t max_iter, uint64_t* label, double* map_builder, double* local, int32_t* waypoints_xy,
+                              uint32_t* n_waypoints) {
+  using namespace vhp::variant;
+  if (!ctx) return VHP_ERR_ARG;
+  if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_planner_solve_variant: no map set");
+  const int nx = ctx->nx, ny = ctx->ny;
+  if (std::max(nx, ny) > 4096) return fail(ctx, VHP_ERR_TOO_LARGE, "variant planner: grid side above 4096");
+  if ((unsigned)start_x >= (unsigned)nx || (unsigned)start_y >= (unsigned)ny) return fail(ctx, VHP_ERR_START_OOB, "Start point is out of bounds.");
+  if ((unsigned)end_x >= (unsigned)nx || (unsigned)end_y >= (unsigned)ny) return fail(ctx, VHP_ERR_END_OOB, "End point is out of bounds.");
+  if (max_iter > (1u << 20)) return fail(ctx, VHP_ERR_ARG, "max_iter too large");
+  VHP_ON_DEVICE(ctx);
+  const size_t cells = (size_t)nx * ny;
+  double *d_uni = nullptr, *d_loc = nullptr;
+  uint32_t* d_lab = nullptr;
+  unsigned long long* d_lab64 = nullptr;
+  int32_t* d_way = nullptr;
+  PlannerCtl* d_ctl = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)d_uni, (void*)d_loc, (void*)d_lab, (void*)d_lab64, (void*)d_way, (void*)d_ctl})
+      if (p) (void)hipFree(p);
+  };
+#define VHP_V(call)                                                                      \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) { cleanup(); return fail(ctx, VHP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } \
+  } while (0)
+  VHP_V(hipMalloc(&d_uni, cells * 8));
+  VHP_V(hipMalloc(&d_loc, cells * 8));
+  VHP_V(hipMalloc(&d_lab, cells * 4));
+  VHP_V(hipMalloc(&d_lab64, cells * 8));
+  VHP_V(hipMalloc(&d_way, 2 * (size_t)(max_iter + 3) * sizeof(int32_t)));
+  VHP_V(hipMalloc(&d_ctl, sizeof(PlannerCtl)));
+  VHP_V(hipMemsetAsync(d_uni, 0, cells * 8, ctx->stream));
+  VHP_V(hipMemsetAsync(d_lab, 0xff, cells * 4, ctx->stream));
+  const int32_t w0[2] = {start_x, start_y};
+  const PlannerCtl c0{1, 0, 0, 0};
+  const uint32_t zero = 0;
+  VHP_V(hipMemcpyAsync(d_way, w0, sizeof(w0), hipMemcpyHostToDevice, ctx->stream));
+  VHP_V(hipMemcpyAsync(d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, ctx->stream));
+  VHP_V(hipMemcpyAsync(d_lab + ((size_t)start_y * nx + start_x), &zero, 4, hipMemcpyHostToDevice, ctx->stream));  // lightSource_enum(start) = 1
+  const unsigned eb = (unsigned)((cells + 255) / 256);
+  PlannerCtl h{};
+  for (;;) {
+    // sweep from the current waypoint (d_way[2*iter]), union + labels, stop test
+    int rc = variant_launch_sweep(ctx, d_way + 2 * h.iter, 1, alpha, 1.0, d_loc);
+    if (rc != VHP_OK) { cleanup(); return rc; }
+    hipLaunchKernelGGL(vhp_variant_update, dim3(eb), dim3(256), 0, ctx->stream, d_loc, d_uni, d_lab, cells, threshold, d_ctl);
+    hipLaunchKernelGGL(vhp_variant_check, dim3(1), dim3(64), 0, ctx->stream, d_loc, nx, end_x, end_y, threshold, d_ctl);
+    hipLaunchKernelGGL(vhp_variant_pick, dim3(1), dim3(1024), 0, ctx->stream, d_uni, nx, ny, end_x, end_y, threshold,
+                       (unsigned long long)max_iter, d_way, d_ctl);
+    VHP_V(hipGetLastError());
+    VHP_V(hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    VHP_V(hipStreamSynchronize(ctx->stream));
+    if (h.done) break;
+  }
+  if (n_waypoints) *n_waypoints = (uint32_t)h.n_way;
+  if (waypoints_xy) VHP_V(hipMemcpyAsync(waypoints_xy, d_way, 2 * (size_t)h.n_way * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (label) {
+    hipLaunchKernelGGL(vhp_variant_labels_to_u64, dim3(eb), dim3(256), 0, ctx->stream, d_lab, d_lab64, cells, ~0ull);
+    VHP_V(hipMemcpyAsync(label, d_lab64, cells * 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (map_builder) VHP_V(hipMemcpyAsync(map_builder, d_uni, cells * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (local) VHP_V(hipMemcpyAsync(local, d_loc, cells * 8, hipMemcpyDeviceToHost, ctx->stream));
+  VHP_V(hipStreamSynchronize(ctx->stream));
+#undef VHP_V
+  cleanup();
+  if (h.status == VHP_ERR_MAX_ITER) ctx->err = "variant planner: max_iter reached";
+  if (h.status == VHP_ERR_NOTHING_LIT) ctx->err = "variant planner: no candidate above the threshold";
+  return h.status;
+}
+
 int vhp_timing(vhp_ctx* ctx, int enable) {
   if (!ctx) return VHP_ERR_ARG;
   ctx->timing = enable != 0;
@@ -589,6 +708,22 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
   ctx->timed = true;
   if (rc != VHP_OK) ctx->err = msg;
   return rc;
+}
+
+int vhp_planner_solve_device(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold, uint64_t max_iter,
+                             uint32_t* n_pivots) {
+  return vhp_planner_solve(ctx, start_x, start_y, end_x, end_y, threshold, max_iter, nullptr, nullptr, nullptr, nullptr, n_pivots);
+}
+
+int vhp_planner_results_device(vhp_ctx* ctx, const uint32_t** labels, const double** vis_global, const double** vis_local,
+                               const int32_t** pivots_xy) {
+  if (!ctx) return VHP_ERR_ARG;
+  if (!ctx->pl.vis_global) return fail(ctx, VHP_ERR_ARG, "vhp_planner_results_device: no planner solve has run on this map");
+  if (labels) *labels = ctx->pl.label;
+  if (vis_global) *vis_global = ctx->pl.vis_global;
+  if (vis_local) *vis_local = ctx->pl.vis_local;
+  if (pivots_xy) *pivots_xy = ctx->pl.pivots;
+  return VHP_OK;
 }
 
 // eval_d of visibilityBasedSolver.h:112-115 (host side, used only for the path length)

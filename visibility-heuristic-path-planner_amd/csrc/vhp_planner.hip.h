@@ -6,13 +6,13 @@
 //
 // All planner state lives in HBM for the whole solve: vis_global, vis_local, labels
 // (cameFrom_ as uint32), the pivot list (lightSources_) and a small control block.
-// One iteration = three kernels on one stream, no host round trip:
+// One iteration = two kernels on one stream, no host round trip:
 //   vhp_planner_sweep    : the front sweep of vhp_sweep.hip.h (its fast path) from the current
 //                          pivot into vis_local;
 //   vhp_planner_epilogue : per visited cell max-union into vis_global, first-lit labelling,
 //                          heuristic h of every lit cell, block arg-min of (h, push rank);
-//   vhp_planner_pick     : merges the block partials, appends the next pivot, evaluates the
-//                          loop condition, raises `done`.
+//                          (the workgroup that finishes last merges the block partials, appends the
+//                          next pivot, evaluates the loop condition and raises `done`: planner_pick)
 // The host enqueues a few iterations at a time and polls the control block; kernels
 // of iterations queued past the end see `done` and return at once.
 //
@@ -55,7 +55,8 @@ struct PlannerDev {
   uint32_t* label;
   int32_t* pivots;      // (x, y) pairs, lightSources_
   PlannerCtl* ctl;
-  PlannerKey* partial;  // one per quadrant workgroup
+  PlannerKey* partial;  // one per epilogue workgroup
+  unsigned int* ticket; // epilogue workgroups that have delivered their partial (the last one picks the pivot)
   double threshold, scale;
   int end_x, end_y;
   unsigned long long max_iter;
@@ -106,10 +107,38 @@ __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (
   sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x, lds, whole_workgroup());
 }
 
+// ls_ = heap_->top(); ++nb_of_sources_; the loop condition (solver.cpp:127-141), by the one thread that holds the minimum
+__device__ __forceinline__ void planner_pick(const DevMap& m, const PlannerDev& d, const PlannerKey& b) {
+  d.ctl->iters += 1;
+  if (b.x < 0) {  // nothing reached the threshold: the reference would call top() on an empty heap
+    d.ctl->status = VHP_ERR_NOTHING_LIT;
+    d.ctl->done = 1;
+    return;
+  }
+  const int nb = d.ctl->nb + 1;  // ls_ = top(); ++nb_of_sources_; lightSources_[nb] = ls_   (solver.cpp:130-133)
+  d.ctl->nb = nb;
+  d.pivots[2 * nb] = b.x;
+  d.pivots[2 * nb + 1] = b.y;
+  if ((unsigned long long)nb > d.max_iter) {  // :134-139
+    d.ctl->status = VHP_ERR_MAX_ITER;
+    d.ctl->done = 1;
+    return;
+  }
+  // the loop condition, :127.  vis_global(end) was written by some workgroup of this kernel: agent-scope load
+  const double ge = __longlong_as_double((long long)__hip_atomic_load(
+      reinterpret_cast<const unsigned long long*>(d.vis_global + (size_t)d.end_y * m.nx + d.end_x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  if (ge > d.threshold) {
+    d.pivots[2 * nb] = d.end_x;  // :141
+    d.pivots[2 * nb + 1] = d.end_y;
+    d.ctl->status = VHP_OK;
+    d.ctl->done = 1;
+  }
+}
+
 // Step 2: the per-cell body of updateVisibility() that follows the store (solver.cpp:417-430)
 // over every cell the sweep visited: max-union into vis_global, first-lit labelling, heuristic
 // of every lit cell, arg-min of (h, push rank).  Embarrassingly parallel and coalesced.
-constexpr int kEpilogueBlocks = 256;
+constexpr int kEpilogueBlocks = 256;  // == the epilogue's workgroup size (the last workgroup merges one partial per thread)
 __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev d) {
   __shared__ PlannerKey slots[4];
   if (d.ctl->done) return;
@@ -152,40 +181,50 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
   }
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) slots[wave] = best;
+  // The workgroup whose partial arrives last merges them all and picks the next pivot: no third kernel, no single-thread
+  // walk over the partials.  Cross-CU hand-off (MI355X_MICROARCH "Valid forms"): every storing wavefront drains its
+  // stores, the workgroup's barrier, then one lane: partial, agent-scope release, drained again, ticket.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  __shared__ int is_last;
   if (threadIdx.x == 0) {
     PlannerKey b = slots[0];
     for (int w = 1; w < 4; ++w)
       if (key_less(slots[w], b)) b = slots[w];
     d.partial[blockIdx.x] = b;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    is_last = __hip_atomic_fetch_add(d.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    if (is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
-}
-
-__global__ void vhp_planner_pick(DevMap m, PlannerDev d) {
-  if (threadIdx.x != 0 || d.ctl->done) return;
-  PlannerKey b = d.partial[0];
-  for (int q = 1; q < kEpilogueBlocks; ++q)
-    if (key_less(d.partial[q], b)) b = d.partial[q];
-  d.ctl->iters += 1;
-  if (b.x < 0) {  // nothing reached the threshold: the reference would call top() on an empty heap
-    d.ctl->status = VHP_ERR_NOTHING_LIT;
-    d.ctl->done = 1;
-    return;
+  __syncthreads();
+  if (!is_last) return;
+  // kEpilogueBlocks == blockDim.x: one partial per thread, agent-scope loads (another CU wrote them)
+  PlannerKey k;
+  {
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(d.partial + threadIdx.x);
+    k.h = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    k.rank = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long xy = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    k.x = (int)(unsigned)xy;
+    k.y = (int)(unsigned)(xy >> 32);
   }
-  const int nb = d.ctl->nb + 1;  // ls_ = top(); ++nb_of_sources_; lightSources_[nb] = ls_   (solver.cpp:130-133)
-  d.ctl->nb = nb;
-  d.pivots[2 * nb] = b.x;
-  d.pivots[2 * nb + 1] = b.y;
-  if ((unsigned long long)nb > d.max_iter) {  // :134-139
-    d.ctl->status = VHP_ERR_MAX_ITER;
-    d.ctl->done = 1;
-    return;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const PlannerKey o = key_shuffle_xor(k, s);
+    if (key_less(o, k)) k = o;
   }
-  if (d.vis_global[(size_t)d.end_y * m.nx + d.end_x] > d.threshold) {  // loop condition, :127
-    d.pivots[2 * nb] = d.end_x;  // :141
-    d.pivots[2 * nb + 1] = d.end_y;
-    d.ctl->status = VHP_OK;
-    d.ctl->done = 1;
+  if ((threadIdx.x & 63) == 0) slots[wave] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PlannerKey bb = slots[0];
+    for (int w = 1; w < 4; ++w)
+      if (key_less(slots[w], bb)) bb = slots[w];
+    *d.ticket = 0;  // for the next iteration (kernels of one stream run in order)
+    planner_pick(m, d, bb);
   }
 }
 
@@ -224,6 +263,7 @@ struct PlannerState {
   int32_t* pivots = nullptr;
   PlannerCtl* ctl = nullptr;
   PlannerKey* partial = nullptr;
+  unsigned int* ticket = nullptr;
   // launch shape of the front sweep and the per-device dynamic-LDS bookkeeping, set by the caller (vhp_capi.hip)
   int R = 2, W = 8;
   bool multi = false;
@@ -238,6 +278,8 @@ inline void planner_free(PlannerState& s) {
   if (s.pivots) (void)hipFree(s.pivots);
   if (s.ctl) (void)hipFree(s.ctl);
   if (s.partial) (void)hipFree(s.partial);
+  if (s.ticket) (void)hipFree(s.ticket);
+  s.ticket = nullptr;
   s.cells = 0;
   s.pivot_cap = 0;
   s.vis_global = s.vis_local = nullptr;
@@ -297,6 +339,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
     VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
     VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
     VHP_PL_HIP(hipMalloc(&s.partial, kEpilogueBlocks * sizeof(PlannerKey)));
+    VHP_PL_HIP(hipMalloc(&s.ticket, sizeof(unsigned int)));
     s.cells = cells;
   }
   if (s.pivot_cap < pcap) {
@@ -310,6 +353,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   VHP_PL_HIP(hipMemsetAsync(s.vis_local, 0, cells * 8, stream));
   VHP_PL_HIP(hipMemsetAsync(s.label, 0xff, cells * 4, stream));
   VHP_PL_HIP(hipMemsetAsync(s.pivots, 0, pcap * sizeof(int32_t), stream));
+  VHP_PL_HIP(hipMemsetAsync(s.ticket, 0, sizeof(unsigned int), stream));
 
   PlannerDev d;
   d.vis_global = s.vis_global;
@@ -318,6 +362,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   d.pivots = s.pivots;
   d.ctl = s.ctl;
   d.partial = s.partial;
+  d.ticket = s.ticket;
   d.threshold = threshold;
   {
     volatile double q = (double)((size_t)ny * ny + (size_t)nx * nx);
@@ -333,7 +378,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   hipLaunchKernelGGL(vhp_planner_init, dim3(1), dim3(64), 0, stream, d, nx, start_x, start_y);
   VHP_PL_HIP(hipGetLastError());
   PlannerCtl ctl{};
-  const int batch = 4;  // iterations enqueued per host poll
+  const int batch = 8;  // iterations enqueued per host poll (those past the end see `done` and return at once)
   for (;;) {
     for (int b = 0; b < batch; ++b) {
       hipError_t e = R == 1 ? (multi ? launch_planner_fronts<1, true>(s, m, d, W, stream) : launch_planner_fronts<1, false>(s, m, d, W, stream))
@@ -341,8 +386,6 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
                             : (multi ? launch_planner_fronts<4, true>(s, m, d, W, stream) : launch_planner_fronts<4, false>(s, m, d, W, stream));
       if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
       hipLaunchKernelGGL(vhp_planner_epilogue, dim3(kEpilogueBlocks), dim3(256), 0, stream, m, d);
-      VHP_PL_HIP(hipGetLastError());
-      hipLaunchKernelGGL(vhp_planner_pick, dim3(1), dim3(64), 0, stream, m, d);
       VHP_PL_HIP(hipGetLastError());
     }
     VHP_PL_HIP(hipMemcpyAsync(&ctl, s.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
