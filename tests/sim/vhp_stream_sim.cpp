@@ -65,33 +65,17 @@ struct SimInfo {
 
 uint32_t lcg(uint32_t& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
-template <int DX, int DY, typename OutT>
-void run_quadrant(const HostMap& h, OutT* field, int sx, int sy, int W, int order_mode, SimInfo& info, uint32_t& rng) {
-  Quad<DX, DY> g;
-  g.init(h.m.nx, h.m.ny, sx, sy);
-  if (g.empty()) return;
-  const Layout L = make_layout(W, h.m.nx, h.m.ny);
-  std::vector<double> lds(L.total, std::numeric_limits<double>::quiet_NaN());
-  Progress<DX, DY> prog;
-  prog.bind(lds.data(), L, W);
-  prog.setup(g);
-  std::vector<XWave<DX, DY, OutT>> xs(W);
-  std::vector<YWave<DX, DY, OutT>> ys(W);
-  for (int w = 0; w < W; ++w) {
-    xs[w].init(h.m, g, field, w, W, lds.data(), L);
-    ys[w].init(h.m, g, field, w, W, lds.data(), L);
-  }
-  auto active = [&](int wv) { return wv < W ? xs[wv].active : ys[wv - W].active; };
-  auto ready = [&](int wv) { return wv < W ? xs[wv].ready() : ys[wv - W].ready(); };
-  auto run = [&](int wv) { if (wv < W) xs[wv].run_unit(); else ys[wv - W].run_unit(); };
-  std::vector<int> order(2 * W);
+// one workgroup sweeping one octant: `n_waves` schedulable wavefronts given by the three callbacks
+template <class Active, class Ready, class Run>
+void interleave(int n_waves, int order_mode, SimInfo& info, uint32_t& rng, Active active, Ready ready, Run run) {
+  std::vector<int> order(n_waves);
   long long passes = 0;
   for (;;) {
     bool any_active = false, progress = false;
-    for (int k = 0; k < 2 * W; ++k) order[k] = k;
-    if (order_mode == 1) for (int k = 0; k < 2 * W; ++k) order[k] = 2 * W - 1 - k;
-    if (order_mode >= 2) for (int k = 2 * W - 1; k > 0; --k) { const int r = lcg(rng) % (k + 1); std::swap(order[k], order[r]); }
-    for (int k = 0; k < 2 * W; ++k) {
+    for (int k = 0; k < n_waves; ++k) order[k] = k;
+    if (order_mode == 1) for (int k = 0; k < n_waves; ++k) order[k] = n_waves - 1 - k;
+    if (order_mode >= 2) for (int k = n_waves - 1; k > 0; --k) { const int r = lcg(rng) % (k + 1); std::swap(order[k], order[r]); }
+    for (int k = 0; k < n_waves; ++k) {
       const int wv = order[k];
       if (!active(wv)) continue;
       any_active = true;
@@ -108,6 +92,37 @@ void run_quadrant(const HostMap& h, OutT* field, int sx, int sy, int W, int orde
   }
   info.slots += passes;
   if (passes > info.max_slots) info.max_slots = passes;
+}
+
+// The two units of a quadrant, each a workgroup of its own with its own (poisoned) LDS: they share nothing.
+template <int DX, int DY, typename OutT>
+void run_quadrant(const HostMap& h, OutT* field, int sx, int sy, int W, int order_mode, SimInfo& info, uint32_t& rng) {
+  Quad<DX, DY> g;
+  g.init(h.m.nx, h.m.ny, sx, sy);
+  if (g.empty()) return;
+  {  // x-major unit
+    const Layout L = make_layout(W, h.m.nx, h.m.ny, true);
+    std::vector<double> lds(lds_doubles(W, h.m.nx, h.m.ny), std::numeric_limits<double>::quiet_NaN());
+    Progress<DX, DY> prog;
+    prog.bind(lds.data(), L, W);
+    prog.setup(g, true);
+    std::vector<XWave<DX, DY, OutT>> xs(W);
+    for (int w = 0; w < W; ++w) xs[w].init(h.m, g, field, w, W, lds.data(), L);
+    interleave(W, order_mode, info, rng, [&](int w) { return xs[w].active; }, [&](int w) { return xs[w].ready(); }, [&](int w) { xs[w].run_unit(); });
+  }
+  if (g.Py > 0) {  // y-major unit: W sweeping wavefronts and the DiagWave
+    const Layout L = make_layout(W, h.m.nx, h.m.ny, false);
+    std::vector<double> lds(lds_doubles(W, h.m.nx, h.m.ny), std::numeric_limits<double>::quiet_NaN());
+    Progress<DX, DY> prog;
+    prog.bind(lds.data(), L, W);
+    prog.setup(g, false);
+    std::vector<YWave<DX, DY, OutT>> ys(W);
+    for (int w = 0; w < W; ++w) ys[w].init(h.m, g, field, w, W, lds.data(), L);
+    DiagWave<DX, DY> dw;
+    dw.init(h.m, g, lds.data(), L);
+    interleave(W + 1, order_mode, info, rng, [&](int w) { return w < W ? ys[w].active : dw.active; },
+               [&](int w) { return w < W ? ys[w].ready() : dw.ready(); }, [&](int w) { if (w < W) ys[w].run_unit(); else dw.run_unit(); });
+  }
 }
 
 template <typename OutT>
@@ -155,6 +170,6 @@ int vhp_sim_stream_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src,
   return run_batch<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), W, order_mode, stats);
 }
 
-int vhp_sim_lds_bytes(int nx, int ny, int W) { return make_layout(W, nx, ny).total * 8; }
+int vhp_sim_lds_bytes(int nx, int ny, int W) { return lds_doubles(W, nx, ny) * 8; }
 
 }  // extern "C"

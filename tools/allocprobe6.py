@@ -12,6 +12,7 @@ src = synth.free_sources(occ, n, seed=7)
 ctx = vhp_amd.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 ctx.set_map(occ)
+ctx.set_option("kernel", int(os.environ.get("VHP_KERNEL", "0")))
 d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
 hip = C.CDLL("libamdhip64.so")
 hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]

@@ -31,7 +31,7 @@ c.timing(True)
 c.sweep_batch_device(d_src.data_ptr(), n, out.data_ptr())
 torch.cuda.synchronize()
 print("kernel ms", c.timing_collect(4))
-nu = 4 * n
+nu = 8 * n
 buf = np.zeros(nu * 16, np.uint64)
 rc = mod._lib.vhp_debug_read_wgtime(C.c_void_p(buf.ctypes.data), nu * 16)
 assert rc == 0
@@ -40,7 +40,7 @@ t0, t1 = w[:, 0].astype(np.int64), w[:, 1].astype(np.int64)
 live = t1 > 0
 base = t0[live].min()
 start, end = (t0 - base) / 100.0, (t1 - base) / 100.0  # us (100 MHz)
-slots = (w[:, 2] & 0xffff).astype(int); ni = ((w[:, 2] >> 16) & 0xffff).astype(int); nj = ((w[:, 2] >> 32) & 0xffff).astype(int)
+slots = (w[:, 2] & 0xffff).astype(int); ni = ((w[:, 2] >> 16) & 0xffff).astype(int); nj = ((w[:, 2] >> 32) & 0xffff).astype(int); octant = ((w[:, 2] >> 48) & 1).astype(int)
 cyc = w[:, 4].astype(np.float64)
 busy = w[:, 8:16].astype(np.float64)
 print("workgroups live %d of %d; launch span %.1f us" % (live.sum(), nu, end[live].max()))
@@ -58,7 +58,7 @@ print("resident workgroups over time:", conc)
 print("sum of slots", slots[live].sum(), " sum of WG-us", dur[live].sum().round(0))
 big = np.argsort(-dur)[:8]
 for b in big:
-    print("  long WG %4d: start %.1f dur %.1f us slots %d ni %d nj %d busy x %s y %s" % (b, start[b], dur[b], slots[b], ni[b], nj[b], frac[b, :4].round(2), frac[b, 4:8].round(2)))
+    print("  long unit %4d (%s): start %.1f dur %.1f us slots %d ni %d nj %d busy x %s y %s" % (b, "xy"[octant[b]], start[b], dur[b], slots[b], ni[b], nj[b], frac[b, :4].round(2), frac[b, 4:8].round(2)))
 np.save(os.path.join(ROOT, "gpurun_out", "stream_timeline.npy"), w)
 # where the cycles of workgroup 0's wavefronts went (XWave / YWave prof[] of the diagnostic build)
 pr = np.zeros(64, np.uint64)
@@ -68,3 +68,10 @@ if mod._lib.vhp_debug_read_prof(C.c_void_p(pr.ctypes.data)) == 0:
         r = pr[wv]
         print("  WG0 wave %d (%s): loads %.0f  steady windows %.0f  diag/pred windows %.0f  single steps %.0f  flushes %.0f  kcycles; %d windows -> %.0f cycles per window" % (
             wv, "x" if wv < 4 else "y", r[0] / 1e3, r[1] / 1e3, r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5], (r[1] + r[2]) / max(r[5], 1)))
+# who shared a CU with the largest units?
+key = ((w[:, 3] >> 32) << 8) | ((w[:, 3] >> 8) & 0xff)
+for b in big[:6]:
+    same = np.where((key == key[b]) & live)[0]
+    ov = [(int(u), round(float(max(0.0, min(end[u], end[b]) - max(start[u], start[b]))), 1), int(ni[u]) * int(nj[u]) // 1000) for u in same if u != b]
+    ov = [o for o in ov if o[1] > 0]
+    print("  unit %d (CU key %#x, %.0f us): %d other units overlapped it on that CU: %s" % (b, int(key[b]), dur[b], len(ov), ov[:12]))

@@ -92,6 +92,9 @@ inline vd and_mask(const vd& v, const vi& m) {
 }
 // bit b (uniform, 0..63) of a lane-private word as 0 / ~0
 inline vi bit_mask(const vu64& w, int b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = ((w.v[l] >> (b & 63)) & 1ull) ? -1 : 0; return r; }
+// bit b (per lane, 0..63) of a lane-private word as 0 / ~0
+inline vi bit_mask_lane(const vu64& w, const vi& b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = ((w.v[l] >> (b.v[l] & 63)) & 1ull) ? -1 : 0; return r; }
+inline int read_lane_i(const vi& v, int l) { return v.v[l & 63]; }
 // the 32-bit half of w that holds bit t (uniform), shifted right by sh (uniform, 0..31)
 inline vu32 half_shifted(const vu64& w, int t, int sh) {
   vu32 r; for (int l = 0; l < kLanes; ++l) r.v[l] = (uint32_t)((t & 32) ? (w.v[l] >> 32) : w.v[l]) >> sh; return r; }
@@ -186,6 +189,8 @@ VHP_LANE_FN vi bit_mask(vu64 w, int b) {
   const uint32_t half = (b & 32) ? (uint32_t)(w >> 32) : (uint32_t)w;
   return __builtin_amdgcn_sbfe(half, b & 31, 1);
 }
+VHP_LANE_FN vi bit_mask_lane(vu64 w, vi b) { return ((w >> (b & 63)) & 1ull) ? -1 : 0; }
+VHP_LANE_FN int read_lane_i(vi v, int l) { return __builtin_amdgcn_readlane(v, l); }
 VHP_LANE_FN vu32 half_shifted(vu64 w, int t, int sh) { return ((t & 32) ? (uint32_t)(w >> 32) : (uint32_t)w) >> sh; }
 VHP_LANE_FN vi sbfe1(vu32 hs, int b) { return __builtin_amdgcn_sbfe(hs, b, 1); }
 
@@ -242,13 +247,21 @@ VHP_LANE_FN void wave_sync() {
 VHP_LANE_FN void pin(double& v) { asm volatile("" : "+v"(v)); }
 VHP_LANE_FN void pin(uint64_t& v) { asm volatile("" : "+v"(v)); }
 VHP_LANE_FN int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
-// release: everything this wavefront has written to LDS has landed (s_waitcnt lgkmcnt(0)), then the progress word
+// Release of LDS data to the other wavefronts of the workgroup: the progress word is an LDS write issued after the data's
+// LDS writes by the same wavefront, and the LDS executes one wavefront's instructions in order -- nothing to wait for.
+// (A workgroup-scope release FENCE would also drain vmcnt: every global store the wavefront has in flight, 5 us per unit
+// under load -- measured: it doubled the time of the largest quadrants.)  Only the compiler must keep the order.
 VHP_LANE_FN void lds_publish(volatile int* word, int value) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
   if ((threadIdx.x & 63u) == 0) *word = value;
+  asm volatile("" ::: "memory");
 }
-// acquire: LDS reads issued after a successful poll are not satisfied by anything older
-VHP_LANE_FN void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// acquire: the poll's value has arrived (the branch on it waited for lgkmcnt); later LDS reads are issued after it, in order
+VHP_LANE_FN void lds_acquire() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 #endif
 
 // RN(num/den) for integers 0 <= num < den <= 16384, given rden = RN(1/den): Markstein's correction, proved

@@ -9,7 +9,7 @@
 namespace vhp {
 namespace stream {
 
-constexpr int kUnits = 4;  // quadrants per source
+constexpr int kUnits = 8;  // units per source: 4 quadrants x {x-major, y-major} octant
 constexpr int kCuSlots = 2048;  // per-CU arrival counters (XCC, SE, SH, CU packed into 11 bits)
 
 #ifdef VHP_EXP_WGTIME  // diagnostic builds only (tools/stream_timeline.py): when each workgroup ran and how busy its wavefronts were
@@ -20,72 +20,68 @@ __device__ unsigned long long g_prof[8 * 8];  // per wavefront of workgroup 0: t
 #define VHP_WG_STAMP(var)
 #endif
 
-template <int DX, int DY, typename OutT>
-__device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, int sy, int W, double* lds, int slot) {
+// One unit: the x-major (OCT == 0) or the y-major (OCT == 1) octant of one quadrant, swept by the workgroup.
+template <int DX, int DY, int OCT, typename OutT>
+__device__ __forceinline__ void run_octant(const Map& m, OutT* field, int sx, int sy, int W, double* lds, int slot) {
   (void)slot;
   Quad<DX, DY> g;
   g.init(m.nx, m.ny, sx, sy);
-  if (g.empty()) return;  // uniform for the workgroup
-  const Layout L = make_layout(W, m.nx, m.ny);
+  if (g.empty() || (OCT == 1 && g.Py == 0)) return;  // uniform for the workgroup
+  const Layout L = make_layout(W, m.nx, m.ny, OCT == 0);
   {
     Progress<DX, DY> prog;
     prog.bind(lds, L, W);
-    if (threadIdx.x == 0) prog.setup(g);
+    if (threadIdx.x == 0) prog.setup(g, OCT == 0);
   }
-  __syncthreads();  // the only workgroup barrier: from here on the wavefronts synchronise through their progress words
+  __syncthreads();  // from here on the wavefronts synchronise through their progress words
   const int wave = uniform((int)(threadIdx.x >> 6));
-#ifndef VHP_EXP_NOPRIO
-  // The launch is as long as its largest quadrants (a full-size one is 1/256 of a 256-source batch: a CU's fair
-  // share all by itself), and two workgroups share a CU: the larger the quadrant, the higher the issue priority of its
-  // wavefronts, so that it runs as if alone and the smaller neighbour fills the gaps.
-  {
-    const long area = (long)g.ni * g.nj, full = (long)m.nx * m.ny;
-    if (4 * area >= 3 * full) __builtin_amdgcn_s_setprio(3);
-    else if (2 * area >= full) __builtin_amdgcn_s_setprio(2);
-    else if (4 * area >= full) __builtin_amdgcn_s_setprio(1);
-  }
-#endif
 #ifdef VHP_EXP_WGTIME
   unsigned long long busy = 0;
   int units = 0;
   const unsigned long long wg_t0 = wall_clock64(), c_begin = __builtin_readcyclecounter();
 #endif
-  if (wave < W) {
-    XWave<DX, DY, OutT> xw;
-    xw.init(m, g, field, wave, W, lds, L);
-    while (xw.active) {
-      while (!xw.ready()) __builtin_amdgcn_s_sleep(4);
-      lds_acquire();
-      VHP_WG_STAMP(c0);
-      xw.run_unit();
+  if (OCT == 0) {
+    if (wave < W) {
+      XWave<DX, DY, OutT> xw;
+      xw.init(m, g, field, wave, W, lds, L);
+      while (xw.active) {
+        while (!xw.ready()) __builtin_amdgcn_s_sleep(4);
+        lds_acquire();
+        VHP_WG_STAMP(c0);
+        xw.run_unit();
 #ifdef VHP_EXP_WGTIME
-      busy += __builtin_readcyclecounter() - c0;
-      ++units;
+        busy += __builtin_readcyclecounter() - c0;
+        ++units;
+#endif
+      }
+#ifdef VHP_EXP_WGTIME
+      if (slot == 0 && (threadIdx.x & 63) == 0)
+        for (int k = 0; k < 6; ++k) g_prof[wave * 8 + k] = xw.prof[k];
 #endif
     }
-#ifdef VHP_EXP_WGTIME
-    if (slot == 0 && (threadIdx.x & 63) == 0)
-      for (int k = 0; k < 6; ++k) g_prof[wave * 8 + k] = xw.prof[k];
-#endif
   } else {
-    // wavefronts k and k + W share a SIMD: the x-major wavefront with the longest strips is paired with the y-major
-    // one with the shortest
-    YWave<DX, DY, OutT> yw;
-    yw.init(m, g, field, W - 1 - (wave - W), W, lds, L);
-    while (yw.active) {
-      while (!yw.ready()) __builtin_amdgcn_s_sleep(4);
-      lds_acquire();
-      VHP_WG_STAMP(c0);
-      yw.run_unit();
+    if (wave < W) {
+      YWave<DX, DY, OutT> yw;
+      yw.init(m, g, field, wave, W, lds, L);
+      while (yw.active) {
+        while (!yw.ready()) __builtin_amdgcn_s_sleep(4);
+        lds_acquire();
+        VHP_WG_STAMP(c0);
+        yw.run_unit();
 #ifdef VHP_EXP_WGTIME
-      busy += __builtin_readcyclecounter() - c0;
-      ++units;
+        busy += __builtin_readcyclecounter() - c0;
+        ++units;
 #endif
+      }
+#ifdef VHP_EXP_WGTIME
+      if (slot == 1 && (threadIdx.x & 63) == 0)
+        for (int k = 0; k < 6; ++k) g_prof[(4 + wave) * 8 + k] = yw.prof[k];
+#endif
+    } else if (wave == W) {
+      DiagWave<DX, DY> dw;
+      dw.init(m, g, lds, L);
+      while (dw.active) dw.run_unit();
     }
-#ifdef VHP_EXP_WGTIME
-    if (slot == 0 && (threadIdx.x & 63) == 0)
-      for (int k = 0; k < 6; ++k) g_prof[wave * 8 + k] = yw.prof[k];
-#endif
   }
 #ifdef VHP_EXP_WGTIME
   if ((threadIdx.x & 63) == 0 && slot < 16384 / 2) {
@@ -96,11 +92,11 @@ __device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, 
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       wv[0] = wg_t0;
       wv[1] = wall_clock64();
-      wv[2] = (unsigned long long)units | ((unsigned long long)g.ni << 16) | ((unsigned long long)g.nj << 32);
+      wv[2] = (unsigned long long)units | ((unsigned long long)g.ni << 16) | ((unsigned long long)g.nj << 32) | ((unsigned long long)OCT << 48);
       wv[3] = ((unsigned long long)xcc << 32) | hwid;
       wv[4] = __builtin_readcyclecounter() - c_begin;
     }
-    if (wave < 8) wv[8 + wave] = busy;   // waves 0..W-1: x-major, W..2W-1: y-major
+    if (wave < W) wv[8 + (OCT ? 4 : 0) + (wave & 3)] = busy;
   }
 #endif
 }
@@ -113,7 +109,7 @@ __device__ __forceinline__ void run_quadrant(const Map& m, OutT* field, int sx, 
 // workgroup busy with a large quadrant simply pulls nothing else.
 // dynamic LDS = make_layout(W, nx, ny).total doubles.
 template <typename OutT, int W>
-__global__ void __launch_bounds__(128 * W, W == 4 ? 4 : 4)
+__global__ void __launch_bounds__(64 * (W + 1), 4)
 vhp_stream_sweep(Map m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride, int* __restrict__ err_flag,
                  const int* __restrict__ order, unsigned long long* __restrict__ queue, int* __restrict__ cu_slots, int n_units) {
   extern __shared__ double lds[];
@@ -152,28 +148,32 @@ vhp_stream_sweep(Map m, const int32_t* __restrict__ src_xy, OutT* __restrict__ o
     const int slot = uniform(next_unit);
     if (slot >= n_units) return;
     const int unit = order ? order[slot] : slot;
-    const int s = unit / kUnits, q = unit - s * kUnits;
+    const int s = unit / kUnits, qo = unit - s * kUnits;
+    const int q = qo >> 1;
     const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
     if (sx < 0 || sy < 0 || sx >= m.nx || sy >= m.ny) {
-      if (threadIdx.x == 0 && q == 0) atomicOr(err_flag, 1);
+      if (threadIdx.x == 0 && qo == 0) atomicOr(err_flag, 1);
     } else {
       OutT* field = out + (size_t)s * field_stride;
       const long ni_ = (q == 0 || q == 3) ? m.nx - sx : sx, nj_ = q < 2 ? m.ny - sy : sy;
       const bool very_large = !tail && 20 * ni_ * nj_ >= 13 * (long)m.nx * m.ny;  // >= 0.65 of the grid
       if (very_large && threadIdx.x == 0) __hip_atomic_store(big_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (q == 0) {
-        // rows/columns no quadrant covers read as zero; quadrant 1 always exists
+      if (qo == 0) {
+        // rows/columns no quadrant covers read as zero; the x-major unit of quadrant 1 always exists
         if (sx > 0)
           for (int y = threadIdx.x; y < m.ny; y += blockDim.x) field[(size_t)y * m.nx] = OutT(0);
         if (sy > 0)
           for (int x = threadIdx.x; x < m.nx; x += blockDim.x) field[x] = OutT(0);
-        run_quadrant<+1, +1>(m, field, sx, sy, W, lds, slot);
-      } else if (q == 1) {
-        run_quadrant<-1, +1>(m, field, sx, sy, W, lds, slot);
-      } else if (q == 2) {
-        run_quadrant<-1, -1>(m, field, sx, sy, W, lds, slot);
-      } else {
-        run_quadrant<+1, -1>(m, field, sx, sy, W, lds, slot);
+      }
+      switch (qo) {
+        case 0: run_octant<+1, +1, 0>(m, field, sx, sy, W, lds, slot); break;
+        case 1: run_octant<+1, +1, 1>(m, field, sx, sy, W, lds, slot); break;
+        case 2: run_octant<-1, +1, 0>(m, field, sx, sy, W, lds, slot); break;
+        case 3: run_octant<-1, +1, 1>(m, field, sx, sy, W, lds, slot); break;
+        case 4: run_octant<-1, -1, 0>(m, field, sx, sy, W, lds, slot); break;
+        case 5: run_octant<-1, -1, 1>(m, field, sx, sy, W, lds, slot); break;
+        case 6: run_octant<+1, -1, 0>(m, field, sx, sy, W, lds, slot); break;
+        default: run_octant<+1, -1, 1>(m, field, sx, sy, W, lds, slot); break;
       }
       if (very_large && threadIdx.x == 0) __hip_atomic_store(big_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -195,13 +195,23 @@ __global__ void __launch_bounds__(1024) vhp_stream_order(const int32_t* __restri
   const int n_units = n_src * kUnits;
   const double inv_area = 1.0 / ((double)nx * (double)ny);
   auto bucket_of = [&](int u) {
-    const int s = u / kUnits, q = u - s * kUnits;
+    const int s = u / kUnits, qo = u - s * kUnits, q = qo >> 1;
     const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
     if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return kBuckets - 1;
     const int ni = (q == 0 || q == 3) ? nx - sx : sx;
     const int nj = (q < 2) ? ny - sy : sy;
-    const double a = (ni <= 0 || nj <= 0) ? 0.0 : (double)ni * (double)nj * inv_area;
-    return (kBuckets - 1) - (int)(a * (kBuckets - 1));  // bucket 0 = largest
+    double cells = 0.0;
+    if (ni > 0 && nj > 0) {
+      if ((qo & 1) == 0) {  // x-major: rows j < min(ni, nj), cells (i, j), j <= i < ni
+        const double r = ni < nj ? ni : nj;
+        cells = r * ni - r * (r - 1) * 0.5;
+      } else {              // y-major: columns i < min(ni, nj - 1), cells (i, j), i < j < nj
+        const double c = ni < nj - 1 ? ni : nj - 1;
+        cells = c > 0 ? c * (nj - 1) - c * (c - 1) * 0.5 : 0.0;
+      }
+    }
+    const double a = cells * inv_area * 1.6;  // an octant holds at most ~5/8 of the grid's cells (the whole grid when 1 cell thin)
+    return (kBuckets - 1) - (int)((a > 1.0 ? 1.0 : a) * (kBuckets - 1));  // bucket 0 = largest
   };
   hist[threadIdx.x] = 0;
   __syncthreads();
@@ -229,7 +239,7 @@ __global__ void __launch_bounds__(1024) vhp_stream_order(const int32_t* __restri
 
 namespace {
 constexpr size_t kLdsLimit = 160 * 1024;
-size_t lds_bytes(int nx, int ny, int W) { return (size_t)stream::make_layout(W, nx, ny).total * sizeof(double); }
+size_t lds_bytes(int nx, int ny, int W) { return (size_t)stream::lds_doubles(W, nx, ny) * sizeof(double); }
 
 template <typename OutT, int W>
 hipError_t launch_t(const StreamArgs& a) {
@@ -251,11 +261,11 @@ hipError_t launch_t(const StreamArgs& a) {
   const int n_units = a.n_src * kUnits;
   int per_cu = (int)(kLdsLimit / lds);
   if (per_cu < 1) per_cu = 1;
-  if (per_cu * 2 * W > 32) per_cu = 32 / (2 * W);  // 32 wavefronts per CU
+  if (per_cu * (W + 1) > 16) per_cu = 16 / (W + 1);  // a workgroup is W + 1 wavefronts (W sweep + the DiagWave of y-major units); 4 per SIMD
   const int resident = per_cu * a.n_cus;
   const int grid = n_units < resident ? n_units : resident;
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(128 * W), lds, a.stream, m, a.d_src, static_cast<OutT*>(a.d_out), a.field_stride,
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * (W + 1)), lds, a.stream, m, a.d_src, static_cast<OutT*>(a.d_out), a.field_stride,
                      a.d_err, (const int*)ord, queue, cu_slots, n_units);
   const hipError_t e = hipGetLastError();
   if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
@@ -272,13 +282,11 @@ extern "C" int vhp_debug_read_prof(unsigned long long* dst) {
 }
 #endif
 
-size_t stream_queue_bytes(int n_src) { return (size_t)(2 + 2 * stream::kCuSlots + 4 * (size_t)n_src) * sizeof(int); }
+size_t stream_queue_bytes(int n_src) { return (size_t)(2 + 2 * stream::kCuSlots + stream::kUnits * (size_t)n_src) * sizeof(int); }
 
 int stream_strips(int nx, int ny) {
   if (nx <= 0 || ny <= 0 || (nx & 7) != 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return 0;
-  if (2 * lds_bytes(nx, ny, 4) <= kLdsLimit) return 4;   // two 8-wavefront workgroups per CU
-  if (lds_bytes(nx, ny, 8) <= kLdsLimit) return 8;       // one 16-wavefront workgroup per CU
-  if (lds_bytes(nx, ny, 4) <= kLdsLimit) return 4;
+  if (lds_bytes(nx, ny, 4) <= kLdsLimit) return 4;  // 8-wavefront workgroups: three per CU at 1000^2, two at 4096^2
   return 0;
 }
 bool stream_supported(int nx, int ny) { return stream_strips(nx, ny) != 0; }

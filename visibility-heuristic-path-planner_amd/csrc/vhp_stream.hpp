@@ -6,9 +6,13 @@
 // previous front: itself and its neighbour one row / column below), organised for a store-bound launch of a
 // thousand quadrants instead of for the latency of one:
 //
-//   * one workgroup per (source, quadrant), 2*W wavefronts: W sweep strips of the x-major octant (64 rows each,
-//     one row per lane), W sweep strips of the y-major octant (128 columns each, two adjacent columns per lane, so
-//     that a lane stores 16 bytes per row and a wavefront 1 KB);
+//   * the unit of scheduling is one OCTANT of one quadrant of one source (8 per source): W wavefronts sweep strips of
+//     an x-major octant (64 rows each, one row per lane), or W wavefronts sweep strips of a y-major octant (128 columns
+//     each, two adjacent columns per lane, so that a lane stores 16 bytes per row and a wavefront 1 KB).  The two octants
+//     of a quadrant share only the diagonal cells, and the y-major unit recomputes those itself (DiagWave: the two-term
+//     recurrence sub(k) = V(k,k-1), diag(k) = sub(k)*occ(k,k) of tests/schedule_model.py, one wavefront running ahead of
+//     the strips), so units never talk to each other: a full-size quadrant is two independent 4 MB units on two CUs
+//     instead of one 8 MB unit that sets the length of the launch (a CU's store path moves ~9 bytes per clock);
 //   * the unit of work is one 64-cell BLOCK of the marching coordinate of one strip -- exactly one word of the
 //     bit-packed occupancy maps, so a lane loads one word per owned row/column and unit.  A wavefront takes the strips
 //     w, w+W, w+2W, ... one after the other, block by block.  There is no workgroup barrier: the workgroup is a small
@@ -22,8 +26,8 @@
 //   * x-major strips stage 16 columns in a wave-private LDS tile and emit every row as whole, aligned 128-byte lines
 //     (8 rows per store instruction).  With a row pitch that is an odd multiple of 64 bytes (1000 columns!) odd and even
 //     rows are half a line apart, so the two row classes flush alternately, each every 16 steps;
-//   * the stale diagonal of the reference (cell (k,k) = cell (k,k-1) * occ) is produced by the x-major strip
-//     that owns row k and handed to the y-major octant, which seeds column k with it, through an LDS array.
+//   * the stale diagonal of the reference (cell (k,k) = cell (k,k-1) * occ) is produced inside the x-major
+//     strip that owns row k; the y-major unit seeds column k with the same value from its own DiagWave, through an LDS array.
 //
 // The code is written against vhp_lanes.hpp and is compiled for gfx950 (vhp_stream.hip) and, unchanged, for the CPU
 // simulator of tests/sim (parity against the oracle without a GPU).  Requires nx % 8 == 0 (whole 64-byte sectors per
@@ -74,39 +78,39 @@ VHP_HD int imin(int a, int b) { return a < b ? a : b; }
 VHP_HD int imax(int a, int b) { return a > b ? a : b; }
 VHP_HD int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-// LDS of one workgroup, in doubles.
+// LDS of one workgroup, in doubles.  A workgroup sweeps one octant at a time: the x-major kind needs W staging tiles,
+// the y-major kind the diagonal array; rings, round row, slabs and progress words are common.  One launch holds both kinds
+// of units, so its dynamic LDS is sized for the larger (lds_doubles).
 struct Layout {
-  int ring_x, ring_y;    // W rings of kRing each (ring w = output of wavefront w of the octant)
-  int round_x, round_y;  // boundary row from the last strip of a round to the first strip of the next, indexed by absolute x / y
-  int diag;              // diag(k), k = quadrant-local index
+  int ring;              // W rings of kRing each (ring w = output of wavefront w)
+  int round;             // boundary row from the last strip of a round to the first strip of the next, indexed by the absolute
+                         // marching coordinate
+  int diag;              // y-major units: diag(k), k = quadrant-local index, written by the DiagWave
   int dummy;             // 8 doubles per wavefront: where lanes that are not the boundary lane "write" theirs
-  int slab;              // 64 doubles per wavefront: the reciprocals of the block it sweeps
-  int tiles;             // W staging tiles of kXRows * kTileStride
-  int sched;             // ints: done[16] (units finished per wavefront), then base_x[strips_x], base_y[strips_y]
-  int strips_x, strips_y;  // capacity of the two base arrays: the most strips an octant of this grid can have
+  int slab;              // 64 doubles per wavefront (+ the DiagWave): the reciprocals of the block it sweeps
+  int tiles;             // x-major units: W staging tiles of kXRows * kTileStride
+  int sched;             // ints: done[16] (units finished per wavefront; [15] = diagonal entries ready), then base[strips]
+  int strips;            // capacity of the base array: the most strips an octant of this grid can have
   int total;
-  int round_x_mask, round_y_mask;
+  int round_mask;
 };
-VHP_HD Layout make_layout(int W, int nx, int ny) {
+VHP_HD Layout make_layout(int W, int nx, int ny, bool x_major) {
   Layout L;
-  const int rx = next_pow2(nx), ry = next_pow2(ny);
+  const int rr = next_pow2(x_major ? nx : ny);
   int o = 0;
-  L.ring_x = o; o += W * kRing;
-  L.ring_y = o; o += W * kRing;
-  L.round_x = o; o += rx;
-  L.round_y = o; o += ry;
-  L.diag = o; o += imax(nx, ny) + 72;
-  L.dummy = o; o += 2 * W * 8;
-  L.slab = o; o += 2 * W * kBlock;
-  L.tiles = o; o += W * kXRows * kTileStride;
-  L.strips_x = (imin(nx, ny) + kXRows - 1) / kXRows + 1;
-  L.strips_y = (imin(nx, ny) + 15 + kYCols - 1) / kYCols + 1;
-  L.sched = o; o += (16 + L.strips_x + L.strips_y) / 2 + 1;
+  L.ring = o; o += W * kRing;
+  L.round = o; o += rr;
+  L.diag = o; if (!x_major) o += imax(nx, ny) + 72;
+  L.dummy = o; o += (W + 1) * 8;
+  L.slab = o; o += (W + 1) * kBlock;
+  L.tiles = o; if (x_major) o += W * kXRows * kTileStride;
+  L.strips = (imin(nx, ny) + kXRows - 1) / kXRows + 2;
+  L.sched = o; o += (16 + L.strips) / 2 + 1;
   L.total = o;
-  L.round_x_mask = rx - 1;
-  L.round_y_mask = ry - 1;
+  L.round_mask = rr - 1;
   return L;
 }
+VHP_HD int lds_doubles(int W, int nx, int ny) { return imax(make_layout(W, nx, ny, true).total, make_layout(W, nx, ny, false).total); }
 
 // Geometry of one quadrant.  x = sx + DX*i, y = sy + DY*j; negative directions stop one cell short of the border
 // (solver.cpp:607-610,638-642).
@@ -155,43 +159,45 @@ struct Quad {
 };
 
 // Progress bookkeeping of a workgroup (ints in LDS at Layout::sched):
-//   done[0..W-1]   units (strip, block) the x-major wavefronts have finished, done[W..2W-1] the y-major ones;
-//   base_x[p]      index of strip p's first block in the unit sequence of its wavefront (p % W): the wavefront has
-//                  finished block n of strip p once done >= base_x[p] + (n - first block of p) + 1;
-//   base_y[q]      the same for the y-major strips.
+//   done[0..W-1]   units (strip, block) the sweeping wavefronts have finished;
+//   done[15]       y-major units: diagonal entries diag(0 .. done[15]-1) are in the LDS array (DiagWave);
+//   base[p]        index of strip p's first block in the unit sequence of its wavefront (p % W): the wavefront has
+//                  finished block n of strip p once done >= base[p] + (n - first block of p) + 1.
 constexpr int kDoneSlots = 16;
+constexpr int kDiagDoneSlot = 15;
 template <int DX, int DY>
 struct Progress {
   volatile int* done;
-  int* base_x;
-  int* base_y;
+  int* base;
   int W;
 
   VHP_FN void bind(double* lds, const Layout& L, int W_) {
     int* p = reinterpret_cast<int*>(lds + L.sched);
     done = p;
-    base_x = p + kDoneSlots;
-    base_y = p + kDoneSlots + L.strips_x;
+    base = p + kDoneSlots;
     W = W_;
   }
   // run by one thread before any wavefront starts
-  VHP_FN void setup(const Quad<DX, DY>& g) {
+  VHP_FN void setup(const Quad<DX, DY>& g, bool x_major) {
     for (int k = 0; k < kDoneSlots; ++k) done[k] = 0;
-    for (int p = 0; p < g.Px; ++p) base_x[p] = p >= W ? base_x[p - W] + (g.Nbx - g.nbx(kXRows * (p - W))) : 0;
-    for (int q = 0; q < g.Py; ++q) base_y[q] = q >= W ? base_y[q - W] + (g.Nby - g.nby(g.ystart(q - W))) : 0;
+    if (x_major)
+      for (int p = 0; p < g.Px; ++p) base[p] = p >= W ? base[p - W] + (g.Nbx - g.nbx(kXRows * (p - W))) : 0;
+    else
+      for (int q = 0; q < g.Py; ++q) base[q] = q >= W ? base[q - W] + (g.Nby - g.nby(g.ystart(q - W))) : 0;
   }
   // has x-major strip p swept block n?  (blocks before the strip's first are nothing to wait for, blocks past the
   // march mean "the whole strip")
   VHP_FN bool x_done(const Quad<DX, DY>& g, int p, int n) const {
     const int nf = g.nbx(kXRows * p);
     if (n < nf) return true;
-    return uniform(done[p % W]) >= base_x[p] + (imin(n, g.Nbx - 1) - nf) + 1;
+    return uniform(done[p % W]) >= base[p] + (imin(n, g.Nbx - 1) - nf) + 1;
   }
   VHP_FN bool y_done(const Quad<DX, DY>& g, int q, int n) const {
     const int nf = g.nby(g.ystart(q));
     if (n < nf) return true;
-    return uniform(done[W + q % W]) >= base_y[q] + (imin(n, g.Nby - 1) - nf) + 1;
+    return uniform(done[q % W]) >= base[q] + (imin(n, g.Nby - 1) - nf) + 1;
   }
+  VHP_FN int diag_ready() const { return uniform(done[kDiagDoneSlot]); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -217,7 +223,6 @@ struct XWave {
   double* ring_base;
   double* round;
   int round_mask;
-  double* diag;
   double* slab;   // reciprocals of the current block's 64 steps, indexed by x & 63
   double* dummy;  // where the lanes that are not the boundary lane "write" theirs
   Progress<DX, DY> prog;
@@ -243,10 +248,9 @@ struct XWave {
   VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
     m = m_; g = g_; out = out_; w = w_; W = W_;
     tile = lds + L.tiles + w * kXRows * kTileStride;
-    ring_base = lds + L.ring_x;
-    round = lds + L.round_x;
-    round_mask = L.round_x_mask;
-    diag = lds + L.diag;
+    ring_base = lds + L.ring;
+    round = lds + L.round;
+    round_mask = L.round_mask;
     slab = lds + L.slab + w * kBlock;
     dummy = lds + L.dummy + w * 8;
     prog.bind(lds, L, W);
@@ -406,7 +410,6 @@ struct XWave {
       const vb isd = lane == (i - j0);
       const vd dcell = and_mask(up, mk);
       v = select(isd, dcell, v);
-      lds_store_if(isd, diag, vi(i), dcell);
     }
     prev = v;
     lds_store(tile, tile_l + (x & 15), v);
@@ -452,7 +455,6 @@ struct XWave {
         const vb isd = lane == (i0 + k - j0);
         const vd dcell = and_mask(up, mk);
         v = select(isd, dcell, v);
-        lds_store_if(isd, diag, vi(i0 + k), dcell);
       }
       prev = v;
       lds_store(tile, tidx + col, v);
@@ -539,12 +541,12 @@ struct YWave {
 
   VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
     m = m_; g = g_; out = out_; w = w_; W = W_;
-    ring_base = lds + L.ring_y;
-    round = lds + L.round_y;
-    round_mask = L.round_y_mask;
+    ring_base = lds + L.ring;
+    round = lds + L.round;
+    round_mask = L.round_mask;
     diag = lds + L.diag;
-    slab = lds + L.slab + (W + w) * kBlock;
-    dummy = lds + L.dummy + (W + w) * 8;
+    slab = lds + L.slab + w * kBlock;
+    dummy = lds + L.dummy + w * 8;
     prog.bind(lds, L, W);
     lane = lane_id();
     active = true;
@@ -584,12 +586,11 @@ struct YWave {
       }
     }
     if (n == nf && q >= W && (q - W + 1) % W != 0 && !prog.y_done(g, q - W + 1, g.Nby - 1)) return false;
-    // the seeds of this block: diag(k) for the strip's columns k among the block's steps, published by the x-major
-    // strip that owns row k when it swept the block that holds step k
+    // the seeds of this block: diag(k) for the strip's columns k among the block's steps, from the DiagWave
     int lo, hi;
     g.ysteps(n, lo, hi);
     const int kmax = imin(imin(hi, i0 + kYCols - 1), g.rows_total - 1);
-    if (kmax >= imax(lo, jstart) && !prog.x_done(g, kmax / kXRows, g.nbx(kmax))) return false;
+    if (kmax >= imax(lo, jstart) && kmax >= prog.diag_ready()) return false;
     return true;
   }
 
@@ -597,7 +598,7 @@ struct YWave {
     sweep_block(n);
     const bool last = n == g.Nby - 1;
     ++my_done;
-    lds_publish(prog.done + W + w, my_done);
+    lds_publish(prog.done + w, my_done);
     if (last) load_strip(q + W); else ++n;
   }
 
@@ -728,7 +729,69 @@ struct YWave {
   }
 };
 
-// rows / columns no quadrant covers read as zero: done by the workgroup of quadrant 1
+// ---------------------------------------------------------------------------------------------------------------
+// The diagonal of a quadrant for its y-major unit.  diag(0) = occ(source); for k >= 1 (tests/schedule_model.py):
+//   sub(k)  = V(k, k-1) = (a - c*(a - b)) * occ(k, k-1),  a = diag(k-1), b = sub(k-1), c = (k-1)/k
+//   diag(k) = sub(k) * occ(k, k)                                            (the stale diagonal)
+// exactly the operations the x-major strip performs on row k-1 at step k and on its diagonal lane.  The chain is serial:
+// one wavefront computes it (every lane the same value), 64 entries per unit, ahead of the strips that need it.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY>
+struct DiagWave {
+  Map m;
+  Quad<DX, DY> g;
+  double* diag;
+  volatile int* ready_word;
+  int k;        // next entry
+  bool active;
+  vi lane;
+  vd dprev, sprev;  // diag(k-1), sub(k-1): the same value in every lane
+
+  VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, double* lds, const Layout& L) {
+    m = m_; g = g_;
+    diag = lds + L.diag;
+    ready_word = reinterpret_cast<volatile int*>(lds + L.sched) + kDiagDoneSlot;
+    lane = lane_id();
+    k = 0;
+    active = g.rows_total > 0;
+    dprev = vd(0.0);
+    sprev = vd(0.0);
+  }
+  VHP_FN bool ready() const { return true; }
+
+  // entries k .. k+63
+  VHP_FN void run_unit() {
+    const int k0 = k, k1 = imin(k0 + kBlock, g.rows_total);
+    // lane l: the occupancy bits of cells (kk, kk-1) and (kk, kk), kk = k0 + l, and 1/kk
+    const vi kk = vmin(lane + k0, g.rows_total - 1);
+    const vi x = kk * DX + g.sx;
+    const vi ya = vmax(kk - 1, 0) * DY + g.sy, yb = kk * DY + g.sy;
+    const vu64 wa = g_load_u64(m.rows, ya * m.wpr + ((x >> 6) + 1));
+    const vu64 wb = g_load_u64(m.rows, yb * m.wpr + ((x >> 6) + 1));
+    const vd rk = g_load_f64(m.recip, kk);
+    const vi ma = bit_mask_lane(wa, x & 63), mb = bit_mask_lane(wb, x & 63);
+    for (int kq = k0; kq < k1; ++kq) {
+      const int l = kq - k0;
+      vd dcur;
+      if (kq == 0) {
+        dcur = and_mask(vd(1.0), vi(read_lane_i(mb, l)));  // the origin: light strength 1 times its occupancy
+        sprev = vd(0.0);
+      } else {
+        const vd c = ratio(vd((double)(kq - 1)), (double)kq, read_lane(rk, l));
+        const vd sub = and_mask(stencil(dprev, sprev, c), vi(read_lane_i(ma, l)));
+        dcur = and_mask(sub, vi(read_lane_i(mb, l)));
+        sprev = sub;
+      }
+      dprev = dcur;
+      lds_store_if(lane == 0, diag, vi(kq), dcur);
+    }
+    k = k1;
+    lds_publish(ready_word, k1);
+    if (k >= g.rows_total) active = false;
+  }
+};
+
+// rows / columns no quadrant covers read as zero: done by the x-major unit of quadrant 1
 template <typename OutT>
 VHP_FN void zero_fill_cell(OutT* out, size_t idx) { out[idx] = OutT(0); }
 
