@@ -321,7 +321,7 @@ def main():
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this
         # command): collected by tools/collect_profiles.sh into profiles/, not measured inside this run
         traffic, traffic_src = None, None
-        kname = "vhp_stream_sweep" if (args.kernel == 2 or (args.kernel == 0 and n_src >= 128 and nx % 8 == 0)) else "vhp_sweep_fronts"
+        kname = {1: "vhp_sweep_fronts", 2: "vhp_stream_sweep"}.get(ctx.last_sweep_kernel(), "unknown")  # what the library launched
         tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s_%s.json" % (args.workload, args.dtype, kname))
         if os.path.exists(tpath):
             try:

@@ -94,39 +94,55 @@ void interleave(int n_waves, int order_mode, SimInfo& info, uint32_t& rng, Activ
   if (passes > info.max_slots) info.max_slots = passes;
 }
 
+// what the launcher would pick (vhp_stream.hip): y-major units sweep with every wavefront but the DiagWave; x-major
+// units pair each sweeping wavefront with a flusher
+struct SimShape {
+  int Wx, Wy, tile_slots;
+  bool lazy_flush;
+};
+
 // The two units of a quadrant, each a workgroup of its own with its own (poisoned) LDS: they share nothing.
 template <int DX, int DY, typename OutT>
-void run_quadrant(const HostMap& h, OutT* field, int sx, int sy, int W, int order_mode, SimInfo& info, uint32_t& rng) {
+void run_quadrant(const HostMap& h, OutT* field, int sx, int sy, const SimShape& sh, int order_mode, SimInfo& info, uint32_t& rng) {
   Quad<DX, DY> g;
   g.init(h.m.nx, h.m.ny, sx, sy);
   if (g.empty()) return;
-  {  // x-major unit
-    const Layout L = make_layout(W, h.m.nx, h.m.ny, true);
-    std::vector<double> lds(lds_doubles(W, h.m.nx, h.m.ny), std::numeric_limits<double>::quiet_NaN());
+  const int lds_n = lds_doubles(sh.Wx, sh.Wy, h.m.nx, h.m.ny, sh.tile_slots);
+  {  // x-major unit: Wx sweeping wavefronts, each with its flusher (run inside the sweeping wavefront's post / wait calls)
+    const int W = sh.Wx;
+    const Layout L = make_layout(W, h.m.nx, h.m.ny, true, sh.tile_slots);
+    std::vector<double> lds(lds_n, std::numeric_limits<double>::quiet_NaN());
     Progress<DX, DY> prog;
     prog.bind(lds.data(), L, W);
     prog.setup(g, true);
-    std::vector<XWave<DX, DY, OutT>> xs(W);
-    for (int w = 0; w < W; ++w) xs[w].init(h.m, g, field, w, W, lds.data(), L);
+    std::vector<XWave<DX, DY, OutT>> xs(W), fl(W);
+    for (int w = 0; w < W; ++w) {
+      fl[w].init_flusher(h.m, g, field, w, W, lds.data(), L);
+      xs[w].flusher = &fl[w];
+      xs[w].lazy = sh.lazy_flush;
+      xs[w].init(h.m, g, field, w, W, lds.data(), L);
+    }
     interleave(W, order_mode, info, rng, [&](int w) { return xs[w].active; }, [&](int w) { return xs[w].ready(); }, [&](int w) { xs[w].run_unit(); });
+    for (int w = 0; w < W; ++w) xs[w].finish();
   }
-  if (g.Py > 0) {  // y-major unit: W sweeping wavefronts and the DiagWave
-    const Layout L = make_layout(W, h.m.nx, h.m.ny, false);
-    std::vector<double> lds(lds_doubles(W, h.m.nx, h.m.ny), std::numeric_limits<double>::quiet_NaN());
+  if (g.Py > 0) {  // y-major unit: Wy sweeping wavefronts and the DiagWave
+    const int W = sh.Wy;
+    const Layout L = make_layout(W, h.m.nx, h.m.ny, false, sh.tile_slots);
+    std::vector<double> lds(lds_n, std::numeric_limits<double>::quiet_NaN());
     Progress<DX, DY> prog;
     prog.bind(lds.data(), L, W);
     prog.setup(g, false);
     std::vector<YWave<DX, DY, OutT>> ys(W);
     for (int w = 0; w < W; ++w) ys[w].init(h.m, g, field, w, W, lds.data(), L);
     DiagWave<DX, DY> dw;
-    dw.init(h.m, g, lds.data(), L);
+    dw.init(h.m, g, W, lds.data(), L);
     interleave(W + 1, order_mode, info, rng, [&](int w) { return w < W ? ys[w].active : dw.active; },
                [&](int w) { return w < W ? ys[w].ready() : dw.ready(); }, [&](int w) { if (w < W) ys[w].run_unit(); else dw.run_unit(); });
   }
 }
 
 template <typename OutT>
-int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int order_mode, long long* stats) {
+int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, const SimShape& sh, int order_mode, long long* stats) {
   HostMap h;
   build_map(occ, nx, ny, h);
   SimInfo info;
@@ -139,10 +155,10 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
     // rows / columns no quadrant covers read as zero: the workgroup of quadrant 1 stores them
     if (sx > 0) for (int y = 0; y < ny; ++y) field[(size_t)y * nx] = OutT(0);
     if (sy > 0) for (int x = 0; x < nx; ++x) field[x] = OutT(0);
-    run_quadrant<+1, +1>(h, field, sx, sy, W, order_mode, info, rng);
-    run_quadrant<-1, +1>(h, field, sx, sy, W, order_mode, info, rng);
-    run_quadrant<-1, -1>(h, field, sx, sy, W, order_mode, info, rng);
-    run_quadrant<+1, -1>(h, field, sx, sy, W, order_mode, info, rng);
+    run_quadrant<+1, +1>(h, field, sx, sy, sh, order_mode, info, rng);
+    run_quadrant<-1, +1>(h, field, sx, sy, sh, order_mode, info, rng);
+    run_quadrant<-1, -1>(h, field, sx, sy, sh, order_mode, info, rng);
+    run_quadrant<+1, -1>(h, field, sx, sy, sh, order_mode, info, rng);
   }
   if (stats) {
     stats[0] = info.slots;
@@ -159,17 +175,24 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
 extern "C" {
 
 // out: n_src fields of nx*ny elements (dtype 0 = double, 1 = float), pre-filled by the caller (e.g. with NaN, to prove
-// that every cell is written).  W: strips per octant and round (>= 3).  order_mode: 0 round robin forward, 1 backward,
-// 2 shuffled, 3 greedy (a wavefront runs while it is ready), 4 shuffled with random bursts.
+// that every cell is written).  W: sweeping wavefronts of an x-major unit (>= 3); a y-major unit sweeps with 2W - 1 (the
+// launcher's shape: 2W wavefronts per workgroup).  order_mode & 7: 0 round robin forward, 1 backward, 2 shuffled,
+// 3 greedy (a wavefront runs while it is ready), 4 shuffled with random bursts;  order_mode & 8: the flushers run as late
+// as the hand-off allows instead of right at the post;  order_mode & 16: two tile slots (no slack) instead of three.
 // stats (5 entries, may be null): scheduler passes in total, most passes of one workgroup, violations (deadlocks),
 // 16-byte / 8-byte store instructions.
 int vhp_sim_stream_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W,
                          int order_mode, long long* stats) {
   if (!occ || !src || !out || nx <= 0 || ny <= 0 || (nx & 7) != 0 || W < 3 || W > 8) return 1;
-  if (dtype == 0) return run_batch<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), W, order_mode, stats);
-  return run_batch<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), W, order_mode, stats);
+  SimShape sh;
+  sh.Wx = W;
+  sh.Wy = 2 * W - 1;
+  sh.tile_slots = (order_mode & 16) ? 2 : 3;
+  sh.lazy_flush = (order_mode & 8) != 0;
+  if (dtype == 0) return run_batch<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), sh, order_mode & 7, stats);
+  return run_batch<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), sh, order_mode & 7, stats);
 }
 
-int vhp_sim_lds_bytes(int nx, int ny, int W) { return lds_doubles(W, nx, ny) * 8; }
+int vhp_sim_lds_bytes(int nx, int ny, int W, int tile_slots) { return lds_doubles(W, 2 * W - 1, nx, ny, tile_slots) * 8; }
 
 }  // extern "C"

@@ -40,5 +40,9 @@ def sweep(occ, sources, dtype=np.float64, W=4, order=0):
     return out, dict(slots=int(stats[0]), max_slots=int(stats[1]), violations=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]))
 
 
-def lds_bytes(nx, ny, W=4):
-    return load().vhp_sim_lds_bytes(nx, ny, W)
+LAZY_FLUSH = 8   # order flag: the flushers of x-major strips run as late as the hand-off allows
+TWO_SLOTS = 16   # order flag: two tile slots (a plain hand-off) instead of three
+
+
+def lds_bytes(nx, ny, W=4, tile_slots=3):
+    return load().vhp_sim_lds_bytes(nx, ny, W, tile_slots)

@@ -16,10 +16,12 @@ def vhp():
     return vhp_amd
 
 
-def _ctx(vhp, occ):
+def _ctx(vhp, occ, tile_slots=0):
     c = vhp.Context(0)
     c.set_map(occ)
     c.set_option("kernel", 2)
+    if tile_slots:
+        c.set_option("stream_tile_slots", tile_slots)
     return c
 
 
@@ -50,6 +52,17 @@ def test_stream_kernel_bit_exact(vhp, oracle, nx, ny, dtype):
     for k, (sx, sy) in enumerate(src):
         want = oracle.sweep_full(occ, int(sx), int(sy))
         _assert_same(got[k], want if dtype == "f64" else want.astype(np.float32), "%dx%d %s stream, source (%d,%d)" % (nx, ny, dtype, sx, sy))
+
+
+@pytest.mark.parametrize("nx,ny", [(264, 9), (200, 163), (640, 603), (1000, 1000), (1024, 700)])
+def test_stream_kernel_two_tile_slots(vhp, oracle, nx, ny):
+    # the staging tiles of x-major strips with two windows instead of three (what grids above ~2000 cells a side get):
+    # the sweeping wavefront hands every window to its flusher before it starts the next
+    occ = maps.random_rect_map(nx, ny, 30, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 5 + ny)
+    src = _sources(occ, 4, nx + 2 * ny)
+    got = _ctx(vhp, occ, tile_slots=2).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d two-slot stream, source (%d,%d)" % (nx, ny, sx, sy))
 
 
 @pytest.mark.parametrize("nx,ny", [(2048, 1500), (1536, 2600), (4096, 4096)])

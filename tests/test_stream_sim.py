@@ -44,19 +44,22 @@ def test_sim_small_and_ragged_grids(oracle, nx, ny):
     nb = max(3, min(40, nx * ny // 400))
     occ = maps.random_rect_map(nx, ny, nb, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 7 + ny)
     src = _sources(occ, 6, nx + ny)
-    for W, order, dtype in [(4, 0, np.float64), (4, 1, np.float64), (4, 2, np.float32), (8, 3, np.float64), (3, 4, np.float64), (4, 3, np.float64)]:
+    L, T = sim_lib.LAZY_FLUSH, sim_lib.TWO_SLOTS
+    for W, order, dtype in [(4, 0, np.float64), (4, 1 | L, np.float64), (4, 2 | L | T, np.float32), (8, 3, np.float64), (3, 4 | T, np.float64),
+                            (4, 3 | L, np.float64)]:
         _check(oracle, occ, src, W, order, dtype, "%dx%d W=%d order=%d %s" % (nx, ny, W, order, dtype.__name__))
 
 
-@pytest.mark.parametrize("nx,ny,W", [(1000, 1000, 4), (1024, 700, 4), (1016, 520, 8), (2048, 1500, 8)])
+@pytest.mark.parametrize("nx,ny,W", [(1000, 1000, 4), (1024, 700, 4), (1016, 520, 8), (2048, 1500, 8), (2176, 2200, 4)])
 def test_sim_multi_round_grids(oracle, nx, ny, W):
     # several rounds of W strips per octant: the round-to-round boundary rows and the diagonal hand-over at full size
     occ = maps.random_rect_map(nx, ny, 40, 5, nx // 8, 5, ny // 8, nx * 3 + ny)
     src = _sources(occ, 2, ny)[:6]
     # greedy (a wavefront runs ahead for as long as it may) and bursty interleavings: these are what an unguarded
     # buffer reuse fails under
-    _check(oracle, occ, src, W, 3, np.float64, "%dx%d W=%d greedy" % (nx, ny, W))
-    _check(oracle, occ, src[:3], W, 4, np.float64, "%dx%d W=%d bursts" % (nx, ny, W))
+    # (2176 x 2200: the diagonal array of the y-major units wraps, kDiagRing entries)
+    _check(oracle, occ, src, W, 3 | sim_lib.LAZY_FLUSH, np.float64, "%dx%d W=%d greedy, late flushers" % (nx, ny, W))
+    _check(oracle, occ, src[:3], W, 4 | sim_lib.TWO_SLOTS, np.float64, "%dx%d W=%d bursts, two tile slots" % (nx, ny, W))
     _check(oracle, occ, src[:3], 3, 3, np.float64, "%dx%d W=3 greedy" % (nx, ny))
 
 

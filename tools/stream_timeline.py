@@ -27,6 +27,7 @@ out = torch.empty((n, side, side), dtype=torch.float64, device="cuda")
 for _ in range(5):
     c.sweep_batch_device(d_src.data_ptr(), n, out.data_ptr())
 torch.cuda.synchronize()
+assert mod._lib.vhp_debug_clear_wgtime() == 0
 c.timing(True)
 c.sweep_batch_device(d_src.data_ptr(), n, out.data_ptr())
 torch.cuda.synchronize()
@@ -50,7 +51,10 @@ print("duration percentiles us  :", np.percentile(dur[live], [0, 25, 50, 75, 100
 sel = live & (slots >= 10)
 print("us per slot (median over WGs with >= 10 slots):", np.median((dur / np.maximum(slots, 1))[sel]).round(2))
 frac = busy / np.maximum(cyc[:, None], 1)
-print("busy fraction per wavefront (mean over WGs with >= 10 slots): x", frac[sel][:, :4].mean(0).round(2), " y", frac[sel][:, 4:8].mean(0).round(2))
+for o, nm in ((0, "x-major units (waves 0-3 sweep, 4-7 flush)"), (1, "y-major units (waves 0-6 sweep)")):
+    so = sel & (octant == o)
+    if so.any():
+        print("busy fraction per wavefront, %s: %s" % (nm, frac[so].mean(0).round(2)))
 print("cycles per slot (median):", np.median((cyc / np.maximum(slots, 1))[sel]).round(0), " clock MHz ~", np.median((cyc / np.maximum(dur, 1e-3))[sel]).round(0))
 ts = np.linspace(0, end[live].max(), 41)
 conc = [(int(((start <= t) & (end > t) & live).sum())) for t in ts]
@@ -58,7 +62,7 @@ print("resident workgroups over time:", conc)
 print("sum of slots", slots[live].sum(), " sum of WG-us", dur[live].sum().round(0))
 big = np.argsort(-dur)[:8]
 for b in big:
-    print("  long unit %4d (%s): start %.1f dur %.1f us slots %d ni %d nj %d busy x %s y %s" % (b, "xy"[octant[b]], start[b], dur[b], slots[b], ni[b], nj[b], frac[b, :4].round(2), frac[b, 4:8].round(2)))
+    print("  long unit %4d (%s): start %.1f dur %.1f us slots %d ni %d nj %d busy %s" % (b, "xy"[octant[b]], start[b], dur[b], slots[b], ni[b], nj[b], frac[b].round(2)))
 np.save(os.path.join(ROOT, "gpurun_out", "stream_timeline.npy"), w)
 # where the cycles of workgroup 0's wavefronts went (XWave / YWave prof[] of the diagnostic build)
 pr = np.zeros(64, np.uint64)
@@ -66,7 +70,7 @@ if mod._lib.vhp_debug_read_prof(C.c_void_p(pr.ctypes.data)) == 0:
     pr = pr.reshape(8, 8).astype(np.float64)
     for wv in range(8):
         r = pr[wv]
-        print("  WG0 wave %d (%s): loads %.0f  steady windows %.0f  diag/pred windows %.0f  single steps %.0f  flushes %.0f  kcycles; %d windows -> %.0f cycles per window" % (
+        print("  a large unit's wave %d (%s): loads %.0f  steady windows %.0f  diag/pred windows %.0f  single steps %.0f  waits for the flusher %.0f  kcycles; %d windows -> %.0f cycles per window" % (
             wv, "x" if wv < 4 else "y", r[0] / 1e3, r[1] / 1e3, r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5], (r[1] + r[2]) / max(r[5], 1)))
 # who shared a CU with the largest units?
 key = ((w[:, 3] >> 32) << 8) | ((w[:, 3] >> 8) & 0xff)

@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "vhp_create", "vhp_destroy", "vhp_last_error", "vhp_set_stream", "vhp_set_map", "vhp_set_map_device",
     "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
     "vhp_raycast_all", "vhp_timing", "vhp_timing_collect", "vhp_set_option", "vhp_sweep_batch_variant", "vhp_planner_solve_variant",
-    "vhp_planner_solve_device", "vhp_planner_results_device",
+    "vhp_planner_solve_device", "vhp_planner_results_device", "vhp_last_sweep_kernel",
     "vhp_last_elapsed_ms", "vhp_version",
 )
 
@@ -93,6 +93,7 @@ def load_library():
     lib.vhp_timing_collect.argtypes = [vp, vp, i32, C.POINTER(i32)]
     lib.vhp_last_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.vhp_version.restype = C.c_char_p
+    lib.vhp_last_sweep_kernel.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -154,6 +155,10 @@ class Context:
     def set_option(self, key, value):
         """Launch-shape override (include/vhp.h vhp_set_option); 0 / -1 = automatic."""
         self._check(self.lib.vhp_set_option(self.h, key.encode(), int(value)))
+
+    def last_sweep_kernel(self):
+        """1 = front sweep, 2 = streaming sweep: what the last batch sweep launched."""
+        return int(self.lib.vhp_last_sweep_kernel(self.h))
 
     def timing(self, enable=True, prealloc=0):
         """prealloc > 1: event pairs created now, so that launches inside a timed loop create none."""

@@ -59,7 +59,8 @@ struct vhp_ctx {
   int opt_slide = -1;         // 0 / 1: y-major column grid slid onto 128-byte lines
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream)
-  int opt_stream_strips = 0;  // streaming sweep: 0 auto, 4 or 8 strips per octant and round
+  int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep
+  int opt_stream_strips = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
   // dynamic-LDS limit already raised on THIS context's device, per kernel function
   std::vector<std::pair<const void*, size_t>> lds_raised;
 
@@ -245,12 +246,13 @@ bool use_stream_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel == 1) return false;
   if (!vhp::stream_supported(c->nx, c->ny)) return false;
   if (c->opt_kernel == 2) return true;
-  // measured on MI355X, one process (tools/ab_libs.py, profiles/r02_*): the streaming sweep wins by 17-20 % on sides of
-  // 2048 and 4096, is level with the front sweep at 1000^2 from ~200 sources up (-4 % at 256) and loses below that
-  // (a lone large quadrant takes 0.39 ms in it against 0.28 ms: the front sweep's pipeline is 8 steps deep, not 64)
+  // measured on MI355X (tools/ab_libs.py; DESIGN.md "which kernel"): the streaming sweep needs a batch that keeps every
+  // CU pulling units for much longer than its largest unit takes (one full-size octant: 0.2 ms at 1000^2, 4.4 ms at
+  // 4096^2).  256 sources at 1000^2: 0.727 against 0.761 ms; 192: 0.564 / 0.607; 128: level; 96: 0.372 / 0.353.
+  // 128 sources at 2048^2: 1.46 / 1.61 ms, at 4096^2: 5.30 / 6.29 ms; 64 sources: 1.09 / 1.01 and 4.69 / 3.95 ms.
   const int maxdim = std::max(c->nx, c->ny);
-  if (maxdim > 1024) return n_src >= 32;
-  return maxdim > 512 && n_src >= 192;
+  if (maxdim > 1024) return n_src >= 128;
+  return maxdim > 512 && n_src >= 160;
 }
 
 template <typename OutT>
@@ -293,7 +295,11 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
 
 template <typename OutT>
 hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
-  if (use_stream_kernel(c, n_src)) return launch_stream_sweep<OutT>(c, d_src, n_src, d_out);
+  if (use_stream_kernel(c, n_src)) {
+    c->last_kernel = 2;
+    return launch_stream_sweep<OutT>(c, d_src, n_src, d_out);
+  }
+  c->last_kernel = 1;
   int R, W;
   bool multi;
   pick_shape(c, std::max(c->nx, c->ny), &R, &W, &multi, n_src, sizeof(OutT) == 8, (c->nx & 7) == 0);
@@ -652,11 +658,13 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "multi_round") { ctx->opt_multi = v != 0; }
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
-  else if (k == "stream_strips") { if (v != 0 && v != 4 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_strips: 0, 4 or 8"); ctx->opt_stream_strips = v; }
+  else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2 or 3"); ctx->opt_stream_strips = v; }
   else if (k == "kernel") { if (v < 0 || v > 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream"); ctx->opt_kernel = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;
 }
+
+int vhp_last_sweep_kernel(const vhp_ctx* ctx) { return ctx ? ctx->last_kernel : 0; }
 
 int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n) {
   if (!ctx || !n || cap < 0 || (cap > 0 && !ms_out)) return VHP_ERR_ARG;

@@ -142,6 +142,8 @@ inline int uniform(int x) { return x; }
 // release: everything this wavefront has written to LDS becomes visible, then the progress word
 inline void lds_publish(volatile int* word, int value) { *word = value; }
 inline void lds_acquire() {}
+inline void lds_post(int* d, int a, int b, int c) { d[0] = a; d[1] = b; d[2] = c; }
+inline void backoff() {}
 
 #else
 // ------------------------------------------------------------------------------------------------------------
@@ -257,6 +259,11 @@ VHP_LANE_FN void lds_publish(volatile int* word, int value) {
   if ((threadIdx.x & 63u) == 0) *word = value;
   asm volatile("" ::: "memory");
 }
+// three uniform words for another wavefront (published by a later lds_publish)
+VHP_LANE_FN void lds_post(int* d, int a, int b, int c) {
+  if ((threadIdx.x & 63u) == 0) { d[0] = a; d[1] = b; d[2] = c; }
+}
+VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(1); }
 // acquire: the poll's value has arrived (the branch on it waited for lgkmcnt); later LDS reads are issued after it, in order
 VHP_LANE_FN void lds_acquire() {
   asm volatile("" ::: "memory");

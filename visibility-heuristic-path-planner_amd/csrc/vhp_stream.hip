@@ -20,14 +20,16 @@ __device__ unsigned long long g_prof[8 * 8];  // per wavefront of workgroup 0: t
 #define VHP_WG_STAMP(var)
 #endif
 
-// One unit: the x-major (OCT == 0) or the y-major (OCT == 1) octant of one quadrant, swept by the workgroup.
-template <int DX, int DY, int OCT, typename OutT>
-__device__ __forceinline__ void run_octant(const Map& m, OutT* field, int sx, int sy, int W, double* lds, int slot) {
+// One unit: the x-major (OCT == 0) or the y-major (OCT == 1) octant of one quadrant, swept by the workgroup of 2*WX
+// wavefronts: WX sweeping wavefronts and their WX flushers, or 2*WX - 1 sweeping wavefronts and the DiagWave.
+template <int DX, int DY, int OCT, int WX, typename OutT>
+__device__ __forceinline__ void run_octant(const Map& m, OutT* field, int sx, int sy, int tile_slots, double* lds, int slot) {
   (void)slot;
+  constexpr int W = OCT == 0 ? WX : 2 * WX - 1;
   Quad<DX, DY> g;
   g.init(m.nx, m.ny, sx, sy);
   if (g.empty() || (OCT == 1 && g.Py == 0)) return;  // uniform for the workgroup
-  const Layout L = make_layout(W, m.nx, m.ny, OCT == 0);
+  const Layout L = make_layout(W, m.nx, m.ny, OCT == 0, tile_slots);
   {
     Progress<DX, DY> prog;
     prog.bind(lds, L, W);
@@ -54,10 +56,25 @@ __device__ __forceinline__ void run_octant(const Map& m, OutT* field, int sx, in
         ++units;
 #endif
       }
+      xw.finish();
 #ifdef VHP_EXP_WGTIME
-      if (slot == 0 && (threadIdx.x & 63) == 0)
+      if (slot < 8 && (threadIdx.x & 63) == 0)
         for (int k = 0; k < 6; ++k) g_prof[wave * 8 + k] = xw.prof[k];
 #endif
+    } else {
+      XWave<DX, DY, OutT> fw;
+      fw.init_flusher(m, g, field, wave - W, W, lds, L);
+#ifdef VHP_EXP_PRIO
+      __builtin_amdgcn_s_setprio(3);
+#endif
+      for (;;) {
+        VHP_WG_STAMP(c0);
+        if (!fw.drain_one()) break;
+#ifdef VHP_EXP_WGTIME
+        busy += __builtin_readcyclecounter() - c0;  // (includes the wait for the descriptor)
+        ++units;
+#endif
+      }
     }
   } else {
     if (wave < W) {
@@ -74,13 +91,17 @@ __device__ __forceinline__ void run_octant(const Map& m, OutT* field, int sx, in
 #endif
       }
 #ifdef VHP_EXP_WGTIME
-      if (slot == 1 && (threadIdx.x & 63) == 0)
+      if (slot < 8 && wave < 4 && (threadIdx.x & 63) == 0)
         for (int k = 0; k < 6; ++k) g_prof[(4 + wave) * 8 + k] = yw.prof[k];
 #endif
-    } else if (wave == W) {
+    } else {
       DiagWave<DX, DY> dw;
-      dw.init(m, g, lds, L);
-      while (dw.active) dw.run_unit();
+      dw.init(m, g, W, lds, L);
+      while (dw.active) {
+        while (!dw.ready()) __builtin_amdgcn_s_sleep(8);
+        lds_acquire();
+        dw.run_unit();
+      }
     }
   }
 #ifdef VHP_EXP_WGTIME
@@ -96,50 +117,42 @@ __device__ __forceinline__ void run_octant(const Map& m, OutT* field, int sx, in
       wv[3] = ((unsigned long long)xcc << 32) | hwid;
       wv[4] = __builtin_readcyclecounter() - c_begin;
     }
-    if (wave < W) wv[8 + (OCT ? 4 : 0) + (wave & 3)] = busy;
+    wv[8 + (wave & 7)] = busy;
   }
 #endif
 }
 
-// Persistent workgroups: the grid is as many workgroups as the chip holds at once (LDS-limited: two 8-wavefront ones per
-// CU at 1000^2), and each takes the next unit -- one quadrant of one source, largest first -- from a global queue until
-// the queue is empty.  A CU's store path moves only ~8-10 bytes per clock, and a full-size quadrant is 8 MB = 1/256 of a
-// 256-source batch, i.e. a CU's whole fair share: with one workgroup per unit, dealt out in launch order, the CUs that
-// happened to get two large quadrants set the length of the launch.  Pulling balances the bytes per CU by itself: a
-// workgroup busy with a large quadrant simply pulls nothing else.
-// dynamic LDS = make_layout(W, nx, ny).total doubles.
-template <typename OutT, int W>
-__global__ void __launch_bounds__(64 * (W + 1), 4)
+// Persistent workgroups: the grid is as many workgroups as the chip holds at once (two 8-wavefront ones per CU: LDS and
+// registers), and each takes the next unit -- one octant of one quadrant of one source -- from a global queue until the
+// queue is empty.  A CU's store path moves only ~9 bytes per clock and a full-size octant is 4 MB, half of a CU's fair
+// share of a 256-source batch: with one workgroup per unit, dealt out in launch order, the CUs that happened to get
+// several large octants set the length of the launch.  Pulling balances the bytes per CU by itself: a workgroup busy with
+// a large octant simply pulls nothing else.
+// dynamic LDS = lds_doubles(WX, 2*WX - 1, nx, ny, tile_slots) doubles.
+template <typename OutT, int WX>
+__global__ void __launch_bounds__(128 * WX, 2)
 vhp_stream_sweep(Map m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride, int* __restrict__ err_flag,
-                 const int* __restrict__ order, unsigned long long* __restrict__ queue, int* __restrict__ cu_slots, int n_units) {
+                 const int* __restrict__ order, unsigned long long* __restrict__ queue, int* __restrict__ cu_slots, int n_units,
+                 int tile_slots) {
   extern __shared__ double lds[];
   __shared__ int next_unit;
-  // Two workgroups share a CU.  The first to arrive on a CU pulls from the head of the queue (largest quadrants first),
+  // Two workgroups share a CU.  The first to arrive on a CU pulls from the head of the queue (largest units first),
   // the second from its tail (smallest first), until the two ends meet: every CU then carries one stream of large
-  // quadrants and one of small ones, instead of some CUs starting with two of the largest.  `queue` packs both ends in
+  // units and one of small ones, instead of some CUs starting with two of the largest (which share that CU's store
+  // path: measured 0.78 ms with every workgroup pulling from the head, 0.73 ms this way, 256 sources on 1000^2).  `queue` packs both ends in
   // one word (low half: units taken from the head, high half: from the tail) so that a pull sees both consistently.
   __shared__ int from_tail;
-  __shared__ int cu_key;
   if (threadIdx.x == 0) {
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const unsigned key = (((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu)) & (kCuSlots - 1);  // XCC | SE, SH, CU of this workgroup
-    cu_key = (int)key;
     from_tail = atomicAdd(&cu_slots[key], 1) & 1;
   }
   __syncthreads();
   const bool tail = from_tail != 0;
-  // cu_slots[kCuSlots + key]: the head workgroup of this CU is sweeping a very large quadrant.  Such a quadrant sets the
-  // length of the launch, and it runs 1.6x slower with a neighbour on its CU (they share the CU's store path): the tail
-  // workgroup of that CU waits it out instead of pulling.
-  int* big_flag = cu_slots + kCuSlots + cu_key;
   for (;;) {
     if (threadIdx.x == 0) {
-      if (tail) {
-        int spins = 0;
-        while (__hip_atomic_load(big_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(32);
-      }
       const unsigned long long old = atomicAdd(queue, tail ? (1ull << 32) : 1ull);
       const unsigned h = (unsigned)old, t = (unsigned)(old >> 32);
       next_unit = (h + t >= (unsigned)n_units) ? n_units : (tail ? n_units - 1 - (int)t : (int)h);
@@ -149,15 +162,11 @@ vhp_stream_sweep(Map m, const int32_t* __restrict__ src_xy, OutT* __restrict__ o
     if (slot >= n_units) return;
     const int unit = order ? order[slot] : slot;
     const int s = unit / kUnits, qo = unit - s * kUnits;
-    const int q = qo >> 1;
     const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
     if (sx < 0 || sy < 0 || sx >= m.nx || sy >= m.ny) {
       if (threadIdx.x == 0 && qo == 0) atomicOr(err_flag, 1);
     } else {
       OutT* field = out + (size_t)s * field_stride;
-      const long ni_ = (q == 0 || q == 3) ? m.nx - sx : sx, nj_ = q < 2 ? m.ny - sy : sy;
-      const bool very_large = !tail && 20 * ni_ * nj_ >= 13 * (long)m.nx * m.ny;  // >= 0.65 of the grid
-      if (very_large && threadIdx.x == 0) __hip_atomic_store(big_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (qo == 0) {
         // rows/columns no quadrant covers read as zero; the x-major unit of quadrant 1 always exists
         if (sx > 0)
@@ -166,16 +175,15 @@ vhp_stream_sweep(Map m, const int32_t* __restrict__ src_xy, OutT* __restrict__ o
           for (int x = threadIdx.x; x < m.nx; x += blockDim.x) field[x] = OutT(0);
       }
       switch (qo) {
-        case 0: run_octant<+1, +1, 0>(m, field, sx, sy, W, lds, slot); break;
-        case 1: run_octant<+1, +1, 1>(m, field, sx, sy, W, lds, slot); break;
-        case 2: run_octant<-1, +1, 0>(m, field, sx, sy, W, lds, slot); break;
-        case 3: run_octant<-1, +1, 1>(m, field, sx, sy, W, lds, slot); break;
-        case 4: run_octant<-1, -1, 0>(m, field, sx, sy, W, lds, slot); break;
-        case 5: run_octant<-1, -1, 1>(m, field, sx, sy, W, lds, slot); break;
-        case 6: run_octant<+1, -1, 0>(m, field, sx, sy, W, lds, slot); break;
-        default: run_octant<+1, -1, 1>(m, field, sx, sy, W, lds, slot); break;
+        case 0: run_octant<+1, +1, 0, WX>(m, field, sx, sy, tile_slots, lds, slot); break;
+        case 1: run_octant<+1, +1, 1, WX>(m, field, sx, sy, tile_slots, lds, slot); break;
+        case 2: run_octant<-1, +1, 0, WX>(m, field, sx, sy, tile_slots, lds, slot); break;
+        case 3: run_octant<-1, +1, 1, WX>(m, field, sx, sy, tile_slots, lds, slot); break;
+        case 4: run_octant<-1, -1, 0, WX>(m, field, sx, sy, tile_slots, lds, slot); break;
+        case 5: run_octant<-1, -1, 1, WX>(m, field, sx, sy, tile_slots, lds, slot); break;
+        case 6: run_octant<+1, -1, 0, WX>(m, field, sx, sy, tile_slots, lds, slot); break;
+        default: run_octant<+1, -1, 1, WX>(m, field, sx, sy, tile_slots, lds, slot); break;
       }
-      if (very_large && threadIdx.x == 0) __hip_atomic_store(big_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();  // every wavefront is through with this unit's LDS before the next unit's setup
   }
@@ -239,13 +247,18 @@ __global__ void __launch_bounds__(1024) vhp_stream_order(const int32_t* __restri
 
 namespace {
 constexpr size_t kLdsLimit = 160 * 1024;
-size_t lds_bytes(int nx, int ny, int W) { return (size_t)stream::lds_doubles(W, nx, ny) * sizeof(double); }
+constexpr int kWX = 4;  // sweeping wavefronts of an x-major unit; a workgroup is 2 * kWX wavefronts
+size_t lds_bytes(int nx, int ny, int tile_slots) { return (size_t)stream::lds_doubles(kWX, 2 * kWX - 1, nx, ny, tile_slots) * sizeof(double); }
+// three tile slots (a window of slack for the flushers) where two workgroups still fit a CU's LDS, else two
+int pick_tile_slots(int nx, int ny) { return 2 * lds_bytes(nx, ny, 3) <= kLdsLimit ? 3 : 2; }
 
-template <typename OutT, int W>
+template <typename OutT>
 hipError_t launch_t(const StreamArgs& a) {
   using namespace stream;
-  auto k = vhp_stream_sweep<OutT, W>;
-  const size_t lds = lds_bytes(a.nx, a.ny, W);
+  auto k = vhp_stream_sweep<OutT, kWX>;
+  const int tile_slots = (a.force_strips == 2 || a.force_strips == 3) ? a.force_strips : pick_tile_slots(a.nx, a.ny);
+  const size_t lds = lds_bytes(a.nx, a.ny, tile_slots);
+  if (lds > kLdsLimit) return hipErrorInvalidValue;
   if (a.raise_lds) {
     hipError_t e = a.raise_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return e;
@@ -260,13 +273,12 @@ hipError_t launch_t(const StreamArgs& a) {
   hipLaunchKernelGGL(vhp_stream_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, ord, queue, cu_slots);
   const int n_units = a.n_src * kUnits;
   int per_cu = (int)(kLdsLimit / lds);
-  if (per_cu < 1) per_cu = 1;
-  if (per_cu * (W + 1) > 16) per_cu = 16 / (W + 1);  // a workgroup is W + 1 wavefronts (W sweep + the DiagWave of y-major units); 4 per SIMD
+  if (per_cu > 2) per_cu = 2;  // 16 wavefronts per CU: 128 vector registers each
   const int resident = per_cu * a.n_cus;
   const int grid = n_units < resident ? n_units : resident;
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * (W + 1)), lds, a.stream, m, a.d_src, static_cast<OutT*>(a.d_out), a.field_stride,
-                     a.d_err, (const int*)ord, queue, cu_slots, n_units);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(128 * kWX), lds, a.stream, m, a.d_src, static_cast<OutT*>(a.d_out), a.field_stride,
+                     a.d_err, (const int*)ord, queue, cu_slots, n_units, tile_slots);
   const hipError_t e = hipGetLastError();
   if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
   return e;
@@ -277,6 +289,14 @@ hipError_t launch_t(const StreamArgs& a) {
 extern "C" int vhp_debug_read_wgtime(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(stream::g_wgtime), (size_t)n_words * 8);
 }
+extern "C" int vhp_debug_clear_wgtime() {
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(stream::g_wgtime));
+  if (e != hipSuccess) return (int)e;
+  e = hipMemset(p, 0, sizeof(stream::g_wgtime));
+  if (e != hipSuccess) return (int)e;
+  return (int)hipDeviceSynchronize();
+}
 extern "C" int vhp_debug_read_prof(unsigned long long* dst) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(stream::g_prof), 64 * 8);
 }
@@ -284,19 +304,17 @@ extern "C" int vhp_debug_read_prof(unsigned long long* dst) {
 
 size_t stream_queue_bytes(int n_src) { return (size_t)(2 + 2 * stream::kCuSlots + stream::kUnits * (size_t)n_src) * sizeof(int); }
 
+// sweeping wavefronts per x-major unit, or 0 if the grid is not one the streaming kernel takes
 int stream_strips(int nx, int ny) {
   if (nx <= 0 || ny <= 0 || (nx & 7) != 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return 0;
-  if (lds_bytes(nx, ny, 4) <= kLdsLimit) return 4;  // 8-wavefront workgroups: three per CU at 1000^2, two at 4096^2
+  if (lds_bytes(nx, ny, 2) <= kLdsLimit) return kWX;
   return 0;
 }
 bool stream_supported(int nx, int ny) { return stream_strips(nx, ny) != 0; }
 
 hipError_t launch_stream(const StreamArgs& a) {
-  int W = stream_strips(a.nx, a.ny);
-  if (W == 0) return hipErrorInvalidValue;
-  if ((a.force_strips == 4 || a.force_strips == 8) && lds_bytes(a.nx, a.ny, a.force_strips) <= kLdsLimit) W = a.force_strips;
-  if (a.dtype == VHP_F64) return W == 4 ? launch_t<double, 4>(a) : launch_t<double, 8>(a);
-  return W == 4 ? launch_t<float, 4>(a) : launch_t<float, 8>(a);
+  if (stream_strips(a.nx, a.ny) == 0) return hipErrorInvalidValue;
+  return a.dtype == VHP_F64 ? launch_t<double>(a) : launch_t<float>(a);
 }
 
 }  // namespace vhp

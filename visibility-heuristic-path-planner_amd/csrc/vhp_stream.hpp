@@ -62,7 +62,8 @@ using namespace vhp::lanes;
 constexpr int kBlock = 64;       // steps per slot: one word of the packed occupancy maps
 constexpr int kRing = 256;       // entries of a strip-to-strip boundary ring: four blocks, indexed by the absolute marching coordinate
                                  // (the reader of block n also needs the last entry of block n-1 while the writer is in block n+1)
-constexpr int kTileStride = 17;  // doubles per tile row: 16 staged columns + 1 (spreads the column writes over the LDS banks)
+constexpr int kDiagRing = 2048;  // entries of the diagonal array of a y-major unit (a ring on grids larger than that)
+constexpr int kDescRing = 8;     // flush descriptors in flight between an x-major wavefront and its flusher
 constexpr int kXRows = 64;       // rows per x-major strip (one per lane)
 constexpr int kYCols = 128;      // columns per y-major strip (two per lane)
 constexpr int kMaxStrips = 136;  // 8192 / 64 + slack
@@ -88,29 +89,35 @@ struct Layout {
   int diag;              // y-major units: diag(k), k = quadrant-local index, written by the DiagWave
   int dummy;             // 8 doubles per wavefront: where lanes that are not the boundary lane "write" theirs
   int slab;              // 64 doubles per wavefront (+ the DiagWave): the reciprocals of the block it sweeps
-  int tiles;             // x-major units: W staging tiles of kXRows * kTileStride
-  int sched;             // ints: done[16] (units finished per wavefront; [15] = diagonal entries ready), then base[strips]
+  int tiles;             // x-major units: W staging tiles of kXRows rows, tile_slots windows of 8 columns (+1 double) per row
+  int tile_slots;        // 2: a 128-byte line exactly; 3: one window of slack between the sweeping wavefront and its flusher
+  int sched;             // ints: the progress words (kDoneSlots), base[strips], then W rings of kDescRing flush descriptors
   int strips;            // capacity of the base array: the most strips an octant of this grid can have
   int total;
   int round_mask;
 };
-VHP_HD Layout make_layout(int W, int nx, int ny, bool x_major) {
+constexpr int kDoneSlots = 32;
+// W = sweeping wavefronts of this kind of unit (x-major and y-major units of one launch may differ)
+VHP_HD Layout make_layout(int W, int nx, int ny, bool x_major, int tile_slots) {
   Layout L;
   const int rr = next_pow2(x_major ? nx : ny);
   int o = 0;
   L.ring = o; o += W * kRing;
   L.round = o; o += rr;
-  L.diag = o; if (!x_major) o += imax(nx, ny) + 72;
+  L.diag = o; if (!x_major) o += imin(imax(nx, ny) + 72, kDiagRing);
   L.dummy = o; o += (W + 1) * 8;
   L.slab = o; o += (W + 1) * kBlock;
-  L.tiles = o; if (x_major) o += W * kXRows * kTileStride;
+  L.tile_slots = tile_slots;
+  L.tiles = o; if (x_major) o += W * kXRows * (8 * tile_slots + 1);
   L.strips = (imin(nx, ny) + kXRows - 1) / kXRows + 2;
-  L.sched = o; o += (16 + L.strips) / 2 + 1;
+  L.sched = o; o += (kDoneSlots + L.strips + (x_major ? W * kDescRing * 4 : 0)) / 2 + 1;
   L.total = o;
   L.round_mask = rr - 1;
   return L;
 }
-VHP_HD int lds_doubles(int W, int nx, int ny) { return imax(make_layout(W, nx, ny, true).total, make_layout(W, nx, ny, false).total); }
+VHP_HD int lds_doubles(int Wx, int Wy, int nx, int ny, int tile_slots) {
+  return imax(make_layout(Wx, nx, ny, true, tile_slots).total, make_layout(Wy, nx, ny, false, tile_slots).total);
+}
 
 // Geometry of one quadrant.  x = sx + DX*i, y = sy + DY*j; negative directions stop one cell short of the border
 // (solver.cpp:607-610,638-642).
@@ -160,11 +167,12 @@ struct Quad {
 
 // Progress bookkeeping of a workgroup (ints in LDS at Layout::sched):
 //   done[0..W-1]   units (strip, block) the sweeping wavefronts have finished;
-//   done[15]       y-major units: diagonal entries diag(0 .. done[15]-1) are in the LDS array (DiagWave);
+//   done[8+w]      x-major units: flush descriptors wavefront w has posted;  done[16+w]: descriptors its flusher has read
+//                  out of the tile (the columns they covered may be overwritten);
+//   done[31]       y-major units: diagonal entries diag(0 .. done[31]-1) have been produced (DiagWave);
 //   base[p]        index of strip p's first block in the unit sequence of its wavefront (p % W): the wavefront has
 //                  finished block n of strip p once done >= base[p] + (n - first block of p) + 1.
-constexpr int kDoneSlots = 16;
-constexpr int kDiagDoneSlot = 15;
+constexpr int kPostedSlot = 8, kDrainedSlot = 16, kDiagDoneSlot = 31;
 template <int DX, int DY>
 struct Progress {
   volatile int* done;
@@ -177,6 +185,7 @@ struct Progress {
     base = p + kDoneSlots;
     W = W_;
   }
+  VHP_FN int* descriptors(const Layout& L, int w) const { return base + L.strips + w * (kDescRing * 4); }
   // run by one thread before any wavefront starts
   VHP_FN void setup(const Quad<DX, DY>& g, bool x_major) {
     for (int k = 0; k < kDoneSlots; ++k) done[k] = 0;
@@ -210,7 +219,17 @@ struct Progress {
 
 // ---------------------------------------------------------------------------------------------------------------
 // x-major wavefront: strips p = w, w+W, ...; rows j = 64p + lane; steps i = 64p .. ni-1; cells (i, j), j <= i.
+//
+// The field leaves through a second wavefront, the strip's FLUSHER.  The sweeping wavefront only computes: it writes
+// its column of 64 values into the wave-private tile every step and, whenever a window of 8 columns completes 128-byte
+// lines, posts a four-word descriptor (which line, which rows, how far the march is) in an LDS ring.  The flusher reads
+// the lines out of the tile and stores them, 8 rows per instruction.  A store instruction stalls the wavefront that
+// issues it for some 300 cycles when the CU's store path is busy -- which in this kernel is always -- and the march of
+// an x-major strip is one dependent chain of ~140 cycles per window of 8 steps: with the stores in line, the largest
+// octants ran at a third of their compute speed and set the length of the launch.  The tile has three windows of 8
+// columns (when the LDS allows: make_layout), so the flusher may lag one window behind; with two it is a plain hand-off.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kDescPred = 1 << 17, kDescExit = 1 << 18;
 template <int DX, int DY, typename OutT>
 struct XWave {
   static constexpr int CB = sizeof(OutT);
@@ -220,6 +239,7 @@ struct XWave {
   OutT* out;
   int w, W;
   double* tile;
+  int nslots, tstride;  // windows of 8 columns per tile row; doubles per tile row (8*nslots + 1: spreads the column writes over the banks)
   double* ring_base;
   double* round;
   int round_mask;
@@ -235,41 +255,75 @@ struct XWave {
   int rin_mask;
   double* rout;
   int rout_mask;
+  // the hand-off to the flusher
+  volatile int* posted_w;
+  volatile int* drained_w;
+  int* desc;
+  int posted;       // sweeping side: descriptors posted so far ...
+  int posted_prev;  // ... and when the window before the current one was entered
+  int cur_win;      // x >> 3 of the window being swept
+  int drained;      // flusher side: descriptors read out of the tile
+  int pf_blk;       // the block (x >> 6) whose operands wait in ow_nx / rv_nx, or -1
+#ifdef VHP_SIM
+  XWave* flusher;   // the simulator runs the flusher inside the sweeping wavefront's calls:
+  bool lazy;        // as late as the protocol allows (only when the sweeping side has to wait), or right at the post
+#endif
   // lanes
   vi lane;
-  VHP_PROF_DECL     // [0] block-start loads, [1] steady windows, [2] diagonal windows, [3] single steps, [4] flushes, [5] windows
-  vi tile_l;        // lane * kTileStride
-  vi fl_t0, fl_d8;  // flush: tile index of the lane's piece for a line that starts at x % 16 == 0 (row slot 0 .. 7), and what
-                    // a line that starts at x % 16 == 8 adds to it
+  VHP_PROF_DECL     // [0] block-start loads, [1] steady windows, [2] diagonal windows, [3] single steps, [4] waits for the flusher, [5] windows
+  vi tile_l;        // lane * tstride
+  vi fl_t0, fl_hi;  // flush: tile index of the lane's piece in tile slot 0 (row slot 0 .. 7), and whether the piece lies in the
+                    // second window of its line
   vu32 fl_off;      // flush: byte offset of the lane's piece from the lowest row of a store instruction, for xa = 0
   vd prev, jd;
-  vu64 ow;
+  vu64 ow, ow_nx;
+  vd rv_nx;
 
-  VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
+  VHP_FN void init_common(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
     m = m_; g = g_; out = out_; w = w_; W = W_;
-    tile = lds + L.tiles + w * kXRows * kTileStride;
+    nslots = L.tile_slots;
+    tstride = 8 * nslots + 1;
+    tile = lds + L.tiles + w * kXRows * tstride;
     ring_base = lds + L.ring;
     round = lds + L.round;
     round_mask = L.round_mask;
     slab = lds + L.slab + w * kBlock;
     dummy = lds + L.dummy + w * 8;
     prog.bind(lds, L, W);
+    posted_w = prog.done + kPostedSlot + w;
+    drained_w = prog.done + kDrainedSlot + w;
+    desc = prog.descriptors(L, w);
+    posted = posted_prev = drained = 0;
+    cur_win = -1;
+    pf_blk = -1;
     r_stride = ((m.nx >> 3) & 1) ? 2 : 1;
     lane = lane_id();
-    tile_l = lane * kTileStride;
+    tile_l = lane * tstride;
     {
       // flush geometry: lane -> (row slot = lane >> 3, piece = lane & 7 = cells xa + 2*piece, +1); the row slots of a
       // store instruction are counted upward in y, so that byte offsets from its lowest row are never negative
       const vi rslot = lane >> 3, pc = lane & 7;
       const vi rs = DY > 0 ? rslot : 7 - rslot;
-      fl_t0 = rslot * (r_stride * kTileStride) + pc * 2;
-      fl_d8 = ((pc * 2) ^ 8) - pc * 2;
+      fl_t0 = rslot * (r_stride * tstride) + ((pc * 2) & 7);
+      fl_hi = pc >> 2;
       fl_off = to_u32((rs * (r_stride * m.nx) + pc * 2) * CB);
     }
     active = true;
     my_done = 0;
+    j0 = 0;
+    rows_here = 0;
+  }
+  // the sweeping wavefront w of an x-major unit
+  VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
+    init_common(m_, g_, out_, w_, W_, lds, L);
     load_strip(w);
   }
+  // the flusher of sweeping wavefront w
+  VHP_FN void init_flusher(const Map& m_, const Quad<DX, DY>& g_, OutT* out_, int w_, int W_, double* lds, const Layout& L) {
+    init_common(m_, g_, out_, w_, W_, lds, L);
+  }
+
+  VHP_FN int slot_of(int win) const { return nslots == 3 ? win % 3 : win & 1; }  // win >= 0
 
   VHP_FN void load_strip(int pn) {
     p = pn;
@@ -283,6 +337,10 @@ struct XWave {
     jd = to_f64(lane + j0);
     if (p % W == 0) { rin = round; rin_mask = round_mask; } else { rin = ring_base + (w - 1) * kRing; rin_mask = kRing - 1; }
     if ((p + 1) % W == 0) { rout = round; rout_mask = round_mask; } else { rout = ring_base + w * kRing; rout_mask = kRing - 1; }
+    // a new strip starts anywhere in the tile: everything posted has to be out first
+    cur_win = -1;
+    posted_prev = posted;
+    pf_blk = -1;
   }
 
   // May the next unit (strip p, block n) run?  Everything it reads from other wavefronts has been produced, and
@@ -316,17 +374,64 @@ struct XWave {
     if (last) load_strip(p + W); else ++n;
   }
 
-  // Emits one 128-byte line (16 cells from xa on; for fp32 fields that is one 64-byte sector) of the rows
-  // r = r_first, r_first + r_stride, ... of this strip from the tile, 8 rows per store instruction.  PRED: only the
-  // cells the march has reached and that belong to the octant (step index i' with j <= i' <= i_now) are stored.
+  // ---- sweeping side of the hand-off ----
+  // One 128-byte line (16 cells from xa on; for fp32 fields one 64-byte sector) of the rows r_first, r_first + r_stride, ...
+  // of this strip is complete in the tile (flags & kDescPred: only in part -- the cells with step index j <= i' <= i_now).
+  VHP_FN void post(int xa, int r_first, int i_now, int flags) {
+    int* d = desc + (posted & (kDescRing - 1)) * 4;
+    lds_post(d, (xa + 16) | (r_first << 16) | flags, i_now, j0 | (rows_here << 16));
+    ++posted;
+    lds_publish(posted_w, posted);
+#ifdef VHP_SIM
+    if (!lazy) flusher->drain_one();
+#endif
+  }
+  VHP_FN void wait_drained(int need) {
+#ifdef VHP_SIM
+    while (*drained_w < need) flusher->drain_one();
+#else
+    while (uniform(*drained_w) < need) backoff();
+    lds_acquire();
+#endif
+  }
+  // the sweeping wavefront has no strip left: its flusher may leave too
+  VHP_FN void finish() {
+    post(0, 0, 0, kDescExit);
+#ifdef VHP_SIM
+    while (flusher->drain_one()) {}
+#endif
+  }
+
+  // ---- flusher side ----
+  // takes the next descriptor (waiting for it) and stores its lines; false once the sweeping wavefront has left
+  VHP_FN bool drain_one() {
+#ifndef VHP_SIM
+    while (uniform(*posted_w) <= drained) backoff();
+    lds_acquire();
+#endif
+    const volatile int* d = desc + (drained & (kDescRing - 1)) * 4;
+    const int d0 = uniform(d[0]), i_now = uniform(d[1]), d2 = uniform(d[2]);
+    if (d0 & kDescExit) return false;
+    j0 = d2 & 0xffff;
+    rows_here = d2 >> 16;
+    const int xa = (d0 & 0xffff) - 16, r_first = (d0 >> 16) & 1;
+    if (d0 & kDescPred) flush<true>(xa, r_first, i_now); else flush<false>(xa, r_first, i_now);
+    ++drained;
+    lds_publish(drained_w, drained);  // (the tile reads above were issued before this write: the LDS keeps the order)
+    return true;
+  }
+
+  // Emits one line of the rows r = r_first, r_first + r_stride, ... of strip j0 from the tile, 8 rows per store instruction.
   template <bool PRED>
   VHP_FN void flush(int xa, int r_first, int i_now) {
     wave_sync();
-    // (arithmetic, not a select between the two members: a select of two loads becomes a load through a selected
-    // address, which keeps the whole wavefront object in scratch memory)
-    const vi t0 = fl_t0 + fl_d8 * ((xa >> 3) & 1) + r_first * kTileStride;
+    const int win = (xa >> 3) + 6;  // (xa may be -8 at the end of a march; 6 is a multiple of both slot counts)
+    const int sA = slot_of(win), sB = slot_of(win + 1);
+    // (arithmetic, not a select between members: a select of two loads becomes a load through a selected address, which
+    // keeps the whole wavefront object in scratch memory)
+    const vi t0 = fl_t0 + fl_hi * (8 * (sB - sA)) + (8 * sA + r_first * tstride);
     const vu32 off = fl_off + (uint32_t)(xa * CB);
-    const int t_step = 8 * r_stride * kTileStride;  // per store instruction: 8 row slots further
+    const int t_step = 8 * r_stride * tstride;  // per store instruction: 8 row slots further
     const long y_low = DY > 0 ? g.Y(j0 + r_first) : g.Y(j0 + r_first + 7 * r_stride);
     OutT* base = out + y_low * (long)m.nx;          // uniform: the row term lives in scalar registers
     const long base_step = (long)(8 * r_stride * DY) * m.nx;
@@ -376,7 +481,7 @@ struct XWave {
     } else {
       r_first = (hbit ^ g.sy ^ j0) & 1;  // rows with (y & 1) == hbit
     }
-    if (steady) flush<false>(xa, r_first, i_now); else flush<true>(xa, r_first, i_now);
+    post(xa, r_first, i_now, steady ? 0 : kDescPred);
   }
 
   // the march of this strip is over: what is still in the tile leaves as partial lines
@@ -384,11 +489,11 @@ struct XWave {
     const int i_now = g.ni - 1;
     const int xe = g.X(i_now);
     if (r_stride == 1) {
-      flush<true>(xe & ~15, 0, i_now);
+      post(xe & ~15, 0, i_now, kDescPred);
     } else {
       for (int ph = 0; ph < 2; ++ph) {  // rows whose lines start at x % 16 == 8*ph
         const int xa = 8 * ph + (((xe - 8 * ph) >> 4) << 4);
-        flush<true>(xa, (ph ^ g.sy ^ j0) & 1, i_now);
+        post(xa, (ph ^ g.sy ^ j0) & 1, i_now, kDescPred);
       }
     }
   }
@@ -412,7 +517,7 @@ struct XWave {
       v = select(isd, dcell, v);
     }
     prev = v;
-    lds_store(tile, tile_l + (x & 15), v);
+    lds_store(tile, tile_l + (slot_of(x >> 3) * 8 + (x & 7)), v);
     if (has_consumer) lds_store_if(lane == 63, rout, vi(x & rout_mask), v);
   }
 
@@ -438,7 +543,7 @@ struct XWave {
       for (int k = 1; k < 9; ++k) rb[k] = lds_bcast(rin, xb + (DX > 0 ? k - 1 : 8 - k));
     }
     const vu32 hs = half_shifted(ow, t0, DX > 0 ? (t0 & 31) : (t0 & 31) - 7);  // step k's bit at position (x & 7)
-    const vi tidx = tile_l + (xw & 15);
+    const vi tidx = tile_l + slot_of(xw >> 3) * 8;
     // every lane writes "its boundary value" each step -- lane 63 into the ring, the others into a dummy slot: one
     // ds_write instead of an exec-masked region per step
     double* wbase = has_consumer ? rout + (xw & rout_mask) : dummy;
@@ -463,6 +568,15 @@ struct XWave {
     }
   }
 
+  // the occupancy word of every lane's row and the reciprocals of the 64 step indices of block blk (x >> 6)
+  VHP_FN void load_block(int blk, vu64& o, vd& rv) {
+    const vi yl = (vmin(lane + j0, g.rows_total - 1)) * DY + g.sy;
+    o = g_load_u64(m.rows, yl * m.wpr + (1 + blk));
+    const vi it = (lane + (blk * 64 - g.sx)) * DX;
+    const vb ok = (it >= 0) && (it < g.ni);
+    rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
+  }
+
   VHP_FN void sweep_block(int nb) {
     int lo, hi;
     g.xsteps(nb, lo, hi);
@@ -471,20 +585,29 @@ struct XWave {
     const int blk = g.X(lo) >> 6;
     VHP_PROF_T0(tl0);
     {
-      const vi yl = (vmin(lane + j0, g.rows_total - 1)) * DY + g.sy;
-      ow = g_load_u64(m.rows, yl * m.wpr + (1 + blk));
-      const vi it = (lane + (blk * 64 - g.sx)) * DX;
-      const vb ok = (it >= 0) && (it < g.ni);
-      vd rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
+      vd rv;
+      if (pf_blk == blk) { ow = ow_nx; rv = rv_nx; } else { load_block(blk, ow, rv); }
       pin(ow);
       pin(rv);
       lds_store(slab, lane, rv);
       wave_sync();
+      // the operands of the strip's next block are fetched a block ahead: this wavefront issues no stores, so waiting for
+      // them later waits for nothing else
+      if (nb + 1 < g.Nbx) { pf_blk = blk + DX; load_block(pf_blk, ow_nx, rv_nx); } else { pf_blk = -1; }
     }
     VHP_PROF_ADD(0, tl0);
     int i = lo;
     while (i <= hi) {
       const int x = g.X(i);
+      if ((x >> 3) != cur_win) {
+        // This window's tile columns were last read by the flushes posted up to two windows ago (three tile slots; one
+        // window ago with two): they must have left the tile.
+        VHP_PROF_T0(tf0);
+        wait_drained(nslots == 3 ? posted_prev : posted);
+        VHP_PROF_ADD(4, tf0);
+        posted_prev = posted;
+        cur_win = x >> 3;
+      }
       const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
       int i_last;
       VHP_PROF_T0(tw0);
@@ -500,9 +623,7 @@ struct XWave {
       i = i_last + 1;
       const int xl = g.X(i_last);
       const bool boundary = DX > 0 ? (xl & 7) == 7 : (xl & 7) == 0;
-      VHP_PROF_T0(tf0);
       if (boundary && i_last != g.ni - 1) flush_completed(xl, i_last);  // (the last step of the march is end_of_march's)
-      VHP_PROF_ADD(4, tf0);
     }
   }
 };
@@ -521,7 +642,7 @@ struct YWave {
   double* ring_base;
   double* round;
   int round_mask;
-  const double* diag;
+  const double* diag;  // diag(k) at k & (kDiagRing - 1)
   double* slab;   // reciprocals of the current block's 64 steps, indexed by y & 63
   double* dummy;
   Progress<DX, DY> prog;
@@ -624,7 +745,7 @@ struct YWave {
     vd v0 = and_mask(stencil(prev0, b0, ratio(id0, dj, rj)), bit_mask(ow0, t));
     vd v1 = and_mask(stencil(prev1, prev0, ratio(id1, dj, rj)), bit_mask(ow1, t));
     if (j <= i0 + kYCols - 1) {  // column j (if this strip owns it) is seeded with diag(j)
-      const double dg = diag[j];
+      const double dg = diag[j & (kDiagRing - 1)];
       v0 = select(ia == j, vd(dg), v0);
       v1 = select(ib == j, vd(dg), v1);
     }
@@ -655,7 +776,7 @@ struct YWave {
     vd dg[8];  // diag(j0w + k)
     if (DIAG) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) dg[k] = lds_bcast(diag, j0w + k);
+      for (int k = 0; k < 8; ++k) dg[k] = lds_bcast(diag, (j0w + k) & (kDiagRing - 1));
     }
     const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
     const vu32 hs0 = half_shifted(ow0, t0, sh), hs1 = half_shifted(ow1, t0, sh);
@@ -742,22 +863,30 @@ struct DiagWave {
   Quad<DX, DY> g;
   double* diag;
   volatile int* ready_word;
+  Progress<DX, DY> prog;
   int k;        // next entry
   bool active;
   vi lane;
   vd dprev, sprev;  // diag(k-1), sub(k-1): the same value in every lane
 
-  VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, double* lds, const Layout& L) {
+  VHP_FN void init(const Map& m_, const Quad<DX, DY>& g_, int W, double* lds, const Layout& L) {
     m = m_; g = g_;
     diag = lds + L.diag;
-    ready_word = reinterpret_cast<volatile int*>(lds + L.sched) + kDiagDoneSlot;
+    prog.bind(lds, L, W);
+    ready_word = prog.done + kDiagDoneSlot;
     lane = lane_id();
     k = 0;
     active = g.rows_total > 0;
     dprev = vd(0.0);
     sprev = vd(0.0);
   }
-  VHP_FN bool ready() const { return true; }
+  // On grids larger than the array the entries live in a ring: entry k overwrites entry k - kDiagRing, the seed of a
+  // column whose strip (and, through the chain of boundary dependencies, every strip before it) must have finished.
+  VHP_FN bool ready() const {
+    const int reused = imin(k + kBlock, g.rows_total) - 1 - kDiagRing;
+    if (reused < 0) return true;
+    return prog.y_done(g, (reused + g.ya) / kYCols, g.Nby - 1);
+  }
 
   // entries k .. k+63
   VHP_FN void run_unit() {
@@ -783,7 +912,7 @@ struct DiagWave {
         sprev = sub;
       }
       dprev = dcur;
-      lds_store_if(lane == 0, diag, vi(kq), dcur);
+      lds_store_if(lane == 0, diag, vi(kq & (kDiagRing - 1)), dcur);
     }
     k = k1;
     lds_publish(ready_word, k1);
