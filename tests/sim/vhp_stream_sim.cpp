@@ -114,6 +114,7 @@ void run_quadrant(const HostMap& h, OutT* field, int sx, int sy, const SimShape&
     std::vector<double> lds(lds_n, std::numeric_limits<double>::quiet_NaN());
     Progress<DX, DY> prog;
     prog.bind(lds.data(), L, W);
+    prog.clear(true, L, 0, 1);
     prog.setup(g, true);
     std::vector<XWave<DX, DY, OutT>> xs(W), fl(W);
     for (int w = 0; w < W; ++w) {
@@ -131,6 +132,7 @@ void run_quadrant(const HostMap& h, OutT* field, int sx, int sy, const SimShape&
     std::vector<double> lds(lds_n, std::numeric_limits<double>::quiet_NaN());
     Progress<DX, DY> prog;
     prog.bind(lds.data(), L, W);
+    prog.clear(false, L, 0, 1);
     prog.setup(g, false);
     std::vector<YWave<DX, DY, OutT>> ys(W);
     for (int w = 0; w < W; ++w) ys[w].init(h.m, g, field, w, W, lds.data(), L);

@@ -59,6 +59,7 @@ struct vhp_ctx {
   int opt_slide = -1;         // 0 / 1: y-major column grid slid onto 128-byte lines
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream)
+  int opt_persistent = 0;      // front sweep: 1 = persistent workgroups pulling slots from a two-ended queue; else one workgroup per slot
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep
   int opt_stream_strips = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
   // dynamic-LDS limit already raised on THIS context's device, per kernel function
@@ -139,8 +140,9 @@ void pick_shape(const vhp_ctx* c, int maxdim, int* R, int* W, bool* multi, int n
   else if (maxdim <= 512) { *R = 2; *W = 4; }
   else if (maxdim <= 1024) { *R = 2; *W = 8; }
   else { *R = 4; *W = 8; }
-  // (Round 1 sent batches of 256+ sources to the one-row-per-lane shape with whole-line flushes; those batches now
-  // take the streaming sweep, vhp_stream.hpp, which is built for them.)
+  // (Round 1 sent batches of 256+ sources to the one-row-per-lane shape with whole-line flushes: -3 % at 1000^2 then,
+  // +2 % when re-measured in round 2 (0.780 against 0.767 ms on one buffer); above 1024 such batches take the streaming
+  // sweep now.  The shape stays reachable through vhp_set_option and is parity-tested.)
   (void)n_src; (void)f64; (void)pitch64;
   if (c && c->opt_rows_per_lane) *R = c->opt_rows_per_lane;
   if (c && c->opt_strips) *W = c->opt_strips;
@@ -164,6 +166,18 @@ void free_map(vhp_ctx* c) {
   c->nx = c->ny = 0;
 }
 
+// the pull queue / per-CU counters of a persistent launch (and the unit order of the streaming sweep)
+hipError_t ensure_queue_scratch(vhp_ctx* c, size_t bytes) {
+  if (c->d_queue_cap >= bytes) return hipSuccess;
+  if (c->d_queue) (void)hipFree(c->d_queue);
+  c->d_queue = nullptr;
+  c->d_queue_cap = 0;
+  hipError_t e = hipMalloc(&c->d_queue, bytes);
+  if (e != hipSuccess) return e;
+  c->d_queue_cap = bytes;
+  return hipSuccess;
+}
+
 template <int R, bool MULTI, typename OutT>
 hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, int W) {
   const bool pack = c->opt_pack != 0;
@@ -185,6 +199,9 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   const size_t n_units = (size_t)n_src * vhp::kUnitsPerSource;
   const int* order = nullptr;
   const int4* desc = nullptr;
+  unsigned long long* queue = nullptr;
+  int* cu_slots = nullptr;
+  unsigned resident = 0;
   if (n_src >= 8) {  // worth a 1-workgroup pre-kernel once the batch spans many CUs
     if (c->d_order_cap < n_units) {
       if (c->d_order) (void)hipFree(c->d_order);
@@ -199,11 +216,25 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     // Packing short quadrants into one workgroup is implemented and parity-tested, but measured slower
     // on MI355X: off unless VHP_PACK is set.
     const int pack_w = (!MULTI && W == 8 && pack) ? W : 0;
+    // Persistent workgroups pulling slots from both ends of the sorted order (vhp_sweep.hip.h), once the batch is
+    // more than the chip holds at once.
+    if (c->opt_persistent > 0) {  // measured: not a gain for this kernel; on request only
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), 128 * W, lds) == hipSuccess && per_cu > 0)
+        resident = (unsigned)per_cu * (unsigned)c->n_cus;
+      if (resident != 0) {
+        hipError_t eq = ensure_queue_scratch(c, (2 + vhp::kCuSlots) * sizeof(int));
+        if (eq != hipSuccess) return eq;
+        queue = reinterpret_cast<unsigned long long*>(c->d_queue);
+        cu_slots = c->d_queue + 2;
+      }
+    }
     hipLaunchKernelGGL(vhp::vhp_order_units, dim3(1), dim3(1024), 0, c->stream, d_src, n_src, c->nx, c->ny, 64 * R, pack_w, d_ord,
-                       d_desc);
+                       d_desc, queue, cu_slots);
     order = d_ord;
     desc = d_desc;
   }
+  const unsigned grid = queue ? (unsigned)std::min<size_t>(n_units, resident) : (unsigned)n_units;
   hipEvent_t ta = nullptr, tb = nullptr;
   if (c->timing) {
     if (!c->event_pool.empty()) {
@@ -215,7 +246,8 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     }
     (void)hipEventRecord(ta, c->stream);
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)n_units), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order, desc);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order, desc, queue, cu_slots,
+                     (int)n_units);
 #ifdef VHP_EXP_SLOTTIME
   {
     (void)hipStreamSynchronize(c->stream);
@@ -246,25 +278,21 @@ bool use_stream_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel == 1) return false;
   if (!vhp::stream_supported(c->nx, c->ny)) return false;
   if (c->opt_kernel == 2) return true;
-  // measured on MI355X (tools/ab_libs.py; DESIGN.md "which kernel"): the streaming sweep needs a batch that keeps every
-  // CU pulling units for much longer than its largest unit takes (one full-size octant: 0.2 ms at 1000^2, 4.4 ms at
-  // 4096^2).  256 sources at 1000^2: 0.727 against 0.761 ms; 192: 0.564 / 0.607; 128: level; 96: 0.372 / 0.353.
-  // 128 sources at 2048^2: 1.46 / 1.61 ms, at 4096^2: 5.30 / 6.29 ms; 64 sources: 1.09 / 1.01 and 4.69 / 3.95 ms.
+  // Measured on MI355X (tools/ab_libs.py on one buffer, tools/ab_bench.sh in fresh processes; DESIGN.md "which kernel").
+  // The streaming sweep needs a batch that keeps every CU pulling units for much longer than its largest unit takes (one
+  // full-size octant: 0.3 ms at 1000^2, 4.4 ms at 4096^2): 128 sources at 2048^2 1.46 against 1.61 ms, at 4096^2 5.30
+  // against 6.29 ms; with 64 sources it loses (1.09 / 1.01, 4.69 / 3.95 ms).  At 1000^2 the answer depends on where the
+  // output buffer lies (DESIGN.md "output placement"): 256 sources take 0.73 ms in it against 0.76 ms on a buffer in
+  // the slow state, 0.64 against 0.56 ms on one in the fast state -- the front sweep has the better expectation there.
   const int maxdim = std::max(c->nx, c->ny);
-  if (maxdim > 1024) return n_src >= 128;
-  return maxdim > 512 && n_src >= 160;
+  return maxdim > 1024 && n_src >= 128;
 }
 
 template <typename OutT>
 hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
-  const size_t qbytes = vhp::stream_queue_bytes(n_src);
-  if (c->d_queue_cap < qbytes) {
-    if (c->d_queue) (void)hipFree(c->d_queue);
-    c->d_queue = nullptr;
-    c->d_queue_cap = 0;
-    hipError_t eo = hipMalloc(&c->d_queue, qbytes);
+  {
+    hipError_t eo = ensure_queue_scratch(c, vhp::stream_queue_bytes(n_src));
     if (eo != hipSuccess) return eo;
-    c->d_queue_cap = qbytes;
   }
   vhp::StreamArgs a;
   a.rows = c->d_rows; a.cols = c->d_cols; a.recip = c->d_recip;
@@ -659,6 +687,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
   else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2 or 3"); ctx->opt_stream_strips = v; }
+  else if (k == "persistent") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "persistent: -1, 0 or 1"); ctx->opt_persistent = v; }
   else if (k == "kernel") { if (v < 0 || v > 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream"); ctx->opt_kernel = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;

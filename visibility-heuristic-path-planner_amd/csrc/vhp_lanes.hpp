@@ -141,9 +141,14 @@ template <typename T> inline void pin(T&) {}
 inline int uniform(int x) { return x; }
 // release: everything this wavefront has written to LDS becomes visible, then the progress word
 inline void lds_publish(volatile int* word, int value) { *word = value; }
+inline int lds_poll(const volatile int* word) { return *word; }
+inline int lds_int_at(const int* p) { return *p; }
+inline void lds_set_int(int* p, int v) { *p = v; }
 inline void lds_acquire() {}
-inline void lds_post(int* d, int a, int b, int c) { d[0] = a; d[1] = b; d[2] = c; }
+inline void lds_post4(int* d, int a, int b, int c, int e) { d[0] = a; d[1] = b; d[2] = c; d[3] = e; }
+inline void lds_read4(const int* d, int& a, int& b, int& c, int& e) { a = d[0]; b = d[1]; c = d[2]; e = d[3]; }
 inline void backoff() {}
+inline void stores_done() {}
 
 #else
 // ------------------------------------------------------------------------------------------------------------
@@ -249,6 +254,7 @@ VHP_LANE_FN void wave_sync() {
 VHP_LANE_FN void pin(double& v) { asm volatile("" : "+v"(v)); }
 VHP_LANE_FN void pin(uint64_t& v) { asm volatile("" : "+v"(v)); }
 VHP_LANE_FN int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+typedef __attribute__((address_space(3))) int lds_int;
 // Release of LDS data to the other wavefronts of the workgroup: the progress word is an LDS write issued after the data's
 // LDS writes by the same wavefront, and the LDS executes one wavefront's instructions in order -- nothing to wait for.
 // (A workgroup-scope release FENCE would also drain vmcnt: every global store the wavefront has in flight, 5 us per unit
@@ -256,14 +262,56 @@ VHP_LANE_FN int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 VHP_LANE_FN void lds_publish(volatile int* word, int value) {
   __builtin_amdgcn_wave_barrier();
   asm volatile("" ::: "memory");
+  // Every lane writes the same value to the same address: no exec masking around it.  The pointer is cast to the LDS
+  // address space: through the generic pointer the compiler emits FLAT instructions, which are slow, are not ordered
+  // with the DS instructions that wrote the data, and count on vmcnt -- a poll would wait for every global store the
+  // wavefront has in flight.
+#if defined(VHP_EXP_FLATPOLL)
   if ((threadIdx.x & 63u) == 0) *word = value;
+#elif defined(VHP_EXP_MASKPUB)
+  if ((threadIdx.x & 63u) == 0) *(volatile lds_int*)word = value;
+#else
+  *(volatile lds_int*)word = value;
+#endif
   asm volatile("" ::: "memory");
 }
-// three uniform words for another wavefront (published by a later lds_publish)
-VHP_LANE_FN void lds_post(int* d, int a, int b, int c) {
-  if ((threadIdx.x & 63u) == 0) { d[0] = a; d[1] = b; d[2] = c; }
+// a (uniform) int that was written to LDS before the wavefronts started
+VHP_LANE_FN int lds_int_at(const int* p) { return __builtin_amdgcn_readfirstlane(*(const lds_int*)p); }
+VHP_LANE_FN void lds_set_int(int* p, int v) { *(lds_int*)p = v; }
+// a progress word of another wavefront, read afresh, as a uniform value (a DS read: see lds_publish)
+#ifdef VHP_EXP_FLATPOLL
+VHP_LANE_FN int lds_poll(const volatile int* word) { return __builtin_amdgcn_readfirstlane(*word); }
+#else
+VHP_LANE_FN int lds_poll(const volatile int* word) { return __builtin_amdgcn_readfirstlane(*(const volatile lds_int*)word); }
+#endif
+// Four uniform words for another wavefront, as ONE 16-byte LDS write (d is 16-byte aligned): every lane writes the same
+// values to the same address, so there is no exec masking, and a reader sees all four words or none.  Ordered after
+// this wavefront's earlier LDS writes like lds_publish.
+VHP_LANE_FN void lds_post4(int* d, int a, int b, int c, int e) {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  *reinterpret_cast<int4*>(d) = make_int4(a, b, c, e);
+  asm volatile("" ::: "memory");
 }
-VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(1); }
+// the four words of lds_post4, read afresh (one 16-byte LDS read), as uniform values
+VHP_LANE_FN void lds_read4(const int* d, int& a, int& b, int& c, int& e) {
+  asm volatile("" ::: "memory");
+  const int4 v = *reinterpret_cast<const int4*>(d);
+  a = __builtin_amdgcn_readfirstlane(v.x);
+  b = __builtin_amdgcn_readfirstlane(v.y);
+  c = __builtin_amdgcn_readfirstlane(v.z);
+  e = __builtin_amdgcn_readfirstlane(v.w);
+}
+#ifndef VHP_EXP_BACKOFF
+#define VHP_EXP_BACKOFF 12
+#endif
+#ifndef VHP_EXP_READYSLEEP
+#define VHP_EXP_READYSLEEP 4
+#endif
+VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(VHP_EXP_BACKOFF); }
+VHP_LANE_FN void ready_backoff() { __builtin_amdgcn_s_sleep(VHP_EXP_READYSLEEP); }
+// waits until every global store (and load) this wavefront has issued has completed
+VHP_LANE_FN void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // acquire: the poll's value has arrived (the branch on it waited for lgkmcnt); later LDS reads are issued after it, in order
 VHP_LANE_FN void lds_acquire() {
   asm volatile("" ::: "memory");

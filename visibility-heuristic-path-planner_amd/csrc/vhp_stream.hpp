@@ -109,7 +109,8 @@ VHP_HD Layout make_layout(int W, int nx, int ny, bool x_major, int tile_slots) {
   L.slab = o; o += (W + 1) * kBlock;
   L.tile_slots = tile_slots;
   L.tiles = o; if (x_major) o += W * kXRows * (8 * tile_slots + 1);
-  L.strips = (imin(nx, ny) + kXRows - 1) / kXRows + 2;
+  L.strips = ((imin(nx, ny) + kXRows - 1) / kXRows + 2 + 3) & ~3;  // (a multiple of 4: the descriptors after it are 16-byte aligned)
+  o = (o + 1) & ~1;
   L.sched = o; o += (kDoneSlots + L.strips + (x_major ? W * kDescRing * 4 : 0)) / 2 + 1;
   L.total = o;
   L.round_mask = rr - 1;
@@ -167,12 +168,12 @@ struct Quad {
 
 // Progress bookkeeping of a workgroup (ints in LDS at Layout::sched):
 //   done[0..W-1]   units (strip, block) the sweeping wavefronts have finished;
-//   done[8+w]      x-major units: flush descriptors wavefront w has posted;  done[16+w]: descriptors its flusher has read
-//                  out of the tile (the columns they covered may be overwritten);
+//   done[16+w]     x-major units: flush descriptors the flusher of wavefront w has read out of the tile (the columns
+//                  they covered may be overwritten);
 //   done[31]       y-major units: diagonal entries diag(0 .. done[31]-1) have been produced (DiagWave);
 //   base[p]        index of strip p's first block in the unit sequence of its wavefront (p % W): the wavefront has
 //                  finished block n of strip p once done >= base[p] + (n - first block of p) + 1.
-constexpr int kPostedSlot = 8, kDrainedSlot = 16, kDiagDoneSlot = 31;
+constexpr int kDrainedSlot = 16, kDiagDoneSlot = 31;
 template <int DX, int DY>
 struct Progress {
   volatile int* done;
@@ -186,27 +187,39 @@ struct Progress {
     W = W_;
   }
   VHP_FN int* descriptors(const Layout& L, int w) const { return base + L.strips + w * (kDescRing * 4); }
-  // run by one thread before any wavefront starts
-  VHP_FN void setup(const Quad<DX, DY>& g, bool x_major) {
-    for (int k = 0; k < kDoneSlots; ++k) done[k] = 0;
+  // Before any wavefront starts: every thread calls clear() (tid of nthreads), then -- after a barrier -- one thread
+  // calls setup().  (DS writes through lds_set_int: the generic pointer would make each of these a FLAT store that is
+  // waited for, 10 us per unit.)
+  VHP_FN void clear(bool x_major, const Layout& L, int tid, int nthreads) {
+    int* d = const_cast<int*>(done);
+    for (int k = tid; k < kDoneSlots; k += nthreads) lds_set_int(d + k, 0);
     if (x_major)
-      for (int p = 0; p < g.Px; ++p) base[p] = p >= W ? base[p - W] + (g.Nbx - g.nbx(kXRows * (p - W))) : 0;
-    else
-      for (int q = 0; q < g.Py; ++q) base[q] = q >= W ? base[q - W] + (g.Nby - g.nby(g.ystart(q - W))) : 0;
+      for (int k = tid; k < W * kDescRing * 4; k += nthreads) lds_set_int(base + L.strips + k, 0);  // no descriptor carries sequence number 0
+  }
+  VHP_FN void setup(const Quad<DX, DY>& g, bool x_major) {
+    if (x_major) {
+      for (int p = 0; p < g.Px; ++p) lds_set_int(base + p, p >= W ? lds_int_at(base + p - W) + (g.Nbx - g.nbx(kXRows * (p - W))) : 0);
+    } else {
+      for (int q = 0; q < g.Py; ++q) lds_set_int(base + q, q >= W ? lds_int_at(base + q - W) + (g.Nby - g.nby(g.ystart(q - W))) : 0);
+    }
   }
   // has x-major strip p swept block n?  (blocks before the strip's first are nothing to wait for, blocks past the
   // march mean "the whole strip")
   VHP_FN bool x_done(const Quad<DX, DY>& g, int p, int n) const {
     const int nf = g.nbx(kXRows * p);
     if (n < nf) return true;
-    return uniform(done[p % W]) >= base[p] + (imin(n, g.Nbx - 1) - nf) + 1;
+    return lds_poll(done + p % W) >= lds_int_at(base + p) + (imin(n, g.Nbx - 1) - nf) + 1;
   }
   VHP_FN bool y_done(const Quad<DX, DY>& g, int q, int n) const {
     const int nf = g.nby(g.ystart(q));
     if (n < nf) return true;
-    return uniform(done[q % W]) >= base[q] + (imin(n, g.Nby - 1) - nf) + 1;
+    return lds_poll(done + q % W) >= lds_int_at(base + q) + (imin(n, g.Nby - 1) - nf) + 1;
   }
-  VHP_FN int diag_ready() const { return uniform(done[kDiagDoneSlot]); }
+  VHP_FN int diag_ready() const { return lds_poll(done + kDiagDoneSlot); }
+  // the same tests with the constants of a strip fetched once (XWave / YWave::load_strip): strip p' has swept block n'
+  // (n' not before its first block nf') once done[p' % W] >= off(p') + min(n', last block), off = base[p'] - nf' + 1
+  VHP_FN int x_off(const Quad<DX, DY>& g, int p) const { return lds_int_at(base + p) - g.nbx(kXRows * p) + 1; }
+  VHP_FN int y_off(const Quad<DX, DY>& g, int q) const { return lds_int_at(base + q) - g.nby(g.ystart(q)) + 1; }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -256,7 +269,6 @@ struct XWave {
   double* rout;
   int rout_mask;
   // the hand-off to the flusher
-  volatile int* posted_w;
   volatile int* drained_w;
   int* desc;
   int posted;       // sweeping side: descriptors posted so far ...
@@ -264,6 +276,10 @@ struct XWave {
   int cur_win;      // x >> 3 of the window being swept
   int drained;      // flusher side: descriptors read out of the tile
   int pf_blk;       // the block (x >> 6) whose operands wait in ow_nx / rv_nx, or -1
+  // the dependencies of the current strip, fetched once per strip (ready() then reads progress words only)
+  int raw_nf, raw_off;            // strip p-1: its first block, Progress::x_off
+  int war_kind, war_nf, war_off;  // who reads what I write: 0 nobody, 1 strip p+1 (my ring), 2 strip p-W+1 (the round row)
+  int reuse_need;                 // my ring's previous reader (strip p-W+1) must have finished: its progress word at least this, or 0
 #ifdef VHP_SIM
   XWave* flusher;   // the simulator runs the flusher inside the sweeping wavefront's calls:
   bool lazy;        // as late as the protocol allows (only when the sweeping side has to wait), or right at the post
@@ -290,7 +306,6 @@ struct XWave {
     slab = lds + L.slab + w * kBlock;
     dummy = lds + L.dummy + w * 8;
     prog.bind(lds, L, W);
-    posted_w = prog.done + kPostedSlot + w;
     drained_w = prog.done + kDrainedSlot + w;
     desc = prog.descriptors(L, w);
     posted = posted_prev = drained = 0;
@@ -341,26 +356,38 @@ struct XWave {
     cur_win = -1;
     posted_prev = posted;
     pf_blk = -1;
+    // dependencies (see ready())
+    raw_nf = raw_off = 0;
+    if (p > 0) { raw_nf = g.nbx(kXRows * (p - 1)); raw_off = prog.x_off(g, p - 1); }
+    war_kind = 0; war_nf = war_off = 0;
+    if (has_consumer) {
+      if ((p + 1) % W != 0) { war_kind = 1; war_nf = g.nbx(kXRows * (p + 1)); war_off = prog.x_off(g, p + 1); }
+      else if (p >= 2 * W - 1) { war_kind = 2; war_nf = g.nbx(kXRows * (p - W + 1)); war_off = prog.x_off(g, p - W + 1); }
+    }
+    reuse_need = (p >= W && (p - W + 1) % W != 0) ? prog.x_off(g, p - W + 1) + (g.Nbx - 1) : 0;
   }
 
   // May the next unit (strip p, block n) run?  Everything it reads from other wavefronts has been produced, and
-  // nothing it overwrites is still needed.
+  // nothing it overwrites is still needed.  (Strip p' has swept block n' once the progress word of its wavefront is at
+  // least x_off(p') + min(n', last block); blocks before its first are nothing to wait for.)
   VHP_FN bool ready() const {
+    // the two progress words this can depend on, read together: strip p-1's wavefront and strip p+1's (= strip p-W+1's)
+    const int w_below = w == 0 ? W - 1 : w - 1, w_above = w == W - 1 ? 0 : w + 1;
+    const int d_below = lds_poll(prog.done + w_below), d_above = lds_poll(prog.done + w_above);
+    const int last = g.Nbx - 1;
     // the boundary row: strip p-1 has swept this block
-    if (p > 0 && !prog.x_done(g, p - 1, n)) return false;
-    if (has_consumer) {
-      if ((p + 1) % W != 0) {
-        // my output ring holds four blocks; writing block n overwrites block n-4, whose last entry the reader needs
-        // while it sweeps block n-3
-        if (!prog.x_done(g, p + 1, n - 3)) return false;
-      } else if (p >= 2 * W - 1) {
-        // I write the round-to-round row: the strip that still reads the previous round's entries from it (strip
-        // p-W+1, the first of my round) needs the last entry of block n while it sweeps block n+1
-        if (!prog.x_done(g, p - W + 1, n + 1)) return false;
-      }
+    if (p > 0 && n >= raw_nf && d_below < raw_off + imin(n, last)) return false;
+    if (war_kind == 1) {
+      // my output ring holds four blocks; writing block n overwrites block n-4, whose last entry the reader needs
+      // while it sweeps block n-3
+      if (n - 3 >= war_nf && d_above < war_off + imin(n - 3, last)) return false;
+    } else if (war_kind == 2) {
+      // I write the round-to-round row: the strip that still reads the previous round's entries from it (strip
+      // p-W+1, the first of my round) needs the last entry of block n while it sweeps block n+1
+      if (n + 1 >= war_nf && d_above < war_off + imin(n + 1, last)) return false;
     }
     // a new strip reuses my output ring: the reader of my previous strip must be through with it
-    if (n == nf && p >= W && (p - W + 1) % W != 0 && !prog.x_done(g, p - W + 1, g.Nbx - 1)) return false;
+    if (n == nf && reuse_need != 0 && d_above < reuse_need) return false;
     return true;
   }
 
@@ -379,9 +406,10 @@ struct XWave {
   // of this strip is complete in the tile (flags & kDescPred: only in part -- the cells with step index j <= i' <= i_now).
   VHP_FN void post(int xa, int r_first, int i_now, int flags) {
     int* d = desc + (posted & (kDescRing - 1)) * 4;
-    lds_post(d, (xa + 16) | (r_first << 16) | flags, i_now, j0 | (rows_here << 16));
     ++posted;
-    lds_publish(posted_w, posted);
+    // One 16-byte LDS write: the sequence number -- what the flusher polls -- in the first and the last word, the
+    // descriptor between them (a reader that sees both numbers equal has not read a half-written descriptor).
+    lds_post4(d, posted, (xa + 16) | (r_first << 16) | flags | (rows_here << 19), i_now | (j0 << 14), posted);
 #ifdef VHP_SIM
     if (!lazy) flusher->drain_one();
 #endif
@@ -390,7 +418,7 @@ struct XWave {
 #ifdef VHP_SIM
     while (*drained_w < need) flusher->drain_one();
 #else
-    while (uniform(*drained_w) < need) backoff();
+    while (lds_poll(drained_w) < need) backoff();
     lds_acquire();
 #endif
   }
@@ -405,19 +433,24 @@ struct XWave {
   // ---- flusher side ----
   // takes the next descriptor (waiting for it) and stores its lines; false once the sweeping wavefront has left
   VHP_FN bool drain_one() {
+    const int* d = desc + (drained & (kDescRing - 1)) * 4;
+    int seq0, d0, d1, seq1;
+    lds_read4(d, seq0, d0, d1, seq1);
 #ifndef VHP_SIM
-    while (uniform(*posted_w) <= drained) backoff();
+    while (seq0 != drained + 1 || seq1 != drained + 1) { backoff(); lds_read4(d, seq0, d0, d1, seq1); }
     lds_acquire();
 #endif
-    const volatile int* d = desc + (drained & (kDescRing - 1)) * 4;
-    const int d0 = uniform(d[0]), i_now = uniform(d[1]), d2 = uniform(d[2]);
     if (d0 & kDescExit) return false;
-    j0 = d2 & 0xffff;
-    rows_here = d2 >> 16;
+    const int i_now = d1 & 0x3fff;
+    j0 = d1 >> 14;
+    rows_here = (d0 >> 19) & 0x7f;
     const int xa = (d0 & 0xffff) - 16, r_first = (d0 >> 16) & 1;
     if (d0 & kDescPred) flush<true>(xa, r_first, i_now); else flush<false>(xa, r_first, i_now);
     ++drained;
     lds_publish(drained_w, drained);  // (the tile reads above were issued before this write: the LDS keeps the order)
+#ifdef VHP_EXP_FDRAIN
+    stores_done();
+#endif
     return true;
   }
 
@@ -647,6 +680,7 @@ struct YWave {
   double* dummy;
   Progress<DX, DY> prog;
   int q, i0, jstart, nf;
+  int raw_nf, raw_off, war_kind, war_nf, war_off, reuse_need;  // the strip's dependencies, as in XWave
   int n;        // the block to sweep next
   int my_done;  // units finished
   bool active, has_consumer, interior;
@@ -695,27 +729,41 @@ struct YWave {
     xoff = to_u32(xlo * CB);
     if (q % W == 0) { rin = round; rin_mask = round_mask; } else { rin = ring_base + (w - 1) * kRing; rin_mask = kRing - 1; }
     if ((q + 1) % W == 0) { rout = round; rout_mask = round_mask; } else { rout = ring_base + w * kRing; rout_mask = kRing - 1; }
+    // dependencies (see ready())
+    raw_nf = raw_off = 0;
+    if (q > 0) { raw_nf = g.nby(g.ystart(q - 1)); raw_off = prog.y_off(g, q - 1); }
+    war_kind = 0; war_nf = war_off = 0;
+    if (has_consumer) {
+      if ((q + 1) % W != 0) { war_kind = 1; war_nf = g.nby(g.ystart(q + 1)); war_off = prog.y_off(g, q + 1); }
+      else if (q >= 2 * W - 1) { war_kind = 2; war_nf = g.nby(g.ystart(q - W + 1)); war_off = prog.y_off(g, q - W + 1); }
+    }
+    reuse_need = (q >= W && (q - W + 1) % W != 0) ? prog.y_off(g, q - W + 1) + (g.Nby - 1) : 0;
   }
 
+  // (the same rules as XWave::ready, plus the seeds)
   VHP_FN bool ready() const {
-    if (q > 0 && !prog.y_done(g, q - 1, n)) return false;
-    if (has_consumer) {
-      if ((q + 1) % W != 0) {
-        if (!prog.y_done(g, q + 1, n - 3)) return false;
-      } else if (q >= 2 * W - 1) {
-        if (!prog.y_done(g, q - W + 1, n + 1)) return false;
-      }
+    const int w_below = w == 0 ? W - 1 : w - 1, w_above = w == W - 1 ? 0 : w + 1;
+    const int d_below = lds_poll(prog.done + w_below), d_above = lds_poll(prog.done + w_above), d_diag = lds_poll(prog.done + kDiagDoneSlot);
+    const int last = g.Nby - 1;
+    if (q > 0 && n >= raw_nf && d_below < raw_off + imin(n, last)) return false;
+    if (war_kind == 1) {
+      if (n - 3 >= war_nf && d_above < war_off + imin(n - 3, last)) return false;
+    } else if (war_kind == 2) {
+      if (n + 1 >= war_nf && d_above < war_off + imin(n + 1, last)) return false;
     }
-    if (n == nf && q >= W && (q - W + 1) % W != 0 && !prog.y_done(g, q - W + 1, g.Nby - 1)) return false;
+    if (n == nf && reuse_need != 0 && d_above < reuse_need) return false;
     // the seeds of this block: diag(k) for the strip's columns k among the block's steps, from the DiagWave
     int lo, hi;
     g.ysteps(n, lo, hi);
     const int kmax = imin(imin(hi, i0 + kYCols - 1), g.rows_total - 1);
-    if (kmax >= imax(lo, jstart) && kmax >= prog.diag_ready()) return false;
+    if (kmax >= imax(lo, jstart) && kmax >= d_diag) return false;
     return true;
   }
 
   VHP_FN void run_unit() {
+#ifdef VHP_EXP_YDRAIN
+    stores_done();
+#endif
     sweep_block(n);
     const bool last = n == g.Nby - 1;
     ++my_done;
@@ -912,7 +960,7 @@ struct DiagWave {
         sprev = sub;
       }
       dprev = dcur;
-      lds_store_if(lane == 0, diag, vi(kq & (kDiagRing - 1)), dcur);
+      lds_store(diag, vi(kq & (kDiagRing - 1)), dcur);  // (every lane holds the same value: one write, no exec masking)
     }
     k = k1;
     lds_publish(ready_word, k1);

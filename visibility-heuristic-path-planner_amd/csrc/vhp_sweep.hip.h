@@ -1147,17 +1147,15 @@ __device__ unsigned long long g_wgtime[3 * 4 * 4096];
 // grid = n_src * 4 workgroups of 128*W threads; dynamic LDS = sweep_lds_bytes(R, W)
 // Register budgets: R <= 2 single-round shapes fit 64 VGPRs so two 16-wavefront workgroups share a
 // CU; the R = 2 multi-round shape runs 8-wavefront workgroups, three per CU.
+// One workgroup slot: slot b sweeps unit b, or (descriptors from vhp_order_units) `count` units
+// order[first .. first+count) side by side, each with 1/G of the wavefronts.
 template <int R, bool MULTI, typename OutT>
-__global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : ((MULTI && R == 2) ? 6 : 8))
-vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
-                 int* __restrict__ err_flag, const int* __restrict__ order, const int4* __restrict__ wg_desc) {
-  extern __shared__ double lds[];
-  // Without descriptors: workgroup b sweeps unit b.  With (vhp_order_units): workgroup b sweeps
-  // `count` units order[first .. first+count) side by side, each with 1/G of the wavefronts; units
-  // are handed out longest first, which with in-order dispatch is LPT scheduling over the CUs.
-  int first = blockIdx.x, count = 1, G = 1;
+__device__ __forceinline__ void sweep_slot(const DevMap& m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
+                                           int* __restrict__ err_flag, const int* __restrict__ order, const int4* __restrict__ wg_desc,
+                                           int b, double* lds) {
+  int first = b, count = 1, G = 1;
   if (wg_desc) {
-    const int4 d = wg_desc[blockIdx.x];
+    const int4 d = wg_desc[b];
     first = d.x;
     count = d.y;
     G = d.z;
@@ -1217,6 +1215,48 @@ vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict_
 #endif
 }
 
+constexpr int kCuSlots = 2048;  // per-CU arrival counters (XCC, SE, SH, CU packed into 11 bits)
+// Classic launch (queue == nullptr): grid = slots, workgroup b sweeps slot b; slots are handed out longest first, which
+// with in-order dispatch is LPT scheduling over the CUs.
+// Persistent launch (queue != nullptr): grid = the workgroups the chip holds at once; each pulls slots until none is
+// left.  The first workgroup to arrive on a CU pulls from the head of the sorted slots (longest first), the second from
+// the tail (shortest first): a CU then carries one stream of large quadrants and one of small ones instead of -- as
+// in-order dispatch deals them -- two of the largest, which share that CU's path to memory and set the length of the
+// launch.  `queue` packs both ends (low half: taken from the head, high half: from the tail).
+template <int R, bool MULTI, typename OutT>
+__global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : ((MULTI && R == 2) ? 6 : 8))
+vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
+                 int* __restrict__ err_flag, const int* __restrict__ order, const int4* __restrict__ wg_desc,
+                 unsigned long long* __restrict__ queue, int* __restrict__ cu_slots, int n_slots) {
+  extern __shared__ double lds[];
+  if (!queue) {
+    sweep_slot<R, MULTI, OutT>(m, src_xy, out, field_stride, err_flag, order, wg_desc, (int)blockIdx.x, lds);
+    return;
+  }
+  __shared__ int next_slot, from_tail;
+  if (threadIdx.x == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned key = (((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu)) & (kCuSlots - 1);
+    from_tail = atomicAdd(&cu_slots[key], 1) & 1;
+  }
+  __syncthreads();
+  const bool tail = from_tail != 0;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      const unsigned long long old = atomicAdd(queue, tail ? (1ull << 32) : 1ull);
+      const unsigned h = (unsigned)old, t = (unsigned)(old >> 32);
+      next_slot = (h + t >= (unsigned)n_slots) ? n_slots : (tail ? n_slots - 1 - (int)t : (int)h);
+    }
+    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(next_slot);
+    if (b >= n_slots) return;
+    sweep_slot<R, MULTI, OutT>(m, src_xy, out, field_stride, err_flag, order, wg_desc, b, lds);
+    __syncthreads();  // every wavefront is through with this slot's LDS (and has read next_slot) before the next pull
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Launch order of the (source, quadrant) units: a quadrant's sweep time grows with the length
 // of its longest front, max(ni, nj).  One workgroup counting-sorts the units by that length,
@@ -1228,7 +1268,12 @@ constexpr int kOrderClasses = 3;  // G = 1, 2, 4 units per workgroup
 // Outputs: order[] (unit indices: class-major, longest first inside a class) and one descriptor
 // per workgroup slot {first, count, G} (count 0 = vacant slot).
 __global__ void __launch_bounds__(1024) vhp_order_units(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int rows_per_strip,
-                                                        int pack_w, int* __restrict__ order, int4* __restrict__ wg_desc) {
+                                                        int pack_w, int* __restrict__ order, int4* __restrict__ wg_desc,
+                                                        unsigned long long* __restrict__ queue, int* __restrict__ cu_slots) {
+  if (queue) {  // a persistent launch follows: its pull queue and per-CU arrival counters start at zero
+    if (threadIdx.x == 0) *queue = 0ull;
+    for (int k = threadIdx.x; k < kCuSlots; k += blockDim.x) cu_slots[k] = 0;
+  }
   __shared__ int hist[kOrderClasses * kOrderBuckets];
   __shared__ int start[kOrderClasses * kOrderBuckets];
   __shared__ int cls_n[kOrderClasses], cls_off[kOrderClasses], wg_off[kOrderClasses + 1];
