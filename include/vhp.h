@@ -161,8 +161,7 @@ int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n);
  * strips per octant), "multi_round" (1 = force the multi-round build), "slide" (0 / 1: y-major
  * column grid slid onto 128-byte lines), "pack" (1 = pack short quadrants), "kernel" (1 = front
  * sweep, 2 = streaming sweep), "stream_tile_slots" (2, 3: staging-tile depth of the streaming
- * sweep), "persistent" (front sweep: 1 = workgroups pull their quadrants from a queue, -1 = one
- * workgroup per quadrant).  The results never depend on these; only the schedule does. */
+ * sweep).  The results never depend on these; only the schedule does. */
 int vhp_set_option(vhp_ctx* ctx, const char* key, long long value);
 /* Which kernel the last batch sweep of this context launched: 1 = front sweep (vhp_sweep_fronts),
  * 2 = streaming sweep (vhp_stream_sweep), 0 = none yet.  For benchmarks and profiles. */

@@ -232,18 +232,16 @@ def test_config3_all_256_fields_of_the_bench_launch(vhp, oracle, dtype, kernel):
 
 
 @pytest.mark.parametrize("shape", [dict(), dict(pack=1), LINE_SHAPE, dict(rows_per_lane=2, strips=4, multi_round=1)])
-@pytest.mark.parametrize("persistent", [1, -1])
-def test_front_sweep_persistent_workgroups(vhp, oracle, shape, persistent):
-    # the front sweep with workgroups that pull their quadrants from both ends of the sorted order (what a batch beyond
-    # one round of workgroups gets by default) against one workgroup per quadrant, in every compiled shape: 40 sources
-    # on a 1000x1000 map, incl. corner and border sources (empty quadrants, packed short ones)
+def test_front_sweep_every_shape_with_border_sources(vhp, oracle, shape):
+    # every compiled shape of the front sweep on one batch: 40 sources on a 1000x1000 map, incl. corner and border
+    # sources (empty quadrants, packed short ones)
     occ, src = maps.config_c3(34)
     src = np.concatenate([src, np.array([[0, 0], [999, 999], [999, 0], [0, 999], [500, 0], [0, 500]], np.int32)])
     occ = occ.copy()
     occ[src[:, 1], src[:, 0]] = 1
-    got = _ctx(vhp, occ, kernel=1, persistent=persistent, **shape).sweep_batch(src)
+    got = _ctx(vhp, occ, kernel=1, **shape).sweep_batch(src)
     for k, (sx, sy) in enumerate(src):
-        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "persistent=%d %r source (%d,%d)" % (persistent, shape, sx, sy))
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%r source (%d,%d)" % (shape, sx, sy))
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

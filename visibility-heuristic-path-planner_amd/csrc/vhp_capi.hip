@@ -59,7 +59,6 @@ struct vhp_ctx {
   int opt_slide = -1;         // 0 / 1: y-major column grid slid onto 128-byte lines
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream)
-  int opt_persistent = 0;      // front sweep: 1 = persistent workgroups pulling slots from a two-ended queue; else one workgroup per slot
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep
   int opt_stream_strips = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
   // dynamic-LDS limit already raised on THIS context's device, per kernel function
@@ -199,9 +198,6 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   const size_t n_units = (size_t)n_src * vhp::kUnitsPerSource;
   const int* order = nullptr;
   const int4* desc = nullptr;
-  unsigned long long* queue = nullptr;
-  int* cu_slots = nullptr;
-  unsigned resident = 0;
   if (n_src >= 8) {  // worth a 1-workgroup pre-kernel once the batch spans many CUs
     if (c->d_order_cap < n_units) {
       if (c->d_order) (void)hipFree(c->d_order);
@@ -216,25 +212,12 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     // Packing short quadrants into one workgroup is implemented and parity-tested, but measured slower
     // on MI355X: off unless VHP_PACK is set.
     const int pack_w = (!MULTI && W == 8 && pack) ? W : 0;
-    // Persistent workgroups pulling slots from both ends of the sorted order (vhp_sweep.hip.h), once the batch is
-    // more than the chip holds at once.
-    if (c->opt_persistent > 0) {  // measured: not a gain for this kernel; on request only
-      int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), 128 * W, lds) == hipSuccess && per_cu > 0)
-        resident = (unsigned)per_cu * (unsigned)c->n_cus;
-      if (resident != 0) {
-        hipError_t eq = ensure_queue_scratch(c, (2 + vhp::kCuSlots) * sizeof(int));
-        if (eq != hipSuccess) return eq;
-        queue = reinterpret_cast<unsigned long long*>(c->d_queue);
-        cu_slots = c->d_queue + 2;
-      }
-    }
     hipLaunchKernelGGL(vhp::vhp_order_units, dim3(1), dim3(1024), 0, c->stream, d_src, n_src, c->nx, c->ny, 64 * R, pack_w, d_ord,
-                       d_desc, queue, cu_slots);
+                       d_desc);
     order = d_ord;
     desc = d_desc;
   }
-  const unsigned grid = queue ? (unsigned)std::min<size_t>(n_units, resident) : (unsigned)n_units;
+  const unsigned grid = (unsigned)n_units;
   hipEvent_t ta = nullptr, tb = nullptr;
   if (c->timing) {
     if (!c->event_pool.empty()) {
@@ -246,8 +229,7 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     }
     (void)hipEventRecord(ta, c->stream);
   }
-  hipLaunchKernelGGL(k, dim3(grid), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order, desc, queue, cu_slots,
-                     (int)n_units);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order, desc);
 #ifdef VHP_EXP_SLOTTIME
   {
     (void)hipStreamSynchronize(c->stream);
@@ -687,7 +669,6 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
   else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2 or 3"); ctx->opt_stream_strips = v; }
-  else if (k == "persistent") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "persistent: -1, 0 or 1"); ctx->opt_persistent = v; }
   else if (k == "kernel") { if (v < 0 || v > 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream"); ctx->opt_kernel = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;

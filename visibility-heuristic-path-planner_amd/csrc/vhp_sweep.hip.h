@@ -322,8 +322,9 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
   const bool rows_alternate = ((m.nx >> 3) & 1) != 0;  // consecutive rows start half a line apart
   int held_chunk = INT32_MIN;                           // chunk whose hold-class rows are still in the tile
   // flush geometry: lane <-> (row-in-group = lane>>2, column pair = lane&3), 16 rows x 64 B per pass
-  const int cp = lane & 3, rsub = lane >> 2;
-  const uint32_t flush_lane_off = (uint32_t)(((g.sy + DY * (j0 + rsub)) * m.nx + 2 * cp) * CB);
+  // (cp, rsub and the lane's byte offset are derived from the lane id inside each flush, behind an opaque move: held in
+  // registers across the step loops they pushed three values into scratch, and a scratch reload waits on vmcnt -- for
+  // every global store the wavefront has in flight)
   const uint32_t flush_pass_stride = (uint32_t)(16 * DY * m.nx * CB);
 
   auto refill = [&](int blk) {  // blocking: once per 64 steps
@@ -459,6 +460,9 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const int xbase = x & ~(kTileCols - 1);
+      int lf = lane;
+      asm volatile("" : "+v"(lf));
+      const int cp = lf & 3, rsub = lf >> 2;
       const int xc = xbase + 2 * cp;
       const int ic0 = DX > 0 ? xc - g.sx : g.sx - xc;
       const int ic1 = DX > 0 ? ic0 + 1 : ic0 - 1;
@@ -582,7 +586,10 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
     if (kMulti && ss.tail) {  // the next round's first strip reads this strip's boundary row from global memory
       if (lane < 8) ss.bnd_out[i + lane] = ring_w[DX > 0 ? lane : 7 - lane];
     }
-    const uint32_t off0 = flush_lane_off + (uint32_t)(xb * CB);
+    int lf = lane;
+    asm volatile("" : "+v"(lf));
+    const int cp = lf & 3, rsub = lf >> 2;
+    const uint32_t off0 = (uint32_t)(((g.sy + DY * (j0 + rsub)) * m.nx + 2 * cp + xb) * CB);
     const int xc = xb + 2 * cp;
     const int y0 = g.sy + DY * (j0 + rsub);
     const double* q0 = tile + rsub * kTileStride + 2 * cp + (xb & (kRingCols - 1));
@@ -1215,46 +1222,17 @@ __device__ __forceinline__ void sweep_slot(const DevMap& m, const int32_t* __res
 #endif
 }
 
-constexpr int kCuSlots = 2048;  // per-CU arrival counters (XCC, SE, SH, CU packed into 11 bits)
-// Classic launch (queue == nullptr): grid = slots, workgroup b sweeps slot b; slots are handed out longest first, which
-// with in-order dispatch is LPT scheduling over the CUs.
-// Persistent launch (queue != nullptr): grid = the workgroups the chip holds at once; each pulls slots until none is
-// left.  The first workgroup to arrive on a CU pulls from the head of the sorted slots (longest first), the second from
-// the tail (shortest first): a CU then carries one stream of large quadrants and one of small ones instead of -- as
-// in-order dispatch deals them -- two of the largest, which share that CU's path to memory and set the length of the
-// launch.  `queue` packs both ends (low half: taken from the head, high half: from the tail).
+// grid = slots: workgroup b sweeps slot b; slots are handed out longest first, which with in-order dispatch is LPT
+// scheduling over the CUs.  (Persistent workgroups pulling slots from a two-ended queue -- what the streaming sweep
+// does -- were tried here in round 2 and lost 3-8 % at 256 sources; the wrapper also cost the kernel its registers:
+// keeping the arguments live across the sweep pushed 26 VGPRs into scratch, whose reloads wait on vmcnt, i.e. for every
+// global store in flight.)
 template <int R, bool MULTI, typename OutT>
 __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : ((MULTI && R == 2) ? 6 : 8))
 vhp_sweep_fronts(DevMap m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride,
-                 int* __restrict__ err_flag, const int* __restrict__ order, const int4* __restrict__ wg_desc,
-                 unsigned long long* __restrict__ queue, int* __restrict__ cu_slots, int n_slots) {
+                 int* __restrict__ err_flag, const int* __restrict__ order, const int4* __restrict__ wg_desc) {
   extern __shared__ double lds[];
-  if (!queue) {
-    sweep_slot<R, MULTI, OutT>(m, src_xy, out, field_stride, err_flag, order, wg_desc, (int)blockIdx.x, lds);
-    return;
-  }
-  __shared__ int next_slot, from_tail;
-  if (threadIdx.x == 0) {
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const unsigned key = (((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu)) & (kCuSlots - 1);
-    from_tail = atomicAdd(&cu_slots[key], 1) & 1;
-  }
-  __syncthreads();
-  const bool tail = from_tail != 0;
-  for (;;) {
-    if (threadIdx.x == 0) {
-      const unsigned long long old = atomicAdd(queue, tail ? (1ull << 32) : 1ull);
-      const unsigned h = (unsigned)old, t = (unsigned)(old >> 32);
-      next_slot = (h + t >= (unsigned)n_slots) ? n_slots : (tail ? n_slots - 1 - (int)t : (int)h);
-    }
-    __syncthreads();
-    const int b = __builtin_amdgcn_readfirstlane(next_slot);
-    if (b >= n_slots) return;
-    sweep_slot<R, MULTI, OutT>(m, src_xy, out, field_stride, err_flag, order, wg_desc, b, lds);
-    __syncthreads();  // every wavefront is through with this slot's LDS (and has read next_slot) before the next pull
-  }
+  sweep_slot<R, MULTI, OutT>(m, src_xy, out, field_stride, err_flag, order, wg_desc, (int)blockIdx.x, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1268,12 +1246,7 @@ constexpr int kOrderClasses = 3;  // G = 1, 2, 4 units per workgroup
 // Outputs: order[] (unit indices: class-major, longest first inside a class) and one descriptor
 // per workgroup slot {first, count, G} (count 0 = vacant slot).
 __global__ void __launch_bounds__(1024) vhp_order_units(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int rows_per_strip,
-                                                        int pack_w, int* __restrict__ order, int4* __restrict__ wg_desc,
-                                                        unsigned long long* __restrict__ queue, int* __restrict__ cu_slots) {
-  if (queue) {  // a persistent launch follows: its pull queue and per-CU arrival counters start at zero
-    if (threadIdx.x == 0) *queue = 0ull;
-    for (int k = threadIdx.x; k < kCuSlots; k += blockDim.x) cu_slots[k] = 0;
-  }
+                                                        int pack_w, int* __restrict__ order, int4* __restrict__ wg_desc) {
   __shared__ int hist[kOrderClasses * kOrderBuckets];
   __shared__ int start[kOrderClasses * kOrderBuckets];
   __shared__ int cls_n[kOrderClasses], cls_off[kOrderClasses], wg_off[kOrderClasses + 1];
