@@ -67,10 +67,19 @@ float run(double* d, int grid) {
 }
 int main(int argc, char** argv) {
   const int nbuf = argc > 1 ? atoi(argv[1]) : 6;
+  const bool one_allocation = argc > 2;  // any second argument: the buffers are 2 GB windows of ONE allocation
   double* d[16];
-  for (int k = 0; k < nbuf; ++k) {
-    if (hipMalloc(&d[k], (size_t)256 * NX * NY * 8 + 4096) != hipSuccess) { printf("hipMalloc %d failed\n", k); return 1; }
-    printf("buffer %d at %p\n", k, (void*)d[k]);
+  const size_t each = (size_t)256 * NX * NY * 8 + 4096;
+  if (one_allocation) {
+    char* big = nullptr;
+    if (hipMalloc(&big, each * nbuf) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+    for (int k = 0; k < nbuf; ++k) d[k] = reinterpret_cast<double*>(big + each * k);
+    printf("one allocation of %zu bytes at %p, %d windows\n", each * nbuf, (void*)big, nbuf);
+  } else {
+    for (int k = 0; k < nbuf; ++k) {
+      if (hipMalloc(&d[k], each) != hipSuccess) { printf("hipMalloc %d failed\n", k); return 1; }
+      printf("buffer %d at %p\n", k, (void*)d[k]);
+    }
   }
   for (int rep = 0; rep < 2; ++rep)
     for (int k = 0; k < nbuf; ++k)

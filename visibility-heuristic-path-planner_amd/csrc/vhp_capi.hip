@@ -142,7 +142,9 @@ void pick_shape(const vhp_ctx* c, int maxdim, int* R, int* W, bool* multi, int n
   // (Round 1 sent batches of 256+ sources to the one-row-per-lane shape with whole-line flushes: -3 % at 1000^2 then,
   // +2 % when re-measured in round 2 (0.780 against 0.767 ms on one buffer); above 1024 such batches take the streaming
   // sweep now.  The shape stays reachable through vhp_set_option and is parity-tested.)
-  (void)n_src; (void)f64; (void)pitch64;
+  // fp32 fields still do: there the 16 staged columns of that shape are one whole 64-byte sector per row, and the
+  // two-rows-per-lane shape spills 52 registers in its fp32 build (0.53 against 0.61 ms at 1000^2, round 1).
+  if (!f64 && maxdim > 256 && maxdim <= 1024 && n_src >= 256 && pitch64) { *R = 1; *W = 8; }
   if (c && c->opt_rows_per_lane) *R = c->opt_rows_per_lane;
   if (c && c->opt_strips) *W = c->opt_strips;
   *multi = (*W) * 64 * (*R) < maxdim;
