@@ -180,7 +180,8 @@ extern "C" {
 // that every cell is written).  W: sweeping wavefronts of an x-major unit (>= 3); a y-major unit sweeps with 2W - 1 (the
 // launcher's shape: 2W wavefronts per workgroup).  order_mode & 7: 0 round robin forward, 1 backward, 2 shuffled,
 // 3 greedy (a wavefront runs while it is ready), 4 shuffled with random bursts;  order_mode & 8: the flushers run as late
-// as the hand-off allows instead of right at the post;  order_mode & 16: two tile slots (no slack) instead of three.
+// as the hand-off allows instead of right at the post;  order_mode & 16: two tile slots (no slack) instead of three;
+// order_mode & 32: y-major units swept by W - 1 wavefronts (the team size when two of them share a workgroup).
 // stats (5 entries, may be null): scheduler passes in total, most passes of one workgroup, violations (deadlocks),
 // 16-byte / 8-byte store instructions.
 int vhp_sim_stream_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W,
@@ -188,7 +189,7 @@ int vhp_sim_stream_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src,
   if (!occ || !src || !out || nx <= 0 || ny <= 0 || (nx & 7) != 0 || W < 3 || W > 8) return 1;
   SimShape sh;
   sh.Wx = W;
-  sh.Wy = 2 * W - 1;
+  sh.Wy = (order_mode & 32) ? W - 1 : 2 * W - 1;
   sh.tile_slots = (order_mode & 16) ? 2 : 3;
   sh.lazy_flush = (order_mode & 8) != 0;
   if (dtype == 0) return run_batch<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), sh, order_mode & 7, stats);

@@ -44,9 +44,9 @@ def test_sim_small_and_ragged_grids(oracle, nx, ny):
     nb = max(3, min(40, nx * ny // 400))
     occ = maps.random_rect_map(nx, ny, nb, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 7 + ny)
     src = _sources(occ, 6, nx + ny)
-    L, T = sim_lib.LAZY_FLUSH, sim_lib.TWO_SLOTS
-    for W, order, dtype in [(4, 0, np.float64), (4, 1 | L, np.float64), (4, 2 | L | T, np.float32), (8, 3, np.float64), (3, 4 | T, np.float64),
-                            (4, 3 | L, np.float64)]:
+    L, T, Y = sim_lib.LAZY_FLUSH, sim_lib.TWO_SLOTS, sim_lib.SMALL_Y_TEAM
+    for W, order, dtype in [(4, 0 | Y, np.float64), (4, 1 | L, np.float64), (4, 2 | L | T | Y, np.float32), (8, 3, np.float64), (3, 4 | T, np.float64),
+                            (4, 3 | L | Y, np.float64)]:
         _check(oracle, occ, src, W, order, dtype, "%dx%d W=%d order=%d %s" % (nx, ny, W, order, dtype.__name__))
 
 
@@ -59,6 +59,7 @@ def test_sim_multi_round_grids(oracle, nx, ny, W):
     # buffer reuse fails under
     # (2176 x 2200: the diagonal array of the y-major units wraps, kDiagRing entries)
     _check(oracle, occ, src, W, 3 | sim_lib.LAZY_FLUSH, np.float64, "%dx%d W=%d greedy, late flushers" % (nx, ny, W))
+    _check(oracle, occ, src[:3], W, 3 | sim_lib.SMALL_Y_TEAM, np.float64, "%dx%d W=%d greedy, small y-major teams" % (nx, ny, W))
     _check(oracle, occ, src[:3], W, 4 | sim_lib.TWO_SLOTS, np.float64, "%dx%d W=%d bursts, two tile slots" % (nx, ny, W))
     _check(oracle, occ, src[:3], 3, 3, np.float64, "%dx%d W=3 greedy" % (nx, ny))
 

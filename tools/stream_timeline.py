@@ -60,6 +60,9 @@ ts = np.linspace(0, end[live].max(), 41)
 conc = [(int(((start <= t) & (end > t) & live).sum())) for t in ts]
 print("resident workgroups over time:", conc)
 print("sum of slots", slots[live].sum(), " sum of WG-us", dur[live].sum().round(0))
+for o, nm in ((0, "x-major"), (1, "y-major")):
+    so = live & (octant == o)
+    print("  %s units: %d, sum of WG-us %.0f, mean busy wavefronts per unit %.2f" % (nm, so.sum(), dur[so].sum(), (frac[so][:, :4 if o == 0 else 7].sum(1) * dur[so]).sum() / max(dur[so].sum(), 1e-9)))
 big = np.argsort(-dur)[:8]
 for b in big:
     print("  long unit %4d (%s): start %.1f dur %.1f us slots %d ni %d nj %d busy %s" % (b, "xy"[octant[b]], start[b], dur[b], slots[b], ni[b], nj[b], frac[b].round(2)))

@@ -6,26 +6,28 @@
 // previous front: itself and its neighbour one row / column below), organised for a store-bound launch of a
 // thousand quadrants instead of for the latency of one:
 //
-//   * the unit of scheduling is one OCTANT of one quadrant of one source (8 per source): W wavefronts sweep strips of
-//     an x-major octant (64 rows each, one row per lane), or W wavefronts sweep strips of a y-major octant (128 columns
-//     each, two adjacent columns per lane, so that a lane stores 16 bytes per row and a wavefront 1 KB).  The two octants
-//     of a quadrant share only the diagonal cells, and the y-major unit recomputes those itself (DiagWave: the two-term
-//     recurrence sub(k) = V(k,k-1), diag(k) = sub(k)*occ(k,k) of tests/schedule_model.py, one wavefront running ahead of
-//     the strips), so units never talk to each other: a full-size quadrant is two independent 4 MB units on two CUs
-//     instead of one 8 MB unit that sets the length of the launch (a CU's store path moves ~9 bytes per clock);
+//   * the unit of scheduling is one OCTANT of one quadrant of one source (8 per source), taken by a workgroup of 2W
+//     wavefronts: W wavefronts sweep strips of an x-major octant (64 rows each, one row per lane) and W more flush what
+//     they produce (below); or 2W-1 wavefronts sweep strips of a y-major octant (128 columns each, two adjacent columns
+//     per lane, so that a lane stores 16 bytes per row and a wavefront 1 KB) and one computes the diagonal.  The two
+//     octants of a quadrant share only the diagonal cells, and the y-major unit recomputes those itself (DiagWave: the
+//     two-term recurrence sub(k) = V(k,k-1), diag(k) = sub(k)*occ(k,k) of tests/schedule_model.py, running ahead of the
+//     strips), so units never talk to each other: a full-size quadrant is two independent 4 MB units instead of one
+//     8 MB unit that sets the length of the launch;
 //   * the unit of work is one 64-cell BLOCK of the marching coordinate of one strip -- exactly one word of the
 //     bit-packed occupancy maps, so a lane loads one word per owned row/column and unit.  A wavefront takes the strips
 //     w, w+W, w+2W, ... one after the other, block by block.  There is no workgroup barrier: the workgroup is a small
 //     dataflow machine.  Every wavefront counts the units it has finished in an LDS word, and before a unit it polls
-//     (once per 64 steps) the counters of the few wavefronts it depends on: the strip below must have swept the same
-//     block (boundary row, through a four-block LDS ring, or through a full-length LDS row from the last strip of a
-//     round to the first strip of the next), the reader of its output ring must not lag more than the ring holds, and
-//     a y-major strip needs the diagonal cells of its columns.  A wavefront that is ahead simply runs ahead, and one
-//     that has nothing to do costs nothing (the barrier-per-slot form of this kernel left 70 % of its wavefront
-//     slots idle and was bound by its largest quadrants: profiles/r02_*);
-//   * x-major strips stage 16 columns in a wave-private LDS tile and emit every row as whole, aligned 128-byte lines
-//     (8 rows per store instruction).  With a row pitch that is an odd multiple of 64 bytes (1000 columns!) odd and even
-//     rows are half a line apart, so the two row classes flush alternately, each every 16 steps;
+//     (once per 64 steps) the counters of the one or two wavefronts it depends on: the strip below must have swept the
+//     same block (boundary row, through a four-block LDS ring, or through a full-length LDS row from the last strip of
+//     a round to the first strip of the next), the reader of its output ring must not lag more than the ring holds, and
+//     a y-major strip needs the diagonal cells of its columns.  A wavefront that is ahead simply runs ahead (the
+//     barrier-per-slot form of this kernel left 70 % of its wavefront slots idle: DESIGN.md section 4b);
+//   * x-major strips stage their columns in a wave-private LDS tile of two or three 8-column windows; whenever a
+//     window completes 128-byte lines of the field, the strip's FLUSHER wavefront -- told so by a 16-byte descriptor in
+//     an LDS ring -- reads them out of the tile and stores them, 8 rows per store instruction.  With a row pitch that is
+//     an odd multiple of 64 bytes (1000 columns!) odd and even rows are half a line apart, so the two row classes flush
+//     alternately, each every 16 steps;
 //   * the stale diagonal of the reference (cell (k,k) = cell (k,k-1) * occ) is produced inside the x-major
 //     strip that owns row k; the y-major unit seeds column k with the same value from its own DiagWave, through an LDS array.
 //
