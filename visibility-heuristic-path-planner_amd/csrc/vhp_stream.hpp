@@ -447,12 +447,9 @@ struct XWave {
     j0 = d1 >> 14;
     rows_here = (d0 >> 19) & 0x7f;
     const int xa = (d0 & 0xffff) - 16, r_first = (d0 >> 16) & 1;
+    // flush() publishes `drained` as soon as its tile reads are issued -- before the stores, whose issue may stall for
+    // hundreds of cycles each: the sweeping wavefront gets its tile columns back that much earlier
     if (d0 & kDescPred) flush<true>(xa, r_first, i_now); else flush<false>(xa, r_first, i_now);
-    ++drained;
-    lds_publish(drained_w, drained);  // (the tile reads above were issued before this write: the LDS keeps the order)
-#ifdef VHP_EXP_FDRAIN
-    stores_done();
-#endif
     return true;
   }
 
@@ -471,13 +468,22 @@ struct XWave {
     OutT* base = out + y_low * (long)m.nx;          // uniform: the row term lives in scalar registers
     const long base_step = (long)(8 * r_stride * DY) * m.nx;
     if (!PRED && rows_here == kXRows) {
-      const int n_inst = kXRows / 8 / r_stride;
-#pragma unroll 4
-      for (int u = 0; u < n_inst; ++u) {
-        const vd a = lds_load(tile, t0 + u * t_step);
-        const vd b = lds_load(tile, t0 + (u * t_step + 1));
-        g_store2(base, off, a, b);
-        base += base_step;
+      // all the lines into registers, the tile handed back, then the stores
+      vd a[8], b[8];
+      if (r_stride == 2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = lds_load(tile, t0 + u * t_step); b[u] = lds_load(tile, t0 + (u * t_step + 1)); }
+        ++drained;
+        lds_publish(drained_w, drained);  // (issued after the tile reads: the LDS keeps the order)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { g_store2(base, off, a[u], b[u]); base += base_step; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = lds_load(tile, t0 + u * t_step); b[u] = lds_load(tile, t0 + (u * t_step + 1)); }
+        ++drained;
+        lds_publish(drained_w, drained);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { g_store2(base, off, a[u], b[u]); base += base_step; }
       }
     } else {
       const vi xc = (lane & 7) * 2 + xa;                             // x of the pair's first cell
@@ -499,6 +505,8 @@ struct XWave {
         }
         base += base_step;
       }
+      ++drained;
+      lds_publish(drained_w, drained);
     }
     wave_sync();
   }
