@@ -104,3 +104,24 @@ def test_stream_rejects_bad_source_and_is_idempotent(vhp):
     with pytest.raises(vhp.VhpError) as e:
         c.sync()
     assert e.value.code == vhp.VHP_ERR_SOURCE_OOB
+
+
+def test_kernel_choice_is_reported(vhp):
+    # which kernel a batch takes is the library's decision (vhp_capi.hip use_stream_kernel); it tells through the ABI
+    occ = np.ones((8, 1104), np.uint8)   # a side above 1024
+    src = np.array([[k, 3] for k in range(96)], np.int32)
+    c = vhp.Context(0)
+    c.set_map(occ)
+    assert c.last_sweep_kernel() == 0
+    c.sweep_batch(src)
+    assert c.last_sweep_kernel() == 2
+    c.sweep_batch(src[:95])
+    assert c.last_sweep_kernel() == 1
+    c.set_option("kernel", 2)
+    c.sweep_batch(src[:3])
+    assert c.last_sweep_kernel() == 2
+    occ = np.ones((40, 1000), np.uint8)  # up to 1024: the front sweep, whatever the batch
+    c = vhp.Context(0)
+    c.set_map(occ)
+    c.sweep_batch(np.array([[k, 3] for k in range(300)], np.int32))
+    assert c.last_sweep_kernel() == 1

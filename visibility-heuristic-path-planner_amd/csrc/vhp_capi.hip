@@ -264,12 +264,13 @@ bool use_stream_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel == 2) return true;
   // Measured on MI355X (tools/ab_libs.py on one buffer, tools/ab_bench.sh in fresh processes; DESIGN.md "which kernel").
   // The streaming sweep needs a batch that keeps every CU pulling units for much longer than its largest unit takes (one
-  // full-size octant: 0.3 ms at 1000^2, 4.4 ms at 4096^2): 128 sources at 2048^2 1.46 against 1.61 ms, at 4096^2 5.30
-  // against 6.29 ms; with 64 sources it loses (1.09 / 1.01, 4.69 / 3.95 ms).  At 1000^2 the answer depends on where the
-  // output buffer lies (DESIGN.md "output placement"): 256 sources take 0.73 ms in it against 0.76 ms on a buffer in
-  // the slow state, 0.64 against 0.56 ms on one in the fast state -- the front sweep has the better expectation there.
+  // full-size octant: 0.3 ms at 1000^2, 4.4 ms at 4096^2).  front / streaming, ms: 128 sources at 1536^2 0.97 / 0.86, at
+  // 2048^2 1.60 / 1.38, at 4096^2 6.44 / 5.32; 96 sources 1.24 / 1.19 and 5.44 / 5.13; 64 sources 1.00 / 1.04 and
+  // 3.80 / 4.48.  At 1000^2 the answer depends on where the output buffer lies (DESIGN.md "output placement"): 256
+  // sources take 0.73-0.75 ms in it against 0.76 ms on a buffer in the slow state, 0.64 against 0.56 ms on one in the
+  // fast state -- the front sweep has the better expectation there.
   const int maxdim = std::max(c->nx, c->ny);
-  return maxdim > 1024 && n_src >= 128;
+  return maxdim > 1024 && n_src >= 96;
 }
 
 template <typename OutT>
