@@ -12,16 +12,16 @@ occ[5, 5] = 1
 for lib in sys.argv[1:]:
     mod._lib = None
     mod.LIB_PATH = os.path.join(mod._HERE, "libvhp_hip.so") if lib == "-" else os.path.join(ROOT, lib)
-    for kopt in (2, 28, 1):
+    for kopt in (2, 22, 1):  # streaming sweep, the same with two tile slots, front sweep
         for srcs in ([[5, 5]], [[500, 500]], [[5, 5]] * 8):
             src = np.array(srcs, np.int32)
             n = len(src)
             c = mod.Context(0)
             c.set_stream(torch.cuda.current_stream().cuda_stream)
             c.set_map(occ)
-            c.set_option("kernel", 2 if kopt == 28 else kopt)
-            if kopt == 28:
-                c.set_option("stream_strips", 8)
+            c.set_option("kernel", 2 if kopt == 22 else kopt)
+            if kopt == 22:
+                c.set_option("stream_tile_slots", 2)
             d_src = torch.from_numpy(src).cuda()
             out = torch.empty((n, 1000, 1000), dtype=torch.float64, device="cuda")
             for _ in range(3):
