@@ -65,10 +65,11 @@ def test_stream_kernel_two_tile_slots(vhp, oracle, nx, ny):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d two-slot stream, source (%d,%d)" % (nx, ny, sx, sy))
 
 
-@pytest.mark.parametrize("nx,ny", [(2048, 1500), (1536, 2600), (4096, 4096)])
+@pytest.mark.parametrize("nx,ny", [(2048, 1500), (1536, 2600), (4096, 4096), (3000, 2504), (8192, 24), (24, 8192)])
 def test_stream_kernel_large_grids(vhp, oracle, nx, ny):
-    # sides above 1024: more rounds per octant, larger round-to-round rows; 16-wavefront workgroups where the LDS asks for it
-    occ = maps.random_rect_map(nx, ny, 40, 10, nx // 6, 10, ny // 6, nx + 3)
+    # sides above 1024: more rounds per octant, larger round-to-round rows, y-major units with the whole workgroup, two tile
+    # slots and (3000 x 2504) a diagonal array that wraps; the thin ones reach the largest side the library takes
+    occ = maps.random_rect_map(nx, ny, 40, min(10, ny // 6 - 1, nx // 6 - 1) if min(nx, ny) < 64 else 10, max(nx // 6, 2), 1 if min(nx, ny) < 64 else 10, max(ny // 6, 2), nx + 3)
     src = _sources(occ, 2, ny)[:6]
     got = _ctx(vhp, occ).sweep_batch(src)
     for k, (sx, sy) in enumerate(src):
