@@ -60,7 +60,7 @@ struct vhp_ctx {
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream)
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep
-  int opt_stream_strips = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
+  int opt_stream_tile_slots = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
   // dynamic-LDS limit already raised on THIS context's device, per kernel function
   std::vector<std::pair<const void*, size_t>> lds_raised;
 
@@ -291,7 +291,7 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.stream = c->stream;
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
   a.ev_begin = a.ev_end = nullptr;
-  a.force_strips = c->opt_stream_strips;
+  a.force_tile_slots = c->opt_stream_tile_slots;
   if (c->timing) {
     if (!c->event_pool.empty()) {
       a.ev_begin = c->event_pool.back().first;
@@ -671,7 +671,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "multi_round") { ctx->opt_multi = v != 0; }
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
-  else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2 or 3"); ctx->opt_stream_strips = v; }
+  else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2 or 3"); ctx->opt_stream_tile_slots = v; }
   else if (k == "kernel") { if (v < 0 || v > 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream"); ctx->opt_kernel = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;

@@ -375,7 +375,7 @@ template <typename OutT>
 hipError_t launch_t(const StreamArgs& a) {
   using namespace stream;
   auto k = vhp_stream_sweep<OutT, kWX>;
-  const StreamShape sh = pick_stream_shape(a.nx, a.ny, (a.force_strips == 2 || a.force_strips == 3) ? a.force_strips : 0);
+  const StreamShape sh = pick_stream_shape(a.nx, a.ny, (a.force_tile_slots == 2 || a.force_tile_slots == 3) ? a.force_tile_slots : 0);
   if (sh.lds == 0 || sh.lds > kLdsLimit) return hipErrorInvalidValue;
   if (a.raise_lds) {
     hipError_t e = a.raise_lds(reinterpret_cast<const void*>(k), sh.lds);

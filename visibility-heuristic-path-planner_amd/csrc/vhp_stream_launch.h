@@ -18,7 +18,7 @@ struct StreamArgs {
   int dtype;              // VHP_F64 / VHP_F32
   long long field_stride; // elements
   int* d_err;             // device flag: a source outside the grid
-  int* d_queue;           // scratch of stream_queue_bytes(n_src): the unit queue, per-CU counters, the launch order
+  int* d_queue;           // scratch of stream_queue_bytes(n_src): the pull queue, per-CU counters, the slots in launch order
   int n_cus;              // compute units of the device (the persistent grid is sized to what the chip holds at once)
   hipStream_t stream;
   // called with (kernel, bytes) before a launch that needs more than the default dynamic LDS: the per-device
@@ -26,12 +26,12 @@ struct StreamArgs {
   std::function<hipError_t(const void*, size_t)> raise_lds;
   // optional per-launch timing events, recorded around the sweep kernel only
   hipEvent_t ev_begin, ev_end;
-  int force_strips;       // 0: automatic; 4 / 8: strips per octant and round (tuning, vhp_set_option "stream_strips")
+  int force_tile_slots;   // 0: automatic; 2 / 3: windows per staging tile (tuning, vhp_set_option "stream_tile_slots")
 };
 
 // true if the streaming kernel can sweep this grid (pitch a multiple of 8 cells, LDS of a workgroup fits)
 bool stream_supported(int nx, int ny);
-// strips per octant and round the launch will use for this grid (4 or 8), 0 if unsupported
+// sweeping wavefronts per x-major unit of a launch on this grid, 0 if unsupported
 int stream_strips(int nx, int ny);
 hipError_t launch_stream(const StreamArgs& a);
 size_t stream_queue_bytes(int n_src);
