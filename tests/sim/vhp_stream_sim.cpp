@@ -190,7 +190,7 @@ int vhp_sim_stream_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src,
   SimShape sh;
   sh.Wx = W;
   sh.Wy = (order_mode & 32) ? W - 1 : 2 * W - 1;
-  sh.tile_slots = (order_mode & 16) ? 2 : 3;
+  sh.tile_slots = (order_mode >> 8) & 15 ? (order_mode >> 8) & 15 : (order_mode & 16) ? 2 : 3;  // bits 8-11: an explicit slot count (4, 6, 8)
   sh.lazy_flush = (order_mode & 8) != 0;
   if (dtype == 0) return run_batch<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), sh, order_mode & 7, stats);
   return run_batch<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), sh, order_mode & 7, stats);

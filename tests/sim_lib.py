@@ -42,6 +42,11 @@ def sweep(occ, sources, dtype=np.float64, W=4, order=0):
 
 LAZY_FLUSH = 8   # order flag: the flushers of x-major strips run as late as the hand-off allows
 TWO_SLOTS = 16   # order flag: two tile slots (a plain hand-off) instead of three
+def tile_slots(n):
+    """order flag: n tile slots (4, 6 or 8: what a launch with one workgroup per CU may use)"""
+    return n << 8
+
+
 SMALL_Y_TEAM = 32  # order flag: y-major units swept by W - 1 wavefronts (two such units share a workgroup on the GPU)
 
 

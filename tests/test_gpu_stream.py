@@ -55,14 +55,16 @@ def test_stream_kernel_bit_exact(vhp, oracle, nx, ny, dtype):
 
 
 @pytest.mark.parametrize("nx,ny", [(264, 9), (200, 163), (640, 603), (1000, 1000), (1024, 700)])
-def test_stream_kernel_two_tile_slots(vhp, oracle, nx, ny):
-    # the staging tiles of x-major strips with two windows instead of three (what grids above ~2000 cells a side get):
-    # the sweeping wavefront hands every window to its flusher before it starts the next
+@pytest.mark.parametrize("slots", [2, 4, 6, 8])
+def test_stream_kernel_tile_slots(vhp, oracle, nx, ny, slots):
+    # the staging tiles of x-major strips with two windows (a plain hand-off: the sweeping wavefront hands every window
+    # to its flusher before it starts the next) and with four, six, eight (what grids above ~2000 cells a side get,
+    # with one workgroup per CU) instead of three
     occ = maps.random_rect_map(nx, ny, 30, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 5 + ny)
     src = _sources(occ, 4, nx + 2 * ny)
-    got = _ctx(vhp, occ, tile_slots=2).sweep_batch(src)
+    got = _ctx(vhp, occ, tile_slots=slots).sweep_batch(src)
     for k, (sx, sy) in enumerate(src):
-        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d two-slot stream, source (%d,%d)" % (nx, ny, sx, sy))
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d %d-slot stream, source (%d,%d)" % (nx, ny, slots, sx, sy))
 
 
 @pytest.mark.parametrize("nx,ny", [(2048, 1500), (1536, 2600), (4096, 4096), (3000, 2504), (8192, 24), (24, 8192)])

@@ -46,7 +46,8 @@ def test_sim_small_and_ragged_grids(oracle, nx, ny):
     src = _sources(occ, 6, nx + ny)
     L, T, Y = sim_lib.LAZY_FLUSH, sim_lib.TWO_SLOTS, sim_lib.SMALL_Y_TEAM
     for W, order, dtype in [(4, 0 | Y, np.float64), (4, 1 | L, np.float64), (4, 2 | L | T | Y, np.float32), (8, 3, np.float64), (3, 4 | T, np.float64),
-                            (4, 3 | L | Y, np.float64)]:
+                            (4, 3 | L | Y, np.float64), (4, 3 | L | sim_lib.tile_slots(4), np.float64), (4, 2 | L | sim_lib.tile_slots(6), np.float64),
+                            (4, 4 | L | sim_lib.tile_slots(8), np.float32)]:
         _check(oracle, occ, src, W, order, dtype, "%dx%d W=%d order=%d %s" % (nx, ny, W, order, dtype.__name__))
 
 

@@ -263,14 +263,15 @@ bool use_stream_kernel(const vhp_ctx* c, int n_src) {
   if (!vhp::stream_supported(c->nx, c->ny)) return false;
   if (c->opt_kernel == 2) return true;
   // Measured on MI355X (tools/ab_libs.py on one buffer, tools/ab_bench.sh in fresh processes; DESIGN.md "which kernel").
-  // The streaming sweep needs a batch that keeps every CU pulling units for much longer than its largest unit takes (one
-  // full-size octant: 0.3 ms at 1000^2, 4.4 ms at 4096^2).  front / streaming, ms: 128 sources at 1536^2 0.97 / 0.86, at
-  // 2048^2 1.60 / 1.38, at 4096^2 6.44 / 5.32; 96 sources 1.24 / 1.19 and 5.44 / 5.13; 64 sources 1.00 / 1.04 and
-  // 3.80 / 4.48.  At 1000^2 the answer depends on where the output buffer lies (DESIGN.md "output placement"): 256
-  // sources take 0.73-0.75 ms in it against 0.76 ms on a buffer in the slow state, 0.64 against 0.56 ms on one in the
-  // fast state -- the front sweep has the better expectation there.
+  // The streaming sweep needs a batch that keeps every CU pulling units for much longer than its largest unit takes.
+  // front / streaming, ms: 128 sources at 1536^2 0.97 / 0.86, at 2048^2 1.60 / 1.41, at 2304^2 1.76 / 1.55, at 3072^2
+  // 3.23 / 2.45, at 4096^2 6.36 / 4.29; 96 sources at 2048^2 1.24 / 1.19, at 4096^2 4.42 / 3.98; 64 sources at 2304^2
+  // 1.23 / 1.25, at 3072^2 2.27 / 2.19, at 4096^2 3.90 / 3.65; 48 sources at 4096^2 3.39 / 3.60.  At 1000^2 the answer
+  // depends on where the output buffer lies (DESIGN.md "output placement"): 256 sources take 0.73-0.75 ms in it against
+  // 0.76 ms on a buffer in the slow state, 0.64 against 0.56-0.62 ms on one in the fast state -- the front sweep has the
+  // better expectation there.
   const int maxdim = std::max(c->nx, c->ny);
-  return maxdim > 1024 && n_src >= 96;
+  return maxdim > 1024 && n_src >= (maxdim >= 3072 ? 64 : 96);
 }
 
 template <typename OutT>
@@ -671,7 +672,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "multi_round") { ctx->opt_multi = v != 0; }
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
-  else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2 or 3"); ctx->opt_stream_tile_slots = v; }
+  else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3 && v != 4 && v != 6 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2, 3, 4, 6 or 8"); ctx->opt_stream_tile_slots = v; }
   else if (k == "kernel") { if (v < 0 || v > 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream"); ctx->opt_kernel = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;

@@ -167,7 +167,7 @@ __device__ __forceinline__ void unit_phase(const Map& m, const int32_t* __restri
 // dynamic LDS = stream LDS size of the launcher (lds_bytes); y_half = doubles of one y-major team when two share a
 // workgroup, 0 when a y-major unit has the whole workgroup.
 template <typename OutT, int WX>
-__global__ void __launch_bounds__(128 * WX, 2)
+__global__ void __launch_bounds__(128 * WX, WX <= 4 ? 2 : 1)
 vhp_stream_sweep(Map m, const int32_t* __restrict__ src_xy, OutT* __restrict__ out, long long field_stride, int* __restrict__ err_flag,
                  const int2* __restrict__ order, unsigned long long* __restrict__ queue, int* __restrict__ cu_slots,
                  const int* __restrict__ n_slots_ptr, int tile_slots, int y_half) {
@@ -342,40 +342,51 @@ __global__ void __launch_bounds__(1024) vhp_stream_order(const int32_t* __restri
 
 namespace {
 constexpr size_t kLdsLimit = 160 * 1024;
-constexpr int kWX = 4;  // sweeping wavefronts of an x-major unit; a workgroup is 2 * kWX wavefronts
+// sweeping wavefronts of an x-major unit; a workgroup is 2 * kWX wavefronts.  (8, i.e. one 16-wavefront workgroup per
+// CU, was measured: 0.92 against 0.75 ms at 1000^2 with 256 sources, 1.39 / 1.45 at 2048^2, level at 4096^2.)
+constexpr int kWX = 4;
 struct StreamShape {
   int tile_slots;  // 3 (a window of slack for the flushers) where two workgroups still fit a CU's LDS, else 2
   int y_half;      // doubles of one y-major team when two y-major units share a workgroup (kWX - 1 sweeping wavefronts each), else 0
   size_t lds;      // dynamic LDS per workgroup, bytes
 };
-StreamShape pick_stream_shape(int nx, int ny, int force_tile_slots) {
+// Tile slots and workgroups per CU.  Slack between a sweeping wavefront and its flusher is worth more than the second
+// workgroup of a CU once the grid is large: 128 sources at 4096^2 take 5.67 ms with two slots and two workgroups per CU,
+// 4.31 ms with three slots and ONE workgroup per CU, 4.28 with four, 4.37 with six; at 3072^2 3.30 / 2.51 / 2.45 ms.
+// Where three slots fit twice into a CU's LDS (sides up to ~2000) two workgroups stay better or level (1000^2: 0.64
+// against 0.87 ms with one workgroup and 4-8 slots; 2048^2: 1.41 against 1.38-1.39).
+StreamShape shape_for(int nx, int ny, int slots) {
   using namespace stream;
-  StreamShape best{};
-  for (int slots = 3; slots >= 2; --slots) {
-    if (force_tile_slots && slots != force_tile_slots) continue;
-    const int x_total = make_layout(kWX, nx, ny, true, slots).total;
-    const int y_pair = (make_layout(kWX - 1, nx, ny, false, slots).total + 1) & ~1;
-    const int y_whole = make_layout(2 * kWX - 1, nx, ny, false, slots).total;
-    const int pair_total = 2 * y_pair > y_whole ? 2 * y_pair : y_whole;  // (a large y-major unit of a paired launch has the whole workgroup)
-    const size_t paired = (size_t)(x_total > pair_total ? x_total : pair_total) * 8;
-    const size_t whole = (size_t)(x_total > y_whole ? x_total : y_whole) * 8;
-    // two y-major units per workgroup unless that costs the CU its second workgroup
-    StreamShape sh{};
-    sh.tile_slots = slots;
-    const bool pair = paired * 2 <= kLdsLimit || paired <= whole;
-    sh.y_half = pair ? y_pair : 0;
-    sh.lds = pair ? paired : whole;
-    if (sh.lds * 2 <= kLdsLimit) return sh;  // two workgroups per CU
-    if (best.lds == 0 || sh.lds < best.lds) best = sh;
-  }
-  return best;
+  const int x_total = make_layout(kWX, nx, ny, true, slots).total;
+  const int y_pair = (make_layout(kWX - 1, nx, ny, false, slots).total + 1) & ~1;
+  const int y_whole = make_layout(2 * kWX - 1, nx, ny, false, slots).total;
+  const int pair_total = 2 * y_pair > y_whole ? 2 * y_pair : y_whole;  // (a large y-major unit of a paired launch has the whole workgroup)
+  const size_t paired = (size_t)(x_total > pair_total ? x_total : pair_total) * 8;
+  const size_t whole = (size_t)(x_total > y_whole ? x_total : y_whole) * 8;
+  // two y-major units per workgroup unless that costs the CU its second workgroup
+  StreamShape sh{};
+  sh.tile_slots = slots;
+  const bool pair = paired * 2 <= kLdsLimit || paired <= whole;  // (with one workgroup per CU pairing is level: 4.36 / 4.26 ms at 4096^2)
+  sh.y_half = pair ? y_pair : 0;
+  sh.lds = pair ? paired : whole;
+  return sh;
+}
+StreamShape pick_stream_shape(int nx, int ny, int force_tile_slots) {
+  if (force_tile_slots) return shape_for(nx, ny, force_tile_slots);
+  StreamShape sh = shape_for(nx, ny, 3);
+  if (sh.lds * 2 <= kLdsLimit) return sh;  // three slots, two workgroups per CU
+  sh = shape_for(nx, ny, 4);
+  if (sh.lds <= kLdsLimit) return sh;      // four slots, one workgroup per CU
+  sh = shape_for(nx, ny, 3);
+  if (sh.lds <= kLdsLimit) return sh;
+  return shape_for(nx, ny, 2);
 }
 
 template <typename OutT>
 hipError_t launch_t(const StreamArgs& a) {
   using namespace stream;
   auto k = vhp_stream_sweep<OutT, kWX>;
-  const StreamShape sh = pick_stream_shape(a.nx, a.ny, (a.force_tile_slots == 2 || a.force_tile_slots == 3) ? a.force_tile_slots : 0);
+  const StreamShape sh = pick_stream_shape(a.nx, a.ny, a.force_tile_slots);
   if (sh.lds == 0 || sh.lds > kLdsLimit) return hipErrorInvalidValue;
   if (a.raise_lds) {
     hipError_t e = a.raise_lds(reinterpret_cast<const void*>(k), sh.lds);
@@ -396,7 +407,7 @@ hipError_t launch_t(const StreamArgs& a) {
                      cu_slots);
   const int n_slots = n_units;  // an upper bound: the order kernel counts them (big y-major units stay unpaired)
   int per_cu = (int)(kLdsLimit / sh.lds);
-  if (per_cu > 2) per_cu = 2;  // 16 wavefronts per CU: 128 vector registers each
+  if (per_cu > 16 / (2 * kWX)) per_cu = 16 / (2 * kWX);  // 16 wavefronts per CU: 128 vector registers each
   const int resident = per_cu * a.n_cus;
   const int grid = n_slots < resident ? n_slots : resident;
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);

@@ -65,7 +65,7 @@ constexpr int kBlock = 64;       // steps per slot: one word of the packed occup
 constexpr int kRing = 256;       // entries of a strip-to-strip boundary ring: four blocks, indexed by the absolute marching coordinate
                                  // (the reader of block n also needs the last entry of block n-1 while the writer is in block n+1)
 constexpr int kDiagRing = 2048;  // entries of the diagonal array of a y-major unit (a ring on grids larger than that)
-constexpr int kDescRing = 8;     // flush descriptors in flight between an x-major wavefront and its flusher
+constexpr int kDescRing = 16;    // flush descriptors in flight between an x-major wavefront and its flusher (at most tile slots + 3)
 constexpr int kXRows = 64;       // rows per x-major strip (one per lane)
 constexpr int kYCols = 128;      // columns per y-major strip (two per lane)
 constexpr int kMaxStrips = 136;  // 8192 / 64 + slack
@@ -274,7 +274,7 @@ struct XWave {
   volatile int* drained_w;
   int* desc;
   int posted;       // sweeping side: descriptors posted so far ...
-  int posted_prev;  // ... and when the window before the current one was entered
+  int hist[7];      // ... and when the window 1, 2, ... 7 windows before the current one was entered (hist[0]: the one before)
   int cur_win;      // x >> 3 of the window being swept
   int drained;      // flusher side: descriptors read out of the tile
   int pf_blk;       // the block (x >> 6) whose operands wait in ow_nx / rv_nx, or -1
@@ -310,7 +310,8 @@ struct XWave {
     prog.bind(lds, L, W);
     drained_w = prog.done + kDrainedSlot + w;
     desc = prog.descriptors(L, w);
-    posted = posted_prev = drained = 0;
+    posted = drained = 0;
+    for (int k = 0; k < 7; ++k) hist[k] = 0;
     cur_win = -1;
     pf_blk = -1;
     r_stride = ((m.nx >> 3) & 1) ? 2 : 1;
@@ -340,7 +341,8 @@ struct XWave {
     init_common(m_, g_, out_, w_, W_, lds, L);
   }
 
-  VHP_FN int slot_of(int win) const { return nslots == 3 ? win % 3 : win & 1; }  // win >= 0
+  // the tile slot of window `win` (>= 0); slot counts: 2, 3, 4, 6, 8
+  VHP_FN int slot_of(int win) const { return nslots == 3 ? win % 3 : nslots == 6 ? win % 6 : win & (nslots - 1); }
 
   VHP_FN void load_strip(int pn) {
     p = pn;
@@ -356,7 +358,7 @@ struct XWave {
     if ((p + 1) % W == 0) { rout = round; rout_mask = round_mask; } else { rout = ring_base + w * kRing; rout_mask = kRing - 1; }
     // a new strip starts anywhere in the tile: everything posted has to be out first
     cur_win = -1;
-    posted_prev = posted;
+    for (int k = 0; k < 7; ++k) hist[k] = posted;
     pf_blk = -1;
     // dependencies (see ready())
     raw_nf = raw_off = 0;
@@ -457,7 +459,7 @@ struct XWave {
   template <bool PRED>
   VHP_FN void flush(int xa, int r_first, int i_now) {
     wave_sync();
-    const int win = (xa >> 3) + 6;  // (xa may be -8 at the end of a march; 6 is a multiple of both slot counts)
+    const int win = (xa >> 3) + 24;  // (xa may be -8 at the end of a march; 24 is a multiple of every slot count)
     const int sA = slot_of(win), sB = slot_of(win + 1);
     // (arithmetic, not a select between members: a select of two loads becomes a load through a selected address, which
     // keeps the whole wavefront object in scratch memory)
@@ -646,9 +648,15 @@ struct XWave {
         // This window's tile columns were last read by the flushes posted up to two windows ago (three tile slots; one
         // window ago with two): they must have left the tile.
         VHP_PROF_T0(tf0);
-        wait_drained(nslots == 3 ? posted_prev : posted);
+        // (with S tile slots: the flushes posted before the window S-2 windows back was entered)
+        int need = posted;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) need = nslots - 3 == k ? hist[k] : need;
+        wait_drained(need);
         VHP_PROF_ADD(4, tf0);
-        posted_prev = posted;
+#pragma unroll
+        for (int k = 6; k > 0; --k) hist[k] = hist[k - 1];
+        hist[0] = posted;
         cur_win = x >> 3;
       }
       const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
