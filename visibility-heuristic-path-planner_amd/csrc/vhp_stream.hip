@@ -350,11 +350,12 @@ struct StreamShape {
   int y_half;      // doubles of one y-major team when two y-major units share a workgroup (kWX - 1 sweeping wavefronts each), else 0
   size_t lds;      // dynamic LDS per workgroup, bytes
 };
-// Tile slots and workgroups per CU.  Slack between a sweeping wavefront and its flusher is worth more than the second
-// workgroup of a CU once the grid is large: 128 sources at 4096^2 take 5.67 ms with two slots and two workgroups per CU,
-// 4.31 ms with three slots and ONE workgroup per CU, 4.28 with four, 4.37 with six; at 3072^2 3.30 / 2.51 / 2.45 ms.
-// Where three slots fit twice into a CU's LDS (sides up to ~2000) two workgroups stay better or level (1000^2: 0.64
-// against 0.87 ms with one workgroup and 4-8 slots; 2048^2: 1.41 against 1.38-1.39).
+// Tile slots and workgroups per CU.  On large grids one workgroup per CU is the better shape, and slack between a
+// sweeping wavefront and its flusher helps on top: 128 sources at 4096^2 take 5.67 ms with two slots and two workgroups
+// per CU, 4.92 ms with three or four slots and two workgroups (a diagnostic build), 4.31 ms with three slots and ONE
+// workgroup per CU, 4.28 with four, 4.37 with six; at 3072^2 3.30 / 2.51 / 2.45 ms.  Where three slots fit twice into a
+// CU's LDS (sides up to ~2000) two workgroups stay better or level (1000^2: 0.64 against 0.87 ms with one workgroup and
+// 4-8 slots; 2048^2: 1.41 against 1.38-1.39).
 StreamShape shape_for(int nx, int ny, int slots) {
   using namespace stream;
   const int x_total = make_layout(kWX, nx, ny, true, slots).total;
