@@ -143,6 +143,13 @@ int vhp_planner_solve_variant(vhp_ctx* ctx, int start_x, int start_y, int end_x,
                               uint64_t max_iter, uint64_t* label, double* map_builder, double* local, int32_t* waypoints_xy,
                               uint32_t* n_waypoints);
 
+/* computeVisibility() (solver.cpp:570-696) with the reference's local `offset` (:573; added to both operands of every c_,
+ * :590-591 ... :686-687) exposed.  offset = 0 is the reference at HEAD and equals vhp_sweep_batch bit for bit (use that:
+ * this entry point runs a plain anti-diagonal kernel, not the tuned ones).  It exists because the reference's published
+ * Samples/SFMLstandAloneVisibility.png was rendered by a build with offset = 1; with it the library reproduces that
+ * image.  fp64 fields, host buffers, cells the reference never writes are 0, grid sides up to 4096. */
+int vhp_sweep_batch_offset(vhp_ctx* ctx, const int32_t* src_xy, int n_src, double offset, double* out_host);
+
 /* Elapsed milliseconds between the first and last kernel of the most recent
  * vhp_sweep_batch_device / planner call, from hipEvents recorded on the context
  * stream.  Blocks until that work has finished. */

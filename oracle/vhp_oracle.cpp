@@ -5,15 +5,27 @@
 //     load this library.  The product (libvhp_hip.so, the vhp CLI, the python
 //     binding) never links, loads or calls it.
 //   * Strict IEEE-754 binary64: build with -O2 -ffp-contract=off, no fast-math.
-//   * PARITY PIN: the reference solver cannot be compiled in this image (it
-//     includes <SFML/Graphics.hpp>, SFML is absent, and building it against a
-//     stand-in header is not allowed).  This restatement is therefore pinned
-//     only against the reference outputs recorded in SURVEY.md section 8c / Q1-Q9
-//     (runs of the real reference made during the survey): maze_6 -> 64 pivots,
-//     first five pivots, path length 1529.55; 1000^2 seed 1 -> pivots
-//     (50,50),(273,350),(525,675), path 1346.71, density 20.3243 %; the 9x9
-//     stale-diagonal probe; row/column 0 never swept.  See tests/test_oracle_kat.py.
-//     Anything those known answers do not exercise is "parity unpinned".
+//   * PARITY PIN.  The reference solver cannot be compiled in this image (it includes
+//     <SFML/Graphics.hpp>, SFML is absent, and building it against a stand-in header is
+//     not allowed), so there is no oracle/_ref for it.  This restatement is pinned against
+//       (1) golden outputs the reference itself ships: Samples/SFMLrayCastingVisibility.png
+//           and Samples/SFMLstandAloneVisibility.png (README.md:27-33), two 1000 x 1000
+//           renderings of raycasting() and computeVisibility() from one map and source
+//           (committed as data: tests/golden/samples_1000.npz).  Ray casting: all 951 360
+//           comparable pixels equal.  The sweep: all 951 360 equal with the reference's
+//           local `offset` (:573) = 1.0, the value the published build had; HEAD has 0.0,
+//           which provably does not match (tests/test_oracle_kat.py::test_reference_sample_*).
+//           This pins the loop nest, the stencil form, the quadrant extents (Q2), the
+//           occupancy handling and the rounding -- not the stale diagonal (Q1), which this
+//           map does not discriminate;
+//       (2) known answers of runs of the real reference recorded in SURVEY.md section 8c /
+//           Q1-Q9: maze_6 -> 64 pivots, first five pivots, path length 1529.55; 1000^2 seed 1
+//           -> pivots (50,50),(273,350),(525,675), path 1346.71, density 20.3243 %; the 9x9
+//           stale-diagonal probe (Q1); row/column 0 never swept.
+//     Samples/SFMLResultingPath.png (a third map) was tried with offset 0 and 1 at thresholds
+//     0.1-0.5 and is NOT reproduced (one of its five pivots, (468,592), appears at offset 1,
+//     thr 0.1): an older planner build; it pins nothing.  The planner's heap/tie-break
+//     (Q6) and heuristic are therefore pinned by (2) only.
 //
 // Every function cites the reference lines it follows
 // (paths relative to /root/reference).
@@ -58,9 +70,14 @@ Grid make_grid(const uint8_t* occ_u8, int nx, int ny) {
 // i == j >= 1, so the diagonal inherits the previous inner iteration's stored
 // value (quirk Q1) -- are what make this a restatement rather than a
 // re-derivation.  `visit(x, y, v)` runs after the cell is stored.
+// `offset` is the reference's local of that name (:384, :573; added to both operands
+// of every c_, :403-404 ... :686-687).  It is 0.0 at HEAD, and 0.0 is what every
+// product-facing entry point of this oracle passes.  It is a parameter only so that
+// tests/test_oracle_kat.py can pin this loop nest against the reference's own
+// Samples/SFMLstandAloneVisibility.png, which was rendered by a build with offset = 1.
 template <class Visit>
 void quadrant_nest(const Grid& g, double* vis, int sx, int sy, int dirx, int diry,
-                   size_t ni, size_t nj, double& v, Visit&& visit) {
+                   size_t ni, size_t nj, double& v, Visit&& visit, double offset = 0.0) {
   for (size_t i = 0; i < ni; ++i) {
     const size_t x = dirx > 0 ? (size_t)sx + i : (size_t)sx - i;
     const size_t xm = dirx > 0 ? x - 1 : x + 1;  // the column one step back toward the source
@@ -74,11 +91,11 @@ void quadrant_nest(const Grid& g, double* vis, int sx, int sy, int dirx, int dir
       } else if (j == 0) {
         v = vis[g.at(xm, y)];
       } else if (i > j) {
-        const double c = (double)j / (double)i;
+        const double c = offset == 0.0 ? (double)j / (double)i : (double)(j + offset) / (i + offset);
         const double a = vis[g.at(xm, y)];
         v = a - c * (a - vis[g.at(xm, ym)]);
       } else if (j > i) {
-        const double c = (double)i / (double)j;
+        const double c = offset == 0.0 ? (double)i / (double)j : (double)(i + offset) / (j + offset);
         const double a = vis[g.at(x, ym)];
         v = a - c * (a - vis[g.at(xm, ym)]);
       }
@@ -92,12 +109,12 @@ void quadrant_nest(const Grid& g, double* vis, int sx, int sy, int dirx, int dir
 // Quadrant order and extents: Q1 (+,+) nx-sx by ny-sy; Q2 (-,+) sx by ny-sy;
 // Q3 (-,-) sx by sy; Q4 (+,-) nx-sx by sy  (solver.cpp:576-577,607-608,637-638,667-668).
 template <class Visit>
-void four_quadrants(const Grid& g, double* vis, int sx, int sy, Visit&& visit) {
+void four_quadrants(const Grid& g, double* vis, int sx, int sy, Visit&& visit, double offset = 0.0) {
   double v = 0.0;
-  quadrant_nest(g, vis, sx, sy, +1, +1, (size_t)(g.nx - sx), (size_t)(g.ny - sy), v, visit);
-  quadrant_nest(g, vis, sx, sy, -1, +1, (size_t)sx, (size_t)(g.ny - sy), v, visit);
-  quadrant_nest(g, vis, sx, sy, -1, -1, (size_t)sx, (size_t)sy, v, visit);
-  quadrant_nest(g, vis, sx, sy, +1, -1, (size_t)(g.nx - sx), (size_t)sy, v, visit);
+  quadrant_nest(g, vis, sx, sy, +1, +1, (size_t)(g.nx - sx), (size_t)(g.ny - sy), v, visit, offset);
+  quadrant_nest(g, vis, sx, sy, -1, +1, (size_t)sx, (size_t)(g.ny - sy), v, visit, offset);
+  quadrant_nest(g, vis, sx, sy, -1, -1, (size_t)sx, (size_t)sy, v, visit, offset);
+  quadrant_nest(g, vis, sx, sy, +1, -1, (size_t)(g.nx - sx), (size_t)sy, v, visit, offset);
 }
 
 // eval_d, visibilityBasedSolver.h:112-115: first product in double, second in int.
@@ -123,6 +140,17 @@ int vhp_oracle_sweep_full(const uint8_t* occ, int nx, int ny, int sx, int sy, do
   if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return 2;
   Grid g = make_grid(occ, nx, ny);
   four_quadrants(g, vis, sx, sy, [](size_t, size_t, double) {});
+  return 0;
+}
+
+// computeVisibility() with the reference's `offset` local (:573) set to something other
+// than its HEAD value 0.0.  TEST-ONLY: exists to pin the loop nest against the reference's
+// published Samples/SFMLstandAloneVisibility.png (offset = 1); nothing else may call it.
+int vhp_oracle_sweep_full_offset(const uint8_t* occ, int nx, int ny, int sx, int sy, double offset, double* vis) {
+  if (!occ || !vis || nx <= 0 || ny <= 0) return 1;
+  if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return 2;
+  Grid g = make_grid(occ, nx, ny);
+  four_quadrants(g, vis, sx, sy, [](size_t, size_t, double) {}, offset);
   return 0;
 }
 
@@ -207,6 +235,7 @@ struct vhp_oracle_planner {
   std::vector<int32_t> pivots;  // x,y pairs; lightSources_
   uint64_t nb = 0;              // nb_of_sources_
   double scale = 0, thr = 0;
+  double offset = 0.0;  // the reference's local of updateVisibility() (:384); 0.0 except in the test-only *_offset entry
   int ex = 0, ey = 0;
   // result of the last planner step
   int top_x = 0, top_y = 0;
@@ -235,7 +264,7 @@ static int planner_step(vhp_oracle_planner& P, int px, int py) {
                        (eval_d((int)x, (int)y, P.ex, P.ey) + eval_d((int)x, (int)y, qx, qy));
       heap.push(HeapNode{x, y, h});
     }
-  });
+  }, P.offset);
   P.pushes = heap.size();
   if (heap.empty()) return 3;  // reference would call top() on an empty heap (UB)
   P.top_x = (int)heap.top().x;
@@ -251,10 +280,10 @@ static int planner_step(vhp_oracle_planner& P, int px, int py) {
 // still filled so tests can look at the live-lock); 3 nothing lit.
 // pivots_xy must hold 2*(max_iter+2) int32.  On return *n_pivots = nb_of_sources_
 // and pivots_xy[2*nb..] = end (:141).
-int vhp_oracle_planner_solve(const uint8_t* occ, int nx, int ny, int start_x, int start_y,
-                             int end_x, int end_y, double threshold, uint64_t max_iter,
-                             uint64_t* came_from, double* vis_global, double* vis_local,
-                             int32_t* pivots_xy, uint32_t* n_pivots, double* top_h_trace) {
+static int planner_solve_impl(const uint8_t* occ, int nx, int ny, int start_x, int start_y,
+                              int end_x, int end_y, double threshold, uint64_t max_iter,
+                              uint64_t* came_from, double* vis_global, double* vis_local,
+                              int32_t* pivots_xy, uint32_t* n_pivots, double* top_h_trace, double offset) {
   if (!occ || nx <= 0 || ny <= 0) return 1;
   auto valid = [&](int x, int y) { return (size_t)x < (size_t)nx && (size_t)y < (size_t)ny; };  // .h:100-102
   if (!valid(start_x, start_y)) return 10;
@@ -270,6 +299,7 @@ int vhp_oracle_planner_solve(const uint8_t* occ, int nx, int ny, int start_x, in
   P.pivots.assign(2 * (max_iter + 2), 0);
   P.scale = std::sqrt((double)((size_t)ny * ny + (size_t)nx * nx));  // :49
   P.thr = threshold;
+  P.offset = offset;
   P.ex = end_x;
   P.ey = end_y;
   int px = start_x, py = start_y;
@@ -298,6 +328,24 @@ int vhp_oracle_planner_solve(const uint8_t* occ, int nx, int ny, int start_x, in
   if (pivots_xy) std::memcpy(pivots_xy, P.pivots.data(), 2 * (size_t)(P.nb + 1) * sizeof(int32_t));
   if (n_pivots) *n_pivots = (uint32_t)P.nb;
   return status;
+}
+
+int vhp_oracle_planner_solve(const uint8_t* occ, int nx, int ny, int start_x, int start_y,
+                             int end_x, int end_y, double threshold, uint64_t max_iter,
+                             uint64_t* came_from, double* vis_global, double* vis_local,
+                             int32_t* pivots_xy, uint32_t* n_pivots, double* top_h_trace) {
+  return planner_solve_impl(occ, nx, ny, start_x, start_y, end_x, end_y, threshold, max_iter, came_from,
+                            vis_global, vis_local, pivots_xy, n_pivots, top_h_trace, 0.0);
+}
+
+// TEST-ONLY twin of the above with the reference's `offset` local (:384) exposed; see
+// vhp_oracle_sweep_full_offset.
+int vhp_oracle_planner_solve_offset(const uint8_t* occ, int nx, int ny, int start_x, int start_y,
+                                    int end_x, int end_y, double threshold, uint64_t max_iter, double offset,
+                                    uint64_t* came_from, double* vis_global, double* vis_local,
+                                    int32_t* pivots_xy, uint32_t* n_pivots) {
+  return planner_solve_impl(occ, nx, ny, start_x, start_y, end_x, end_y, threshold, max_iter, came_from,
+                            vis_global, vis_local, pivots_xy, n_pivots, nullptr, offset);
 }
 
 // A single updateVisibility() on caller-owned state (for step-level parity tests).

@@ -16,6 +16,16 @@ c1_rnd1_mask.npz : BASELINE config 1's 101x101 occupancy mask.  MATLAB_code/rnd_
              kept free), with randi(n) taken as floor(n*rand)+1 -- MATLAB itself is not
              available here, so whether its randi draws exactly like that is unverified: the
              committed MASK is the fixture, not the generator.
+samples_1000.npz : the reference's own published outputs of this path, Samples/SFMLstandAloneVisibility.png and
+             Samples/SFMLrayCastingVisibility.png (README.md:27-33): two 1000 x 1000 images written by the real
+             reference's saveStandAloneVisibility / saveRayCastingVisibility (src/visibilityBasedSolver.cpp:898-955,
+             960-1017) from one map and the source (500, 500).  Decoded to DATA: image row r <-> field y = 999 - r
+             (row y = 0 is never drawn, :903); blocked cells are exactly the pure-red pixels (:943-949; the same
+             set in both files); grey level = uint8(255 * v) (:906-908); the yellow disc of radius 15 (+ black ring
+             of radius 16, :918-941) hides the cells around the source.  Stored: the RGB pixels of both images as they
+             are (image orientation), the source, the ball radius; synth.samples_1000() derives the occupancy and
+             the grey planes.  Cells whose value the images show = y >= 1, not blocked, farther than 16 from the
+             source (951 360 of them).
 """
 import os
 
@@ -37,6 +47,28 @@ def main():
     c1 = c1_mask_from_rnd1()
     np.savez_compressed(os.path.join(OUT, "c1_rnd1_mask.npz"), packed=np.packbits(c1, axis=1), nx=c1.shape[1], ny=c1.shape[0])
     print("c1_rnd1_mask", c1.shape, "free cells", int(c1.sum()))
+    samples_1000()
+
+
+def samples_1000():
+    def pixels(name):
+        im = np.array(Image.open(os.path.join(REF, "Samples", name)))
+        assert im.shape == (1000, 1000, 4) and (im[..., 3] == 255).all()
+        return im[..., :3]                # image orientation: row r is field row y = 999 - r
+    sweep, ray = pixels("SFMLstandAloneVisibility.png"), pixels("SFMLrayCastingVisibility.png")
+    is_red = lambda im: (im[..., 0] == 255) & (im[..., 1] == 0) & (im[..., 2] == 0)
+    is_yellow = lambda im: (im[..., 0] == 255) & (im[..., 1] == 255) & (im[..., 2] == 0)
+    assert (is_red(sweep) == is_red(ray)).all() and (is_yellow(sweep) == is_yellow(ray)).all()
+    rows, xs = np.nonzero(is_yellow(sweep))
+    src = (int(round(xs.mean())), 999 - int(round(rows.mean())))
+    assert src == (500, 500) and len(xs) == 709          # a whole disc of radius 15: nothing blocked under it
+    for im in (sweep, ray):                               # everything that is neither red nor yellow is a grey level
+        rest = ~is_red(im) & ~is_yellow(im)
+        assert (im[..., 0][rest] == im[..., 1][rest]).all() and (im[..., 1][rest] == im[..., 2][rest]).all()
+        assert not im[999].any()                          # field row y = 0 is never drawn (:903): the constructor's black
+    np.savez_compressed(os.path.join(OUT, "samples_1000.npz"), sweep_rgb=sweep, ray_rgb=ray,
+                        source=np.array(src, np.int32), ball_radius=15)
+    print("samples_1000: blocked", int(is_red(sweep).sum()), "source", src)
 
 
 def c1_mask_from_rnd1(n=101):

@@ -30,6 +30,10 @@ def load(path=None):
         build()
     lib = C.CDLL(path)
     lib.vhp_oracle_sweep_full.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f64p]
+    lib.vhp_oracle_sweep_full_offset.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f64p]
+    lib.vhp_oracle_planner_solve_offset.argtypes = [
+        _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_double,
+        _u64p, _f64p, _f64p, _i32p, C.POINTER(C.c_uint32)]
     lib.vhp_oracle_sweep_queue.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f64p]
     lib.vhp_oracle_planner_solve.argtypes = [
         _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
@@ -43,9 +47,10 @@ def load(path=None):
     lib.vhp_oracle_generate_env.argtypes = [
         C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _u8p]
     lib.vhp_oracle_raycast_all.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f64p]
-    lib.vhp_oracle_sweep_matlab.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f64p]
-    lib.vhp_oracle_planner_matlab.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
-                                              C.c_uint64, _u64p, _f64p, _f64p, _i32p, C.POINTER(C.c_uint32)]
+    if hasattr(lib, "vhp_oracle_sweep_matlab"):  # both libraries are built from both sources; tolerate an older fast build
+        lib.vhp_oracle_sweep_matlab.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f64p]
+        lib.vhp_oracle_planner_matlab.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                  C.c_uint64, _u64p, _f64p, _f64p, _i32p, C.POINTER(C.c_uint32)]
     lib.vhp_oracle_time_sweeps.restype = C.c_double
     lib.vhp_oracle_time_sweeps.argtypes = [_u8p, C.c_int, C.c_int, _i32p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     return lib
@@ -61,6 +66,14 @@ class Oracle:
         ny, nx = occ.shape
         vis = np.zeros((ny, nx), np.float64) if vis is None else vis
         rc = self.lib.vhp_oracle_sweep_full(np.ascontiguousarray(occ, np.uint8), nx, ny, sx, sy, vis)
+        assert rc == 0, rc
+        return vis
+
+    def sweep_full_offset(self, occ, sx, sy, offset):
+        """TEST-ONLY: computeVisibility() with the reference's `offset` local (solver.cpp:573) set to `offset`."""
+        ny, nx = occ.shape
+        vis = np.zeros((ny, nx), np.float64)
+        rc = self.lib.vhp_oracle_sweep_full_offset(np.ascontiguousarray(occ, np.uint8), nx, ny, sx, sy, float(offset), vis)
         assert rc == 0, rc
         return vis
 

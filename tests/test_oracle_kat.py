@@ -1,13 +1,76 @@
-"""Pins the CPU oracle to outputs of the REAL reference recorded in SURVEY.md 8c / Q1-Q9.
+"""Pins the CPU oracle to outputs of the REAL reference.
 
-The reference solver cannot be compiled here (SFML absent), so these recorded
-known answers are the only pin; see oracle/vhp_oracle.cpp header.
+Two kinds of pin (see the oracle/vhp_oracle.cpp header):
+  * golden outputs the reference itself ships -- Samples/SFMLrayCastingVisibility.png and
+    Samples/SFMLstandAloneVisibility.png, two 1000 x 1000 renderings of its ray casting and of
+    computeVisibility() from one map and source (tests/golden/samples_1000.npz): 951 360 comparable
+    pixels each, all of them equal (test_reference_sample_*);
+  * known answers of runs of the real reference recorded in SURVEY.md 8c / Q1-Q9 (the solver cannot
+    be compiled here: SFML is absent).
 """
 import numpy as np
 import pytest
 
 import maps
 from oracle_lib import UNLABELLED
+
+
+def test_reference_sample_raycasting(oracle):
+    """Samples/SFMLrayCastingVisibility.png (the reference's benchmark(), src/visibilityBasedSolver.cpp:226-237 ->
+    saveRayCastingVisibility) == uint8(255 * oracle ray casting) on every pixel that shows a field value."""
+    g = maps.samples_1000()
+    m = g["comparable"]
+    assert int(m.sum()) == 951360
+    ray = oracle.raycast_all(g["occ"], *g["source"])
+    got = (255 * ray).astype(np.uint8)           # sf::Color(255 * v, ...): double -> Uint8 truncates (:906-908)
+    assert int((got[m] != g["ray_grey"][m]).sum()) == 0
+    assert 100000 < int((g["ray_grey"][m] == 0).sum()) < 900000   # not vacuous: the image has both shadow and light
+
+
+def test_reference_sample_sweep(oracle):
+    """Samples/SFMLstandAloneVisibility.png (computeVisibility() -> saveStandAloneVisibility, :217-224, 898-955).
+
+    The published image was rendered by a build whose local `offset` (:573; c_ = (j + offset) / (i + offset), :590-591)
+    was 1.0; HEAD has 0.0.  With offset = 1 the oracle's loop nest -- i outer, j inner, one running v, four quadrants in
+    order, v *= occupancy -- reproduces all 951 360 comparable pixels over 256 grey levels; with HEAD's offset = 0 it
+    must NOT (the penumbrae sit ~0.7 px elsewhere), so the test cannot pass vacuously.  What this pins: stencil form,
+    loop structure, quadrant extents, occupancy handling, rounding to grey.  What it does not discriminate on this
+    map: the stale diagonal (a proper-diagonal variant matches as well) -- that stays pinned by the
+    9 x 9 probe recorded from the real reference (test_stale_diagonal_q1)."""
+    g = maps.samples_1000()
+    m = g["comparable"]
+    v1 = oracle.sweep_full_offset(g["occ"], *g["source"], 1.0)
+    assert int(((255 * v1).astype(np.uint8)[m] != g["sweep_grey"][m]).sum()) == 0
+    assert len(np.unique(g["sweep_grey"][m])) == 256
+    v0 = oracle.sweep_full_offset(g["occ"], *g["source"], 0.0)
+    assert int(((255 * v0).astype(np.uint8)[m] != g["sweep_grey"][m]).sum()) > 100000
+    # offset = 0 through the test-only entry IS the product-facing oracle, bit for bit
+    assert v0.tobytes() == oracle.sweep_full(g["occ"], *g["source"]).tobytes()
+    # column 0 is drawn and never swept (Q2): black in the reference's image, 0 in the oracle
+    assert not g["sweep_grey"][1:, 0].any() and not v1[:, 0].any()
+
+
+def test_reference_sample_whole_images(oracle):
+    """Every pixel of both published images -- source ball, ring, red obstacles, the undrawn row y = 0 and the unswept
+    column x = 0 included -- from the oracle's arrays through saveStandAloneVisibility restated (tests/test_gpu_cli.py
+    render_field; the CLI's C++ renderer is held to the same images in tests/test_gpu_golden_samples.py)."""
+    from test_gpu_cli import render_field
+    g = maps.samples_1000()
+    for field, want in ((oracle.raycast_all(g["occ"], *g["source"]), g["ray_rgb"]),
+                        (oracle.sweep_full_offset(g["occ"], *g["source"], 1.0), g["sweep_rgb"])):
+        got = render_field(field, g["occ"], g["source"], g["ball_radius"])
+        assert np.array_equal(got[..., :3], want) and (got[..., 3] == 255).all()
+
+
+def test_fast_oracle_build_loads():
+    # bench.py's cpu_baseline times this build (the reference's own flags); it must bind every symbol oracle_lib uses
+    import os
+    import oracle_lib
+    oracle_lib.build(fast=True)
+    o = oracle_lib.Oracle(os.path.join(oracle_lib.ORACLE_DIR, "libvhp_oracle_fast.so"))
+    occ = np.ones((40, 40), np.uint8)
+    occ[10:20, 25:30] = 0
+    assert np.allclose(o.sweep_full(occ, 3, 4), oracle_lib.Oracle().sweep_full(occ, 3, 4), atol=1e-12)
 
 
 def test_env_generator_density_seed1(oracle):

@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
     "vhp_raycast_all", "vhp_timing", "vhp_timing_collect", "vhp_set_option", "vhp_sweep_batch_variant", "vhp_planner_solve_variant",
     "vhp_planner_solve_device", "vhp_planner_results_device", "vhp_last_sweep_kernel",
-    "vhp_last_elapsed_ms", "vhp_version",
+    "vhp_last_elapsed_ms", "vhp_version", "vhp_sweep_batch_offset",
 )
 
 
@@ -88,6 +88,7 @@ def load_library():
     lib.vhp_planner_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.vhp_sweep_batch_variant.argtypes = [vp, vp, i32, f64, f64, vp]
     lib.vhp_planner_solve_variant.argtypes = [vp, i32, i32, i32, i32, f64, f64, u64, vp, vp, vp, vp, C.POINTER(u32)]
+    lib.vhp_sweep_batch_offset.argtypes = [vp, vp, i32, f64, vp]
     lib.vhp_raycast_all.argtypes = [vp, i32, i32, vp]
     lib.vhp_timing.argtypes = [vp, i32]
     lib.vhp_timing_collect.argtypes = [vp, vp, i32, C.POINTER(i32)]
@@ -209,6 +210,13 @@ class Context:
         src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
         out = np.empty((len(src), self.ny, self.nx), np.float64)
         self._check(self.lib.vhp_sweep_batch_variant(self.h, _ptr(src), len(src), float(alpha), float(fac), _ptr(out)))
+        return out
+
+    def sweep_batch_offset(self, sources, offset):
+        """computeVisibility() with the reference's `offset` local exposed (include/vhp.h): fields [n, ny, nx] float64."""
+        src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
+        out = np.empty((len(src), self.ny, self.nx), np.float64)
+        self._check(self.lib.vhp_sweep_batch_offset(self.h, _ptr(src), len(src), float(offset), _ptr(out)))
         return out
 
     def planner_solve_variant(self, start, end, threshold, alpha, max_iter):

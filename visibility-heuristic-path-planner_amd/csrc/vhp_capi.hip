@@ -576,6 +576,46 @@ int vhp_sweep_batch_variant(vhp_ctx* ctx, const int32_t* src_xy, int n_src, doub
   return VHP_OK;
 }
 
+int vhp_sweep_batch_offset(vhp_ctx* ctx, const int32_t* src_xy, int n_src, double offset, double* out_host) {
+  if (!ctx || !src_xy || !out_host || n_src < 0 || !(offset >= 0)) return fail(ctx, VHP_ERR_ARG, "vhp_sweep_batch_offset: bad argument");
+  if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_sweep_batch_offset: no map set");
+  if (std::max(ctx->nx, ctx->ny) > 4096) return fail(ctx, VHP_ERR_TOO_LARGE, "offset sweeps: grid side above 4096");
+  for (int s = 0; s < n_src; ++s)
+    if (src_xy[2 * s] < 0 || src_xy[2 * s + 1] < 0 || src_xy[2 * s] >= ctx->nx || src_xy[2 * s + 1] >= ctx->ny)
+      return fail(ctx, VHP_ERR_SOURCE_OOB, "a sweep source lies outside the grid");
+  if (n_src == 0) return VHP_OK;
+  VHP_ON_DEVICE(ctx);
+  const size_t cells = (size_t)ctx->nx * ctx->ny;
+  const int slice = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_src, ((size_t)1 << 30) / (cells * 8)));
+  if (ctx->d_src_cap < (size_t)slice) {
+    if (ctx->d_src) hipFree(ctx->d_src);
+    ctx->d_src = nullptr;
+    VHP_HIP(hipMalloc(&ctx->d_src, (size_t)slice * 2 * sizeof(int32_t)));
+    ctx->d_src_cap = slice;
+  }
+  if (ctx->d_out_cap < (size_t)slice * cells * 8) {
+    if (ctx->d_out) hipFree(ctx->d_out);
+    ctx->d_out = nullptr;
+    VHP_HIP(hipMalloc(&ctx->d_out, (size_t)slice * cells * 8));
+    ctx->d_out_cap = (size_t)slice * cells * 8;
+  }
+  const size_t lds = (size_t)3 * (std::max(ctx->nx, ctx->ny) + 1) * sizeof(double);
+  auto k = vhp::variant::vhp_offset_sweep;
+  hipError_t e = raise_lds_limit(ctx, reinterpret_cast<const void*>(k), lds);
+  if (e != hipSuccess) return fail(ctx, VHP_ERR_HIP, std::string("offset sweep: ") + hipGetErrorString(e));
+  for (int s0 = 0; s0 < n_src; s0 += slice) {
+    const int n = std::min(slice, n_src - s0);
+    VHP_HIP(hipMemcpyAsync(ctx->d_src, src_xy + 2 * (size_t)s0, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    VHP_HIP(hipMemsetAsync(ctx->d_out, 0, (size_t)n * cells * 8, ctx->stream));  // a freshly reset() solver
+    hipLaunchKernelGGL(k, dim3((unsigned)(4 * n)), dim3(1024), lds, ctx->stream, ctx->nx, ctx->ny, ctx->d_occ, ctx->d_src,
+                       static_cast<double*>(ctx->d_out), (long long)cells, offset, ctx->d_err);
+    VHP_HIP(hipGetLastError());
+    VHP_HIP(hipMemcpyAsync(out_host + (size_t)s0 * cells, ctx->d_out, (size_t)n * cells * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VHP_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return VHP_OK;
+}
+
 int vhp_planner_solve_variant(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold, double alpha,
                               uint64_t max_iter, uint64_t* label, double* map_builder, double* local, int32_t* waypoints_xy,
                               uint32_t* n_waypoints) {

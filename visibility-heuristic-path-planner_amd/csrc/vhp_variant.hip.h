@@ -66,6 +66,63 @@ __global__ void __launch_bounds__(1024) vhp_variant_sweep(int nx, int ny, const 
   }
 }
 
+// computeVisibility() (reference src/visibilityBasedSolver.cpp:570-696) with its local `offset` (:573, added to both
+// operands of every c_: :590-591 ... :686-687) as a parameter.  It is 0.0 at the reference's HEAD -- that case is what
+// the tuned kernels compute -- but the reference's own published Samples/SFMLstandAloneVisibility.png was rendered by a
+// build with offset = 1, and this kernel is how the library reproduces that image pixel for pixel
+// (tests/test_gpu_golden_samples.py).  C++ semantics, not MATLAB's: the diagonal inherits the stored (x, y -+ 1)
+// (on front d = 2i that is p1[i]), quadrants 2-4 stop short of column/row 0 (Q2), cells nobody writes
+// keep the caller's zero fill.  Same anti-diagonal organisation as vhp_variant_sweep; correctness first.
+__global__ void __launch_bounds__(1024) vhp_offset_sweep(int nx, int ny, const uint8_t* __restrict__ occ, const int32_t* __restrict__ src_xy,
+                                                         double* __restrict__ out, long long field_stride, double offset,
+                                                         int* __restrict__ err_flag) {
+  extern __shared__ double fronts[];
+  const int s = blockIdx.x >> 2, q = blockIdx.x & 3;
+  const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
+  if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) {
+    if (threadIdx.x == 0 && q == 0) atomicOr(err_flag, 1);
+    return;
+  }
+  const int dirx = (q == 0 || q == 3) ? 1 : -1, diry = q < 2 ? 1 : -1;
+  const int ni = dirx > 0 ? nx - sx : sx, nj = diry > 0 ? ny - sy : sy;  // max_x_, max_y_ of the four nests (:576-577, 607-608, 637-638, 667-668)
+  if (ni == 0 || nj == 0) return;
+  const int L = (nx > ny ? nx : ny) + 1;
+  double* field = out + (size_t)s * field_stride;
+  for (int d = 0; d <= ni + nj - 2; ++d) {
+    double* cur = fronts + (d % 3) * L;
+    const double* p1 = fronts + ((d + 2) % 3) * L;  // front d-1
+    const double* p2 = fronts + ((d + 1) % 3) * L;  // front d-2
+    const int i_lo = d - (nj - 1) > 0 ? d - (nj - 1) : 0, i_hi = d < ni - 1 ? d : ni - 1;
+    for (int i = i_lo + (int)threadIdx.x; i <= i_hi; i += blockDim.x) {
+      const int j = d - i;
+      const int x = sx + dirx * i, y = sy + diry * j;
+      double v;
+      if (i == 0 && j == 0) v = 1.0;
+      else if (i == 0) v = p1[i];
+      else if (j == 0) v = p1[i - 1];
+      else if (i > j) {
+        const double c = ((double)j + offset) / ((double)i + offset);
+        const double a = p1[i - 1];
+        const double t = a - p2[i - 1];
+        const double u = c * t;
+        v = a - u;
+      } else if (j > i) {
+        const double c = ((double)i + offset) / ((double)j + offset);
+        const double a = p1[i];
+        const double t = a - p2[i - 1];
+        const double u = c * t;
+        v = a - u;
+      } else v = p1[i];                                               // i == j: the running v of the inner loop, i.e. (x, y -+ 1) as stored
+      v = v * (occ[(size_t)y * nx + x] ? 1.0 : 0.0);
+      cur[i] = v;
+      // quadrants overlap on the axes with identical values; a later nest of the reference overwrites an
+      // earlier one with the same number, so concurrent stores of equal bits are the same result
+      field[(size_t)y * nx + x] = v;
+    }
+    __syncthreads();
+  }
+}
+
 struct PlannerCtl {
   int n_way;    // waypoints so far (waypoints[0] = start)
   int done;

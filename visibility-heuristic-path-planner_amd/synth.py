@@ -75,3 +75,23 @@ def maze_6():
     z = np.load(os.path.join(GOLDEN, "maze_6.npz"))
     nx, ny = int(z["nx"]), int(z["ny"])
     return np.unpackbits(z["packed"], axis=1)[:, :nx].astype(np.uint8).reshape(ny, nx)
+
+
+def samples_1000():
+    """The reference's published 1000 x 1000 sample outputs (Samples/SFML{standAlone,rayCasting}Visibility.png) as
+    committed by tests/golden/make_fixtures.py.  Returns dict(sweep_rgb / ray_rgb: the images' own pixels [row, x, 3];
+    occ [y, x] uint8 (blocked = the pure-red pixels; field row y = 999 - image row; row y = 0 is never drawn and taken
+    as free -- nothing reads it, quadrants march away from the source); source (x, y); ball_radius; sweep_grey / ray_grey
+    uint8 [y, x] = uint8(255 v); comparable = the cells whose grey level the images show)."""
+    z = np.load(os.path.join(GOLDEN, "samples_1000.npz"))
+    sweep, ray = z["sweep_rgb"], z["ray_rgb"]
+    red = (sweep[..., 0] == 255) & (sweep[..., 1] == 0) & (sweep[..., 2] == 0)
+    occ = np.ascontiguousarray((~red)[::-1]).astype(np.uint8)
+    ny, nx = occ.shape
+    sx, sy = (int(v) for v in z["source"])
+    r = int(z["ball_radius"])
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    comparable = (yy >= 1) & (occ == 1) & ((xx - sx) ** 2 + (yy - sy) ** 2 > (r + 1) ** 2)
+    return dict(occ=occ, source=(sx, sy), ball_radius=r, sweep_rgb=sweep, ray_rgb=ray,
+                sweep_grey=np.ascontiguousarray(sweep[::-1, :, 2]), ray_grey=np.ascontiguousarray(ray[::-1, :, 2]),
+                comparable=comparable)
