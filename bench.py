@@ -55,6 +55,10 @@ def parse():
                          "best) are only reported, in config.output_placement")
     ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2],
                     help="0 = the library's own choice, 1 = front sweep, 2 = streaming sweep (vhp_set_option \"kernel\")")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise the launcher, the rendezvous, the barriers and the max-over-ranks timing with a CPU stub in "
+                         "place of the sweep (no GPU, no library): for the CPU test of `bench.py --gpus N`; never a result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -104,15 +108,18 @@ def cpu_baseline(occ, src, seconds):
     import oracle_lib
     fast = os.path.join(ROOT, "oracle", "libvhp_oracle_fast.so")
     flags = "-O3 -Ofast -march=native"
+    fallback = ""
     try:
         if os.path.exists(fast):
             os.remove(fast)
         oracle_lib.build(fast=True)
         orc = oracle_lib.Oracle(fast)
-    except Exception:
+    except (OSError, AttributeError, subprocess.CalledProcessError) as e:
+        # the reference-flags build could not be made or loaded on this host: time the strict build and SAY SO
         oracle_lib.build()
         orc = oracle_lib.Oracle()
         flags = "-O2 -ffp-contract=off"
+        fallback = "; FALLBACK to the strict build because the -Ofast build failed: %r" % (e,)
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -134,8 +141,9 @@ def cpu_baseline(occ, src, seconds):
             break
     return {
         "value": round(done / wall, 2), "unit": "fields/s", "cores": cores, "kind": "port",
+        "flags": flags, "fallback": bool(fallback),
         "sample": "oracle computeVisibility port (%s), %d sweeps of the same %dx%d workload on %d threads; "
-                  "single thread: %.1f fields/s (best sweep %.2f ms)" % (flags, done, occ.shape[1], occ.shape[0], cores, one, best1 * 1e3),
+                  "single thread: %.1f fields/s (best sweep %.2f ms)%s" % (flags, done, occ.shape[1], occ.shape[0], cores, one, best1 * 1e3, fallback),
         "single_thread_value": round(one, 2),
     }
 
@@ -196,13 +204,80 @@ def bench_planner(args):
     print(json.dumps(out), flush=True)
 
 
+def launch_workers(args):
+    """`python bench.py --gpus N` typed by hand (no torchrun around it): start the N ranks ourselves.
+
+    Must run before anything in this process touches the GPU (a process that has initialised HIP must not start
+    replacing itself, and the children need the devices untouched): it imports nothing but the standard library.  The
+    children are `python -m torch.distributed.run` workers of this same file with the same arguments; rank 0's JSON line
+    comes through on stdout; the exit code is the launcher's (non-zero if any rank failed)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def bench_dry_run(args, rank, world):
+    """--dry-run: the protocol of main() -- rendezvous, warm-up, barrier, K timed steps, barrier, max over ranks, one JSON
+    line from rank 0 -- with a CPU stub as the step.  Checks plumbing only; prints "dry_run": true and no roofline."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    vdist = import_module("visibility-heuristic-path-planner_amd.dist")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend)
+    n_src = args.sources or 256
+    lo, hi = vdist.shard_bounds(world * n_src, rank, world)       # this rank's block of the job's sources
+    work = np.arange(lo, hi, dtype=np.float64)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        work.sum()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        work.sum()
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "visibility fields/sec on 1000x1000 grid", "value": round(world * n_src * args.steps / float(t.item()), 2),
+                          "unit": "fields/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "dry_run": True, "config": {"workload": "DRY RUN: CPU stub, no sweep", "sources_per_gpu": n_src,
+                                                       "sharding": "sources/%d" % world, "backend": args.backend}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is what runs" % (args.gpus, world), file=sys.stderr)
+    if args.dry_run:
+        return bench_dry_run(args, rank, world)
+    if args.backend != "nccl":
+        raise SystemExit("bench.py: --backend gloo exists for --dry-run only (the sweep runs on the GPU, RCCL is its collective)")
     if args.workload == "c4":
         return bench_planner(args)
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np

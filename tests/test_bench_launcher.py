@@ -1,0 +1,44 @@
+"""`python bench.py --gpus N` as the driver types it: when no launcher is around it (WORLD_SIZE unset) bench.py starts the N
+ranks itself, before anything touches a GPU.  Driven here on CPU with the gloo backend and the --dry-run stub in place of
+the sweep: what is checked is the launcher, the rendezvous on 127.0.0.1, the barriers, the max over ranks and that exactly
+one JSON line with "n_gpus": N comes out -- and that a failing rank fails the command."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=600, env=env)
+
+
+def _json_lines(out):
+    return [json.loads(line) for line in out.splitlines() if line.startswith("{")]
+
+
+def test_gpus_2_spawns_two_ranks():
+    r = _run("--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--sources", "100")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["steps"] == 4 and line["warmup"] == 1
+    assert line["config"]["sharding"] == "sources/2" and line["scaling"] == "weak"
+    # whole-job aggregate: both ranks' sources over the slowest rank's time
+    assert abs(line["value"] - 2 * 100 * 4 / (line["ms_per_step"] * 4e-3)) <= 0.02 * line["value"]
+
+
+def test_gpus_1_runs_in_process():
+    r = _run("--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _json_lines(r.stdout)[0]["n_gpus"] == 1
+
+
+def test_a_failing_rank_fails_the_command():
+    # gloo is refused outside --dry-run (the sweep has no CPU path): every rank exits non-zero and so must the launcher
+    r = _run("--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert not _json_lines(r.stdout)

@@ -1,6 +1,7 @@
 """The streaming sweep kernel (csrc/vhp_stream.hpp, gfx950 build) through the C ABI against the oracle, bit for bit.
-Batches of 128+ sources take this kernel by default; here it is selected explicitly (vhp_set_option "kernel" = 2) so
-that small batches exercise it too.  The same source runs on the CPU simulator in tests/test_stream_sim.py."""
+Which batches take this kernel by default is decided in vhp_capi.hip (use_stream_kernel; today sides above 1024 from 96
+sources, from 64 at 3072 and up -- tests/test_gpu_sweep.py::test_config5_the_launch_that_ships checks that launch as it
+ships); here it is selected explicitly (vhp_set_option "kernel" = 2) so that small batches exercise it too.  The same source runs on the CPU simulator in tests/test_stream_sim.py."""
 import numpy as np
 import pytest
 

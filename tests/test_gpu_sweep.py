@@ -137,7 +137,8 @@ def test_large_grids_multi_round(vhp, oracle, nx, ny):
 
 
 def test_config5_4096_subset(vhp, oracle):
-    # BASELINE config 5 map (4096x4096, 50 obstacles scaled x4), a few of its sources
+    # BASELINE config 5 map (4096x4096, 50 obstacles scaled x4), a few of its sources through the host-buffer entry
+    # point (a batch this small takes the front sweep; the 128-source launch is test_config5_the_launch_that_ships)
     occ, src = maps.config_c5(128)
     pick = np.concatenate([src[[0, 77]], np.array([[0, 0]], np.int32) if occ[0, 0] else src[[5]]])
     got = _ctx(vhp, occ).sweep_batch(pick)
@@ -257,16 +258,60 @@ def test_4096_large_batch_shape_eight_rounds(vhp, oracle, dtype):
         _assert_same(got[k], want if dtype == "f64" else want.astype(np.float32), "4096^2 %s 8-round shape, source (%d,%d)" % (dtype, sx, sy))
 
 
-def test_config5_sixteen_bench_sources(vhp, oracle):
-    # 16 of the exact 128 sources bench.py --workload c5 sweeps on rank 0, in the shape and grid slide that launch uses
+def _shipping_launch(vhp, oracle, occ, src, what, every):
+    """The launch bench.py times for this workload -- all sources of rank 0, device-resident, the library's own choice of
+    kernel and shape -- on a NaN-filled output: every cell of every field must be written, a second launch must leave
+    the same bytes, and every `every`-th field must equal the oracle's cell for cell.  Returns the kernel that ran."""
+    import torch
+    c = _ctx(vhp, occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
+    d_out = torch.full((len(src),) + occ.shape, float("nan"), dtype=torch.float64, device="cuda")
+    c.sweep_batch_device(d_src.data_ptr(), len(src), d_out.data_ptr())
+    c.sync()
+    kernel = c.last_sweep_kernel()
+    for lo in range(0, len(src), 16):                              # in slices: isnan() of 17 GB at once needs another 2 GB
+        assert not bool(torch.isnan(d_out[lo: lo + 16]).any()), "%s: cells left unwritten in fields %d.." % (what, lo)
+    picks = list(range(0, len(src), every))
+    first = d_out[picks].clone()
+    for n, k in enumerate(picks):
+        sx, sy = int(src[k][0]), int(src[k][1])
+        _assert_same(first[n].cpu().numpy(), oracle.sweep_full(occ, sx, sy), "%s (kernel %d), source %d (%d,%d)" % (what, kernel, k, sx, sy))
+    checks = [d_out[k].sum().item() for k in range(len(src))]
+    c.sweep_batch_device(d_src.data_ptr(), len(src), d_out.data_ptr())
+    c.sync()
+    assert c.last_sweep_kernel() == kernel
+    assert torch.equal(first, d_out[picks])
+    assert checks == [d_out[k].sum().item() for k in range(len(src))]
+    return kernel
+
+
+def test_config5_the_launch_that_ships(vhp, oracle):
+    # bench.py --workload c5: 128 rank-0 sources at 4096^2 (17 GB of fields), default kernel choice -- the loaded launch,
+    # with its queue contended and every kind of unit side by side; 16 of its fields (every 8th) against the oracle
+    occ, src = maps.config_c5(128)
+    kernel = _shipping_launch(vhp, oracle, occ, src, "C5 bench launch", 8)
+    assert kernel in (1, 2, 3)
+
+
+def test_3072_sixtyfour_sources_the_launch_that_ships(vhp, oracle):
+    # the other threshold of the kernel choice (vhp_capi.hip use_stream_kernel): 64 sources from 3072 up
+    occ = maps.random_rect_map(3072, 3072, 50, 60, 300, 60, 300, seed=2)
+    src = maps.free_sources(occ, 64, seed=13)
+    _shipping_launch(vhp, oracle, occ, src, "3072^2 x 64", 8)
+
+
+def test_config5_fronts_sixteen_sources(vhp, oracle):
+    # the front sweep's own 4096^2 shape (four rows per lane, slid grid) on 16 of the C5 sources: what a batch below the
+    # streaming threshold runs in
     import torch
     occ, src = maps.config_c5(128)
     pick = src[::8]
-    assert len(pick) == 16
-    c = _ctx(vhp, occ, slide=1)  # 128 sources => slid grid; 16 would not slide by themselves
+    c = _ctx(vhp, occ, kernel=1, slide=1)
     d_out = _device_launch(vhp, c, pick, occ.shape, torch.float64, vhp.F64)
+    assert c.last_sweep_kernel() == 1
     for k, (sx, sy) in enumerate(pick):
-        _assert_same(d_out[k].cpu().numpy(), oracle.sweep_full(occ, int(sx), int(sy)), "C5 bench source %d (%d,%d)" % (8 * k, sx, sy))
+        _assert_same(d_out[k].cpu().numpy(), oracle.sweep_full(occ, int(sx), int(sy)), "C5 front sweep, source %d (%d,%d)" % (8 * k, sx, sy))
 
 
 @pytest.mark.parametrize("nx,ny", [(1500, 1100), (2500, 2300)])

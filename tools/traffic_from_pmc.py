@@ -19,9 +19,10 @@ def per_kernel(path, counter):
 
 fetch_csv, write_csv, workload, dtype, out_dir = sys.argv[1:6]
 fetch, write = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
-names = [k for k in write if "vhp_stream_sweep" in k or "vhp_sweep_fronts" in k]
+KERNELS = ("vhp_stream_sweep", "vhp_sweep_fronts", "vhp_tile_sweep")   # the batch-sweep kernels (bench.py names them the same way)
+names = [k for k in write if any(n in k for n in KERNELS)]
 name = max(names, key=lambda k: sum(write[k]))
-short = "vhp_stream_sweep" if "vhp_stream_sweep" in name else "vhp_sweep_fronts"
+short = next(n for n in KERNELS if n in name)
 w = sum(write[name]) / len(write[name])
 fch = sum(fetch[name]) / len(fetch[name])
 out = {
@@ -30,7 +31,7 @@ out = {
     "hbm_bytes_per_launch": (2.0 * fch + w) * 1024.0,
     "hbm_bytes_per_launch_fetch_uncorrected": (fch + w) * 1024.0,
     "source": [os.path.basename(fetch_csv), os.path.basename(write_csv)],
-    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline`; "
+    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the bench command of this workload (tools/collect_profiles.sh); "
             "mean over the launches of the process; FETCH_SIZE doubled (gfx950 correction, an upper bound for this read pattern)",
 }
 path = os.path.join(out_dir, "traffic_%s_%s_%s.json" % (workload, dtype, short))
