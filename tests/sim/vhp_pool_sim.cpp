@@ -1,0 +1,234 @@
+// vhp_pool_sim.cpp -- CPU simulator of the pool sweep kernel.  TEST INFRASTRUCTURE ONLY.
+//
+// Compiles csrc/vhp_pool.hpp -- the very source hipcc builds for gfx950 -- with -DVHP_SIM, where a wavefront's lane
+// vector is an array of 64 values (csrc/vhp_lanes.hpp).  The kernel is blocking code (a wavefront that has to wait loops
+// over backoff()), so every wavefront runs as a coroutine (ucontext) on a stack of its own: backoff() switches to the
+// scheduler below, which picks the next wavefront under one of several policies, and the places where a device
+// wavefront can be overtaken between a read and the compare-and-swap that depends on it (sim_point) switch too, always or
+// at random.  G workgroups of W wavefronts share the unit queue, each workgroup with its own NaN-poisoned LDS; the
+// diagonal scratch lines start as NaN as well.  Every interleaving must give the oracle's bytes; when every wavefront
+// has waited many times in a row without any of them getting anything done the run is reported as a deadlock.
+//
+// Only tests/ loads this library (tests/sim_lib.py).  It is not a CPU fallback of the product: libvhp_hip.so neither
+// links nor loads it.
+#define VHP_SIM
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <vector>
+
+#include "../../visibility-heuristic-path-planner_amd/csrc/vhp_pool.hpp"
+
+using namespace vhp::pool;
+
+namespace {
+
+struct HostMap {
+  std::vector<uint64_t> rows, cols;
+  std::vector<double> recip;
+  Map m;
+};
+
+// the packed maps and the reciprocal table, as vhp_set_map builds them (vhp_capi.hip finish_set_map)
+void build_map(const uint8_t* occ, int nx, int ny, HostMap& h) {
+  const int wpr = (nx + 63) / 64 + 2, wpc = (ny + 63) / 64 + 2;
+  h.rows.assign((size_t)ny * wpr, 0);
+  h.cols.assign((size_t)nx * wpc, 0);
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x)
+      if (occ[(size_t)y * nx + x]) {
+        h.rows[(size_t)y * wpr + 1 + (x >> 6)] |= 1ull << (x & 63);
+        h.cols[(size_t)x * wpc + 1 + (y >> 6)] |= 1ull << (y & 63);
+      }
+  const int nrec = (nx > ny ? nx : ny) + 1 + 8;
+  h.recip.resize(nrec);
+  h.recip[0] = 0.0;
+  for (int k = 1; k < nrec; ++k) {
+    volatile double d = (double)k;
+    h.recip[k] = 1.0 / d;
+  }
+  h.m.rows = h.rows.data();
+  h.m.cols = h.cols.data();
+  h.m.recip = h.recip.data();
+  h.m.wpr = wpr;
+  h.m.wpc = wpc;
+  h.m.nx = nx;
+  h.m.ny = ny;
+}
+
+// ---- coroutines ----------------------------------------------------------------------------------------------------
+struct Coro {
+  ucontext_t ctx;
+  std::unique_ptr<char[]> stack;
+  bool done = false;
+  void (*entry)(void*) = nullptr;
+  void* arg = nullptr;
+};
+constexpr size_t kStack = 2u << 20;
+ucontext_t g_sched;
+Coro* g_cur = nullptr;
+long long g_progress = 0, g_switches = 0;
+int g_point_mode = 0;  // 0: points never switch, 1: always, 2: at random
+uint32_t g_rng = 1;
+
+uint32_t lcg() { g_rng = g_rng * 1664525u + 1013904223u; return g_rng >> 8; }
+void do_yield() { ++g_switches; swapcontext(&g_cur->ctx, &g_sched); }
+void hook_yield() { do_yield(); }
+void hook_progress() { ++g_progress; }
+void hook_point() { if (g_point_mode == 1 || (g_point_mode == 2 && (lcg() & 1))) do_yield(); }
+void trampoline() {
+  g_cur->entry(g_cur->arg);
+  g_cur->done = true;
+  swapcontext(&g_cur->ctx, &g_sched);
+}
+
+template <typename OutT>
+void worker_entry(void* p) { static_cast<Worker<OutT>*>(p)->run(); }
+
+// policy & 7: 0 round robin, 1 backward, 2 random wavefront, 3 greedy (the same wavefront again while it gets things done),
+// 4 random with bursts;  policy & 8: sim points always switch;  policy & 16: sim points switch at random
+template <typename OutT>
+int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int C, int G, int policy,
+              uint32_t seed, long long* stats) {
+  HostMap h;
+  build_map(occ, nx, ny, h);
+  const Layout L = make_layout(W, C, nx, ny);
+  const int n_units = n_src * kUnits;
+  // launch order: by cell count, largest first, as vhp_pool_order does (policy & 32: shuffled instead -- the result must not depend on it)
+  std::vector<int> order(n_units), line_base(n_units, 0);
+  std::vector<double> weight(n_units, -1.0);
+  long long line_blocks = 0;
+  for (int u = 0; u < n_units; ++u) {
+    order[u] = u;
+    line_base[u] = (int)line_blocks;
+    const int s = u / kUnits, qo = u % kUnits, sx = src[2 * s], sy = src[2 * s + 1];
+    if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) continue;
+    UnitGeo g;
+    g.init(nx, ny, qo, sx, sy);
+    line_blocks += g.line_blocks();
+    if (g.n_strips > 0) weight[u] = g.x_major ? (double)g.rows_total * g.ni - 0.5 * g.rows_total * (g.rows_total - 1.0)
+                                              : (double)g.cols_total * (g.nj - 1) - 0.5 * g.cols_total * (g.cols_total - 1.0);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+  g_rng = seed * 2654435761u + 12345u;
+  if (policy & 32) for (int k = n_units - 1; k > 0; --k) std::swap(order[k], order[lcg() % (k + 1)]);
+  int queue = 0, err = 0;
+  const int dstride = ((nx < ny ? nx : ny) + 64 + 15) & ~15;
+  std::vector<double> diag((size_t)n_src * 4 * dstride, std::numeric_limits<double>::quiet_NaN());
+  Args<OutT> a;
+  a.m = h.m;
+  a.src_xy = src;
+  a.out = out;
+  a.field_stride = (long long)nx * ny;
+  a.err_flag = &err;
+  a.order = order.data();
+  a.queue = &queue;
+  a.n_units = n_units;
+  a.diag = diag.data();
+  a.diag_stride = dstride;
+  // The boundary lines start with entries of an EARLIER launch (same values poisoned, tag epoch - 1) and, here and there,
+  // with a tag from the future of the same scratch region laid out differently: only this launch's tag may be taken.
+  const uint64_t epoch = 0x5A17000000000000ull + 7 + seed;
+  std::vector<vhp::lanes::Tagged> lines((size_t)line_blocks * 64 + 64);
+  for (size_t k = 0; k < lines.size(); ++k) { lines[k].v = std::numeric_limits<double>::quiet_NaN(); lines[k].tag = (k % 5 == 0) ? 0 : epoch - 1 - (k % 3); }
+  a.lines = lines.data();
+  a.line_base = line_base.data();
+  a.epoch = epoch;
+
+  std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
+  std::vector<Worker<OutT>> workers((size_t)G * W);
+  std::vector<Coro> coros((size_t)G * W);
+  for (int gI = 0; gI < G; ++gI) {
+    Worker<OutT>::clear(lds[gI].data(), L, 0, 1);
+    for (int w = 0; w < W; ++w) {
+      Worker<OutT>& wk = workers[(size_t)gI * W + w];
+      wk.init(a, lds[gI].data(), L, w);
+      Coro& c = coros[(size_t)gI * W + w];
+      c.stack.reset(new char[kStack]);
+      c.entry = worker_entry<OutT>;
+      c.arg = &wk;
+      getcontext(&c.ctx);
+      c.ctx.uc_stack.ss_sp = c.stack.get();
+      c.ctx.uc_stack.ss_size = kStack;
+      c.ctx.uc_link = nullptr;
+      makecontext(&c.ctx, trampoline, 0);
+    }
+  }
+  vhp::lanes::sim_hooks().yield = hook_yield;
+  vhp::lanes::sim_hooks().progress = hook_progress;
+  vhp::lanes::sim_hooks().point = hook_point;
+  vhp::lanes::store_stats() = vhp::lanes::StoreStats();
+  g_point_mode = (policy & 8) ? 1 : (policy & 16) ? 2 : 0;
+  g_progress = g_switches = 0;
+  const int n = G * W, mode = policy & 7;
+  int cur = mode == 1 ? n - 1 : 0, alive = n, burst = 0;
+  long long last_progress = 0, stale = 0, deadlock = 0;
+  while (alive > 0) {
+    // pick
+    if (mode == 0) cur = (cur + 1) % n;
+    else if (mode == 1) cur = (cur + n - 1) % n;
+    else if (mode == 2) cur = (int)(lcg() % n);
+    else if (mode == 3) { if (g_progress == last_progress) cur = (cur + 1) % n; }   // greedy: stay while it gets things done
+    else { if (burst-- <= 0) { cur = (int)(lcg() % n); burst = (int)(lcg() % 6); } }
+    int tries = 0;
+    while (coros[cur].done && tries++ < n) cur = (cur + 1) % n;
+    if (coros[cur].done) break;
+    last_progress = g_progress;
+    g_cur = &coros[cur];
+    swapcontext(&g_sched, &g_cur->ctx);
+    if (coros[cur].done) --alive;
+    if (g_progress == last_progress) { if (++stale > 4000LL * n) { deadlock = 1; break; } } else stale = 0;
+  }
+  vhp::lanes::sim_hooks() = vhp::lanes::SimHooks();
+  if (deadlock && getenv("VHP_SIM_DUMP")) {  // the scheduler words of every workgroup, for debugging a stuck protocol
+    for (int gI = 0; gI < G; ++gI) {
+      Shared sh;
+      sh.lds = lds[gI].data();
+      sh.L = L;
+      const int* sc = sh.sched();
+      fprintf(stderr, "wg %d: queue_empty %d seq %d (queue %d of %d)\n", gI, sc[kQEmpty], sc[kSeq], queue, n_units);
+      for (int c = 0; c < C; ++c) {
+        const int* cx = sh.ctx(c);
+        fprintf(stderr, "  ctx %d: state %d word %x unit %d (qo %d) strips %d left %d sx %d sy %d diag %d\n   prog:", c, cx[kState], cx[kWord], cx[kUnit],
+                cx[kUnit] & 7, cx[kNStrips], cx[kLeft], cx[kSxSy] & 0xffff, cx[kSxSy] >> 16, cx[kDiagReady]);
+        for (int p = 0; p < cx[kNStrips] && p < L.S; ++p) fprintf(stderr, " %d", sh.prog(c)[p]);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+  if (stats) {
+    stats[0] = g_switches;
+    stats[1] = g_progress;
+    stats[2] = deadlock;
+    stats[3] = vhp::lanes::store_stats().n16;
+    stats[4] = vhp::lanes::store_stats().n8;
+    stats[5] = err;
+    stats[6] = queue;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// out: n_src fields of nx*ny elements (dtype 0 = double, 1 = float), pre-filled by the caller (NaN: an unwritten cell shows).
+// W wavefronts per workgroup, C contexts, G workgroups sharing the queue.  stats (7 entries, may be null):
+// coroutine switches, progress events, deadlock (0/1), 16-byte / 8-byte store instructions, the error flag, units pulled.
+int vhp_sim_pool_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W, int C, int G,
+                       int policy, unsigned seed, long long* stats) {
+  if (!occ || !src || !out || nx <= 0 || ny <= 0 || (nx & 7) != 0 || W < 1 || W > 16 || C < 1 || C > 16 || G < 1) return 1;
+  if (dtype == 0) return run_batch<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), W, C, G, policy, seed, stats);
+  return run_batch<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), W, C, G, policy, seed, stats);
+}
+
+int vhp_sim_pool_lds_bytes(int nx, int ny, int W, int C) { return make_layout(W, C, nx, ny).total * 8; }
+
+}  // extern "C"

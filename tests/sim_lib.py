@@ -18,7 +18,7 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", SIM_DIR])
+        subprocess.check_call(["make", "-s", "-C", SIM_DIR, "libvhp_stream_sim.so"])
         lib = C.CDLL(os.path.join(SIM_DIR, "libvhp_stream_sim.so"))
         lib.vhp_sim_stream_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                              C.c_int, C.c_void_p]
@@ -38,6 +38,40 @@ def sweep(occ, sources, dtype=np.float64, W=4, order=0):
                                   out.ctypes.data, W, order, stats.ctypes.data)
     assert rc == 0, rc
     return out, dict(slots=int(stats[0]), max_slots=int(stats[1]), violations=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]))
+
+
+_pool = None
+
+
+def load_pool():
+    global _pool
+    if _pool is None:
+        subprocess.check_call(["make", "-s", "-C", SIM_DIR, "libvhp_pool_sim.so"])
+        lib = C.CDLL(os.path.join(SIM_DIR, "libvhp_pool_sim.so"))
+        lib.vhp_sim_pool_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_uint, C.c_void_p]
+        _pool = lib
+    return _pool
+
+
+# pool simulator policies: who runs next (& 7), and whether the marked race points switch wavefronts (always / at random)
+POOL_ROUND_ROBIN, POOL_BACKWARD, POOL_RANDOM, POOL_GREEDY, POOL_BURSTS = 0, 1, 2, 3, 4
+POOL_POINTS_ALWAYS, POOL_POINTS_RANDOM, POOL_SHUFFLED_QUEUE = 8, 16, 32
+
+
+def pool_sweep(occ, sources, dtype=np.float64, W=12, C=4, G=1, policy=0, seed=1):
+    """Fields [n, ny, nx] of the simulated pool kernel (csrc/vhp_pool.hpp; pre-filled with NaN) and the stats dict."""
+    lib = load_pool()
+    occ = np.ascontiguousarray(occ, np.uint8)
+    ny, nx = occ.shape
+    src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
+    out = np.full((len(src), ny, nx), np.nan, dtype)
+    stats = np.zeros(7, np.int64)
+    rc = lib.vhp_sim_pool_sweep(occ.ctypes.data, nx, ny, src.ctypes.data, len(src), 0 if dtype == np.float64 else 1, out.ctypes.data,
+                                W, C, G, policy, seed, stats.ctypes.data)
+    assert rc == 0, rc
+    return out, dict(switches=int(stats[0]), progress=int(stats[1]), deadlock=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]),
+                     err=int(stats[5]), pulled=int(stats[6]))
 
 
 LAZY_FLUSH = 8   # order flag: the flushers of x-major strips run as late as the hand-off allows

@@ -1,0 +1,107 @@
+"""The pool sweep kernel (csrc/vhp_pool.hpp, gfx950 build) through the C ABI against the oracle, bit for bit.
+Selected explicitly (vhp_set_option "kernel" = 3) so that small batches exercise it; the same source runs on the CPU
+simulator in tests/test_pool_sim.py."""
+import numpy as np
+import pytest
+
+import maps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vhp():
+    import torch  # noqa: F401
+    import vhp_amd
+    return vhp_amd
+
+
+def _ctx(vhp, occ, contexts=0):
+    c = vhp.Context(0)
+    c.set_map(occ)
+    c.set_option("kernel", 3)
+    if contexts:
+        c.set_option("pool_contexts", contexts)
+    return c
+
+
+def _assert_same(got, want, what):
+    if got.tobytes() != want.tobytes():
+        bad = np.argwhere(~((got == want) | (np.isnan(got) & np.isnan(want))))
+        y, x = bad[0][-2:]
+        raise AssertionError("%s: %d cells differ, first at (x=%d,y=%d): got %r want %r" % (what, len(bad), x, y, got[tuple(bad[0])], want[tuple(bad[0])]))
+
+
+def _sources(occ, n, seed):
+    ny, nx = occ.shape
+    src = list(map(tuple, maps.free_sources(occ, n, seed)))
+    src += [(0, 0), (nx - 1, ny - 1), (nx - 1, 0), (0, ny - 1), (min(1, nx - 1), max(ny - 2, 0)), (nx // 2, 0), (0, ny // 2)]
+    src = np.array(sorted(set(src)), np.int32)
+    occ[src[:, 1], src[:, 0]] = 1
+    return src
+
+
+@pytest.mark.parametrize("nx,ny", [(8, 8), (8, 1), (16, 3), (8, 200), (264, 9), (104, 77), (96, 96), (200, 163), (328, 300),
+                                   (640, 603), (72, 1100), (1104, 72), (1000, 1000), (1024, 700), (1016, 520)])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_pool_kernel_bit_exact(vhp, oracle, nx, ny, dtype):
+    nb = max(3, min(40, nx * ny // 400))
+    occ = maps.random_rect_map(nx, ny, nb, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 7 + ny)
+    src = _sources(occ, 4, nx + ny)
+    c = _ctx(vhp, occ)
+    got = c.sweep_batch(src, dtype=vhp.F64 if dtype == "f64" else vhp.F32)
+    assert c.last_sweep_kernel() == 3
+    for k, (sx, sy) in enumerate(src):
+        want = oracle.sweep_full(occ, int(sx), int(sy))
+        _assert_same(got[k], want if dtype == "f64" else want.astype(np.float32), "%dx%d %s pool, source (%d,%d)" % (nx, ny, dtype, sx, sy))
+
+
+@pytest.mark.parametrize("contexts", [1, 2, 8, 11])
+def test_pool_kernel_context_counts(vhp, oracle, contexts):
+    occ = maps.random_rect_map(640, 603, 30, 1, 80, 1, 75, 5 * 640 + 603)
+    src = _sources(occ, 9, 640 + 2 * 603)
+    got = _ctx(vhp, occ, contexts).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%d contexts, source (%d,%d)" % (contexts, sx, sy))
+
+
+@pytest.mark.parametrize("nx,ny", [(2048, 1500), (1536, 2600), (4096, 4096), (3000, 2504), (8192, 24), (24, 8192)])
+def test_pool_kernel_large_grids(vhp, oracle, nx, ny):
+    occ = maps.random_rect_map(nx, ny, 40, min(10, ny // 6 - 1, nx // 6 - 1) if min(nx, ny) < 64 else 10, max(nx // 6, 2), 1 if min(nx, ny) < 64 else 10, max(ny // 6, 2), nx + 3)
+    src = _sources(occ, 2, ny)[:6]
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d pool, source (%d,%d)" % (nx, ny, sx, sy))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_pool_kernel_all_256_fields_of_the_bench_launch(vhp, oracle, dtype):
+    # the C3 launch bench.py times, through the pool sweep: EVERY field against the oracle, cell by cell; NaN-filled
+    # output (every cell written), a second launch leaves the same bytes, a bad source is reported
+    import torch
+    occ, src = maps.config_c3(256)
+    c = _ctx(vhp, occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_src = torch.from_numpy(src).cuda()
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    d_out = torch.full((256, 1000, 1000), float("nan"), dtype=tdt, device="cuda")
+    c.sweep_batch_device(d_src.data_ptr(), 256, d_out.data_ptr(), dtype=vhp.F64 if dtype == "f64" else vhp.F32)
+    c.sync()
+    assert c.last_sweep_kernel() == 3
+    assert not bool(torch.isnan(d_out).any())
+    first = d_out.clone()
+    c.sweep_batch_device(d_src.data_ptr(), 256, d_out.data_ptr(), dtype=vhp.F64 if dtype == "f64" else vhp.F32)
+    c.sync()
+    assert torch.equal(first, d_out)
+    for lo in range(0, 256, 32):
+        got = first[lo: lo + 32].cpu().numpy()
+        for k in range(32):
+            sx, sy = int(src[lo + k][0]), int(src[lo + k][1])
+            want = oracle.sweep_full(occ, sx, sy)
+            _assert_same(got[k], want if dtype == "f64" else want.astype(np.float32), "C3 %s pool launch, source %d (%d,%d)" % (dtype, lo + k, sx, sy))
+    bad = d_src.clone()
+    bad[3, 0] = 1000
+    c.sweep_batch_device(bad.data_ptr(), 256, d_out.data_ptr(), dtype=vhp.F64 if dtype == "f64" else vhp.F32)
+    with pytest.raises(vhp.VhpError) as e:
+        c.sync()
+    assert e.value.code == vhp.VHP_ERR_SOURCE_OOB

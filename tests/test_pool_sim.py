@@ -1,0 +1,96 @@
+"""The pool sweep kernel (csrc/vhp_pool.hpp) on the CPU simulator against the oracle, bit for bit.
+
+The simulator (tests/sim/vhp_pool_sim.cpp) compiles the kernel's own source with 64 explicit lanes per wavefront and runs
+every wavefront of G workgroups as a coroutine: backoff() (a wavefront that has to wait) switches to the scheduler, and so
+do -- always or at random -- the marked places where a device wavefront can be overtaken between a read and the
+compare-and-swap that depends on it.  Whatever the interleaving, the fields must equal the oracle's in every cell (the
+output, the LDS and the diagonal scratch start as NaN), every unit must have been pulled exactly once, and no run may end
+with every wavefront waiting.  No GPU needed; the gfx950 build of the same source is checked in tests/test_gpu_pool.py.
+"""
+import numpy as np
+import pytest
+
+import maps
+import sim_lib
+from sim_lib import (POOL_BACKWARD, POOL_BURSTS, POOL_GREEDY, POOL_POINTS_ALWAYS, POOL_POINTS_RANDOM, POOL_RANDOM, POOL_ROUND_ROBIN,
+                     POOL_SHUFFLED_QUEUE)
+
+
+def _check(oracle, occ, src, what, dtype=np.float64, **kw):
+    got, st = sim_lib.pool_sweep(occ, src, dtype, **kw)
+    assert st["deadlock"] == 0, "%s: every wavefront waiting %r" % (what, st)
+    assert st["err"] == 0
+    assert st["pulled"] >= 8 * len(src), "%s: %d units pulled of %d" % (what, st["pulled"], 8 * len(src))
+    for k, (sx, sy) in enumerate(src):
+        want = oracle.sweep_full(occ, int(sx), int(sy)).astype(dtype)
+        if got[k].tobytes() != want.tobytes():
+            bad = np.argwhere(~((got[k] == want) | (np.isnan(got[k]) & np.isnan(want))))
+            y, x = bad[0]
+            raise AssertionError("%s, source (%d,%d): %d cells differ, first at (x=%d,y=%d): got %r want %r" % (
+                what, sx, sy, len(bad), x, y, got[k][y, x], want[y, x]))
+    return st
+
+
+def _sources(occ, n, seed):
+    ny, nx = occ.shape
+    src = list(map(tuple, maps.free_sources(occ, n, seed)))
+    src += [(0, 0), (nx - 1, ny - 1), (nx - 1, 0), (0, ny - 1), (min(1, nx - 1), max(ny - 2, 0)), (nx // 2, 0), (0, ny // 2)]
+    src = np.array(sorted(set(src)), np.int32)
+    occ[src[:, 1], src[:, 0]] = 1
+    return src
+
+
+SIZES = [(8, 8), (8, 1), (16, 3), (8, 200), (264, 9), (104, 77), (96, 96), (200, 163), (328, 300), (640, 603), (72, 1100), (1104, 72)]
+SHAPES = [  # W wavefronts, C contexts, G workgroups, policy, dtype
+    (12, 4, 1, POOL_ROUND_ROBIN | POOL_POINTS_ALWAYS, np.float64),
+    (12, 4, 2, POOL_RANDOM | POOL_POINTS_RANDOM, np.float64),
+    (4, 2, 1, POOL_GREEDY | POOL_POINTS_ALWAYS, np.float32),
+    (6, 4, 3, POOL_BURSTS | POOL_POINTS_RANDOM | POOL_SHUFFLED_QUEUE, np.float64),
+    (2, 1, 1, POOL_BACKWARD | POOL_POINTS_ALWAYS, np.float64),
+    (1, 3, 1, POOL_ROUND_ROBIN, np.float64),   # one wavefront does everything: no interleaving can be needed for progress
+    (16, 8, 1, POOL_GREEDY, np.float64),
+]
+
+
+@pytest.mark.parametrize("nx,ny", SIZES)
+def test_pool_sim_small_and_ragged_grids(oracle, nx, ny):
+    nb = max(3, min(40, nx * ny // 400))
+    occ = maps.random_rect_map(nx, ny, nb, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 7 + ny)
+    src = _sources(occ, 6, nx + ny)
+    for W, C, G, policy, dtype in SHAPES:
+        _check(oracle, occ, src, "%dx%d W=%d C=%d G=%d policy=%d %s" % (nx, ny, W, C, G, policy, dtype.__name__), dtype,
+               W=W, C=C, G=G, policy=policy, seed=nx + ny)
+
+
+@pytest.mark.parametrize("nx,ny", [(1000, 1000), (1024, 700), (1016, 520), (2048, 1500), (2176, 2200)])
+def test_pool_sim_large_grids(oracle, nx, ny):
+    # full-size octants: up to 34 strips of one unit, marches of up to 35 blocks
+    occ = maps.random_rect_map(nx, ny, 40, 5, nx // 8, 5, ny // 8, nx * 3 + ny)
+    src = _sources(occ, 2, ny)[:5]
+    _check(oracle, occ, src, "%dx%d random" % (nx, ny), W=12, C=4, G=1, policy=POOL_RANDOM | POOL_POINTS_RANDOM, seed=3)
+    _check(oracle, occ, src[:3], "%dx%d greedy" % (nx, ny), W=12, C=4, G=2, policy=POOL_GREEDY | POOL_POINTS_ALWAYS, seed=4)
+    _check(oracle, occ, src[:3], "%dx%d narrow pool" % (nx, ny), W=2, C=1, G=1, policy=POOL_BURSTS | POOL_POINTS_RANDOM, seed=5)
+
+
+def test_pool_sim_config3_sources(oracle):
+    # BASELINE config 3: the first sources of the bench batch; every store instruction is 16 bytes per lane, and the batch
+    # needs at most 1.25x the minimum number of them
+    occ, src = maps.config_c3(256)
+    st = _check(oracle, occ, src[:6], "C3", W=12, C=4, G=2, policy=POOL_RANDOM | POOL_POINTS_RANDOM)
+    assert st["st8"] == 0
+    assert st["st16"] * 1024 <= 1.25 * 6 * 8 * 1000 * 1000
+
+
+def test_pool_sim_open_grid_walls_and_a_rejected_source(oracle):
+    occ = np.ones((136, 120), np.uint8)
+    src = np.array([(60, 67), (0, 0), (119, 135), (119, 0), (0, 135)], np.int32)
+    _check(oracle, occ, src, "open", W=5, C=3, policy=POOL_RANDOM | POOL_POINTS_ALWAYS)
+    occ[40:100, 64] = 0   # a wall exactly on a 64-cell block boundary
+    occ[63, 10:90] = 0
+    occ[64, 30:50] = 0
+    _check(oracle, occ, src, "walls on block boundaries", W=5, C=3, policy=POOL_RANDOM | POOL_POINTS_ALWAYS)
+    # a source outside the grid raises the error flag, and its units do nothing
+    bad = np.array([(60, 67), (120, 5)], np.int32)
+    got, st = sim_lib.pool_sweep(occ, bad, W=4, C=2)
+    assert st["err"] == 1 and st["deadlock"] == 0
+    assert got[0].tobytes() == oracle.sweep_full(occ, 60, 67).tobytes() and np.isnan(got[1]).all()

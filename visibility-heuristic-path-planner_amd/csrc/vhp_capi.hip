@@ -48,6 +48,9 @@ struct vhp_ctx {
   size_t d_order_cap = 0;
   int* d_queue = nullptr;   // streaming sweep: unit queue, per-CU counters, launch order
   size_t d_queue_cap = 0;
+  int* d_pool = nullptr;    // pool sweep: pull counter, unit order, diagonal lines, tagged boundary lines (zeroed when allocated)
+  size_t d_pool_cap = 0;
+  unsigned long long pool_epoch = 0x5A17000000000000ull;  // tag of the last pool launch
   bool timing = false;      // per-launch event pairs around the sweep kernel (vhp_timing)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_launches;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;  // recycled pairs: no hipEventCreate inside a timed loop
@@ -58,8 +61,9 @@ struct vhp_ctx {
   int opt_multi = 0;          // 1: force the multi-round build
   int opt_slide = -1;         // 0 / 1: y-major column grid slid onto 128-byte lines
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
-  int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream)
-  int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep
+  int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream), 3 pool sweep (vhp_pool)
+  int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep, 3 pool sweep
+  int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
   int opt_stream_tile_slots = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
   // dynamic-LDS limit already raised on THIS context's device, per kernel function
   std::vector<std::pair<const void*, size_t>> lds_raised;
@@ -258,6 +262,12 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
 
 // Which kernel sweeps a batch: the streaming sweep (vhp_stream.hpp) is built for throughput -- many quadrants in
 // flight, whole-line stores, one barrier per 64 steps -- the front sweep (vhp_sweep.hip.h) for the latency of a few.
+bool use_pool_kernel(const vhp_ctx* c, int n_src) {
+  (void)n_src;
+  if (c->opt_kernel != 3) return false;
+  return vhp::pool_supported(c->nx, c->ny);
+}
+
 bool use_stream_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel == 1) return false;
   if (!vhp::stream_supported(c->nx, c->ny)) return false;
@@ -274,10 +284,24 @@ bool use_stream_kernel(const vhp_ctx* c, int n_src) {
   return maxdim > 1024 && n_src >= (maxdim >= 3072 ? 64 : 96);
 }
 
+// the pool sweep's scratch: its own allocation (nothing else may write the tagged lines), zero when new
+hipError_t ensure_pool_scratch(vhp_ctx* c, size_t bytes) {
+  if (c->d_pool_cap >= bytes) return hipSuccess;
+  if (c->d_pool) (void)hipFree(c->d_pool);
+  c->d_pool = nullptr;
+  c->d_pool_cap = 0;
+  hipError_t e = hipMalloc(&c->d_pool, bytes);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(c->d_pool, 0, bytes, c->stream);
+  if (e != hipSuccess) return e;
+  c->d_pool_cap = bytes;
+  return hipSuccess;
+}
+
 template <typename OutT>
-hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
+hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, bool pool = false) {
   {
-    hipError_t eo = ensure_queue_scratch(c, vhp::stream_queue_bytes(n_src));
+    hipError_t eo = pool ? ensure_pool_scratch(c, vhp::pool_scratch_bytes(n_src, c->nx, c->ny)) : ensure_queue_scratch(c, vhp::stream_queue_bytes(n_src));
     if (eo != hipSuccess) return eo;
   }
   vhp::StreamArgs a;
@@ -287,28 +311,39 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.dtype = sizeof(OutT) == 8 ? VHP_F64 : VHP_F32;
   a.field_stride = (long long)c->nx * c->ny;
   a.d_err = c->d_err;
-  a.d_queue = c->d_queue;
+  a.d_queue = pool ? c->d_pool : c->d_queue;
+  a.pool_epoch = pool ? ++c->pool_epoch : 0;
   a.n_cus = c->n_cus;
   a.stream = c->stream;
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
   a.ev_begin = a.ev_end = nullptr;
   a.force_tile_slots = c->opt_stream_tile_slots;
+  a.pool_contexts = c->opt_pool_contexts;
   if (c->timing) {
     if (!c->event_pool.empty()) {
       a.ev_begin = c->event_pool.back().first;
       a.ev_end = c->event_pool.back().second;
       c->event_pool.pop_back();
-    } else if (hipEventCreate(&a.ev_begin) != hipSuccess || hipEventCreate(&a.ev_end) != hipSuccess) {
-      return hipErrorOutOfMemory;
+    } else {
+      if (hipEventCreate(&a.ev_begin) != hipSuccess) return hipErrorOutOfMemory;
+      if (hipEventCreate(&a.ev_end) != hipSuccess) { (void)hipEventDestroy(a.ev_begin); return hipErrorOutOfMemory; }
     }
   }
-  const hipError_t e = vhp::launch_stream(a);
-  if (c->timing) c->timed_launches.push_back({a.ev_begin, a.ev_end});
+  const hipError_t e = pool ? vhp::launch_pool(a) : vhp::launch_stream(a);
+  if (c->timing) {
+    // (a launch that failed before its events were recorded must not leave a pair that can never be waited for)
+    if (e == hipSuccess) c->timed_launches.push_back({a.ev_begin, a.ev_end});
+    else c->event_pool.push_back({a.ev_begin, a.ev_end});
+  }
   return e;
 }
 
 template <typename OutT>
 hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
+  if (use_pool_kernel(c, n_src)) {
+    c->last_kernel = 3;
+    return launch_stream_sweep<OutT>(c, d_src, n_src, d_out, true);
+  }
   if (use_stream_kernel(c, n_src)) {
     c->last_kernel = 2;
     return launch_stream_sweep<OutT>(c, d_src, n_src, d_out);
@@ -400,6 +435,7 @@ int vhp_destroy(vhp_ctx* ctx) {
   if (ctx->d_bnd) hipFree(ctx->d_bnd);
   if (ctx->d_order) hipFree(ctx->d_order);
   if (ctx->d_queue) hipFree(ctx->d_queue);
+  if (ctx->d_pool) hipFree(ctx->d_pool);
   for (auto& pr : ctx->timed_launches) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (ctx->d_err) hipFree(ctx->d_err);
@@ -713,7 +749,8 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
   else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3 && v != 4 && v != 6 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2, 3, 4, 6 or 8"); ctx->opt_stream_tile_slots = v; }
-  else if (k == "kernel") { if (v < 0 || v > 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream"); ctx->opt_kernel = v; }
+  else if (k == "kernel") { if (v < 0 || v > 3) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream, 3 pool"); ctx->opt_kernel = v; }
+  else if (k == "pool_contexts") { if (v < 0 || v > 11) return fail(ctx, VHP_ERR_ARG, "pool_contexts: 0 (automatic) .. 11"); ctx->opt_pool_contexts = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;
 }

@@ -147,8 +147,36 @@ inline void lds_set_int(int* p, int v) { *p = v; }
 inline void lds_acquire() {}
 inline void lds_post4(int* d, int a, int b, int c, int e) { d[0] = a; d[1] = b; d[2] = c; d[3] = e; }
 inline void lds_read4(const int* d, int& a, int& b, int& c, int& e) { a = d[0]; b = d[1]; c = d[2]; e = d[3]; }
-inline void backoff() {}
+// The pool kernel (vhp_pool.hpp) is written as blocking code: a wavefront that has to wait loops over backoff().  The
+// simulator runs every wavefront as a coroutine and installs a hook here that switches to its scheduler; sim_progress()
+// tells the scheduler that the calling wavefront got something done (deadlock detection), sim_point() marks a place
+// where a device wavefront can be overtaken by another (between a read and the compare-and-swap that depends on it).
+struct SimHooks { void (*yield)() = nullptr; void (*progress)() = nullptr; void (*point)() = nullptr; };
+inline SimHooks& sim_hooks() { static SimHooks h; return h; }
+inline void backoff() { if (sim_hooks().yield) sim_hooks().yield(); }
+inline void ready_backoff() { backoff(); }
+inline void sim_progress() { if (sim_hooks().progress) sim_hooks().progress(); }
+inline void sim_point() { if (sim_hooks().point) sim_hooks().point(); }
 inline void stores_done() {}
+// LDS atomics, executed once per wavefront (every lane sees the returned old value)
+inline int lds_cas(int* p, int expected, int desired) { const int old = *p; if (old == expected) *p = desired; return old; }
+inline int lds_add(int* p, int v) { const int old = *p; *p = old + v; return old; }
+inline int lds_or(int* p, int v) { const int old = *p; *p = old | v; return old; }
+inline int lds_and(int* p, int v) { const int old = *p; *p = old & v; return old; }
+// global memory: one atomic add per wavefront; a lane vector stored / loaded as 64 consecutive doubles
+inline int g_add(int* p, int v) { const int old = *p; *p = old + v; return old; }
+inline void g_store_f64(double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) base[idx.v[l]] = v.v[l]; }
+inline void g_store_f64_if(const vb& p, double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v.v[l]; }
+template <typename T> inline void g_store_scalar_if(const vb& p, T* base, const vi& idx, T v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v; }
+inline int ffs_u32(uint32_t v) { return v ? __builtin_ctz(v) : -1; }
+// Tagged 16-byte entries in global memory ({value, tag}): how a strip hands its boundary line to the strip that reads it
+// (vhp_pool.hpp).  The store writes both words at once; the load tells, per lane, whether the entry carries `tag`.
+struct Tagged { double v; uint64_t tag; };
+inline void g_store_tagged(Tagged* base, const vi& idx, const vd& v, uint64_t tag) { for (int l = 0; l < kLanes; ++l) { base[idx.v[l]].v = v.v[l]; base[idx.v[l]].tag = tag; } }
+inline vb g_load_tagged(const Tagged* base, const vi& idx, uint64_t tag, vd& v) {
+  vb ok; for (int l = 0; l < kLanes; ++l) { v.v[l] = base[idx.v[l]].v; ok.v[l] = base[idx.v[l]].tag == tag; } return ok; }
+inline bool wave_all(const vb& p) { for (int l = 0; l < kLanes; ++l) if (!p.v[l]) return false; return true; }
+inline void lds_store_i_if(const vb& p, int* base, const vi& idx, int v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v; }
 
 #else
 // ------------------------------------------------------------------------------------------------------------
@@ -308,6 +336,55 @@ VHP_LANE_FN void lds_read4(const int* d, int& a, int& b, int& c, int& e) {
 #ifndef VHP_EXP_READYSLEEP
 #define VHP_EXP_READYSLEEP 4
 #endif
+VHP_LANE_FN void sim_progress() {}
+VHP_LANE_FN void sim_point() {}
+// LDS atomics executed by one lane of the wavefront, the old value returned to all of them as a uniform.  The pointers
+// are cast to the LDS address space: through a generic pointer these would be FLAT atomics (slow, and counted on vmcnt).
+VHP_LANE_FN int lds_cas(int* p, int expected, int desired) {
+  int old = 0;
+  if ((threadIdx.x & 63u) == 0) {
+    int e = expected;
+    __hip_atomic_compare_exchange_strong((lds_int*)p, &e, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = e;
+  }
+  return __builtin_amdgcn_readfirstlane(old);
+}
+VHP_LANE_FN int lds_add(int* p, int v) {
+  int old = 0;
+  if ((threadIdx.x & 63u) == 0) old = __hip_atomic_fetch_add((lds_int*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __builtin_amdgcn_readfirstlane(old);
+}
+VHP_LANE_FN int lds_or(int* p, int v) {
+  int old = 0;
+  if ((threadIdx.x & 63u) == 0) old = __hip_atomic_fetch_or((lds_int*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __builtin_amdgcn_readfirstlane(old);
+}
+VHP_LANE_FN int lds_and(int* p, int v) {
+  int old = 0;
+  if ((threadIdx.x & 63u) == 0) old = __hip_atomic_fetch_and((lds_int*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __builtin_amdgcn_readfirstlane(old);
+}
+// one global atomic add per wavefront (the unit queue), the old value as a uniform
+VHP_LANE_FN int g_add(int* p, int v) {
+  int old = 0;
+  if ((threadIdx.x & 63u) == 0) old = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_amdgcn_readfirstlane(old);
+}
+VHP_LANE_FN void g_store_f64(double* base, vi idx, vd v) { base[idx] = v; }
+VHP_LANE_FN void g_store_f64_if(bool p, double* base, vi idx, vd v) { if (p) base[idx] = v; }
+template <typename T> VHP_LANE_FN void g_store_scalar_if(bool p, T* base, vi idx, T v) { if (p) base[idx] = v; }
+VHP_LANE_FN int ffs_u32(uint32_t v) { return v ? __builtin_ctz(v) : -1; }
+// Tagged 16-byte entries in global memory: one 16-byte store per lane (both words reach the L2 together); the loads are
+// agent-scope (they miss the CU's L1, which a poll may have filled with the line's previous contents), tag first.
+struct alignas(16) Tagged { double v; uint64_t tag; };
+VHP_LANE_FN void g_store_tagged(Tagged* base, vi idx, vd v, uint64_t tag) { base[idx] = Tagged{v, tag}; }
+VHP_LANE_FN bool g_load_tagged(const Tagged* base, vi idx, uint64_t tag, vd& v) {
+  const uint64_t t = __hip_atomic_load(&base[idx].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __hip_atomic_load(&base[idx].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return t == tag;
+}
+VHP_LANE_FN bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0ull; }
+VHP_LANE_FN void lds_store_i_if(bool p, int* base, vi idx, int v) { if (p) ((lds_int*)base)[idx] = v; }
 VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(VHP_EXP_BACKOFF); }
 VHP_LANE_FN void ready_backoff() { __builtin_amdgcn_s_sleep(VHP_EXP_READYSLEEP); }
 // waits until every global store (and load) this wavefront has issued has completed

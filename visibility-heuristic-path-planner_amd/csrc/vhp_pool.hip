@@ -1,0 +1,183 @@
+// vhp_pool.hip -- gfx950 build of the pool sweep (vhp_pool.hpp), its unit-order pre-kernel and its launcher.
+#include "vhp_stream_launch.h"
+
+#include <hip/hip_runtime.h>
+
+#include "vhp.h"
+#include "vhp_pool.hpp"
+
+namespace vhp {
+namespace pool {
+
+// One persistent workgroup per CU; every wavefront is a Worker.  kWaves wavefronts: three per SIMD, 168 vector registers each.
+constexpr int kWaves = 12;
+
+template <typename OutT>
+__global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, int n_ctx) {
+  extern __shared__ double lds[];
+  const Layout L = make_layout(kWaves, n_ctx, a.m.nx, a.m.ny);
+  Worker<OutT>::clear(lds, L, (int)threadIdx.x, 64 * kWaves);
+  __syncthreads();
+  Worker<OutT> wk;
+  wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
+  wk.run();
+}
+
+// Launch order: one workgroup counting-sorts the 8 n_src units by cell count, largest first, zeroes the pull queue, and
+// lays the units' boundary lines out in the scratch (line_base[u]: first 64-entry block of unit u; exclusive prefix sum
+// of UnitGeo::line_blocks in unit order).  Units of out-of-range sources weigh nothing and sort last (they are rejected
+// when they are installed).  If the lines do not fit `capacity_blocks` (the launcher sizes the scratch by an upper
+// bound, so they do) nothing is swept and the error flag says so.
+constexpr int kBuckets = 1024;
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* wave_tot, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { before += k < wv ? wave_tot[k] : 0; all += wave_tot[k]; }
+  __syncthreads();
+  if (total) *total = all;
+  return before + inc - v;
+}
+__global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order,
+                                                       int* __restrict__ line_base, long long capacity_blocks, int* __restrict__ queue,
+                                                       int* __restrict__ err_flag) {
+  __shared__ int hist[kBuckets];
+  __shared__ int start[kBuckets];
+  __shared__ int wave_tot[16];
+  const int n_units = n_src * kUnits;
+  {
+    // boundary lines: thread t lays out the units [t * per, (t + 1) * per)
+    auto blocks_of = [&](int u) {
+      const int s = u / kUnits, qo = u - s * kUnits;
+      const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
+      if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return 0;
+      UnitGeo g;
+      g.init(nx, ny, qo, sx, sy);
+      return g.line_blocks();
+    };
+    const int per = (n_units + 1023) / 1024;
+    const int u0 = (int)threadIdx.x * per, u1 = u0 + per < n_units ? u0 + per : n_units;
+    int mine = 0;
+    for (int u = u0; u < u1; ++u) mine += blocks_of(u);
+    int total = 0;
+    int at = block_exclusive_scan_1024(mine, wave_tot, &total);
+    for (int u = u0; u < u1; ++u) { line_base[u] = at; at += blocks_of(u); }
+    if (threadIdx.x == 0) {
+      const bool fits = (long long)total <= capacity_blocks;
+      *queue = fits ? 0 : n_units;
+      if (!fits) atomicOr(err_flag, 4);
+    }
+  }
+  const double inv_area = 1.0 / ((double)nx * (double)ny);
+  auto bucket_of = [&](int u) {  // bucket 0 = largest
+    const int s = u / kUnits, qo = u - s * kUnits;
+    const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
+    if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return kBuckets - 1;
+    UnitGeo g;
+    g.init(nx, ny, qo, sx, sy);
+    double cells = 0.0;
+    if (g.n_strips > 0) {
+      if (g.x_major) { const double r = g.rows_total; cells = r * g.ni - r * (r - 1) * 0.5; }
+      else { const double c = g.cols_total; cells = c * (g.nj - 1) - c * (c - 1) * 0.5; }
+    }
+    double f = cells * inv_area * 1.6;  // an octant holds at most ~5/8 of the grid's cells
+    if (f > 1.0) f = 1.0;
+    return (kBuckets - 1) - (int)(f * (kBuckets - 1));
+  };
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int u = threadIdx.x; u < n_units; u += blockDim.x) atomicAdd(&hist[bucket_of(u)], 1);
+  __syncthreads();
+  start[threadIdx.x] = block_exclusive_scan_1024(hist[threadIdx.x], wave_tot, nullptr);
+  __syncthreads();
+  for (int u = threadIdx.x; u < n_units; u += blockDim.x) order[atomicAdd(&start[bucket_of(u)], 1)] = u;
+}
+
+}  // namespace pool
+
+namespace {
+constexpr size_t kLdsLimit = 160 * 1024;
+constexpr int kQueueInts = 16;  // the pull counter (and padding) ahead of the order array
+
+// scratch of a launch: [pull counter, order[n_units], line_base[n_units]] [diagonal lines] [boundary lines]
+int diag_stride_of(int nx, int ny) { return ((nx < ny ? nx : ny) + 64 + 15) & ~15; }
+size_t head_bytes(int n_src) { return (((size_t)(kQueueInts + 2 * pool::kUnits * (size_t)n_src) * sizeof(int)) + 255) & ~(size_t)255; }
+size_t diag_bytes(int n_src, int nx, int ny) { return (((size_t)n_src * 4 * (size_t)diag_stride_of(nx, ny) * sizeof(double)) + 255) & ~(size_t)255; }
+// 64-entry blocks of boundary lines a source can need, an upper bound: over its four quadrants ni * nj sums to nx * ny;
+// an x-major unit takes at most (min(ni,nj)/64) * (ni/64 + 2) blocks, a y-major one (ni/128 + 1) * (nj/64 + 2)
+long long line_blocks_per_source(int nx, int ny) { return (3LL * nx * ny) / 8192 + (nx + ny) / 4 + 64; }
+
+struct PoolShape { int n_ctx; size_t lds; };
+// as many contexts (units a workgroup holds at once) as asked for (default 4) that fit the LDS
+PoolShape pool_shape(int nx, int ny, int force_ctx) {
+  PoolShape s;
+  s.n_ctx = force_ctx > 0 ? force_ctx : 4;
+  if (s.n_ctx > 16) s.n_ctx = 16;
+  for (;; --s.n_ctx) {
+    s.lds = (size_t)pool::make_layout(pool::kWaves, s.n_ctx, nx, ny).total * 8;
+    if (s.lds <= kLdsLimit || s.n_ctx == 1) break;
+  }
+  return s;
+}
+
+template <typename OutT>
+hipError_t launch_pool_t(const StreamArgs& a) {
+  using namespace pool;
+  auto k = vhp_pool_sweep<OutT>;
+  const PoolShape sh = pool_shape(a.nx, a.ny, a.pool_contexts);
+  if (sh.lds > kLdsLimit || a.pool_epoch == 0) return hipErrorInvalidValue;
+  if (a.raise_lds) {
+    hipError_t e = a.raise_lds(reinterpret_cast<const void*>(k), sh.lds);
+    if (e != hipSuccess) return e;
+  }
+  char* scratch = reinterpret_cast<char*>(a.d_queue);
+  Args<OutT> g;
+  g.m.rows = a.rows; g.m.cols = a.cols; g.m.recip = a.recip;
+  g.m.wpr = a.wpr; g.m.wpc = a.wpc; g.m.nx = a.nx; g.m.ny = a.ny;
+  g.src_xy = a.d_src;
+  g.out = static_cast<OutT*>(a.d_out);
+  g.field_stride = a.field_stride;
+  g.err_flag = a.d_err;
+  g.queue = a.d_queue;
+  g.n_units = a.n_src * kUnits;
+  int* order = a.d_queue + kQueueInts;
+  int* line_base = order + g.n_units;
+  g.order = order;
+  g.line_base = line_base;
+  g.diag = reinterpret_cast<double*>(scratch + head_bytes(a.n_src));
+  g.diag_stride = diag_stride_of(a.nx, a.ny);
+  g.lines = reinterpret_cast<vhp::lanes::Tagged*>(scratch + head_bytes(a.n_src) + diag_bytes(a.n_src, a.nx, a.ny));
+  g.epoch = a.pool_epoch;
+  if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs
+  hipLaunchKernelGGL(vhp_pool_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, order, line_base,
+                     line_blocks_per_source(a.nx, a.ny) * a.n_src, a.d_queue, a.d_err);
+  hipLaunchKernelGGL(k, dim3((unsigned)a.n_cus), dim3(64 * kWaves), sh.lds, a.stream, g, sh.n_ctx);
+  const hipError_t e = hipGetLastError();
+  if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
+  return e;
+}
+}  // namespace
+
+size_t pool_scratch_bytes(int n_src, int nx, int ny) {
+  return head_bytes(n_src) + diag_bytes(n_src, nx, ny) + (size_t)line_blocks_per_source(nx, ny) * (size_t)n_src * 64 * sizeof(vhp::lanes::Tagged);
+}
+
+bool pool_supported(int nx, int ny) {
+  if (nx <= 0 || ny <= 0 || (nx & 7) != 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return false;
+  return pool_shape(nx, ny, 0).lds <= kLdsLimit;
+}
+
+hipError_t launch_pool(const StreamArgs& a) {
+  if (!pool_supported(a.nx, a.ny)) return hipErrorInvalidValue;
+  return a.dtype == VHP_F64 ? launch_pool_t<double>(a) : launch_pool_t<float>(a);
+}
+
+}  // namespace vhp

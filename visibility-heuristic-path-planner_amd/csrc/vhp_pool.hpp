@@ -1,0 +1,902 @@
+// vhp_pool.hpp -- the pool sweep: computeVisibility() (reference src/visibilityBasedSolver.cpp:570-696) for large
+// batches of sources, organised as a pool of wavefronts per CU that pull STRIPS.
+//
+// Same mathematics and the same per-step code as the streaming sweep (vhp_stream.hpp: a quadrant is an x-major octant
+// whose fronts are columns and a y-major octant whose fronts are rows; a unit is one octant; a strip is 64 rows / 128
+// columns of it; a block is 64 steps of a strip), a different machine around it.  What the streaming sweep left on the
+// table: a workgroup sweeps ONE unit with a fixed team, wavefront w owns strips w, w+W, ... one
+// after the other (wavefront 0 of a full-size octant: 2424 dependent steps), half of an x-major team only flushes, a
+// y-major team keeps 2 of 7 wavefronts busy, and so a launch without stores still takes 0.46 ms for 0.1 ms of
+// arithmetic.  Here
+//
+//   * ONE workgroup of W wavefronts per CU, persistent, holds up to C units at once (contexts in LDS);
+//   * every wavefront is a worker: it claims the next strip of a context whose predecessor strip has got far enough
+//     (compare-and-swap on the context's claim word), sweeps it from its first block to the end of the march, and
+//     looks for the next.  A full-size octant has all of its strips in flight at once, a block apart; small units fill
+//     the wavefronts the large ones leave.  When no strip is ready and a context is free, the wavefront installs the
+//     next unit of the launch's queue (units sorted by cell count, largest first: vhp_pool_order);
+//   * the boundary line of strip p goes to strip p+1 through GLOBAL memory (the L2), a block of 64 entries at a time:
+//     16-byte entries {value, tag}, the tag being the launch's epoch, so that a reader can tell an entry of this launch
+//     from whatever the scratch held before -- no fence, no wait for the producer's stores (a workgroup-scope release
+//     drains every store the wavefront has in flight: DESIGN.md 4b).  A progress word per strip in LDS (blocks finished)
+//     tells the reader when to look.  Nothing is ever overwritten, so a strip waits only for strips claimed before it:
+//     the machine cannot deadlock, whatever the number of wavefronts, contexts and strips.  (A first version kept
+//     four-block rings in LDS: with the reader of a ring not yet claimed its writer stalls, and on marches longer than
+//     ~4 W blocks every wavefront can end up stalled behind an unclaimed reader -- the simulator found it);
+//   * an x-major strip flushes its own staging tile: after every 8-step window the rows whose 128-byte line is
+//     complete leave as whole lines, 8 rows per store instruction, issued by the wavefront that computed them (a
+//     wavefront stalled in a store is covered by the other wavefronts of its SIMD: that is what a pool is for);
+//   * the stale diagonal of a y-major unit is produced by the wavefront that installed the unit -- the serial
+//     two-term recurrence of stream::DiagWave -- into a scratch line in global memory, 64 entries at a time; a strip
+//     loads the seeds of its own columns into registers when it starts.
+//
+// Written against vhp_lanes.hpp: compiled for gfx950 (vhp_pool.hip) and, unchanged, for the CPU simulator of tests/sim,
+// where every wavefront is a coroutine and backoff() switches to the simulator's scheduler.
+#pragma once
+#include "vhp_stream.hpp"
+
+namespace vhp {
+namespace pool {
+
+using namespace vhp::lanes;
+using stream::imax;
+using stream::imin;
+using stream::Map;
+using stream::Quad;
+
+constexpr int kBlock = stream::kBlock;
+constexpr int kXRows = stream::kXRows;
+constexpr int kYCols = stream::kYCols;
+constexpr int kTStride = 17;  // doubles per tile row: two windows of 8 columns + 1 (spreads the column writes over the banks)
+constexpr int kUnits = 8;     // units per source: 4 quadrants x {x-major, y-major}
+
+// ---- LDS of a workgroup -------------------------------------------------------------------------------------------
+// doubles per wavefront: the staging tile, the reciprocal slab, the boundary line of the strip below for the current
+// block (66 entries: the block's 64 and the neighbour of its first step on either side), the boundary values this strip
+// produces in the current block, a dummy slot; then the scheduler's ints:
+//   [0] queue empty   [2] units installed so far (sequence numbers)
+//   per context: state (0 free, 1 being installed, 2 active), claim word (seq << 8 | next strip; -1 while not active),
+//   unit, strips, strips not yet finished, sx | sy << 16, diagonal entries ready, (pad), then progress[strip]
+constexpr int kSchedHead = 8, kCtxHead = 8;
+constexpr int kBin = 72;  // doubles of a boundary-in slab (66 used)
+enum { kQEmpty = 0, kSeq = 2 };
+enum { kState = 0, kWord = 1, kUnit = 2, kNStrips = 3, kLeft = 4, kSxSy = 5, kDiagReady = 6 };
+struct Layout {
+  int W, C, S;
+  int tiles, slabs, bins, bouts, dummies, sched, ctx_stride, total;
+};
+VHP_HD Layout make_layout(int W, int C, int nx, int ny) {
+  Layout L;
+  L.W = W; L.C = C;
+  L.S = ((imax(nx, ny) + 63) / 64 + 2 + 3) & ~3;  // most strips a unit can have (+ slack)
+  int o = 0;
+  L.tiles = o; o += W * kXRows * kTStride;
+  L.slabs = o; o += W * kBlock;
+  L.bins = o; o += W * kBin;
+  L.bouts = o; o += W * kBlock;
+  L.dummies = o; o += W * 8;
+  L.sched = o;
+  L.ctx_stride = kCtxHead + L.S;
+  o += (kSchedHead + C * L.ctx_stride + 1) / 2;
+  L.total = o;
+  return L;
+}
+
+struct Shared {
+  double* lds;
+  Layout L;
+  VHP_FN int* sched() const { return reinterpret_cast<int*>(lds + L.sched); }
+  VHP_FN int* ctx(int c) const { return sched() + kSchedHead + c * L.ctx_stride; }
+  VHP_FN int* prog(int c) const { return ctx(c) + kCtxHead; }
+};
+
+template <typename OutT>
+struct Args {
+  Map m;
+  const int32_t* src_xy;
+  OutT* out;
+  long long field_stride;
+  int* err_flag;
+  const int* order;   // unit ids, largest first
+  int* queue;         // units taken so far
+  int n_units;
+  double* diag;       // scratch: diag(k) of the y-major unit of (source s, quadrant q) at (4 s + q) * diag_stride + k
+  int diag_stride;
+  Tagged* lines;      // scratch: the boundary lines; strip p of unit u at 64 * (line_base[u] + p * blocks(u)) entries
+  const int* line_base;
+  uint64_t epoch;     // the tag of this launch (never 0, never repeated on this scratch)
+};
+
+// Geometry of a unit without the direction templates: what the scheduler needs to tell whether a strip may start.
+struct UnitGeo {
+  int ni, nj, rows_total, cols_total, ya, n_strips, ph, nb;
+  bool x_major;
+  VHP_FN void init(int nx, int ny, int qo, int sx, int sy) {
+    const int q = qo >> 1;
+    const int dx = (q == 0 || q == 3) ? 1 : -1, dy = q < 2 ? 1 : -1;
+    x_major = (qo & 1) == 0;
+    ni = dx > 0 ? nx - sx : sx;
+    nj = dy > 0 ? ny - sy : sy;
+    rows_total = imin(ni, nj);
+    cols_total = imax(imin(ni, nj - 1), 0);
+    ya = dx > 0 ? (sx & 15) : ((-(sx + 1)) & 15);
+    ph = dy > 0 ? (sy & 63) : 63 - (sy & 63);  // block number of y-major step j: (ph + j) >> 6
+    const int phx = dx > 0 ? (sx & 63) : 63 - (sx & 63);
+    nb = x_major ? (ni > 0 ? ((phx + ni - 1) >> 6) + 1 : 0) : (nj > 0 ? ((ph + nj - 1) >> 6) + 1 : 0);  // blocks of the march (Quad::Nbx / Nby)
+    if (ni <= 0 || nj <= 0) n_strips = 0;
+    else if (x_major) n_strips = (rows_total + kXRows - 1) / kXRows;
+    else n_strips = cols_total > 0 ? (cols_total + ya + kYCols - 1) / kYCols : 0;
+  }
+  // first block of strip p (x-major: block p exactly)
+  VHP_FN int first_block(int p) const { return x_major ? p : (ph + imax(kYCols * p - ya, 0)) >> 6; }
+  // diagonal entries a y-major strip needs before it starts
+  VHP_FN int diag_need(int p) const { return x_major ? 0 : imin(kYCols * p - ya + kYCols, rows_total); }
+  // 64-entry blocks of boundary-line scratch: one line of nb blocks per strip that has a reader
+  VHP_FN int line_blocks() const { return n_strips > 1 ? (n_strips - 1) * nb : 0; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// x-major strip p of a unit: rows j = 64p + lane; steps i = 64p .. ni-1; cells (i, j), j <= i.  The step code is the
+// streaming sweep's (stream::XWave::window8 / step1); the tile has two windows and the wavefront flushes it itself.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY, typename OutT>
+struct XStrip {
+  static constexpr int CB = sizeof(OutT);
+  Map m;
+  Quad<DX, DY> g;
+  OutT* out;
+  double* tile;
+  double* slab;   // reciprocals of the current block's 64 steps, indexed by x & 63
+  double* dummy;  // where the lanes that are not the boundary lane "write" theirs
+  int r_stride;   // 2: the row pitch is an odd multiple of 64 bytes, odd and even rows are half a line apart; else 1
+  int p, j0, rows_here;
+  bool has_consumer;
+  double* bin;        // the boundary line of strip p-1 for the current block: entry of x at 1 + (x & 63); 0 / 65: the neighbours
+  double* bout;       // what lane 63 produces in the current block, at x & 63
+  const Tagged* line_in;  // strip p-1's line in global memory (entry of x in block n at 64 n + (x & 63)), nullptr for strip 0
+  Tagged* line_out;       // mine, nullptr without a reader
+  uint64_t epoch;
+  bool primed;
+  int pf_blk;         // the block (x >> 6) whose operands wait in ow_nx / rv_nx, or -1
+  vi lane, tile_l, fl_t0, fl_hi;
+  vu32 fl_off;
+  vd prev, jd;
+  vu64 ow, ow_nx;
+  vd rv_nx;
+
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int p_, const Tagged* line_in_, Tagged* line_out_, uint64_t epoch_) {
+    m = m_; out = out_;
+    g.init(m.nx, m.ny, sx, sy);
+    tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
+    slab = sh.lds + sh.L.slabs + w * kBlock;
+    bin = sh.lds + sh.L.bins + w * kBin;
+    bout = sh.lds + sh.L.bouts + w * kBlock;
+    dummy = sh.lds + sh.L.dummies + w * 8;
+    r_stride = ((m.nx >> 3) & 1) ? 2 : 1;
+    lane = lane_id();
+    tile_l = lane * kTStride;
+    {
+      // flush geometry: lane -> (row slot = lane >> 3, piece = lane & 7 = cells xa + 2*piece, +1); the row slots of a
+      // store instruction are counted upward in y, so that byte offsets from its lowest row are never negative
+      const vi rslot = lane >> 3, pc = lane & 7;
+      const vi rs = DY > 0 ? rslot : 7 - rslot;
+      fl_t0 = rslot * (r_stride * kTStride) + ((pc * 2) & 7);
+      fl_hi = pc >> 2;
+      fl_off = to_u32((rs * (r_stride * m.nx) + pc * 2) * CB);
+    }
+    p = p_;
+    j0 = kXRows * p;
+    rows_here = imin(kXRows, g.rows_total - j0);
+    has_consumer = p + 1 < g.Px;
+    line_in = line_in_; line_out = line_out_; epoch = epoch_;
+    primed = false;
+    prev = vd(0.0);
+    jd = to_f64(lane + j0);
+    pf_blk = -1;
+  }
+
+  // Emits one line of the rows r = r_first, r_first + r_stride, ... of this strip from the tile, 8 rows per store instruction.
+  // (PRED: only the cells with step index j <= i' <= i_now.)
+  template <bool PRED>
+  VHP_FN void flush(int xa, int r_first, int i_now) {
+    wave_sync();
+    const int win = (xa >> 3) + 24;  // (xa may be -8 at the end of a march)
+    const int sA = win & 1, sB = sA ^ 1;
+    const vi t0 = fl_t0 + fl_hi * (8 * (sB - sA)) + (8 * sA + r_first * kTStride);
+    const vu32 off = fl_off + (uint32_t)(xa * CB);
+    const int t_step = 8 * r_stride * kTStride;  // per store instruction: 8 row slots further
+    const long y_low = DY > 0 ? g.Y(j0 + r_first) : g.Y(j0 + r_first + 7 * r_stride);
+    OutT* base = out + y_low * (long)m.nx;
+    const long base_step = (long)(8 * r_stride * DY) * m.nx;
+    if (!PRED && rows_here == kXRows) {
+      vd a[8], b[8];
+      if (r_stride == 2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = lds_load(tile, t0 + u * t_step); b[u] = lds_load(tile, t0 + (u * t_step + 1)); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { g_store2(base, off, a[u], b[u]); base += base_step; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = lds_load(tile, t0 + u * t_step); b[u] = lds_load(tile, t0 + (u * t_step + 1)); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { g_store2(base, off, a[u], b[u]); base += base_step; }
+      }
+    } else {
+      const vi xc = (lane & 7) * 2 + xa;                             // x of the pair's first cell
+      const vi i0c = (xc - g.sx) * DX, i1c = (xc + 1 - g.sx) * DX;  // step indices of the two cells
+      const vi r0 = (lane >> 3) * r_stride + r_first;
+      for (int u = 0; r_first + r_stride * 8 * u < rows_here; ++u) {
+        const vi r = r0 + 8 * r_stride * u;
+        const vb row_ok = r < rows_here;
+        const vi tix = select(row_ok, t0 + u * t_step, vi(0));
+        const vd a = lds_load(tile, tix);
+        const vd b = lds_load(tile, tix + 1);
+        if (!PRED) {
+          g_store2_if(row_ok, vb(false), vb(false), base, off, a, b);
+        } else {
+          const vi jr = r + j0;
+          const vb ok0 = row_ok && (i0c >= jr) && (i0c <= i_now);
+          const vb ok1 = row_ok && (i1c >= jr) && (i1c <= i_now);
+          g_store2_if(ok0 && ok1, ok0, ok1, base, off, a, b);
+        }
+        base += base_step;
+      }
+    }
+    wave_sync();
+  }
+
+  // After the step at x_b, which ends an 8-cell window of x: the rows whose 128-byte line this completes leave.
+  // (y*nx + x) % 16 == 0 marks a line start; with nx = 8*m that is x % 16 == 8 * ((y*m) & 1).
+  VHP_FN void flush_completed(int x_b, int i_now) {
+    const int edge = DX > 0 ? x_b + 1 : x_b;
+    const int hbit = (edge >> 3) & 1;
+    const int xa = DX > 0 ? x_b - 15 : x_b;
+    const bool steady = i_now - 15 >= j0 + kXRows - 1;  // the line's first-marched cell is past every row's diagonal
+    int r_first = 0;
+    if (r_stride == 1) {
+      if (hbit != 0) return;
+    } else {
+      r_first = (hbit ^ g.sy ^ j0) & 1;  // rows with (y & 1) == hbit
+    }
+    if (steady) flush<false>(xa, r_first, i_now); else flush<true>(xa, r_first, i_now);
+  }
+
+  // the march of this strip is over: what is still in the tile leaves as partial lines
+  VHP_FN void end_of_march() {
+    const int i_now = g.ni - 1;
+    const int xe = g.X(i_now);
+    if (r_stride == 1) {
+      flush<true>(xe & ~15, 0, i_now);
+    } else {
+      for (int ph = 0; ph < 2; ++ph) {  // rows whose lines start at x % 16 == 8*ph
+        const int xa = 8 * ph + (((xe - 8 * ph) >> 4) << 4);
+        flush<true>(xa, (ph ^ g.sy ^ j0) & 1, i_now);
+      }
+    }
+  }
+
+  // one generic step
+  VHP_FN void step1(int i) {
+    const int x = g.X(i);
+    const int t = x & 63;
+    const double ri = slab[t];
+    const double di = (double)i;
+    double fill = 0.0, dsrc = 1.0;  // OLD / NEW value of the row just below lane 0's (1.0 = light strength at the origin)
+    if (p > 0) { fill = bin[1 + (x & 63) - DX]; dsrc = bin[1 + (x & 63)]; }
+    const vd b = shift_up(prev, vd(fill));
+    const vi mk = bit_mask(ow, t);
+    vd v = and_mask(stencil(prev, b, ratio(jd, di, ri)), mk);
+    if (i < j0 + kXRows) {
+      // the diagonal cell (i,i) inherits the NEW value of the row below it times its own occupancy
+      const vd up = shift_up(v, vd(dsrc));
+      const vb isd = lane == (i - j0);
+      const vd dcell = and_mask(up, mk);
+      v = select(isd, dcell, v);
+    }
+    prev = v;
+    lds_store(tile, tile_l + (((x >> 3) & 1) * 8 + (x & 7)), v);
+    if (has_consumer) lds_store_if(lane == 63, bout, vi(x & 63), v);
+  }
+
+  // eight steps covering one aligned window of x; DIAG: the strip's diagonal may fall into it
+  template <bool DIAG>
+  VHP_FN void window8(int i0) {
+    const int x0 = g.X(i0);
+    const int t0 = x0 & 63;
+    const int xw = x0 & ~7;  // lowest x of the window
+    vd rr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rr[k] = lds_bcast(slab, (xw & 63) + (DX > 0 ? k : 7 - k));
+    // the boundary row of the strip below: rb[k] = its value at x(i0 + k) - DX, the OLD neighbour of lane 0 at step k
+    // (and rb[k + 1] the NEW one, which the diagonal cell of row j0 takes)
+    vd rb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rb[k] = vd(0.0);
+    if (p > 0) {
+      rb[0] = lds_bcast(bin, 1 + (x0 & 63) - DX);
+      const int xb = 1 + (xw & 63);
+#pragma unroll
+      for (int k = 1; k < 9; ++k) rb[k] = lds_bcast(bin, xb + (DX > 0 ? k - 1 : 8 - k));
+    }
+    const vu32 hs = half_shifted(ow, t0, DX > 0 ? (t0 & 31) : (t0 & 31) - 7);  // step k's bit at position (x & 7)
+    const vi tidx = tile_l + ((xw >> 3) & 1) * 8;
+    // every lane writes "its boundary value" each step -- lane 63 into the block's out slab, the others into a dummy
+    // slot: one ds_write instead of an exec-masked region per step
+    double* wbase = has_consumer ? bout + (xw & 63) : dummy;
+    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
+    vd di = vd((double)i0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int col = DX > 0 ? k : 7 - k;
+      const vd b = shift_up(prev, rb[k]);
+      const vi mk = sbfe1(hs, col);
+      vd v = and_mask(stencil(prev, b, ratio(jd, di, rr[k])), mk);
+      if (DIAG) {
+        const vd up = shift_up(v, p > 0 ? rb[k + 1] : vd(1.0));  // strip 0: 1.0 = light strength at the origin
+        const vb isd = lane == (i0 + k - j0);
+        const vd dcell = and_mask(up, mk);
+        v = select(isd, dcell, v);
+      }
+      prev = v;
+      lds_store(tile, tidx + col, v);
+      lds_store(wbase, widx + col, v);
+      di = di + 1.0;
+    }
+  }
+
+  // the occupancy word of every lane's row and the reciprocals of the 64 step indices of block blk (x >> 6)
+  VHP_FN void load_block(int blk, vu64& o, vd& rv) {
+    const vi yl = (vmin(lane + j0, g.rows_total - 1)) * DY + g.sy;
+    o = g_load_u64(m.rows, yl * m.wpr + (1 + blk));
+    const vi it = (lane + (blk * 64 - g.sx)) * DX;
+    const vb ok = (it >= 0) && (it < g.ni);
+    rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
+  }
+
+  // Block nb of the line of strip p-1 into the in slab (the caller has seen strip p-1 publish the block; the entries may
+  // still be on their way to the L2: the tag tells).  The neighbour of the block's first step on the side the march
+  // comes from is the previous block's last entry; before the strip's first block it is fetched by itself.
+  VHP_FN void load_boundary(int nb, int first_step) {
+    if (!primed) {
+      primed = true;
+      const int ic = first_step - 1;
+      if (ic >= 0 && g.nbx(ic) != nb) {
+        vd c;
+        while (!wave_all(g_load_tagged(line_in, vi(64 * g.nbx(ic) + (g.X(ic) & 63)), epoch, c))) backoff();
+        lds_store(bin, vi(DX > 0 ? 64 : 1), c);
+        wave_sync();
+      }
+    }
+    const double carry = DX > 0 ? bin[64] : bin[1];
+    vd v;
+    while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) backoff();
+    wave_sync();
+    lds_store(bin, lane + 1, v);
+    lds_store(bin, vi(DX > 0 ? 0 : 65), vd(carry));
+    wave_sync();
+  }
+  // what lane 63 produced in block nb goes to my line
+  VHP_FN void store_boundary(int nb) {
+    wave_sync();
+    g_store_tagged(line_out, lane + 64 * nb, lds_load(bout, lane), epoch);
+    wave_sync();
+  }
+
+  VHP_FN void sweep_block(int nb) {
+    int lo, hi;
+    g.xsteps(nb, lo, hi);
+    lo = imax(lo, j0);
+    if (lo > hi) return;
+    const int blk = g.X(lo) >> 6;
+    if (p > 0) load_boundary(nb, j0);
+    {
+      vd rv;
+      if (pf_blk == blk) { ow = ow_nx; rv = rv_nx; } else { load_block(blk, ow, rv); }
+      pin(ow);
+      pin(rv);
+      lds_store(slab, lane, rv);
+      wave_sync();
+      if (nb + 1 < g.Nbx) { pf_blk = blk + DX; load_block(pf_blk, ow_nx, rv_nx); } else { pf_blk = -1; }
+    }
+    int i = lo;
+    while (i <= hi) {
+      const int x = g.X(i);
+      const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
+      int i_last;
+      if (aligned && i + 7 <= hi) {
+        if (i < j0 + kXRows) window8<true>(i); else window8<false>(i);
+        i_last = i + 7;
+      } else {
+        step1(i);
+        i_last = i;
+      }
+      i = i_last + 1;
+      const int xl = g.X(i_last);
+      const bool boundary = DX > 0 ? (xl & 7) == 7 : (xl & 7) == 0;
+      if (boundary && i_last != g.ni - 1) flush_completed(xl, i_last);  // (the last step of the march is end_of_march's)
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// y-major strip q of a unit: columns i = 128q - ya + 2*lane + {0,1}; steps j = max(i0,0) .. nj-1; cells (i, j), i <= j
+// (the diagonal cell is the seed diag(j), stored again with its neighbour).  stream::YWave's step code; the seeds of the
+// lane's two columns wait in registers.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY, typename OutT>
+struct YStrip {
+  static constexpr int CB = sizeof(OutT);
+  Map m;
+  Quad<DX, DY> g;
+  OutT* out;
+  double* slab;   // reciprocals of the current block's 64 steps, indexed by y & 63
+  double* dummy;
+  int q, i0, jstart;
+  bool has_consumer, interior;
+  double* bin;        // as XStrip's, along y
+  double* bout;
+  const Tagged* line_in;
+  Tagged* line_out;
+  uint64_t epoch;
+  bool primed;
+  vi lane, ia, ib;
+  vd prev0, prev1, id0, id1, dg0, dg1;
+  vu64 ow0, ow1;
+  vu32 xoff;  // byte offset of the lane's pair inside a row
+
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const Tagged* line_in_, Tagged* line_out_, uint64_t epoch_,
+                   const double* diag) {
+    m = m_; out = out_;
+    g.init(m.nx, m.ny, sx, sy);
+    slab = sh.lds + sh.L.slabs + w * kBlock;
+    bin = sh.lds + sh.L.bins + w * kBin;
+    bout = sh.lds + sh.L.bouts + w * kBlock;
+    dummy = sh.lds + sh.L.dummies + w * 8;
+    lane = lane_id();
+    q = q_;
+    i0 = g.ycol0(q);
+    jstart = g.ystart(q);
+    has_consumer = q + 1 < g.Py;
+    interior = i0 >= 0 && i0 + kYCols - 1 < g.ni;  // every column of the strip is a column of the grid
+    ia = lane * 2 + i0;
+    ib = ia + 1;
+    prev0 = vd(0.0);
+    prev1 = vd(0.0);
+    id0 = to_f64(ia);
+    id1 = to_f64(ib);
+    // the seeds of my columns (columns that have none are never seeded: the index is only kept inside the line)
+    dg0 = g_load_f64(diag, vmin(vmax(ia, 0), g.rows_total - 1));
+    dg1 = g_load_f64(diag, vmin(vmax(ib, 0), g.rows_total - 1));
+    pin(dg0);
+    pin(dg1);
+    const vi xlo = DX > 0 ? ia + g.sx : (-ib) + g.sx;  // the pair's lower x: x(ia) marching up, x(ib) marching down
+    xoff = to_u32(xlo * CB);
+    line_in = line_in_; line_out = line_out_; epoch = epoch_;
+    primed = false;
+  }
+
+  // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below the diagonal
+  VHP_FN void store_pred(OutT* row, int j, vd v0, vd v1) {
+    const vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
+    const vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
+    if (DX > 0) g_store2_if(ok0 && ok1, ok0, ok1, row, xoff, v0, v1);
+    else g_store2_if(ok0 && ok1, ok1, ok0, row, xoff, v1, v0);
+  }
+  VHP_FN OutT* row_ptr(int y) const { return out + (size_t)y * (size_t)m.nx; }
+
+  VHP_FN void step1(int j) {
+    const int y = g.Y(j);
+    const int t = y & 63;
+    const double rj = slab[t];
+    const double dj = (double)j;
+    double fill = 0.0;
+    if (q > 0) fill = bin[1 + (y & 63) - DY];
+    const vd b0 = shift_up(prev1, vd(fill));
+    vd v0 = and_mask(stencil(prev0, b0, ratio(id0, dj, rj)), bit_mask(ow0, t));
+    vd v1 = and_mask(stencil(prev1, prev0, ratio(id1, dj, rj)), bit_mask(ow1, t));
+    if (j <= i0 + kYCols - 1) {  // column j (if this strip owns it) is seeded with diag(j)
+      v0 = select(ia == j, dg0, v0);
+      v1 = select(ib == j, dg1, v1);
+    }
+    store_pred(row_ptr(y), j, v0, v1);
+    prev0 = v0;
+    prev1 = v1;
+    if (has_consumer) lds_store_if(lane == 63, bout, vi(y & 63), v1);
+  }
+
+  // eight steps covering one aligned window of y.  DIAG: seeding may happen (implies PRED); PRED: predicated stores
+  template <bool DIAG, bool PRED>
+  VHP_FN void window8(int j0w) {
+    const int y0 = g.Y(j0w);
+    const int t0 = y0 & 63;
+    const int yb = y0 & ~7;
+    vd rr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rr[k] = lds_bcast(slab, (yb & 63) + (DY > 0 ? k : 7 - k));
+    vd rb[8];  // the boundary column of the strip below at y(j0w + k) - DY
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rb[k] = vd(0.0);
+    if (q > 0) {
+      rb[0] = lds_bcast(bin, 1 + (y0 & 63) - DY);
+      const int yq = 1 + (yb & 63);
+#pragma unroll
+      for (int k = 1; k < 8; ++k) rb[k] = lds_bcast(bin, yq + (DY > 0 ? k - 1 : 8 - k));
+    }
+    const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
+    const vu32 hs0 = half_shifted(ow0, t0, sh), hs1 = half_shifted(ow1, t0, sh);
+    double* wbase = has_consumer ? bout + (yb & 63) : dummy;
+    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
+    vd dj = vd((double)j0w);
+    OutT* row = row_ptr(y0);
+    const long rowstep = (long)DY * m.nx;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bit = DY > 0 ? k : 7 - k;
+      const vd b0 = shift_up(prev1, rb[k]);
+      vd v0 = and_mask(stencil(prev0, b0, ratio(id0, dj, rr[k])), sbfe1(hs0, bit));
+      vd v1 = and_mask(stencil(prev1, prev0, ratio(id1, dj, rr[k])), sbfe1(hs1, bit));
+      if (DIAG) {
+        v0 = select(ia == j0w + k, dg0, v0);
+        v1 = select(ib == j0w + k, dg1, v1);
+      }
+      if (PRED) store_pred(row, j0w + k, v0, v1);
+      else if (DX > 0) g_store2(row, xoff, v0, v1);
+      else g_store2(row, xoff, v1, v0);
+      prev0 = v0;
+      prev1 = v1;
+      lds_store(wbase, widx + bit, v1);
+      dj = dj + 1.0;
+      row += rowstep;
+    }
+  }
+
+  VHP_FN void load_boundary(int nb, int first_step) {  // (XStrip::load_boundary along y)
+    if (!primed) {
+      primed = true;
+      const int jc = first_step - 1;
+      if (jc >= 0 && g.nby(jc) != nb) {
+        vd c;
+        while (!wave_all(g_load_tagged(line_in, vi(64 * g.nby(jc) + (g.Y(jc) & 63)), epoch, c))) backoff();
+        lds_store(bin, vi(DY > 0 ? 64 : 1), c);
+        wave_sync();
+      }
+    }
+    const double carry = DY > 0 ? bin[64] : bin[1];
+    vd v;
+    while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) backoff();
+    wave_sync();
+    lds_store(bin, lane + 1, v);
+    lds_store(bin, vi(DY > 0 ? 0 : 65), vd(carry));
+    wave_sync();
+  }
+  VHP_FN void store_boundary(int nb) {
+    wave_sync();
+    g_store_tagged(line_out, lane + 64 * nb, lds_load(bout, lane), epoch);
+    wave_sync();
+  }
+
+  VHP_FN void sweep_block(int nb) {
+    int lo, hi;
+    g.ysteps(nb, lo, hi);
+    lo = imax(lo, jstart);
+    if (lo > hi) return;
+    const int blk = g.Y(lo) >> 6;
+    if (q > 0) load_boundary(nb, jstart);
+    {
+      const vi xa = vmin(vmax(ia, 0), g.ni - 1) * DX + g.sx;
+      const vi xb = vmin(vmax(ib, 0), g.ni - 1) * DX + g.sx;
+      ow0 = g_load_u64(m.cols, xa * m.wpc + (1 + blk));
+      ow1 = g_load_u64(m.cols, xb * m.wpc + (1 + blk));
+      const vi jt = (lane + (blk * 64 - g.sy)) * DY;
+      const vb ok = (jt >= 0) && (jt < g.nj);
+      vd rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
+      pin(ow0);
+      pin(ow1);
+      pin(rv);
+      lds_store(slab, lane, rv);
+      wave_sync();
+    }
+    int j = lo;
+    while (j <= hi) {
+      const int y = g.Y(j);
+      const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
+      if (aligned && j + 7 <= hi) {
+        if (j <= i0 + kYCols - 1) window8<true, true>(j);
+        else if (!interior) window8<false, true>(j);
+        else window8<false, false>(j);
+        j += 8;
+      } else {
+        step1(j);
+        j += 1;
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// The diagonal of a quadrant for its y-major unit (stream::DiagWave's recurrence), into the unit's scratch line in global
+// memory, 64 entries per call.  diag(0) = occ(source); for k >= 1:
+//   sub(k)  = V(k, k-1) = (a - c*(a - b)) * occ(k, k-1),  a = diag(k-1), b = sub(k-1), c = (k-1)/k
+//   diag(k) = sub(k) * occ(k, k)                                            (the stale diagonal)
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY>
+struct DiagTask {
+  Map m;
+  Quad<DX, DY> g;
+  double* diag;
+  int k;
+  vi lane;
+  vd dprev, sprev;
+
+  VHP_FN void init(const Map& m_, int sx, int sy, double* diag_) {
+    m = m_;
+    g.init(m.nx, m.ny, sx, sy);
+    diag = diag_;
+    lane = lane_id();
+    k = 0;
+    dprev = vd(0.0);
+    sprev = vd(0.0);
+  }
+  VHP_FN bool done() const { return k >= g.rows_total; }
+  // entries k .. k+63; returns the number of entries ready afterwards
+  VHP_FN int run_chunk() {
+    const int k0 = k, k1 = imin(k0 + kBlock, g.rows_total);
+    const vi kk = vmin(lane + k0, g.rows_total - 1);
+    const vi x = kk * DX + g.sx;
+    const vi ya = vmax(kk - 1, 0) * DY + g.sy, yb = kk * DY + g.sy;
+    const vu64 wa = g_load_u64(m.rows, ya * m.wpr + ((x >> 6) + 1));
+    const vu64 wb = g_load_u64(m.rows, yb * m.wpr + ((x >> 6) + 1));
+    const vd rk = g_load_f64(m.recip, kk);
+    const vi ma = bit_mask_lane(wa, x & 63), mb = bit_mask_lane(wb, x & 63);
+    vd acc = vd(0.0);
+    for (int kq = k0; kq < k1; ++kq) {
+      const int l = kq - k0;
+      vd dcur;
+      if (kq == 0) {
+        dcur = and_mask(vd(1.0), vi(read_lane_i(mb, l)));  // the origin: light strength 1 times its occupancy
+        sprev = vd(0.0);
+      } else {
+        const vd c = ratio(vd((double)(kq - 1)), (double)kq, read_lane(rk, l));
+        const vd sub = and_mask(stencil(dprev, sprev, c), vi(read_lane_i(ma, l)));
+        dcur = and_mask(sub, vi(read_lane_i(mb, l)));
+        sprev = sub;
+      }
+      dprev = dcur;
+      acc = select(lane == l, dcur, acc);
+    }
+    g_store_f64_if(lane < (k1 - k0), diag, lane + k0, acc);
+    k = k1;
+    return k1;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// One wavefront of the pool.
+// ---------------------------------------------------------------------------------------------------------------
+enum { kFound = 0, kRetry = 1, kIdle = 2, kExit = 3 };
+
+template <typename OutT>
+struct Worker {
+  Args<OutT> a;
+  Shared sh;
+  int w;
+  vi lane;
+
+  VHP_FN void init(const Args<OutT>& a_, double* lds, const Layout& L, int w_) {
+    a = a_;
+    sh.lds = lds;
+    sh.L = L;
+    w = w_;
+    lane = lane_id();
+  }
+
+  // Before any wavefront runs: every thread of the workgroup calls this (tid of nthreads), then a barrier.
+  static VHP_FN void clear(double* lds, const Layout& L, int tid, int nthreads) {
+    Shared s;
+    s.lds = lds;
+    s.L = L;
+    int* sc = s.sched();
+    const int n = kSchedHead + L.C * L.ctx_stride;
+    for (int k = tid; k < n; k += nthreads) lds_set_int(sc + k, 0);
+  }
+
+  // Finds a strip to sweep, or installs a unit, or tells that there is nothing left.  A strip may be claimed when its
+  // predecessor has finished the strip's first block (and, y-major, its seeds are there); the oldest context goes first.
+  // A running strip waits only for strips that were claimed before it (nothing is ever overwritten: see the header), so
+  // whatever the wavefronts do, the oldest running strip of every context can always finish.
+  VHP_FN int find_work(int& c_out, int& p_out, int& qo_out, int& sx_out, int& sy_out) {
+    int* sc = sh.sched();
+    int best_c = -1, best_seq = 0x7fffffff, best_p = 0, best_word = 0, best_qo = 0, best_sx = 0, best_sy = 0;
+    int free_c = -1;
+    bool unclaimed = false, installing = false;
+    for (int c = 0; c < sh.L.C; ++c) {
+      int* cx = sh.ctx(c);
+      const int st = lds_poll(cx + kState);
+      if (st == 0) { free_c = c; continue; }
+      if (st == 1) { installing = true; continue; }
+      const int word = lds_poll(cx + kWord);
+      if (word < 0) continue;  // being recycled
+      const int p = word & 255, seq = word >> 8;
+      const int ns = lds_poll(cx + kNStrips);
+      if (p >= ns) continue;
+      unclaimed = true;
+      if (seq >= best_seq) continue;
+      const int unit = lds_poll(cx + kUnit), sxsy = lds_poll(cx + kSxSy);
+      const int qo = unit & 7, sx = sxsy & 0xffff, sy = sxsy >> 16;
+      UnitGeo ug;
+      ug.init(a.m.nx, a.m.ny, qo, sx, sy);
+      if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_block(p) + 1) continue;
+      if (!ug.x_major && lds_poll(cx + kDiagReady) < ug.diag_need(p)) continue;
+      best_c = c; best_seq = seq; best_p = p; best_word = word; best_qo = qo; best_sx = sx; best_sy = sy;
+    }
+    if (best_c >= 0) {
+      sim_point();
+      if (lds_cas(sh.ctx(best_c) + kWord, best_word, best_word + 1) != best_word) return kRetry;
+      c_out = best_c; p_out = best_p; qo_out = best_qo; sx_out = best_sx; sy_out = best_sy;
+      sim_progress();
+      return kFound;
+    }
+    const bool q_empty = lds_poll(sc + kQEmpty) != 0;
+    if (free_c >= 0 && !q_empty) {
+      sim_point();
+      if (lds_cas(sh.ctx(free_c) + kState, 0, 1) == 0) install(free_c);
+      return kRetry;
+    }
+    if (q_empty && !unclaimed && !installing) return kExit;
+    return kIdle;
+  }
+
+  // Takes the next unit of the queue into context c (state 1: mine).
+  VHP_FN void install(int c) {
+    int* sc = sh.sched();
+    int* cx = sh.ctx(c);
+    const int idx = g_add(a.queue, 1);
+    sim_progress();
+    if (idx >= a.n_units) {
+      lds_publish(sc + kQEmpty, 1);
+      lds_publish(cx + kState, 0);
+      return;
+    }
+    const int unit = uniform(a.order[idx]);
+    const int s = unit / kUnits, qo = unit - s * kUnits;
+    const int sx = uniform(a.src_xy[2 * s]), sy = uniform(a.src_xy[2 * s + 1]);
+    if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
+      if (qo == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
+      lds_publish(cx + kState, 0);
+      return;
+    }
+    UnitGeo ug;
+    ug.init(a.m.nx, a.m.ny, qo, sx, sy);
+    OutT* field = a.out + (size_t)s * a.field_stride;
+    if (qo == 0) {
+      // rows/columns no quadrant covers read as zero; the x-major unit of quadrant 1 always exists
+      if (sx > 0)
+        for (int y0 = 0; y0 < a.m.ny; y0 += kLanes) g_store_scalar_if(lane + y0 < a.m.ny, field, (lane + y0) * a.m.nx, OutT(0));
+      if (sy > 0)
+        for (int x0 = 0; x0 < a.m.nx; x0 += kLanes) g_store_scalar_if(lane + x0 < a.m.nx, field, lane + x0, OutT(0));
+    }
+    if (ug.n_strips == 0) {
+      lds_publish(cx + kState, 0);
+      return;
+    }
+    lds_set_int(cx + kUnit, unit);
+    lds_set_int(cx + kNStrips, ug.n_strips);
+    lds_set_int(cx + kLeft, ug.n_strips);
+    lds_set_int(cx + kSxSy, sx | (sy << 16));
+    lds_set_int(cx + kDiagReady, 0);
+    for (int k0 = 0; k0 < ug.n_strips; k0 += kLanes) lds_store_i_if(lane + k0 < ug.n_strips, sh.prog(c), lane + k0, 0);
+    const int seq = lds_add(sc + kSeq, 1) + 1;
+    lds_publish(cx + kWord, seq << 8);
+    lds_publish(cx + kState, 2);
+    if (!ug.x_major) {
+      double* dline = a.diag + (size_t)(4 * s + (qo >> 1)) * a.diag_stride;
+      switch (qo >> 1) {
+        case 0: run_diag<+1, +1>(cx, sx, sy, dline); break;
+        case 1: run_diag<-1, +1>(cx, sx, sy, dline); break;
+        case 2: run_diag<-1, -1>(cx, sx, sy, dline); break;
+        default: run_diag<+1, -1>(cx, sx, sy, dline); break;
+      }
+    }
+  }
+
+  template <int DX, int DY>
+  VHP_FN void run_diag(int* cx, int sx, int sy, double* dline) {
+    DiagTask<DX, DY> dt;
+    dt.init(a.m, sx, sy, dline);
+    while (!dt.done()) {
+      const int ready = dt.run_chunk();
+      stores_done();  // the entries are in memory (L2) before the count says so: the strips that load them run on this CU
+      lds_publish(cx + kDiagReady, ready);
+      sim_progress();
+      sim_point();
+    }
+  }
+
+  // A strip of context c is finished: count down, free the context after the last.
+  VHP_FN void strip_done(int c) {
+    int* cx = sh.ctx(c);
+    if (lds_add(cx + kLeft, -1) == 1) {
+      lds_publish(cx + kWord, -1);
+      lds_publish(cx + kState, 0);
+    }
+    sim_progress();
+  }
+
+  // waits until strip p-1 has published block n (its boundary entries are then in the L2 or on their way)
+  VHP_FN void wait_block(int c, int p, int n) {
+    if (p == 0) return;
+    const int* pr = sh.prog(c) + (p - 1);
+    while (lds_poll(pr) < n + 1) ready_backoff();
+    lds_acquire();
+  }
+  // the boundary line of strip p of `unit`
+  VHP_FN Tagged* line_of(int unit, int p, int nb) const { return a.lines + (size_t)64 * ((size_t)uniform(a.line_base[unit]) + (size_t)p * nb); }
+
+  template <int DX, int DY>
+  VHP_FN void run_x(int c, int unit, int p, int sx, int sy, OutT* field) {
+    XStrip<DX, DY, OutT> xs;
+    Quad<DX, DY> g;
+    g.init(a.m.nx, a.m.ny, sx, sy);
+    xs.init(a.m, sx, sy, field, sh, w, p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr, a.epoch);
+    int* mine = sh.prog(c) + p;
+    for (int n = p; n < xs.g.Nbx; ++n) {
+      wait_block(c, p, n);
+      xs.sweep_block(n);
+      if (n == xs.g.Nbx - 1) xs.end_of_march();
+      if (xs.has_consumer) xs.store_boundary(n);
+      lds_publish(mine, n + 1);
+      sim_progress();
+      sim_point();
+    }
+    strip_done(c);
+  }
+
+  template <int DX, int DY>
+  VHP_FN void run_y(int c, int unit, int q, int sx, int sy, OutT* field, const double* dline) {
+    YStrip<DX, DY, OutT> ys;
+    Quad<DX, DY> g;
+    g.init(a.m.nx, a.m.ny, sx, sy);
+    ys.init(a.m, sx, sy, field, sh, w, q, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr, a.epoch, dline);
+    int* mine = sh.prog(c) + q;
+    for (int n = ys.g.nby(ys.jstart); n < ys.g.Nby; ++n) {
+      wait_block(c, q, n);
+      ys.sweep_block(n);
+      if (ys.has_consumer) ys.store_boundary(n);
+      lds_publish(mine, n + 1);
+      sim_progress();
+      sim_point();
+    }
+    strip_done(c);
+  }
+
+  VHP_FN void run_strip(int c, int p, int qo, int sx, int sy) {
+    const int unit = lds_int_at(sh.ctx(c) + kUnit);
+    const int s = unit / kUnits;
+    OutT* field = a.out + (size_t)s * a.field_stride;
+    const double* dline = a.diag + (size_t)(4 * s + (qo >> 1)) * a.diag_stride;
+    switch (qo) {
+      case 0: run_x<+1, +1>(c, unit, p, sx, sy, field); break;
+      case 1: run_y<+1, +1>(c, unit, p, sx, sy, field, dline); break;
+      case 2: run_x<-1, +1>(c, unit, p, sx, sy, field); break;
+      case 3: run_y<-1, +1>(c, unit, p, sx, sy, field, dline); break;
+      case 4: run_x<-1, -1>(c, unit, p, sx, sy, field); break;
+      case 5: run_y<-1, -1>(c, unit, p, sx, sy, field, dline); break;
+      case 6: run_x<+1, -1>(c, unit, p, sx, sy, field); break;
+      default: run_y<+1, -1>(c, unit, p, sx, sy, field, dline); break;
+    }
+  }
+
+  VHP_FN void run() {
+    for (;;) {
+      int c = 0, p = 0, qo = 0, sx = 0, sy = 0;
+      const int r = find_work(c, p, qo, sx, sy);
+      if (r == kExit) break;
+      if (r == kIdle) { backoff(); continue; }
+      if (r == kRetry) continue;
+      run_strip(c, p, qo, sx, sy);
+    }
+  }
+};
+
+}  // namespace pool
+}  // namespace vhp

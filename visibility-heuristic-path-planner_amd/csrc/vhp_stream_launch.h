@@ -1,4 +1,5 @@
-// vhp_stream_launch.h -- host-side interface of the streaming sweep kernel (vhp_stream.hip), used by vhp_capi.hip.
+// vhp_stream_launch.h -- host-side interface of the streaming sweep (vhp_stream.hip) and of the pool sweep (vhp_pool.hip),
+// used by vhp_capi.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,6 +28,8 @@ struct StreamArgs {
   // optional per-launch timing events, recorded around the sweep kernel only
   hipEvent_t ev_begin, ev_end;
   int force_tile_slots;   // 0: automatic; 2 / 3: windows per staging tile (tuning, vhp_set_option "stream_tile_slots")
+  int pool_contexts = 0;  // pool sweep: units a workgroup holds at once (0: automatic; vhp_set_option "pool_contexts")
+  unsigned long long pool_epoch = 0;  // pool sweep: the tag of this launch's boundary-line entries: never 0, never reused on this scratch
 };
 
 // true if the streaming kernel can sweep this grid (pitch a multiple of 8 cells, LDS of a workgroup fits)
@@ -35,5 +38,12 @@ bool stream_supported(int nx, int ny);
 int stream_strips(int nx, int ny);
 hipError_t launch_stream(const StreamArgs& a);
 size_t stream_queue_bytes(int n_src);
+
+// The pool sweep (vhp_pool.hip): same arguments; d_queue is scratch of pool_scratch_bytes (pull counter, unit order, the
+// diagonal lines of the y-major units, the boundary lines of the strips) that is ZERO when it is first used and is
+// written by nothing else; pool_epoch differs from launch to launch.
+bool pool_supported(int nx, int ny);
+hipError_t launch_pool(const StreamArgs& a);
+size_t pool_scratch_bytes(int n_src, int nx, int ny);
 
 }  // namespace vhp
