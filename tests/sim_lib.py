@@ -56,7 +56,7 @@ def load_pool():
 
 # pool simulator policies: who runs next (& 7), and whether the marked race points switch wavefronts (always / at random)
 POOL_ROUND_ROBIN, POOL_BACKWARD, POOL_RANDOM, POOL_GREEDY, POOL_BURSTS = 0, 1, 2, 3, 4
-POOL_POINTS_ALWAYS, POOL_POINTS_RANDOM, POOL_SHUFFLED_QUEUE = 8, 16, 32
+POOL_POINTS_ALWAYS, POOL_POINTS_RANDOM, POOL_SHUFFLED_QUEUE, POOL_TIGHT_BUSY_CAP = 8, 16, 32, 64
 
 
 def pool_sweep(occ, sources, dtype=np.float64, W=12, C=4, G=1, policy=0, seed=1):

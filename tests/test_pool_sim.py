@@ -13,7 +13,7 @@ import pytest
 import maps
 import sim_lib
 from sim_lib import (POOL_BACKWARD, POOL_BURSTS, POOL_GREEDY, POOL_POINTS_ALWAYS, POOL_POINTS_RANDOM, POOL_RANDOM, POOL_ROUND_ROBIN,
-                     POOL_SHUFFLED_QUEUE)
+                     POOL_SHUFFLED_QUEUE, POOL_TIGHT_BUSY_CAP)
 
 
 def _check(oracle, occ, src, what, dtype=np.float64, **kw):
@@ -45,7 +45,7 @@ SHAPES = [  # W wavefronts, C contexts, G workgroups, policy, dtype
     (12, 4, 1, POOL_ROUND_ROBIN | POOL_POINTS_ALWAYS, np.float64),
     (12, 4, 2, POOL_RANDOM | POOL_POINTS_RANDOM, np.float64),
     (4, 2, 1, POOL_GREEDY | POOL_POINTS_ALWAYS, np.float32),
-    (6, 4, 3, POOL_BURSTS | POOL_POINTS_RANDOM | POOL_SHUFFLED_QUEUE, np.float64),
+    (6, 4, 3, POOL_BURSTS | POOL_POINTS_RANDOM | POOL_SHUFFLED_QUEUE | POOL_TIGHT_BUSY_CAP, np.float64),
     (2, 1, 1, POOL_BACKWARD | POOL_POINTS_ALWAYS, np.float64),
     (1, 3, 1, POOL_ROUND_ROBIN, np.float64),   # one wavefront does everything: no interleaving can be needed for progress
     (16, 8, 1, POOL_GREEDY, np.float64),

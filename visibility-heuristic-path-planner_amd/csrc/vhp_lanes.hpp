@@ -155,6 +155,7 @@ struct SimHooks { void (*yield)() = nullptr; void (*progress)() = nullptr; void 
 inline SimHooks& sim_hooks() { static SimHooks h; return h; }
 inline void backoff() { if (sim_hooks().yield) sim_hooks().yield(); }
 inline void ready_backoff() { backoff(); }
+inline void wave_priority(int) {}
 inline void sim_progress() { if (sim_hooks().progress) sim_hooks().progress(); }
 inline void sim_point() { if (sim_hooks().point) sim_hooks().point(); }
 inline void stores_done() {}
@@ -336,6 +337,13 @@ VHP_LANE_FN void lds_read4(const int* d, int& a, int& b, int& c, int& e) {
 #ifndef VHP_EXP_READYSLEEP
 #define VHP_EXP_READYSLEEP 4
 #endif
+// instruction-arbitration priority of this wavefront (0 lowest .. 3): s_setprio takes an immediate
+VHP_LANE_FN void wave_priority(int p) {
+  if (p >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
 VHP_LANE_FN void sim_progress() {}
 VHP_LANE_FN void sim_point() {}
 // LDS atomics executed by one lane of the wavefront, the old value returned to all of them as a uniform.  The pointers

@@ -10,17 +10,40 @@ namespace vhp {
 namespace pool {
 
 // One persistent workgroup per CU; every wavefront is a Worker.  kWaves wavefronts: three per SIMD, 168 vector registers each.
-constexpr int kWaves = 12;
+#ifndef VHP_POOL_WAVES
+#define VHP_POOL_WAVES 12
+#endif
+constexpr int kWaves = VHP_POOL_WAVES;
+
+#ifdef VHP_EXP_POOLPROF  // diagnostic builds only (tools/pool_timeline.py)
+__device__ unsigned long long g_poolprof[512 * 16 * 12];
+#endif
 
 template <typename OutT>
 __global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, int n_ctx) {
   extern __shared__ double lds[];
   const Layout L = make_layout(kWaves, n_ctx, a.m.nx, a.m.ny);
+#ifdef VHP_EXP_POOLPROF
+  const unsigned long long t_begin = wall_clock64(), c_begin = __builtin_readcyclecounter();
+#endif
   Worker<OutT>::clear(lds, L, (int)threadIdx.x, 64 * kWaves);
   __syncthreads();
   Worker<OutT> wk;
   wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
   wk.run();
+#ifdef VHP_EXP_POOLPROF
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) {
+    unsigned long long* o = g_poolprof + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 12;
+    for (int k = 0; k < 8; ++k) o[k] = wk.prof[k];
+    o[8] = t_begin;
+    o[9] = wall_clock64();
+    o[10] = __builtin_readcyclecounter() - c_begin;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[11] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 // Launch order: one workgroup counting-sorts the 8 n_src units by cell count, largest first, zeroes the pull queue, and
@@ -156,6 +179,7 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   g.diag_stride = diag_stride_of(a.nx, a.ny);
   g.lines = reinterpret_cast<vhp::lanes::Tagged*>(scratch + head_bytes(a.n_src) + diag_bytes(a.n_src, a.nx, a.ny));
   g.epoch = a.pool_epoch;
+  g.busy_cap = a.pool_busy_cap > 0 ? a.pool_busy_cap : kWaves;
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs
   hipLaunchKernelGGL(vhp_pool_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, order, line_base,
                      line_blocks_per_source(a.nx, a.ny) * a.n_src, a.d_queue, a.d_err);
@@ -174,6 +198,12 @@ bool pool_supported(int nx, int ny) {
   if (nx <= 0 || ny <= 0 || (nx & 7) != 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return false;
   return pool_shape(nx, ny, 0).lds <= kLdsLimit;
 }
+
+#ifdef VHP_EXP_POOLPROF
+extern "C" int vhp_debug_read_poolprof(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_poolprof), (size_t)n_words * 8);
+}
+#endif
 
 hipError_t launch_pool(const StreamArgs& a) {
   if (!pool_supported(a.nx, a.ny)) return hipErrorInvalidValue;

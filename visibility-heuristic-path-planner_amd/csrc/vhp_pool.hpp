@@ -54,12 +54,12 @@ constexpr int kUnits = 8;     // units per source: 4 quadrants x {x-major, y-maj
 // doubles per wavefront: the staging tile, the reciprocal slab, the boundary line of the strip below for the current
 // block (66 entries: the block's 64 and the neighbour of its first step on either side), the boundary values this strip
 // produces in the current block, a dummy slot; then the scheduler's ints:
-//   [0] queue empty   [2] units installed so far (sequence numbers)
+//   [0] queue empty   [2] units installed so far (sequence numbers)   [3] wavefronts sweeping a strip right now
 //   per context: state (0 free, 1 being installed, 2 active), claim word (seq << 8 | next strip; -1 while not active),
 //   unit, strips, strips not yet finished, sx | sy << 16, diagonal entries ready, (pad), then progress[strip]
 constexpr int kSchedHead = 8, kCtxHead = 8;
 constexpr int kBin = 72;  // doubles of a boundary-in slab (66 used)
-enum { kQEmpty = 0, kSeq = 2 };
+enum { kQEmpty = 0, kSeq = 2, kBusy = 3 };
 enum { kState = 0, kWord = 1, kUnit = 2, kNStrips = 3, kLeft = 4, kSxSy = 5, kDiagReady = 6 };
 struct Layout {
   int W, C, S;
@@ -105,6 +105,7 @@ struct Args {
   Tagged* lines;      // scratch: the boundary lines; strip p of unit u at 64 * (line_base[u] + p * blocks(u)) entries
   const int* line_base;
   uint64_t epoch;     // the tag of this launch (never 0, never repeated on this scratch)
+  int busy_cap;       // a workgroup takes another unit only while fewer than this many of its wavefronts are sweeping
 };
 
 // Geometry of a unit without the direction templates: what the scheduler needs to tell whether a strip may start.
@@ -199,6 +200,9 @@ struct XStrip {
   // (PRED: only the cells with step index j <= i' <= i_now.)
   template <bool PRED>
   VHP_FN void flush(int xa, int r_first, int i_now) {
+#ifdef VHP_EXP_NOXSTORE  // diagnostic builds only: what the x-major stores cost
+    return;
+#endif
     wave_sync();
     const int win = (xa >> 3) + 24;  // (xa may be -8 at the end of a march)
     const int sA = win & 1, sB = sA ^ 1;
@@ -539,9 +543,13 @@ struct YStrip {
         v0 = select(ia == j0w + k, dg0, v0);
         v1 = select(ib == j0w + k, dg1, v1);
       }
+#ifndef VHP_EXP_NOYSTORE  // diagnostic builds only: what the y-major stores cost
       if (PRED) store_pred(row, j0w + k, v0, v1);
       else if (DX > 0) g_store2(row, xoff, v0, v1);
       else g_store2(row, xoff, v1, v0);
+#else
+      asm volatile("" :: "v"(v0), "v"(v1));
+#endif
       prev0 = v0;
       prev1 = v1;
       lds_store(wbase, widx + bit, v1);
@@ -675,12 +683,27 @@ struct DiagTask {
 // ---------------------------------------------------------------------------------------------------------------
 enum { kFound = 0, kRetry = 1, kIdle = 2, kExit = 3 };
 
+#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)  // diagnostic builds only (tools/pool_timeline.py): where a wavefront's cycles go
+#define VHP_PP_T0(var) const unsigned long long var = __builtin_readcyclecounter()
+#define VHP_PP_ADD(slot, var) prof[slot] += __builtin_readcyclecounter() - var
+#define VHP_PP_COUNT(slot) prof[slot] += 1
+#else
+#define VHP_PP_T0(var)
+#define VHP_PP_ADD(slot, var)
+#define VHP_PP_COUNT(slot)
+#endif
+
 template <typename OutT>
 struct Worker {
   Args<OutT> a;
   Shared sh;
   int w;
   vi lane;
+#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+  // cycles: [0] looking for work / idle, [1] waiting for the strip below, [2] sweeping (stores included), [3] installing units
+  // (diagonal chains included), [4] boundary line out; counts: [5] strips, [6] blocks, [7] units installed
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
   VHP_FN void init(const Args<OutT>& a_, double* lds, const Layout& L, int w_) {
     a = a_;
@@ -737,9 +760,17 @@ struct Worker {
       return kFound;
     }
     const bool q_empty = lds_poll(sc + kQEmpty) != 0;
-    if (free_c >= 0 && !q_empty) {
+    // Another unit only while the workgroup is short of work: a CU that holds a large unit (many strips in flight) keeps
+    // its whole share of the store path for it -- the march of a full-size octant is the longest dependent chain of the
+    // launch, and every other unit on its CU slows each of its steps down.
+    if (free_c >= 0 && !q_empty && lds_poll(sc + kBusy) < a.busy_cap) {
       sim_point();
-      if (lds_cas(sh.ctx(free_c) + kState, 0, 1) == 0) install(free_c);
+      if (lds_cas(sh.ctx(free_c) + kState, 0, 1) == 0) {
+        VHP_PP_T0(ti);
+        install(free_c);
+        VHP_PP_ADD(3, ti);
+        VHP_PP_COUNT(7);
+      }
       return kRetry;
     }
     if (q_empty && !unclaimed && !installing) return kExit;
@@ -839,11 +870,19 @@ struct Worker {
     g.init(a.m.nx, a.m.ny, sx, sy);
     xs.init(a.m, sx, sy, field, sh, w, p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr, a.epoch);
     int* mine = sh.prog(c) + p;
+    VHP_PP_COUNT(5);
     for (int n = p; n < xs.g.Nbx; ++n) {
+      VHP_PP_T0(tw);
       wait_block(c, p, n);
+      VHP_PP_ADD(1, tw);
+      VHP_PP_T0(ts);
       xs.sweep_block(n);
       if (n == xs.g.Nbx - 1) xs.end_of_march();
+      VHP_PP_ADD(2, ts);
+      VHP_PP_T0(tb);
       if (xs.has_consumer) xs.store_boundary(n);
+      VHP_PP_ADD(4, tb);
+      VHP_PP_COUNT(6);
       lds_publish(mine, n + 1);
       sim_progress();
       sim_point();
@@ -858,10 +897,18 @@ struct Worker {
     g.init(a.m.nx, a.m.ny, sx, sy);
     ys.init(a.m, sx, sy, field, sh, w, q, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr, a.epoch, dline);
     int* mine = sh.prog(c) + q;
+    VHP_PP_COUNT(5);
     for (int n = ys.g.nby(ys.jstart); n < ys.g.Nby; ++n) {
+      VHP_PP_T0(tw);
       wait_block(c, q, n);
+      VHP_PP_ADD(1, tw);
+      VHP_PP_T0(ts);
       ys.sweep_block(n);
+      VHP_PP_ADD(2, ts);
+      VHP_PP_T0(tb);
       if (ys.has_consumer) ys.store_boundary(n);
+      VHP_PP_ADD(4, tb);
+      VHP_PP_COUNT(6);
       lds_publish(mine, n + 1);
       sim_progress();
       sim_point();
@@ -889,11 +936,27 @@ struct Worker {
   VHP_FN void run() {
     for (;;) {
       int c = 0, p = 0, qo = 0, sx = 0, sy = 0;
+      VHP_PP_T0(tf);
       const int r = find_work(c, p, qo, sx, sy);
       if (r == kExit) break;
-      if (r == kIdle) { backoff(); continue; }
+      if (r == kIdle) { backoff(); VHP_PP_ADD(0, tf); continue; }
       if (r == kRetry) continue;
+      VHP_PP_ADD(0, tf);
+      lds_add(sh.sched() + kBusy, 1);
+#ifdef VHP_EXP_PRIO  // diagnostic: strips of the largest units first at the CU's issue arbiter (the store path included)
+      {
+        UnitGeo ug;
+        ug.init(a.m.nx, a.m.ny, qo, sx, sy);
+        const int full = ((imax(a.m.nx, a.m.ny) + 63) >> 6);
+        const int size = ug.n_strips * (ug.x_major ? 1 : 2) * ug.nb * 16 / (full * full);  // 0 .. 16: strips x blocks of a full octant
+        wave_priority(size >= 10 ? 3 : size >= 6 ? 2 : size >= 3 ? 1 : 0);
+      }
+#endif
       run_strip(c, p, qo, sx, sy);
+#ifdef VHP_EXP_PRIO
+      wave_priority(0);
+#endif
+      lds_add(sh.sched() + kBusy, -1);
     }
   }
 };
