@@ -119,7 +119,8 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] > weight[b]; });
   g_rng = seed * 2654435761u + 12345u;
   if (policy & 32) for (int k = n_units - 1; k > 0; --k) std::swap(order[k], order[lcg() % (k + 1)]);
-  int queue = 0, err = 0;
+  unsigned long long queue = 0;
+  int err = 0;
   const int dstride = ((nx < ny ? nx : ny) + 64 + 15) & ~15;
   std::vector<double> diag((size_t)n_src * 4 * dstride, std::numeric_limits<double>::quiet_NaN());
   Args<OutT> a;
@@ -141,6 +142,7 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   a.lines = lines.data();
   a.line_base = line_base.data();
   a.epoch = epoch;
+  a.n_head = 1 + (int)(seed % 3);  // one to three contexts pull from the head of the queue
   a.busy_cap = (policy & 64) ? 2 : W;   // policy & 64: a tight cap on the wavefronts that may sweep while units are installed
 
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
@@ -166,6 +168,7 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   vhp::lanes::sim_hooks().progress = hook_progress;
   vhp::lanes::sim_hooks().point = hook_point;
   vhp::lanes::store_stats() = vhp::lanes::StoreStats();
+  vhp::lanes::sim_counts() = vhp::lanes::SimCounts();
   g_point_mode = (policy & 8) ? 1 : (policy & 16) ? 2 : 0;
   g_progress = g_switches = 0;
   const int n = G * W, mode = policy & 7;
@@ -194,7 +197,7 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
       sh.lds = lds[gI].data();
       sh.L = L;
       const int* sc = sh.sched();
-      fprintf(stderr, "wg %d: queue_empty %d seq %d (queue %d of %d)\n", gI, sc[kQEmpty], sc[kSeq], queue, n_units);
+      fprintf(stderr, "wg %d: queue_empty %d seq %d (queue %llu of %d)\n", gI, sc[kQEmpty], sc[kSeq], queue, n_units);
       for (int c = 0; c < C; ++c) {
         const int* cx = sh.ctx(c);
         fprintf(stderr, "  ctx %d: state %d word %x unit %d (qo %d) strips %d left %d sx %d sy %d diag %d\n   prog:", c, cx[kState], cx[kWord], cx[kUnit],
@@ -211,7 +214,8 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
     stats[3] = vhp::lanes::store_stats().n16;
     stats[4] = vhp::lanes::store_stats().n8;
     stats[5] = err;
-    stats[6] = queue;
+    stats[6] = (long long)((queue & 0xffffffffull) + (queue >> 32));
+    for (int k = 0; k < 4; ++k) stats[7 + k] = vhp::lanes::sim_counts().c[k];  // hand-offs: from the ring, from global memory, "too far ahead", "overwritten while copying"
   }
   return 0;
 }
@@ -221,7 +225,7 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
 extern "C" {
 
 // out: n_src fields of nx*ny elements (dtype 0 = double, 1 = float), pre-filled by the caller (NaN: an unwritten cell shows).
-// W wavefronts per workgroup, C contexts, G workgroups sharing the queue.  stats (7 entries, may be null):
+// W wavefronts per workgroup, C contexts, G workgroups sharing the queue.  stats (11 entries, may be null):
 // coroutine switches, progress events, deadlock (0/1), 16-byte / 8-byte store instructions, the error flag, units pulled.
 int vhp_sim_pool_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W, int C, int G,
                        int policy, unsigned seed, long long* stats) {

@@ -72,6 +72,21 @@ def test_pool_sim_large_grids(oracle, nx, ny):
     _check(oracle, occ, src[:3], "%dx%d narrow pool" % (nx, ny), W=2, C=1, G=1, policy=POOL_BURSTS | POOL_POINTS_RANDOM, seed=5)
 
 
+def test_pool_sim_every_hand_off_path_is_taken(oracle):
+    # a strip takes the boundary values of the strip below out of that wavefront's LDS ring (fast) or, a block at a time,
+    # out of global memory (the writer is far ahead, has moved on, or overwrote the entries while they were copied): each of
+    # these must happen in some interleaving here, and none may change a bit
+    occ = maps.random_rect_map(640, 603, 40, 1, 80, 1, 75, 640 * 7 + 603)
+    src = maps.free_sources(occ, 4, 5)
+    seen = dict(from_ring=0, from_global=0, too_far=0, overwritten=0)
+    for W, C, G, policy in [(12, 4, 1, POOL_ROUND_ROBIN | POOL_POINTS_ALWAYS), (2, 1, 1, POOL_BACKWARD | POOL_POINTS_ALWAYS),
+                            (8, 3, 1, POOL_GREEDY | POOL_POINTS_RANDOM)]:
+        st = _check(oracle, occ, src, "W=%d C=%d policy=%d" % (W, C, policy), W=W, C=C, G=G, policy=policy)
+        for k in seen:
+            seen[k] += st[k]
+    assert all(v > 0 for v in seen.values()), seen
+
+
 def test_pool_sim_config3_sources(oracle):
     # BASELINE config 3: the first sources of the bench batch; every store instruction is 16 bytes per lane, and the batch
     # needs at most 1.25x the minimum number of them

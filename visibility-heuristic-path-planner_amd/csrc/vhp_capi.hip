@@ -64,6 +64,7 @@ struct vhp_ctx {
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream), 3 pool sweep (vhp_pool)
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep, 3 pool sweep
   int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
+  int opt_pool_heads = 0;      // pool sweep: contexts that pull the largest units (0 auto)
   int opt_pool_busy_cap = 0;   // pool sweep: no new unit while this many wavefronts of the workgroup are sweeping (0 auto)
   int opt_stream_tile_slots = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
   // dynamic-LDS limit already raised on THIS context's device, per kernel function
@@ -321,6 +322,7 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.force_tile_slots = c->opt_stream_tile_slots;
   a.pool_contexts = c->opt_pool_contexts;
   a.pool_busy_cap = c->opt_pool_busy_cap;
+  a.pool_heads = c->opt_pool_heads;
   if (c->timing) {
     if (!c->event_pool.empty()) {
       a.ev_begin = c->event_pool.back().first;
@@ -752,6 +754,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "pack") { ctx->opt_pack = v != 0; }
   else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3 && v != 4 && v != 6 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2, 3, 4, 6 or 8"); ctx->opt_stream_tile_slots = v; }
   else if (k == "kernel") { if (v < 0 || v > 3) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream, 3 pool"); ctx->opt_kernel = v; }
+  else if (k == "pool_heads") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_heads: 0 (automatic) .. 16"); ctx->opt_pool_heads = v; }
   else if (k == "pool_busy_cap") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_busy_cap: 0 (automatic) .. 16"); ctx->opt_pool_busy_cap = v; }
   else if (k == "pool_contexts") { if (v < 0 || v > 11) return fail(ctx, VHP_ERR_ARG, "pool_contexts: 0 (automatic) .. 11"); ctx->opt_pool_contexts = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");

@@ -156,6 +156,10 @@ inline SimHooks& sim_hooks() { static SimHooks h; return h; }
 inline void backoff() { if (sim_hooks().yield) sim_hooks().yield(); }
 inline void ready_backoff() { backoff(); }
 inline void wave_priority(int) {}
+// event counters of the simulator (which path a hand-off took); the device build counts nothing
+struct SimCounts { long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+inline SimCounts& sim_counts() { static SimCounts s; return s; }
+inline void sim_count(int k) { sim_counts().c[k] += 1; }
 inline void sim_progress() { if (sim_hooks().progress) sim_hooks().progress(); }
 inline void sim_point() { if (sim_hooks().point) sim_hooks().point(); }
 inline void stores_done() {}
@@ -166,6 +170,7 @@ inline int lds_or(int* p, int v) { const int old = *p; *p = old | v; return old;
 inline int lds_and(int* p, int v) { const int old = *p; *p = old & v; return old; }
 // global memory: one atomic add per wavefront; a lane vector stored / loaded as 64 consecutive doubles
 inline int g_add(int* p, int v) { const int old = *p; *p = old + v; return old; }
+inline unsigned long long g_add_u64(unsigned long long* p, unsigned long long v) { const unsigned long long old = *p; *p = old + v; return old; }
 inline void g_store_f64(double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) base[idx.v[l]] = v.v[l]; }
 inline void g_store_f64_if(const vb& p, double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v.v[l]; }
 template <typename T> inline void g_store_scalar_if(const vb& p, T* base, const vi& idx, T v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v; }
@@ -344,6 +349,7 @@ VHP_LANE_FN void wave_priority(int p) {
   else if (p == 1) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
 }
+VHP_LANE_FN void sim_count(int) {}
 VHP_LANE_FN void sim_progress() {}
 VHP_LANE_FN void sim_point() {}
 // LDS atomics executed by one lane of the wavefront, the old value returned to all of them as a uniform.  The pointers
@@ -377,6 +383,12 @@ VHP_LANE_FN int g_add(int* p, int v) {
   int old = 0;
   if ((threadIdx.x & 63u) == 0) old = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return __builtin_amdgcn_readfirstlane(old);
+}
+VHP_LANE_FN unsigned long long g_add_u64(unsigned long long* p, unsigned long long v) {
+  unsigned long long old = 0;
+  if ((threadIdx.x & 63u) == 0) old = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)old), hi = __builtin_amdgcn_readfirstlane((unsigned)(old >> 32));
+  return ((unsigned long long)hi << 32) | lo;
 }
 VHP_LANE_FN void g_store_f64(double* base, vi idx, vd v) { base[idx] = v; }
 VHP_LANE_FN void g_store_f64_if(bool p, double* base, vi idx, vd v) { if (p) base[idx] = v; }

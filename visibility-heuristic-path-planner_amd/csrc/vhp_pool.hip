@@ -17,6 +17,7 @@ constexpr int kWaves = VHP_POOL_WAVES;
 
 #ifdef VHP_EXP_POOLPROF  // diagnostic builds only (tools/pool_timeline.py)
 __device__ unsigned long long g_poolprof[512 * 16 * 12];
+__device__ unsigned long long g_unit_times[2 * 8 * 1024];
 #endif
 
 template <typename OutT>
@@ -70,8 +71,8 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* wave_tot, i
   return before + inc - v;
 }
 __global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order,
-                                                       int* __restrict__ line_base, long long capacity_blocks, int* __restrict__ queue,
-                                                       int* __restrict__ err_flag) {
+                                                       int* __restrict__ line_base, long long capacity_blocks,
+                                                       unsigned long long* __restrict__ queue, int* __restrict__ err_flag) {
   __shared__ int hist[kBuckets];
   __shared__ int start[kBuckets];
   __shared__ int wave_tot[16];
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict
     for (int u = u0; u < u1; ++u) { line_base[u] = at; at += blocks_of(u); }
     if (threadIdx.x == 0) {
       const bool fits = (long long)total <= capacity_blocks;
-      *queue = fits ? 0 : n_units;
+      *queue = fits ? 0ull : (unsigned long long)n_units;
       if (!fits) atomicOr(err_flag, 4);
     }
   }
@@ -140,9 +141,12 @@ long long line_blocks_per_source(int nx, int ny) { return (3LL * nx * ny) / 8192
 
 struct PoolShape { int n_ctx; size_t lds; };
 // as many contexts (units a workgroup holds at once) as asked for (default 4) that fit the LDS
+// Measured (tools/ab_libs.py, 256 sources at 1000^2 on one buffer): 1 / 2 / 3 / 4 / 6 / 8 contexts 1.20 / 0.78 / 0.75-0.77 /
+// 0.77-0.82 / 0.83 / 0.80 ms; 128 sources at 4096^2: 4.44 / 4.68 / - / 4.50-4.95 ms -- units that large (a 4096^2 octant is
+// 67 MB, 64 strips) keep every wavefront busy by themselves and only lose to a neighbour.
 PoolShape pool_shape(int nx, int ny, int force_ctx) {
   PoolShape s;
-  s.n_ctx = force_ctx > 0 ? force_ctx : 4;
+  s.n_ctx = force_ctx > 0 ? force_ctx : ((nx > ny ? nx : ny) > 2048 ? 1 : 3);
   if (s.n_ctx > 16) s.n_ctx = 16;
   for (;; --s.n_ctx) {
     s.lds = (size_t)pool::make_layout(pool::kWaves, s.n_ctx, nx, ny).total * 8;
@@ -169,7 +173,7 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   g.out = static_cast<OutT*>(a.d_out);
   g.field_stride = a.field_stride;
   g.err_flag = a.d_err;
-  g.queue = a.d_queue;
+  g.queue = reinterpret_cast<unsigned long long*>(a.d_queue);
   g.n_units = a.n_src * kUnits;
   int* order = a.d_queue + kQueueInts;
   int* line_base = order + g.n_units;
@@ -180,9 +184,15 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   g.lines = reinterpret_cast<vhp::lanes::Tagged*>(scratch + head_bytes(a.n_src) + diag_bytes(a.n_src, a.nx, a.ny));
   g.epoch = a.pool_epoch;
   g.busy_cap = a.pool_busy_cap > 0 ? a.pool_busy_cap : kWaves;
+  // two contexts take the largest units left, the others the smallest (0.75 against 0.78 ms with one head at 1000^2)
+  g.n_head = a.pool_heads > 0 ? a.pool_heads : (sh.n_ctx >= 3 ? 2 : 1);
+  g.unit_times = nullptr;
+#ifdef VHP_EXP_POOLPROF
+  if (a.n_src <= 1024) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_unit_times)) == hipSuccess) g.unit_times = static_cast<unsigned long long*>(p); }
+#endif
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs
   hipLaunchKernelGGL(vhp_pool_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, order, line_base,
-                     line_blocks_per_source(a.nx, a.ny) * a.n_src, a.d_queue, a.d_err);
+                     line_blocks_per_source(a.nx, a.ny) * a.n_src, reinterpret_cast<unsigned long long*>(a.d_queue), a.d_err);
   hipLaunchKernelGGL(k, dim3((unsigned)a.n_cus), dim3(64 * kWaves), sh.lds, a.stream, g, sh.n_ctx);
   const hipError_t e = hipGetLastError();
   if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
@@ -202,6 +212,9 @@ bool pool_supported(int nx, int ny) {
 #ifdef VHP_EXP_POOLPROF
 extern "C" int vhp_debug_read_poolprof(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_poolprof), (size_t)n_words * 8);
+}
+extern "C" int vhp_debug_read_unit_times(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_unit_times), (size_t)n_words * 8);
 }
 #endif
 

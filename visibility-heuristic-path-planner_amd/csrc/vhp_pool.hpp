@@ -12,17 +12,26 @@
 //   * ONE workgroup of W wavefronts per CU, persistent, holds up to C units at once (contexts in LDS);
 //   * every wavefront is a worker: it claims the next strip of a context whose predecessor strip has got far enough
 //     (compare-and-swap on the context's claim word), sweeps it from its first block to the end of the march, and
-//     looks for the next.  A full-size octant has all of its strips in flight at once, a block apart; small units fill
-//     the wavefronts the large ones leave.  When no strip is ready and a context is free, the wavefront installs the
-//     next unit of the launch's queue (units sorted by cell count, largest first: vhp_pool_order);
-//   * the boundary line of strip p goes to strip p+1 through GLOBAL memory (the L2), a block of 64 entries at a time:
-//     16-byte entries {value, tag}, the tag being the launch's epoch, so that a reader can tell an entry of this launch
-//     from whatever the scratch held before -- no fence, no wait for the producer's stores (a workgroup-scope release
-//     drains every store the wavefront has in flight: DESIGN.md 4b).  A progress word per strip in LDS (blocks finished)
-//     tells the reader when to look.  Nothing is ever overwritten, so a strip waits only for strips claimed before it:
-//     the machine cannot deadlock, whatever the number of wavefronts, contexts and strips.  (A first version kept
-//     four-block rings in LDS: with the reader of a ring not yet claimed its writer stalls, and on marches longer than
-//     ~4 W blocks every wavefront can end up stalled behind an unclaimed reader -- the simulator found it);
+//     looks for the next.  A full-size octant has all of its strips in flight at once, a window apart; small units fill
+//     the wavefronts the large ones leave.  When no strip is ready and a context is free, the wavefront installs a unit
+//     of the launch's queue (units sorted by cell count: vhp_pool_order): context 0 takes the LARGEST unit left, the
+//     other contexts the SMALLEST -- a strip occupies its wavefront until its march ends, so what runs beside a large
+//     unit must be short, or that unit's next strip finds no wavefront when it becomes ready (with every context pulling
+//     from the head the largest octants took the whole launch, 0.7 ms, waiting for wavefronts);
+//   * the boundary line of strip p goes to strip p+1 twice.  DURABLY through global memory (the L2), a block of 64 entries
+//     at a time: 16-byte entries {value, tag}, the tag being the launch's epoch, so that a reader can tell an entry of
+//     this launch from whatever the scratch held before -- no fence, no wait for the producer's stores (a workgroup-scope
+//     release drains every store the wavefront has in flight: DESIGN.md 4b).  And FAST through a 256-entry ring in LDS
+//     that belongs to the writing wavefront and that it overwrites without ever waiting for anybody: a reader that
+//     follows closely (the normal case) copies the few entries of its next window out of the ring and checks the
+//     writer's header word -- which strip the ring belongs to, how far it has got -- before and after; if the writer is
+//     more than ~240 steps ahead, or has moved on to another strip, the reader takes the whole block from global memory
+//     instead.  So a strip follows the strip below it by one 8-step window instead of a 64-step block (the launch is
+//     as long as the pipelines of its largest units: with block hand-offs a full-size octant needs 31 block times for
+//     16 blocks of march), and a strip still waits only for strips claimed before it: the machine cannot deadlock,
+//     whatever the number of wavefronts, contexts and strips.  (A first version had rings that were never overwritten:
+//     with the reader of a ring not yet claimed its writer stalls, and on marches longer than ~4 W blocks every
+//     wavefront can end up stalled behind an unclaimed reader -- the simulator found it);
 //   * an x-major strip flushes its own staging tile: after every 8-step window the rows whose 128-byte line is
 //     complete leave as whole lines, 8 rows per store instruction, issued by the wavefront that computed them (a
 //     wavefront stalled in a store is covered by the other wavefronts of its SIMD: that is what a pool is for);
@@ -50,20 +59,37 @@ constexpr int kYCols = stream::kYCols;
 constexpr int kTStride = 17;  // doubles per tile row: two windows of 8 columns + 1 (spreads the column writes over the banks)
 constexpr int kUnits = 8;     // units per source: 4 quadrants x {x-major, y-major}
 
+#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)  // diagnostic builds only (tools/pool_timeline.py): where a wavefront's cycles go
+#define VHP_PP_T0(var) const unsigned long long var = __builtin_readcyclecounter()
+#define VHP_PP_ADD(slot, var) prof[slot] += __builtin_readcyclecounter() - var
+#define VHP_PP_ADDP(pp, slot, var) (pp)[slot] += __builtin_readcyclecounter() - var
+#define VHP_PP_COUNT(slot) prof[slot] += 1
+#else
+#define VHP_PP_T0(var)
+#define VHP_PP_ADD(slot, var)
+#define VHP_PP_ADDP(pp, slot, var)
+#define VHP_PP_COUNT(slot)
+#endif
+
 // ---- LDS of a workgroup -------------------------------------------------------------------------------------------
 // doubles per wavefront: the staging tile, the reciprocal slab, the boundary line of the strip below for the current
-// block (66 entries: the block's 64 and the neighbour of its first step on either side), the boundary values this strip
-// produces in the current block, a dummy slot; then the scheduler's ints:
+// block (66 entries: the block's 64 and the neighbour of its first step on either side), the ring of the boundary values
+// this strip produces (its last 256 steps), a dummy slot; then the scheduler's ints:
 //   [0] queue empty   [2] units installed so far (sequence numbers)   [3] wavefronts sweeping a strip right now
+//   [8 + w] header of wavefront w's ring: tag of the strip it belongs to << 14 | steps of it that are in the ring
 //   per context: state (0 free, 1 being installed, 2 active), claim word (seq << 8 | next strip; -1 while not active),
-//   unit, strips, strips not yet finished, sx | sy << 16, diagonal entries ready, (pad), then progress[strip]
-constexpr int kSchedHead = 8, kCtxHead = 8;
-constexpr int kBin = 72;  // doubles of a boundary-in slab (66 used)
+//   unit, strips, strips not yet finished, sx | sy << 16, diagonal entries ready, (pad), then progress[strip] (steps
+//   swept) and owner[strip] (the wavefront that sweeps it)
+constexpr int kSchedHead = 8 + 16, kCtxHead = 8;
+constexpr int kHdr = 8;
+constexpr int kBin = 72;   // doubles of a boundary-in slab (66 used)
+constexpr int kRing = 256; // entries of a wavefront's boundary ring, indexed by the marching coordinate & 255
+constexpr int kRingSafe = 232;  // a reader trusts ring entries only while the writer is at most this many steps past them
 enum { kQEmpty = 0, kSeq = 2, kBusy = 3 };
 enum { kState = 0, kWord = 1, kUnit = 2, kNStrips = 3, kLeft = 4, kSxSy = 5, kDiagReady = 6 };
 struct Layout {
   int W, C, S;
-  int tiles, slabs, bins, bouts, dummies, sched, ctx_stride, total;
+  int tiles, slabs, bins, rings, dummies, sched, ctx_stride, total;
 };
 VHP_HD Layout make_layout(int W, int C, int nx, int ny) {
   Layout L;
@@ -73,10 +99,10 @@ VHP_HD Layout make_layout(int W, int C, int nx, int ny) {
   L.tiles = o; o += W * kXRows * kTStride;
   L.slabs = o; o += W * kBlock;
   L.bins = o; o += W * kBin;
-  L.bouts = o; o += W * kBlock;
+  L.rings = o; o += W * kRing;
   L.dummies = o; o += W * 8;
   L.sched = o;
-  L.ctx_stride = kCtxHead + L.S;
+  L.ctx_stride = kCtxHead + 2 * L.S;
   o += (kSchedHead + C * L.ctx_stride + 1) / 2;
   L.total = o;
   return L;
@@ -88,6 +114,10 @@ struct Shared {
   VHP_FN int* sched() const { return reinterpret_cast<int*>(lds + L.sched); }
   VHP_FN int* ctx(int c) const { return sched() + kSchedHead + c * L.ctx_stride; }
   VHP_FN int* prog(int c) const { return ctx(c) + kCtxHead; }
+  VHP_FN int* owner(int c) const { return ctx(c) + kCtxHead + L.S; }
+  VHP_FN int* hdr(int w) const { return sched() + kHdr + w; }
+  VHP_FN double* ring(int w) const { return lds + L.rings + w * kRing; }
+  VHP_FN double* bin(int w) const { return lds + L.bins + w * kBin; }
 };
 
 template <typename OutT>
@@ -98,7 +128,7 @@ struct Args {
   long long field_stride;
   int* err_flag;
   const int* order;   // unit ids, largest first
-  int* queue;         // units taken so far
+  unsigned long long* queue;  // units taken so far: from the head (low word) and from the tail (high word)
   int n_units;
   double* diag;       // scratch: diag(k) of the y-major unit of (source s, quadrant q) at (4 s + q) * diag_stride + k
   int diag_stride;
@@ -106,6 +136,8 @@ struct Args {
   const int* line_base;
   uint64_t epoch;     // the tag of this launch (never 0, never repeated on this scratch)
   int busy_cap;       // a workgroup takes another unit only while fewer than this many of its wavefronts are sweeping
+  int n_head;         // contexts 0 .. n_head-1 take the largest unit left, the others the smallest
+  unsigned long long* unit_times;  // diagnostic builds: when unit u was installed / finished (wall clock), or nullptr
 };
 
 // Geometry of a unit without the direction templates: what the scheduler needs to tell whether a strip may start.
@@ -128,12 +160,127 @@ struct UnitGeo {
     else if (x_major) n_strips = (rows_total + kXRows - 1) / kXRows;
     else n_strips = cols_total > 0 ? (cols_total + ya + kYCols - 1) / kYCols : 0;
   }
-  // first block of strip p (x-major: block p exactly)
-  VHP_FN int first_block(int p) const { return x_major ? p : (ph + imax(kYCols * p - ya, 0)) >> 6; }
+  // first step of strip p
+  VHP_FN int first_step(int p) const { return x_major ? kXRows * p : imax(kYCols * p - ya, 0); }
   // diagonal entries a y-major strip needs before it starts
   VHP_FN int diag_need(int p) const { return x_major ? 0 : imin(kYCols * p - ya + kYCols, rows_total); }
   // 64-entry blocks of boundary-line scratch: one line of nb blocks per strip that has a reader
   VHP_FN int line_blocks() const { return n_strips > 1 ? (n_strips - 1) * nb : 0; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// The boundary line between a strip and its neighbours: what a strip reads from the strip below it and what it hands to
+// the strip above.  D = direction of the marching coordinate, c0 = the source's coordinate: step i is at c0 + D i.
+// A strip's tag: claim sequence number of its unit (9 bits) << 8 | strip.
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+struct Link {
+  // reading side (nothing of it is used by the first strip of a unit)
+  double* bin;             // entry of coordinate x of the current block at 1 + (x & 63); 0 / 65: the neighbours of the block
+  const double* rd_ring;   // the ring of the wavefront that sweeps the strip below
+  const int* rd_hdr;
+  int rd_tag;
+  const Tagged* line_in;   // the strip below's line in global memory: entry of x in block n at 64 n + (x & 63)
+  int bin_block;           // the block that is in `bin` as a whole (from global memory), or -1
+  bool primed;
+  int first_step;
+  // writing side
+  double* ring;            // mine: entry of x at x & 255
+  int* hdr;
+  int my_tag;
+  Tagged* line_out;        // nullptr without a reader
+  int* prog;               // my progress word in the context: steps swept
+  uint64_t epoch;
+  int c0;
+  vi lane;
+  unsigned long long* pp;  // diagnostic builds: the wavefront's cycle accounts (Worker::prof), else unused
+
+  VHP_FN int coord(int i) const { return c0 + D * i; }
+  VHP_FN int block_of(int i) const { const int b = coord(i) >> 6; return D > 0 ? b - (c0 >> 6) : (c0 >> 6) - b; }
+
+  VHP_FN void init(const Shared& sh, int w, int c0_, int first_step_, int tag, int* prog_, const Tagged* line_in_, Tagged* line_out_, uint64_t epoch_,
+                   int below_w, int below_tag) {
+    bin = sh.bin(w);
+    ring = sh.ring(w);
+    hdr = sh.hdr(w);
+    my_tag = tag;
+    prog = prog_;
+    line_in = line_in_; line_out = line_out_; epoch = epoch_;
+    c0 = c0_;
+    first_step = first_step_;
+    bin_block = -1;
+    primed = false;
+    lane = lane_id();
+    rd_ring = below_w >= 0 ? sh.ring(below_w) : nullptr;
+    rd_hdr = below_w >= 0 ? sh.hdr(below_w) : nullptr;
+    rd_tag = below_tag;
+    lds_publish(hdr, my_tag << 14);  // the ring is this strip's from here on (before its first entry is written)
+  }
+  // steps 0 .. steps-1 of this strip are swept: their boundary values are in the ring
+  VHP_FN void publish(int steps) {
+    lds_publish(hdr, (my_tag << 14) | steps);
+    lds_publish(prog, steps);
+  }
+  // the whole block nb (coordinate block blk = x >> 6) goes to my line in global memory, out of the ring
+  VHP_FN void store_block(int nb, int blk) {
+    wave_sync();
+    g_store_tagged(line_out, lane + 64 * nb, lds_load(ring, lane + 64 * (blk & 3)), epoch);
+  }
+  // block nb of the strip below from global memory into the slab (it has been stored, or is about to be; the tag tells)
+  VHP_FN void load_block(int nb) {
+    if (!primed) {
+      primed = true;
+      const int ic = first_step - 1;
+      if (ic >= 0 && block_of(ic) != nb) {
+        vd c;
+        while (!wave_all(g_load_tagged(line_in, vi(64 * block_of(ic) + (coord(ic) & 63)), epoch, c))) backoff();
+        lds_store(bin, vi(D > 0 ? 64 : 1), c);
+        wave_sync();
+      }
+    }
+    const double carry = D > 0 ? bin[64] : bin[1];
+    vd v;
+    while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) backoff();
+    wave_sync();
+    lds_store(bin, lane + 1, v);
+    lds_store(bin, vi(D > 0 ? 0 : 65), vd(carry));
+    wave_sync();
+    bin_block = nb;
+  }
+  // Makes the boundary values of steps ia-1 .. ib of the strip below (all of block nb but possibly the first) readable in
+  // the slab.  Fast: out of the writer's ring, with its header read before and after the copy.  Otherwise the whole
+  // block from global memory.
+  VHP_FN void fetch(int ia, int ib, int nb) {
+    if (bin_block == nb) return;
+    VHP_PP_T0(tq);
+    fetch_(ia, ib, nb);
+    VHP_PP_ADDP(pp, 1, tq);
+  }
+  VHP_FN void fetch_(int ia, int ib, int nb) {
+    for (;;) {
+      const int h = lds_poll(rd_hdr);
+      if ((h >> 14) != rd_tag) break;                 // the writer has finished that strip: its line is (being) stored
+      const int steps = h & 0x3fff;
+      if (steps <= ib) { ready_backoff(); continue; }  // not swept yet
+      if (steps - (ia - 1) > kRingSafe) { sim_count(2); break; }  // far ahead: the ring may be overwritten any moment, the block is stored
+      lds_acquire();
+      sim_point();
+      primed = true;
+      const vi st = vmin(lane + (ia - 1), ib);        // lane l: step ia - 1 + l (clamped: the same entry again)
+      const vi x = st * D + c0;
+      const vd v = lds_load(rd_ring, x & (kRing - 1));
+      // the neighbour entry (step ia - 1) goes next to step ia's slot; the others to their own
+      const vi slot = select(lane == 0, vi(1 + (coord(ia) & 63) - D), (x & 63) + 1);
+      const int h2 = lds_poll(rd_hdr);
+      if ((h2 >> 14) != rd_tag || (h2 & 0x3fff) - (ia - 1) > kRingSafe + 8) { sim_count(3); break; }  // (the writer may be 8 steps past what it has published)
+      lds_store(bin, slot, v);
+      wave_sync();
+      sim_count(0);
+      return;
+    }
+    sim_count(1);
+    load_block(nb);
+  }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -152,12 +299,8 @@ struct XStrip {
   int r_stride;   // 2: the row pitch is an odd multiple of 64 bytes, odd and even rows are half a line apart; else 1
   int p, j0, rows_here;
   bool has_consumer;
-  double* bin;        // the boundary line of strip p-1 for the current block: entry of x at 1 + (x & 63); 0 / 65: the neighbours
-  double* bout;       // what lane 63 produces in the current block, at x & 63
-  const Tagged* line_in;  // strip p-1's line in global memory (entry of x in block n at 64 n + (x & 63)), nullptr for strip 0
-  Tagged* line_out;       // mine, nullptr without a reader
-  uint64_t epoch;
-  bool primed;
+  Link<DX> lk;        // the boundary lines: strip p-1's (read) and mine (written)
+  double* bin;        // = lk.bin
   int pf_blk;         // the block (x >> 6) whose operands wait in ow_nx / rv_nx, or -1
   vi lane, tile_l, fl_t0, fl_hi;
   vu32 fl_off;
@@ -165,13 +308,13 @@ struct XStrip {
   vu64 ow, ow_nx;
   vd rv_nx;
 
-  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int p_, const Tagged* line_in_, Tagged* line_out_, uint64_t epoch_) {
+  // (the caller has initialised lk)
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int p_) {
     m = m_; out = out_;
     g.init(m.nx, m.ny, sx, sy);
     tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
     slab = sh.lds + sh.L.slabs + w * kBlock;
-    bin = sh.lds + sh.L.bins + w * kBin;
-    bout = sh.lds + sh.L.bouts + w * kBlock;
+    bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * 8;
     r_stride = ((m.nx >> 3) & 1) ? 2 : 1;
     lane = lane_id();
@@ -189,8 +332,6 @@ struct XStrip {
     j0 = kXRows * p;
     rows_here = imin(kXRows, g.rows_total - j0);
     has_consumer = p + 1 < g.Px;
-    line_in = line_in_; line_out = line_out_; epoch = epoch_;
-    primed = false;
     prev = vd(0.0);
     jd = to_f64(lane + j0);
     pf_blk = -1;
@@ -299,7 +440,7 @@ struct XStrip {
     }
     prev = v;
     lds_store(tile, tile_l + (((x >> 3) & 1) * 8 + (x & 7)), v);
-    if (has_consumer) lds_store_if(lane == 63, bout, vi(x & 63), v);
+    if (has_consumer) lds_store_if(lane == 63, lk.ring, vi(x & (kRing - 1)), v);
   }
 
   // eight steps covering one aligned window of x; DIAG: the strip's diagonal may fall into it
@@ -326,7 +467,7 @@ struct XStrip {
     const vi tidx = tile_l + ((xw >> 3) & 1) * 8;
     // every lane writes "its boundary value" each step -- lane 63 into the block's out slab, the others into a dummy
     // slot: one ds_write instead of an exec-masked region per step
-    double* wbase = has_consumer ? bout + (xw & 63) : dummy;
+    double* wbase = has_consumer ? lk.ring + (xw & (kRing - 1)) : dummy;
     const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
     vd di = vd((double)i0);
 #pragma unroll
@@ -357,43 +498,14 @@ struct XStrip {
     rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
   }
 
-  // Block nb of the line of strip p-1 into the in slab (the caller has seen strip p-1 publish the block; the entries may
-  // still be on their way to the L2: the tag tells).  The neighbour of the block's first step on the side the march
-  // comes from is the previous block's last entry; before the strip's first block it is fetched by itself.
-  VHP_FN void load_boundary(int nb, int first_step) {
-    if (!primed) {
-      primed = true;
-      const int ic = first_step - 1;
-      if (ic >= 0 && g.nbx(ic) != nb) {
-        vd c;
-        while (!wave_all(g_load_tagged(line_in, vi(64 * g.nbx(ic) + (g.X(ic) & 63)), epoch, c))) backoff();
-        lds_store(bin, vi(DX > 0 ? 64 : 1), c);
-        wave_sync();
-      }
-    }
-    const double carry = DX > 0 ? bin[64] : bin[1];
-    vd v;
-    while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) backoff();
-    wave_sync();
-    lds_store(bin, lane + 1, v);
-    lds_store(bin, vi(DX > 0 ? 0 : 65), vd(carry));
-    wave_sync();
-  }
-  // what lane 63 produced in block nb goes to my line
-  VHP_FN void store_boundary(int nb) {
-    wave_sync();
-    g_store_tagged(line_out, lane + 64 * nb, lds_load(bout, lane), epoch);
-    wave_sync();
-  }
-
   VHP_FN void sweep_block(int nb) {
     int lo, hi;
     g.xsteps(nb, lo, hi);
     lo = imax(lo, j0);
     if (lo > hi) return;
     const int blk = g.X(lo) >> 6;
-    if (p > 0) load_boundary(nb, j0);
     {
+      VHP_PP_T0(tl);
       vd rv;
       if (pf_blk == blk) { ow = ow_nx; rv = rv_nx; } else { load_block(blk, ow, rv); }
       pin(ow);
@@ -401,6 +513,7 @@ struct XStrip {
       lds_store(slab, lane, rv);
       wave_sync();
       if (nb + 1 < g.Nbx) { pf_blk = blk + DX; load_block(pf_blk, ow_nx, rv_nx); } else { pf_blk = -1; }
+      VHP_PP_ADDP(lk.pp, 4, tl);
     }
     int i = lo;
     while (i <= hi) {
@@ -408,17 +521,21 @@ struct XStrip {
       const bool aligned = DX > 0 ? (x & 7) == 0 : (x & 7) == 7;
       int i_last;
       if (aligned && i + 7 <= hi) {
+        if (p > 0) lk.fetch(i, i + 7, nb);
         if (i < j0 + kXRows) window8<true>(i); else window8<false>(i);
         i_last = i + 7;
       } else {
+        if (p > 0) lk.fetch(i, i, nb);
         step1(i);
         i_last = i;
       }
+      if (has_consumer) lk.publish(i_last + 1);
       i = i_last + 1;
       const int xl = g.X(i_last);
       const bool boundary = DX > 0 ? (xl & 7) == 7 : (xl & 7) == 0;
       if (boundary && i_last != g.ni - 1) flush_completed(xl, i_last);  // (the last step of the march is end_of_march's)
     }
+    if (has_consumer) lk.store_block(nb, blk);
   }
 };
 
@@ -437,24 +554,19 @@ struct YStrip {
   double* dummy;
   int q, i0, jstart;
   bool has_consumer, interior;
-  double* bin;        // as XStrip's, along y
-  double* bout;
-  const Tagged* line_in;
-  Tagged* line_out;
-  uint64_t epoch;
-  bool primed;
+  Link<DY> lk;        // the boundary lines, along y
+  double* bin;        // = lk.bin
   vi lane, ia, ib;
   vd prev0, prev1, id0, id1, dg0, dg1;
   vu64 ow0, ow1;
   vu32 xoff;  // byte offset of the lane's pair inside a row
 
-  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const Tagged* line_in_, Tagged* line_out_, uint64_t epoch_,
-                   const double* diag) {
+  // (the caller has initialised lk)
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const double* diag) {
     m = m_; out = out_;
     g.init(m.nx, m.ny, sx, sy);
     slab = sh.lds + sh.L.slabs + w * kBlock;
-    bin = sh.lds + sh.L.bins + w * kBin;
-    bout = sh.lds + sh.L.bouts + w * kBlock;
+    bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * 8;
     lane = lane_id();
     q = q_;
@@ -475,8 +587,6 @@ struct YStrip {
     pin(dg1);
     const vi xlo = DX > 0 ? ia + g.sx : (-ib) + g.sx;  // the pair's lower x: x(ia) marching up, x(ib) marching down
     xoff = to_u32(xlo * CB);
-    line_in = line_in_; line_out = line_out_; epoch = epoch_;
-    primed = false;
   }
 
   // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below the diagonal
@@ -505,7 +615,7 @@ struct YStrip {
     store_pred(row_ptr(y), j, v0, v1);
     prev0 = v0;
     prev1 = v1;
-    if (has_consumer) lds_store_if(lane == 63, bout, vi(y & 63), v1);
+    if (has_consumer) lds_store_if(lane == 63, lk.ring, vi(y & (kRing - 1)), v1);
   }
 
   // eight steps covering one aligned window of y.  DIAG: seeding may happen (implies PRED); PRED: predicated stores
@@ -528,7 +638,7 @@ struct YStrip {
     }
     const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
     const vu32 hs0 = half_shifted(ow0, t0, sh), hs1 = half_shifted(ow1, t0, sh);
-    double* wbase = has_consumer ? bout + (yb & 63) : dummy;
+    double* wbase = has_consumer ? lk.ring + (yb & (kRing - 1)) : dummy;
     const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
     vd dj = vd((double)j0w);
     OutT* row = row_ptr(y0);
@@ -558,38 +668,12 @@ struct YStrip {
     }
   }
 
-  VHP_FN void load_boundary(int nb, int first_step) {  // (XStrip::load_boundary along y)
-    if (!primed) {
-      primed = true;
-      const int jc = first_step - 1;
-      if (jc >= 0 && g.nby(jc) != nb) {
-        vd c;
-        while (!wave_all(g_load_tagged(line_in, vi(64 * g.nby(jc) + (g.Y(jc) & 63)), epoch, c))) backoff();
-        lds_store(bin, vi(DY > 0 ? 64 : 1), c);
-        wave_sync();
-      }
-    }
-    const double carry = DY > 0 ? bin[64] : bin[1];
-    vd v;
-    while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) backoff();
-    wave_sync();
-    lds_store(bin, lane + 1, v);
-    lds_store(bin, vi(DY > 0 ? 0 : 65), vd(carry));
-    wave_sync();
-  }
-  VHP_FN void store_boundary(int nb) {
-    wave_sync();
-    g_store_tagged(line_out, lane + 64 * nb, lds_load(bout, lane), epoch);
-    wave_sync();
-  }
-
   VHP_FN void sweep_block(int nb) {
     int lo, hi;
     g.ysteps(nb, lo, hi);
     lo = imax(lo, jstart);
     if (lo > hi) return;
     const int blk = g.Y(lo) >> 6;
-    if (q > 0) load_boundary(nb, jstart);
     {
       const vi xa = vmin(vmax(ia, 0), g.ni - 1) * DX + g.sx;
       const vi xb = vmin(vmax(ib, 0), g.ni - 1) * DX + g.sx;
@@ -598,26 +682,32 @@ struct YStrip {
       const vi jt = (lane + (blk * 64 - g.sy)) * DY;
       const vb ok = (jt >= 0) && (jt < g.nj);
       vd rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
+      VHP_PP_T0(tl);
       pin(ow0);
       pin(ow1);
       pin(rv);
       lds_store(slab, lane, rv);
       wave_sync();
+      VHP_PP_ADDP(lk.pp, 4, tl);
     }
     int j = lo;
     while (j <= hi) {
       const int y = g.Y(j);
       const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
       if (aligned && j + 7 <= hi) {
+        if (q > 0) lk.fetch(j, j + 7, nb);
         if (j <= i0 + kYCols - 1) window8<true, true>(j);
         else if (!interior) window8<false, true>(j);
         else window8<false, false>(j);
         j += 8;
       } else {
+        if (q > 0) lk.fetch(j, j, nb);
         step1(j);
         j += 1;
       }
+      if (has_consumer) lk.publish(j);
     }
+    if (has_consumer) lk.store_block(nb, blk);
   }
 };
 
@@ -683,15 +773,6 @@ struct DiagTask {
 // ---------------------------------------------------------------------------------------------------------------
 enum { kFound = 0, kRetry = 1, kIdle = 2, kExit = 3 };
 
-#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)  // diagnostic builds only (tools/pool_timeline.py): where a wavefront's cycles go
-#define VHP_PP_T0(var) const unsigned long long var = __builtin_readcyclecounter()
-#define VHP_PP_ADD(slot, var) prof[slot] += __builtin_readcyclecounter() - var
-#define VHP_PP_COUNT(slot) prof[slot] += 1
-#else
-#define VHP_PP_T0(var)
-#define VHP_PP_ADD(slot, var)
-#define VHP_PP_COUNT(slot)
-#endif
 
 template <typename OutT>
 struct Worker {
@@ -702,7 +783,7 @@ struct Worker {
 #if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
   // cycles: [0] looking for work / idle, [1] waiting for the strip below, [2] sweeping (stores included), [3] installing units
   // (diagonal chains included), [4] boundary line out; counts: [5] strips, [6] blocks, [7] units installed
-  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ([1]: inside the sweep, waiting for / copying the boundary values; [4]: block-start loads)
 #endif
 
   VHP_FN void init(const Args<OutT>& a_, double* lds, const Layout& L, int w_) {
@@ -743,18 +824,20 @@ struct Worker {
       const int ns = lds_poll(cx + kNStrips);
       if (p >= ns) continue;
       unclaimed = true;
-      if (seq >= best_seq) continue;
+      const int rank = c < a.n_head ? c : seq + 16;  // the large units of the head contexts first, then the oldest
+      if (rank >= best_seq) continue;
       const int unit = lds_poll(cx + kUnit), sxsy = lds_poll(cx + kSxSy);
       const int qo = unit & 7, sx = sxsy & 0xffff, sy = sxsy >> 16;
       UnitGeo ug;
       ug.init(a.m.nx, a.m.ny, qo, sx, sy);
-      if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_block(p) + 1) continue;
+      if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_step(p) + 8 + 1) continue;  // the strip below has swept my first window
       if (!ug.x_major && lds_poll(cx + kDiagReady) < ug.diag_need(p)) continue;
-      best_c = c; best_seq = seq; best_p = p; best_word = word; best_qo = qo; best_sx = sx; best_sy = sy;
+      best_c = c; best_seq = rank; best_p = p; best_word = word; best_qo = qo; best_sx = sx; best_sy = sy;
     }
     if (best_c >= 0) {
       sim_point();
       if (lds_cas(sh.ctx(best_c) + kWord, best_word, best_word + 1) != best_word) return kRetry;
+      lds_set_int(sh.owner(best_c) + best_p, w);
       c_out = best_c; p_out = best_p; qo_out = best_qo; sx_out = best_sx; sy_out = best_sy;
       sim_progress();
       return kFound;
@@ -781,9 +864,12 @@ struct Worker {
   VHP_FN void install(int c) {
     int* sc = sh.sched();
     int* cx = sh.ctx(c);
-    const int idx = g_add(a.queue, 1);
+    const bool from_tail = c >= a.n_head;
+    const unsigned long long old = g_add_u64(a.queue, from_tail ? (1ull << 32) : 1ull);
+    const unsigned taken_head = (unsigned)old, taken_tail = (unsigned)(old >> 32);
+    const int idx = from_tail ? a.n_units - 1 - (int)taken_tail : (int)taken_head;
     sim_progress();
-    if (idx >= a.n_units) {
+    if (taken_head + taken_tail >= (unsigned)a.n_units) {
       lds_publish(sc + kQEmpty, 1);
       lds_publish(cx + kState, 0);
       return;
@@ -810,6 +896,9 @@ struct Worker {
       lds_publish(cx + kState, 0);
       return;
     }
+#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+    if ((threadIdx.x & 63) == 0 && a.unit_times) a.unit_times[2 * unit] = wall_clock64();
+#endif
     lds_set_int(cx + kUnit, unit);
     lds_set_int(cx + kNStrips, ug.n_strips);
     lds_set_int(cx + kLeft, ug.n_strips);
@@ -847,46 +936,43 @@ struct Worker {
   VHP_FN void strip_done(int c) {
     int* cx = sh.ctx(c);
     if (lds_add(cx + kLeft, -1) == 1) {
+#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+      if ((threadIdx.x & 63) == 0 && a.unit_times) a.unit_times[2 * lds_int_at(cx + kUnit) + 1] = wall_clock64();
+#endif
       lds_publish(cx + kWord, -1);
       lds_publish(cx + kState, 0);
     }
     sim_progress();
   }
 
-  // waits until strip p-1 has published block n (its boundary entries are then in the L2 or on their way)
-  VHP_FN void wait_block(int c, int p, int n) {
-    if (p == 0) return;
-    const int* pr = sh.prog(c) + (p - 1);
-    while (lds_poll(pr) < n + 1) ready_backoff();
-    lds_acquire();
-  }
   // the boundary line of strip p of `unit`
   VHP_FN Tagged* line_of(int unit, int p, int nb) const { return a.lines + (size_t)64 * ((size_t)uniform(a.line_base[unit]) + (size_t)p * nb); }
+  // tag of strip p of the unit in context c (claim sequence number of the unit, strip)
+  VHP_FN int tag_of(int c, int p) const { return (((lds_int_at(sh.ctx(c) + kWord) >> 8) & 0x1ff) << 8) | p; }  // 17 bits: tag << 14 stays positive
 
   template <int DX, int DY>
   VHP_FN void run_x(int c, int unit, int p, int sx, int sy, OutT* field) {
     XStrip<DX, DY, OutT> xs;
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
-    xs.init(a.m, sx, sy, field, sh, w, p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr, a.epoch);
     int* mine = sh.prog(c) + p;
+    xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr,
+               a.epoch, p > 0 ? lds_int_at(sh.owner(c) + (p - 1)) : -1, p > 0 ? tag_of(c, p - 1) : 0);
+    xs.init(a.m, sx, sy, field, sh, w, p);
+#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+    xs.lk.pp = prof;
+#endif
     VHP_PP_COUNT(5);
     for (int n = p; n < xs.g.Nbx; ++n) {
-      VHP_PP_T0(tw);
-      wait_block(c, p, n);
-      VHP_PP_ADD(1, tw);
       VHP_PP_T0(ts);
       xs.sweep_block(n);
       if (n == xs.g.Nbx - 1) xs.end_of_march();
       VHP_PP_ADD(2, ts);
-      VHP_PP_T0(tb);
-      if (xs.has_consumer) xs.store_boundary(n);
-      VHP_PP_ADD(4, tb);
       VHP_PP_COUNT(6);
-      lds_publish(mine, n + 1);
       sim_progress();
       sim_point();
     }
+    lds_publish(mine, 0x3fff);  // finished: whatever the strip above needs to start is there (a march can end before its first window does)
     strip_done(c);
   }
 
@@ -895,24 +981,23 @@ struct Worker {
     YStrip<DX, DY, OutT> ys;
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
-    ys.init(a.m, sx, sy, field, sh, w, q, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr, a.epoch, dline);
     int* mine = sh.prog(c) + q;
+    ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr,
+               a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
+    ys.init(a.m, sx, sy, field, sh, w, q, dline);
+#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+    ys.lk.pp = prof;
+#endif
     VHP_PP_COUNT(5);
     for (int n = ys.g.nby(ys.jstart); n < ys.g.Nby; ++n) {
-      VHP_PP_T0(tw);
-      wait_block(c, q, n);
-      VHP_PP_ADD(1, tw);
       VHP_PP_T0(ts);
       ys.sweep_block(n);
       VHP_PP_ADD(2, ts);
-      VHP_PP_T0(tb);
-      if (ys.has_consumer) ys.store_boundary(n);
-      VHP_PP_ADD(4, tb);
       VHP_PP_COUNT(6);
-      lds_publish(mine, n + 1);
       sim_progress();
       sim_point();
     }
+    lds_publish(mine, 0x3fff);
     strip_done(c);
   }
 
