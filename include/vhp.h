@@ -156,8 +156,8 @@ int vhp_sweep_batch_offset(vhp_ctx* ctx, const int32_t* src_xy, int n_src, doubl
 int vhp_last_elapsed_ms(vhp_ctx* ctx, float* ms);
 
 /* Per-launch kernel timing for benchmarks.  vhp_timing(ctx, 1) makes every following
- * vhp_sweep_batch_device call bracket its sweep kernel (only that kernel, not the unit-ordering
- * pre-kernel) with a pair of hipEvents on the context stream; vhp_timing_collect waits for them,
+ * vhp_sweep_batch_device call bracket what it launches -- the unit-ordering pre-kernel and the
+ * sweep kernel -- with a pair of hipEvents on the context stream; vhp_timing_collect waits for them,
  * writes up to `cap` durations in milliseconds (oldest first), returns their count in *n and
  * clears the list.  vhp_timing(ctx, 0) switches it off. */
 int vhp_timing(vhp_ctx* ctx, int enable);  /* enable > 1: also pre-creates that many event pairs */

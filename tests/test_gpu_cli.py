@@ -183,6 +183,67 @@ def test_mode2_image_flip(tmp_path, oracle):
     assert _read(tmp_path, "lightSources.txt") == "".join("%d %d\n" % (x, ny - 1 - y) for x, y in piv)
 
 
+def _interface_m_walk(tmp_path, start_cfg, end_cfg):
+    """What interface.m does with the files (reference interface.m:58-162), restated: readtable with ' ' as delimiter (a numeric
+    matrix per file, one row per line), cameFrom = T + 1 (:85), pivots = T + 1 (:133), then from the end point
+    pt = pivots(cameFrom(pt(2), pt(1)), :) until pt is the start point (:141-162), summing norm() of the hops.  start / end
+    are the config's own numbers (+ 1): in mode 2 the files and the config share the image's y orientation."""
+    def table(name):
+        return np.array([[float(t) for t in line.split()] for line in (tmp_path / "output" / name).read_text().splitlines()])
+    came = table("cameFrom.txt") + 1
+    pivots = table("lightSources.txt") + 1
+    sp, pt = np.array(start_cfg, float) + 1, np.array(end_cfg, float) + 1
+    path, total = [pt.copy()], 0.0
+    for _ in range(len(pivots) + 2):            # the MATLAB loop has no bound; a consistent parent table needs at most this many hops
+        if pt[0] == sp[0] and pt[1] == sp[1]:
+            break
+        label = came[int(pt[1]) - 1, int(pt[0]) - 1]          # cameFrom(pt(2), pt(1)), 1-based
+        assert 1 <= label <= len(pivots), "cameFrom + 1 = %r is not a row of pivots" % label
+        pt = pivots[int(label) - 1].copy()
+        total += float(np.linalg.norm(pt - path[-1]))
+        path.append(pt.copy())
+    assert pt[0] == sp[0] and pt[1] == sp[1], "the back-track of interface.m:141-162 does not reach the start"
+    return np.array(path) - 1, total, came - 1, pivots - 1
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_files_as_interface_m_reads_them(tmp_path, oracle, mode):
+    # the consumer's view of the .txt surface: interface.m's own parsing and back-track over the CLI's files terminates on the
+    # start, and equals vhp_reconstruct_path over the same arrays and the "Path length" the CLI prints
+    import vhp_amd
+    if mode == 1:
+        nx, ny, nb, seed = 210, 160, 18, 5
+        occ = oracle.generate_env(nx, ny, nb, 4, 30, 4, 30, seed)
+        free = np.argwhere(occ == 1)
+        (sy, sx), (ey, ex) = free[10], free[-10]
+        start_cfg, end_cfg = (int(sx), int(sy)), (int(ex), int(ey))
+        cfg = BASE.format(mode=1, nx=nx, ny=ny, nb=nb, seed=seed, image="none", sx=sx, sy=sy, ex=ex, ey=ey, max_iter=80, thr=0.25)
+    else:
+        occ = maps.random_rect_map(150, 120, 14, 4, 25, 4, 25, 3)
+        ny, nx = occ.shape
+        host = host_lib.load()
+        rgba = np.zeros((ny, nx, 4), np.uint8)
+        rgba[..., 0] = np.where(occ == 1, 255, 0)
+        rgba[..., 3] = 255
+        png = str(tmp_path / "map.png")
+        assert host.vhp_host_save_png(png.encode(), rgba.ctypes.data, nx, ny) == 0
+        free = np.argwhere(occ == 1)
+        (sy, sx), (ey, ex) = free[5], free[-5]
+        start_cfg, end_cfg = (int(sx), int(ny - 1 - sy)), (int(ex), int(ny - 1 - ey))   # bottom-up in the config (solver.cpp:83-86)
+        cfg = BASE.format(mode=2, nx=1, ny=1, nb=0, seed=0, image=png, sx=start_cfg[0], sy=start_cfg[1], ex=end_cfg[0], ey=end_cfg[1],
+                          max_iter=80, thr=0.2)
+    r = _run(tmp_path, cfg)
+    assert r.returncode == 0, r.stderr
+    path, total, came, pivots = _interface_m_walk(tmp_path, start_cfg, end_cfg)
+    assert len(path) >= 2 and tuple(path[-1]) == tuple(map(float, start_cfg)) and tuple(path[0]) == tuple(map(float, end_cfg))
+    # the library's own reconstruction over the arrays the files hold (the trailing `end` entry is not in lightSources.txt)
+    piv_all = np.concatenate([pivots, np.array([end_cfg], float)]).astype(np.int32)
+    length, lib_path = vhp_amd.reconstruct_path(came.astype(np.uint64), piv_all, end_cfg)
+    assert [tuple(p) for p in lib_path.tolist()] == [tuple(int(v) for v in p) for p in path[::-1]]
+    assert abs(length - total) <= 1e-9 * max(1.0, total)
+    assert ("Path length: %g\n" % length) in r.stdout
+
+
 def test_error_messages_and_untouched_output(tmp_path, oracle):
     occ = oracle.generate_env(100, 100, 10, 4, 30, 4, 30, 9)
     by, bx = np.argwhere(occ == 0)[0]

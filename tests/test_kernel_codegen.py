@@ -1,0 +1,50 @@
+"""Code-generation invariants of the two dataflow kernels (streaming sweep, pool sweep), checked on the gfx950 assembly.
+
+Their cross-wavefront protocols (progress words, ring headers, descriptors) are ordered by the LDS executing one
+wavefront's DS instructions in issue order, with compiler barriers only.  That holds as long as every LDS access IS a DS
+instruction: a pointer that loses its address space compiles to FLAT instructions, which are not ordered with the DS
+ones (and count on vmcnt) -- silently, and the CPU simulator would still pass.  Scratch traffic in these kernels means a
+spilled value is reloaded behind vmcnt, i.e. behind every store in flight.  hipcc cross-compiles without a GPU."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "visibility-heuristic-path-planner_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _asm(src, tmp_path):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / (src + ".s"))
+    subprocess.check_call([HIPCC, "-std=c++17", "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                           "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernels(asm, name):
+    """{mangled name: body} of the kernels whose name contains `name`"""
+    out = {}
+    for m in re.finditer(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % name, asm, re.S | re.M):
+        out[m.group(1)] = m.group(2)
+    return out
+
+
+@pytest.mark.parametrize("src,kernel", [("vhp_stream.hip", "vhp_stream_sweep"), ("vhp_pool.hip", "vhp_pool_sweep")])
+def test_no_flat_and_no_scratch_instructions(tmp_path, src, kernel):
+    asm = _asm(src, tmp_path)
+    ks = _kernels(asm, kernel)
+    assert len(ks) == 2, "fp64 and fp32 instantiations of %s expected, found %r" % (kernel, list(ks))
+    for name, body in ks.items():
+        flat = re.findall(r"^\s+flat_\w+", body, re.M)
+        scratch = re.findall(r"^\s+scratch_\w+", body, re.M)
+        assert not flat, "%s: FLAT instructions %r" % (name, sorted(set(flat)))
+        assert not scratch, "%s: scratch instructions %r" % (name, sorted(set(scratch)))
+        assert re.search(r"^\s+ds_write", body, re.M) and re.search(r"^\s+global_store_dwordx[24]", body, re.M)
+    for name in ks:
+        m = re.search(r"\.name:\s*%s\n\s*\.private_segment_fixed_size:\s*(\d+)" % re.escape(name), asm)
+        assert m and int(m.group(1)) == 0, "%s uses scratch memory" % name

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -67,8 +69,6 @@ struct vhp_ctx {
   int opt_pool_heads = 0;      // pool sweep: contexts that pull the largest units (0 auto)
   int opt_pool_busy_cap = 0;   // pool sweep: no new unit while this many wavefronts of the workgroup are sweeping (0 auto)
   int opt_stream_tile_slots = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
-  // dynamic-LDS limit already raised on THIS context's device, per kernel function
-  std::vector<std::pair<const void*, size_t>> lds_raised;
 
   vhp::PlannerState pl;  // device-resident planner state
   vhp::QueueScratch qs;  // scratch of the queue-variant sweep
@@ -90,17 +90,17 @@ struct DeviceGuard {
   }
 };
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: remember it per context.
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (device, function) pair, not to a context: two contexts on
+// one device share it.  Kept process-wide and monotonic -- the attribute is never set to a smaller value than before, so a
+// context that raised it for a large grid is not undercut by another context's small one.
 hipError_t raise_lds_limit(vhp_ctx* c, const void* fn, size_t bytes) {
-  for (auto& e : c->lds_raised)
-    if (e.first == fn) {
-      if (e.second >= bytes) return hipSuccess;
-      hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      if (r == hipSuccess) e.second = bytes;
-      return r;
-    }
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> raised;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = raised[{c->device, fn}];
+  if (have >= bytes) return hipSuccess;
   hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (r == hipSuccess) c->lds_raised.push_back({fn, bytes});
+  if (r == hipSuccess) have = bytes;
   return r;
 }
 
@@ -206,13 +206,27 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   const size_t n_units = (size_t)n_src * vhp::kUnitsPerSource;
   const int* order = nullptr;
   const int4* desc = nullptr;
+  // per-launch timing: from before the unit-ordering pre-kernel (part of what a launch costs) to after the sweep
+  hipEvent_t ta = nullptr, tb = nullptr;
+  if (c->timing) {
+    if (!c->event_pool.empty()) {
+      ta = c->event_pool.back().first;
+      tb = c->event_pool.back().second;
+      c->event_pool.pop_back();
+    } else {
+      if (hipEventCreate(&ta) != hipSuccess) return hipErrorOutOfMemory;
+      if (hipEventCreate(&tb) != hipSuccess) { (void)hipEventDestroy(ta); return hipErrorOutOfMemory; }
+    }
+  }
+  auto give_back = [&]() { if (ta) c->event_pool.push_back({ta, tb}); };
+  if (ta) (void)hipEventRecord(ta, c->stream);
   if (n_src >= 8) {  // worth a 1-workgroup pre-kernel once the batch spans many CUs
     if (c->d_order_cap < n_units) {
       if (c->d_order) (void)hipFree(c->d_order);
       c->d_order = nullptr;
       c->d_order_cap = 0;
       hipError_t eo = hipMalloc(&c->d_order, n_units * (sizeof(int) + sizeof(int4)) + 16);
-      if (eo != hipSuccess) return eo;
+      if (eo != hipSuccess) { give_back(); return eo; }
       c->d_order_cap = n_units;
     }
     int4* d_desc = reinterpret_cast<int4*>(c->d_order);                      // n_units descriptors first (16-byte aligned)
@@ -226,36 +240,9 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     desc = d_desc;
   }
   const unsigned grid = (unsigned)n_units;
-  hipEvent_t ta = nullptr, tb = nullptr;
-  if (c->timing) {
-    if (!c->event_pool.empty()) {
-      ta = c->event_pool.back().first;
-      tb = c->event_pool.back().second;
-      c->event_pool.pop_back();
-    } else if (hipEventCreate(&ta) != hipSuccess || hipEventCreate(&tb) != hipSuccess) {
-      return hipErrorOutOfMemory;
-    }
-    (void)hipEventRecord(ta, c->stream);
-  }
   hipLaunchKernelGGL(k, dim3(grid), dim3(128 * W), lds, c->stream, m, d_src, d_out, stride, c->d_err, order, desc);
-#ifdef VHP_EXP_SLOTTIME
-  {
-    (void)hipStreamSynchronize(c->stream);
-    std::vector<unsigned long long> h(4 * 16 * 160 * 2);
-    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(vhp::g_slottime), h.size() * 8);
-    if (FILE* f = fopen("gpurun_out/slottime.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-  }
-#endif
-#ifdef VHP_EXP_WGTIME
-  if (n_units <= 4 * 4096) {
-    (void)hipStreamSynchronize(c->stream);
-    std::vector<unsigned long long> h(3 * n_units);
-    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(vhp::g_wgtime), h.size() * 8);
-    if (FILE* f = fopen("gpurun_out/wgtime.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-  }
-#endif
   const hipError_t el = hipGetLastError();
-  if (c->timing) {
+  if (ta) {
     (void)hipEventRecord(tb, c->stream);
     c->timed_launches.push_back({ta, tb});
   }
@@ -356,10 +343,21 @@ hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out
   int R, W;
   bool multi;
   pick_shape(c, std::max(c->nx, c->ny), &R, &W, &multi, n_src, sizeof(OutT) == 8, (c->nx & 7) == 0);
-  switch (R) {
-    case 1: return multi ? launch_sweep_t<1, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<1, false, OutT>(c, d_src, n_src, d_out, W);
-    case 2: return multi ? launch_sweep_t<2, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<2, false, OutT>(c, d_src, n_src, d_out, W);
-    default: return multi ? launch_sweep_t<4, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<4, false, OutT>(c, d_src, n_src, d_out, W);
+  if constexpr (sizeof(OutT) == 4) {
+    // fp32 fields: only the one-row-per-lane shape of the front sweep is built.  The two- and four-rows-per-lane fp32
+    // instantiations needed 72-276 bytes of scratch per lane at 128 registers (round-2 verdict), and a scratch reload in
+    // the flush path serialises the stores with their own completion; they are gone.  (Sides above 1024 take the streaming
+    // sweep from 64-96 sources up as before; smaller fp32 batches there run one row per lane in rounds of 512 rows.)
+    (void)R;
+    const int Wf = c->opt_strips ? W : 8;
+    const bool multi_f = Wf * 64 < std::max(c->nx, c->ny) || c->opt_multi;
+    return multi_f ? launch_sweep_t<1, true, OutT>(c, d_src, n_src, d_out, Wf) : launch_sweep_t<1, false, OutT>(c, d_src, n_src, d_out, Wf);
+  } else {
+    switch (R) {
+      case 1: return multi ? launch_sweep_t<1, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<1, false, OutT>(c, d_src, n_src, d_out, W);
+      case 2: return multi ? launch_sweep_t<2, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<2, false, OutT>(c, d_src, n_src, d_out, W);
+      default: return multi ? launch_sweep_t<4, true, OutT>(c, d_src, n_src, d_out, W) : launch_sweep_t<4, false, OutT>(c, d_src, n_src, d_out, W);
+    }
   }
 }
 
@@ -766,17 +764,22 @@ int vhp_last_sweep_kernel(const vhp_ctx* ctx) { return ctx ? ctx->last_kernel : 
 int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n) {
   if (!ctx || !n || cap < 0 || (cap > 0 && !ms_out)) return VHP_ERR_ARG;
   VHP_ON_DEVICE(ctx);
-  int k = 0;
+  int k = 0, bad = 0;
   for (auto& pr : ctx->timed_launches) {
     float ms = 0.f;
-    VHP_HIP(hipEventSynchronize(pr.second));
-    VHP_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
-    if (k < cap) ms_out[k] = ms;
-    ++k;
+    // a pair that cannot be read (e.g. never recorded) is dropped, not left to fail every later call
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      if (k < cap) ms_out[k] = ms;
+      ++k;
+    } else {
+      ++bad;
+      (void)hipGetLastError();
+    }
     ctx->event_pool.push_back(pr);  // recycled by the next timed launches
   }
   ctx->timed_launches.clear();
   *n = std::min(k, cap);
+  if (bad) return fail(ctx, VHP_ERR_HIP, "vhp_timing_collect: " + std::to_string(bad) + " timed launch(es) could not be read");
   return VHP_OK;
 }
 

@@ -16,6 +16,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "vhp_diag.h"
+
 #ifdef VHP_SIM
 #include <cmath>
 #include <cstring>
@@ -240,28 +242,16 @@ VHP_LANE_FN vd lds_load(const double* base, vi idx) { return base[idx]; }
 VHP_LANE_FN vd lds_bcast(const double* base, int idx) { return base[idx]; }
 VHP_LANE_FN void lds_store(double* base, vi idx, vd v) { base[idx] = v; }
 VHP_LANE_FN void lds_store_if(bool p, double* base, vi idx, vd v) { if (p) base[idx] = v; }
-#ifdef VHP_EXP_NOLOAD  // diagnostic builds only: no vector loads, so no s_waitcnt vmcnt ever drains the stores (wrong results)
-VHP_LANE_FN vu64 g_load_u64(const uint64_t*, vi idx) { return ~0ull - (uint64_t)(idx & 1); }
-VHP_LANE_FN vd g_load_f64(const double*, vi idx) { return 1.0 / (double)(idx + 1); }
-#else
 VHP_LANE_FN vu64 g_load_u64(const uint64_t* base, vi idx) { return base[idx]; }
 VHP_LANE_FN vd g_load_f64(const double* base, vi idx) { return base[idx]; }
-#endif
 
 template <typename OutT> struct alignas(2 * sizeof(OutT)) Pair { OutT a, b; };
-#ifdef VHP_EXP_NOSTORE  // diagnostic builds only (tools/): all the work, none of the stores
-#define VHP_EXP_STORE_GUARD(a, b, off) { asm volatile("" :: "v"(a), "v"(b), "v"(off)); return; }
-#elif defined(VHP_EXP_SMALLSTORE)  // all stores issued, into a 64 KB window: no HBM traffic
-#define VHP_EXP_STORE_GUARD(a, b, off) off &= 0xfff0u; base = reinterpret_cast<OutT*>(reinterpret_cast<uintptr_t>(base) & ~(uintptr_t)0xffff);
-#else
-#define VHP_EXP_STORE_GUARD(a, b, off)
-#endif
 template <typename OutT> VHP_LANE_FN void g_store2(OutT* base, vu32 off, vd a, vd b) {
-  VHP_EXP_STORE_GUARD(a, b, off)
+  VHP_DIAG_STORE_GUARD(a, b, off)
   *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
 }
 template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p_hi, OutT* base, vu32 off, vd a, vd b) {
-  VHP_EXP_STORE_GUARD(a, b, off)
+  VHP_DIAG_STORE_GUARD(a, b, off)
   vd single = p_lo ? a : b;
   asm volatile("" : "+v"(single));  // keep the compiler from splitting the 16-byte store to share a half with the single
   if (p2) *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
@@ -275,13 +265,7 @@ template <typename OutT> VHP_LANE_FN void g_store1_if(bool p1, OutT* base, vu32 
 // instructions of one wavefront in issue order, so a read issued after a write sees it without an s_waitcnt in between:
 // only the compiler must be kept from moving the read up (wave_barrier is a scheduling barrier, it emits no code).
 VHP_LANE_FN void wave_sync() {
-#ifdef VHP_EXP_HEAVYSYNC  // the conservative form: fences make the compiler wait for lgkmcnt(0) on both sides
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-  __builtin_amdgcn_wave_barrier();
-#endif
 }
 // Makes a just-loaded value count as "used here": the compiler then waits for the load at this point instead of at
 // the first real use (where the s_waitcnt vmcnt would also drain every store issued in between).
@@ -300,24 +284,14 @@ VHP_LANE_FN void lds_publish(volatile int* word, int value) {
   // address space: through the generic pointer the compiler emits FLAT instructions, which are slow, are not ordered
   // with the DS instructions that wrote the data, and count on vmcnt -- a poll would wait for every global store the
   // wavefront has in flight.
-#if defined(VHP_EXP_FLATPOLL)
-  if ((threadIdx.x & 63u) == 0) *word = value;
-#elif defined(VHP_EXP_MASKPUB)
-  if ((threadIdx.x & 63u) == 0) *(volatile lds_int*)word = value;
-#else
   *(volatile lds_int*)word = value;
-#endif
   asm volatile("" ::: "memory");
 }
 // a (uniform) int that was written to LDS before the wavefronts started
 VHP_LANE_FN int lds_int_at(const int* p) { return __builtin_amdgcn_readfirstlane(*(const lds_int*)p); }
 VHP_LANE_FN void lds_set_int(int* p, int v) { *(lds_int*)p = v; }
 // a progress word of another wavefront, read afresh, as a uniform value (a DS read: see lds_publish)
-#ifdef VHP_EXP_FLATPOLL
-VHP_LANE_FN int lds_poll(const volatile int* word) { return __builtin_amdgcn_readfirstlane(*word); }
-#else
 VHP_LANE_FN int lds_poll(const volatile int* word) { return __builtin_amdgcn_readfirstlane(*(const volatile lds_int*)word); }
-#endif
 // Four uniform words for another wavefront, as ONE 16-byte LDS write (d is 16-byte aligned): every lane writes the same
 // values to the same address, so there is no exec masking, and a reader sees all four words or none.  Ordered after
 // this wavefront's earlier LDS writes like lds_publish.
@@ -336,12 +310,6 @@ VHP_LANE_FN void lds_read4(const int* d, int& a, int& b, int& c, int& e) {
   c = __builtin_amdgcn_readfirstlane(v.z);
   e = __builtin_amdgcn_readfirstlane(v.w);
 }
-#ifndef VHP_EXP_BACKOFF
-#define VHP_EXP_BACKOFF 12
-#endif
-#ifndef VHP_EXP_READYSLEEP
-#define VHP_EXP_READYSLEEP 4
-#endif
 // instruction-arbitration priority of this wavefront (0 lowest .. 3): s_setprio takes an immediate
 VHP_LANE_FN void wave_priority(int p) {
   if (p >= 3) __builtin_amdgcn_s_setprio(3);
@@ -405,8 +373,8 @@ VHP_LANE_FN bool g_load_tagged(const Tagged* base, vi idx, uint64_t tag, vd& v) 
 }
 VHP_LANE_FN bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0ull; }
 VHP_LANE_FN void lds_store_i_if(bool p, int* base, vi idx, int v) { if (p) ((lds_int*)base)[idx] = v; }
-VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(VHP_EXP_BACKOFF); }
-VHP_LANE_FN void ready_backoff() { __builtin_amdgcn_s_sleep(VHP_EXP_READYSLEEP); }
+VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(VHP_BACKOFF_SLEEP); }
+VHP_LANE_FN void ready_backoff() { __builtin_amdgcn_s_sleep(VHP_READY_SLEEP); }
 // waits until every global store (and load) this wavefront has issued has completed
 VHP_LANE_FN void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // acquire: the poll's value has arrived (the branch on it waited for lgkmcnt); later LDS reads are issued after it, in order
@@ -420,7 +388,7 @@ VHP_LANE_FN void lds_acquire() {
 // bit-identical to the division by oracle/markstein_check.c.  num is a lane vector, den and rden are uniform.
 template <typename D, typename R>
 VHP_LANE_FN vd ratio(vd num, D den, R rden) {
-#ifdef VHP_EXP_NOMATH  // diagnostic builds only: the memory traffic of the sweep without its arithmetic (wrong results)
+#ifdef VHP_DIAG_NOMATH  // diagnostic builds only: the memory traffic of the sweep without its arithmetic (wrong results)
   return num;
 #endif
   const vd q = num * vd(rden);
@@ -429,7 +397,7 @@ VHP_LANE_FN vd ratio(vd num, D den, R rden) {
 }
 // the reference's update (solver.cpp:592-594 / 598-600): a - c*(a - b), no contraction
 VHP_LANE_FN vd stencil(vd a, vd b, vd c) {
-#ifdef VHP_EXP_NOMATH
+#ifdef VHP_DIAG_NOMATH
   return a;
 #endif
   const vd t = a - b;

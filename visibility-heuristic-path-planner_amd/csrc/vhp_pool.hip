@@ -15,7 +15,7 @@ namespace pool {
 #endif
 constexpr int kWaves = VHP_POOL_WAVES;
 
-#ifdef VHP_EXP_POOLPROF  // diagnostic builds only (tools/pool_timeline.py)
+#ifdef VHP_DIAG_POOLPROF  // diagnostic builds only (tools/pool_timeline.py)
 __device__ unsigned long long g_poolprof[512 * 16 * 12];
 __device__ unsigned long long g_unit_times[2 * 8 * 1024];
 #endif
@@ -24,7 +24,7 @@ template <typename OutT>
 __global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, int n_ctx) {
   extern __shared__ double lds[];
   const Layout L = make_layout(kWaves, n_ctx, a.m.nx, a.m.ny);
-#ifdef VHP_EXP_POOLPROF
+#ifdef VHP_DIAG_POOLPROF
   const unsigned long long t_begin = wall_clock64(), c_begin = __builtin_readcyclecounter();
 #endif
   Worker<OutT>::clear(lds, L, (int)threadIdx.x, 64 * kWaves);
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, i
   Worker<OutT> wk;
   wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
   wk.run();
-#ifdef VHP_EXP_POOLPROF
+#ifdef VHP_DIAG_POOLPROF
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) {
     unsigned long long* o = g_poolprof + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 12;
     for (int k = 0; k < 8; ++k) o[k] = wk.prof[k];
@@ -187,7 +187,7 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   // two contexts take the largest units left, the others the smallest (0.75 against 0.78 ms with one head at 1000^2)
   g.n_head = a.pool_heads > 0 ? a.pool_heads : (sh.n_ctx >= 3 ? 2 : 1);
   g.unit_times = nullptr;
-#ifdef VHP_EXP_POOLPROF
+#ifdef VHP_DIAG_POOLPROF
   if (a.n_src <= 1024) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_unit_times)) == hipSuccess) g.unit_times = static_cast<unsigned long long*>(p); }
 #endif
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs
@@ -209,7 +209,7 @@ bool pool_supported(int nx, int ny) {
   return pool_shape(nx, ny, 0).lds <= kLdsLimit;
 }
 
-#ifdef VHP_EXP_POOLPROF
+#ifdef VHP_DIAG_POOLPROF
 extern "C" int vhp_debug_read_poolprof(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_poolprof), (size_t)n_words * 8);
 }

@@ -59,7 +59,7 @@ constexpr int kYCols = stream::kYCols;
 constexpr int kTStride = 17;  // doubles per tile row: two windows of 8 columns + 1 (spreads the column writes over the banks)
 constexpr int kUnits = 8;     // units per source: 4 quadrants x {x-major, y-major}
 
-#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)  // diagnostic builds only (tools/pool_timeline.py): where a wavefront's cycles go
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)  // diagnostic builds only (tools/pool_timeline.py): where a wavefront's cycles go
 #define VHP_PP_T0(var) const unsigned long long var = __builtin_readcyclecounter()
 #define VHP_PP_ADD(slot, var) prof[slot] += __builtin_readcyclecounter() - var
 #define VHP_PP_ADDP(pp, slot, var) (pp)[slot] += __builtin_readcyclecounter() - var
@@ -341,7 +341,7 @@ struct XStrip {
   // (PRED: only the cells with step index j <= i' <= i_now.)
   template <bool PRED>
   VHP_FN void flush(int xa, int r_first, int i_now) {
-#ifdef VHP_EXP_NOXSTORE  // diagnostic builds only: what the x-major stores cost
+#ifdef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
     return;
 #endif
     wave_sync();
@@ -653,7 +653,7 @@ struct YStrip {
         v0 = select(ia == j0w + k, dg0, v0);
         v1 = select(ib == j0w + k, dg1, v1);
       }
-#ifndef VHP_EXP_NOYSTORE  // diagnostic builds only: what the y-major stores cost
+#ifndef VHP_DIAG_NOYSTORE  // diagnostic builds only: what the y-major stores cost
       if (PRED) store_pred(row, j0w + k, v0, v1);
       else if (DX > 0) g_store2(row, xoff, v0, v1);
       else g_store2(row, xoff, v1, v0);
@@ -780,7 +780,7 @@ struct Worker {
   Shared sh;
   int w;
   vi lane;
-#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
   // cycles: [0] looking for work / idle, [1] waiting for the strip below, [2] sweeping (stores included), [3] installing units
   // (diagonal chains included), [4] boundary line out; counts: [5] strips, [6] blocks, [7] units installed
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ([1]: inside the sweep, waiting for / copying the boundary values; [4]: block-start loads)
@@ -896,7 +896,7 @@ struct Worker {
       lds_publish(cx + kState, 0);
       return;
     }
-#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
     if ((threadIdx.x & 63) == 0 && a.unit_times) a.unit_times[2 * unit] = wall_clock64();
 #endif
     lds_set_int(cx + kUnit, unit);
@@ -936,7 +936,7 @@ struct Worker {
   VHP_FN void strip_done(int c) {
     int* cx = sh.ctx(c);
     if (lds_add(cx + kLeft, -1) == 1) {
-#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
       if ((threadIdx.x & 63) == 0 && a.unit_times) a.unit_times[2 * lds_int_at(cx + kUnit) + 1] = wall_clock64();
 #endif
       lds_publish(cx + kWord, -1);
@@ -959,7 +959,7 @@ struct Worker {
     xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr,
                a.epoch, p > 0 ? lds_int_at(sh.owner(c) + (p - 1)) : -1, p > 0 ? tag_of(c, p - 1) : 0);
     xs.init(a.m, sx, sy, field, sh, w, p);
-#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
     xs.lk.pp = prof;
 #endif
     VHP_PP_COUNT(5);
@@ -985,7 +985,7 @@ struct Worker {
     ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr,
                a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
     ys.init(a.m, sx, sy, field, sh, w, q, dline);
-#if defined(VHP_EXP_POOLPROF) && !defined(VHP_SIM)
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
     ys.lk.pp = prof;
 #endif
     VHP_PP_COUNT(5);
@@ -1028,19 +1028,7 @@ struct Worker {
       if (r == kRetry) continue;
       VHP_PP_ADD(0, tf);
       lds_add(sh.sched() + kBusy, 1);
-#ifdef VHP_EXP_PRIO  // diagnostic: strips of the largest units first at the CU's issue arbiter (the store path included)
-      {
-        UnitGeo ug;
-        ug.init(a.m.nx, a.m.ny, qo, sx, sy);
-        const int full = ((imax(a.m.nx, a.m.ny) + 63) >> 6);
-        const int size = ug.n_strips * (ug.x_major ? 1 : 2) * ug.nb * 16 / (full * full);  // 0 .. 16: strips x blocks of a full octant
-        wave_priority(size >= 10 ? 3 : size >= 6 ? 2 : size >= 3 ? 1 : 0);
-      }
-#endif
       run_strip(c, p, qo, sx, sy);
-#ifdef VHP_EXP_PRIO
-      wave_priority(0);
-#endif
       lds_add(sh.sched() + kBusy, -1);
     }
   }

@@ -12,7 +12,7 @@ namespace stream {
 constexpr int kUnits = 8;  // units per source: 4 quadrants x {x-major, y-major} octant
 constexpr int kCuSlots = 2048;  // per-CU arrival counters (XCC, SE, SH, CU packed into 11 bits)
 
-#ifdef VHP_EXP_WGTIME  // diagnostic builds only (tools/stream_timeline.py): when each workgroup ran and how busy its wavefronts were
+#ifdef VHP_DIAG_WGTIME  // diagnostic builds only (tools/stream_timeline.py): when each workgroup ran and how busy its wavefronts were
 __device__ unsigned long long g_wgtime[8 * 16384];
 __device__ unsigned long long g_prof[8 * 8];  // per wavefront of workgroup 0: the XWave / YWave prof[] words
 #define VHP_WG_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -44,7 +44,7 @@ __device__ __forceinline__ void octant_phase(const Map& m, OutT* field, int sx, 
   }
   // from here on the wavefronts synchronise through their progress words
   const int wave = uniform(team_tid >> 6);
-#ifdef VHP_EXP_WGTIME
+#ifdef VHP_DIAG_WGTIME
   unsigned long long busy = 0;
   int units = 0;
   const unsigned long long wg_t0 = wall_clock64(), c_begin = __builtin_readcyclecounter();
@@ -58,13 +58,13 @@ __device__ __forceinline__ void octant_phase(const Map& m, OutT* field, int sx, 
         lds_acquire();
         VHP_WG_STAMP(c0);
         xw.run_unit();
-#ifdef VHP_EXP_WGTIME
+#ifdef VHP_DIAG_WGTIME
         busy += __builtin_readcyclecounter() - c0;
         ++units;
 #endif
       }
       xw.finish();
-#ifdef VHP_EXP_WGTIME
+#ifdef VHP_DIAG_WGTIME
       if (uid < 64 && (team_tid & 63) == 0)
         for (int k = 0; k < 6; ++k) g_prof[wave * 8 + k] = xw.prof[k];
 #endif
@@ -74,7 +74,7 @@ __device__ __forceinline__ void octant_phase(const Map& m, OutT* field, int sx, 
       for (;;) {
         VHP_WG_STAMP(c0);
         if (!fw.drain_one()) break;
-#ifdef VHP_EXP_WGTIME
+#ifdef VHP_DIAG_WGTIME
         busy += __builtin_readcyclecounter() - c0;  // (includes the wait for the descriptor)
         ++units;
 #endif
@@ -89,12 +89,12 @@ __device__ __forceinline__ void octant_phase(const Map& m, OutT* field, int sx, 
         lds_acquire();
         VHP_WG_STAMP(c0);
         yw.run_unit();
-#ifdef VHP_EXP_WGTIME
+#ifdef VHP_DIAG_WGTIME
         busy += __builtin_readcyclecounter() - c0;
         ++units;
 #endif
       }
-#ifdef VHP_EXP_WGTIME
+#ifdef VHP_DIAG_WGTIME
       if (uid < 64 && wave < 4 && (team_tid & 63) == 0)
         for (int k = 0; k < 6; ++k) g_prof[(4 + wave) * 8 + k] = yw.prof[k];
 #endif
@@ -108,7 +108,7 @@ __device__ __forceinline__ void octant_phase(const Map& m, OutT* field, int sx, 
       }
     }
   }
-#ifdef VHP_EXP_WGTIME
+#ifdef VHP_DIAG_WGTIME
   if ((team_tid & 63) == 0 && uid < 16384 / 2) {
     unsigned long long* wv = g_wgtime + (size_t)uid * 16;
     if (wave == 0) {
@@ -247,9 +247,7 @@ __device__ __forceinline__ int exclusive_scan_1024(int v, int* wave_tot) {  // b
   __syncthreads();
   return before + inc - v;
 }
-#ifndef VHP_EXP_WHOLE_COLS
-#define VHP_EXP_WHOLE_COLS 640
-#endif
+constexpr int kWholeCols = 640;  // a y-major unit with more columns than this keeps the whole workgroup
 __global__ void __launch_bounds__(1024) vhp_stream_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int pair_y,
                                                          int2* __restrict__ order, int* __restrict__ ysorted, int* __restrict__ n_slots_out,
                                                          unsigned long long* __restrict__ queue, int* __restrict__ cu_slots) {
@@ -295,7 +293,7 @@ __global__ void __launch_bounds__(1024) vhp_stream_order(const int32_t* __restri
     const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
     if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return false;
     const int ni = (q == 0 || q == 3) ? nx - sx : sx, nj = (q < 2) ? ny - sy : sy;
-    return (ni < nj - 1 ? ni : nj - 1) > VHP_EXP_WHOLE_COLS;
+    return (ni < nj - 1 ? ni : nj - 1) > kWholeCols;
   };
   // 1. the y-major units (odd unit numbers): the big ones first, then the others, each group largest first
   auto ybucket = [&](int u) { return (bucket_of_weight(cells_of(u)) >> 1) + (is_big(u) ? 0 : kBuckets / 2); };
@@ -341,7 +339,7 @@ __global__ void __launch_bounds__(1024) vhp_stream_order(const int32_t* __restri
 }  // namespace stream
 
 namespace {
-constexpr size_t kLdsLimit = 160 * 1024;
+constexpr size_t kLdsLimit = 160 * 1024 - 256;  // dynamic LDS: the kernel's 8 bytes of static LDS and the allocation granule stay free
 // sweeping wavefronts of an x-major unit; a workgroup is 2 * kWX wavefronts.  (8, i.e. one 16-wavefront workgroup per
 // CU, was measured: 0.92 against 0.75 ms at 1000^2 with 256 sources, 1.39 / 1.45 at 2048^2, level at 4096^2.)
 constexpr int kWX = 4;
@@ -373,7 +371,10 @@ StreamShape shape_for(int nx, int ny, int slots) {
   return sh;
 }
 StreamShape pick_stream_shape(int nx, int ny, int force_tile_slots) {
-  if (force_tile_slots) return shape_for(nx, ny, force_tile_slots);
+  if (force_tile_slots) {
+    const StreamShape forced = shape_for(nx, ny, force_tile_slots);
+    if (forced.lds <= kLdsLimit) return forced;  // (a forced depth that does not fit this grid: the automatic shape instead)
+  }
   StreamShape sh = shape_for(nx, ny, 3);
   if (sh.lds * 2 <= kLdsLimit) return sh;  // three slots, two workgroups per CU
   sh = shape_for(nx, ny, 4);
@@ -404,6 +405,7 @@ hipError_t launch_t(const StreamArgs& a) {
   int* ysorted = a.d_queue + 2 + kCuSlots + 2 * n_units;
   int* n_slots_dev = ysorted + n_y;
   const int pair_y = sh.y_half > 0 ? 1 : 0;
+  if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs
   hipLaunchKernelGGL(vhp_stream_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, pair_y, ord, ysorted, n_slots_dev, queue,
                      cu_slots);
   const int n_slots = n_units;  // an upper bound: the order kernel counts them (big y-major units stay unpaired)
@@ -411,7 +413,6 @@ hipError_t launch_t(const StreamArgs& a) {
   if (per_cu > 16 / (2 * kWX)) per_cu = 16 / (2 * kWX);  // 16 wavefronts per CU: 128 vector registers each
   const int resident = per_cu * a.n_cus;
   const int grid = n_slots < resident ? n_slots : resident;
-  if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(128 * kWX), sh.lds, a.stream, m, a.d_src, static_cast<OutT*>(a.d_out), a.field_stride,
                      a.d_err, (const int2*)ord, queue, cu_slots, (const int*)n_slots_dev, sh.tile_slots, sh.y_half);
   const hipError_t e = hipGetLastError();
@@ -420,7 +421,7 @@ hipError_t launch_t(const StreamArgs& a) {
 }
 }  // namespace
 
-#ifdef VHP_EXP_WGTIME
+#ifdef VHP_DIAG_WGTIME
 extern "C" int vhp_debug_read_wgtime(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(stream::g_wgtime), (size_t)n_words * 8);
 }

@@ -42,7 +42,7 @@ namespace stream {
 
 using namespace vhp::lanes;
 
-#if defined(VHP_EXP_WGTIME) && !defined(VHP_SIM)  // diagnostic builds only: where a wavefront's cycles go
+#if defined(VHP_DIAG_WGTIME) && !defined(VHP_SIM)  // diagnostic builds only: where a wavefront's cycles go
 #define VHP_PROF_DECL unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
 #define VHP_PROF_T0(var) const unsigned long long var = __builtin_readcyclecounter()
 #define VHP_PROF_ADD(slot, var) prof[slot] += __builtin_readcyclecounter() - var
@@ -779,9 +779,6 @@ struct YWave {
   }
 
   VHP_FN void run_unit() {
-#ifdef VHP_EXP_YDRAIN
-    stores_done();
-#endif
     sweep_block(n);
     const bool last = n == g.Nby - 1;
     ++my_done;

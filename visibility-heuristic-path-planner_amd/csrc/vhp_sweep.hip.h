@@ -54,6 +54,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "vhp_diag.h"
+
 #include <algorithm>
 #include <type_traits>
 
@@ -88,9 +90,6 @@ struct DevMap {
   int slide;  // 1: slide the y-major column grid onto 128-byte lines (y_grid_slide)
 };
 
-#ifdef VHP_EXP_SLOTTIME
-__device__ unsigned long long g_slottime[4 * 16 * 160 * 2];
-#endif
 // the reciprocal table never changes during a launch: wave-uniform reads through the
 // constant address space become scalar loads
 typedef const __attribute__((address_space(4))) double* crecip_p;
@@ -213,15 +212,6 @@ __device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
 // (Raw buffer stores with out-of-range offsets as predication were measured slower than
 // exec-masked global stores here: every store instruction costs the issuing wavefront
 // ~60-80 cycles whether or not its lanes are dropped.)
-#ifdef VHP_EXP_NOSTORE  // diagnostic builds only (tools/): all the work, none of the stores
-#define VHP_EXP_STORE_GUARD if (nx != 0x7fffffff) return;
-#elif defined(VHP_EXP_NOSTORE_X) || defined(VHP_EXP_NOSTORE_Y)  // one octant's stores dropped
-#define VHP_EXP_STORE_GUARD if (nx == -12345) return;
-#elif defined(VHP_EXP_SMALLSTORE)  // all stores issued, into a 64 KB window per field: no HBM traffic
-#define VHP_EXP_STORE_GUARD off &= 0xffffu;
-#else
-#define VHP_EXP_STORE_GUARD
-#endif
 template <typename OutT, bool MULTI = false>
 struct StoreEmit {
   static constexpr int kCellBytes = sizeof(OutT);
@@ -233,14 +223,14 @@ struct StoreEmit {
   __device__ __forceinline__ StoreEmit(OutT* field, int nx_, int) : out(field), nx(nx_) {}
   // both cells valid; off = (y*nx + x) * kCellBytes, maintained incrementally by the caller
   __device__ __forceinline__ void pair_at(uint32_t off, int, int, double v0, double v1) {
-    VHP_EXP_STORE_GUARD
+    VHP_DIAG_FRONT_STORE_GUARD
     *reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
   }
   // `both`: store the pair; else `one`: store only the cell at off + sel*kCellBytes (value vs)
   __device__ __forceinline__ void pair_or_single_at(uint32_t off, int, int, double v0, double v1, bool both, bool one,
                                                     int sel, double vs) {
     asm volatile("" : "+v"(vs));  // keep the compiler from splitting the 16-byte store to share a half with the single
-    VHP_EXP_STORE_GUARD
+    VHP_DIAG_FRONT_STORE_GUARD
     if (both)
       *reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
     else if (one)
@@ -248,11 +238,11 @@ struct StoreEmit {
   }
   // one cell at byte offset off
   __device__ __forceinline__ void single_at(uint32_t off, int, int, double v) {
-    VHP_EXP_STORE_GUARD
+    VHP_DIAG_FRONT_STORE_GUARD
     *reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off) = static_cast<OutT>(v);
   }
   __device__ __forceinline__ void pair(int x, int y, double v0, double v1, bool ok0, bool ok1) {
-    VHP_EXP_STORE_GUARD
+    VHP_DIAG_FRONT_STORE_GUARD
     OutT* p = out + (size_t)y * nx + x;
     if (ok0) p[0] = static_cast<OutT>(v0);
     if (ok1) p[1] = static_cast<OutT>(v1);
@@ -267,12 +257,7 @@ struct StoreEmit {
 template <int R, int DX, int DY, typename Emit>
 __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const UnitGeom g, const StripSlot ss, double* ring_base,
                                         double* tile, double* diag_ring) {
-#ifdef VHP_EXP_NOSTORE_X
-  Emit emit = emit_;
-  emit.nx = -12345;
-#else
   Emit& emit = emit_;
-#endif
   const int p = ss.pg, tmax = ss.tmax;
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
@@ -328,9 +313,6 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
   const uint32_t flush_pass_stride = (uint32_t)(16 * DY * m.nx * CB);
 
   auto refill = [&](int blk) {  // blocking: once per 64 steps
-#ifdef VHP_EXP_NOREFILL  // diagnostic builds only: wrong results, shows what the reloads cost
-    if (cur_blk != INT32_MIN) { cur_blk = blk; return; }
-#endif
     cur_blk = blk;
     const int xt = blk * 64 + lane;
     const int it = DX > 0 ? xt - g.sx : g.sx - xt;
@@ -690,17 +672,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
         }
       }
     }
-#ifdef VHP_EXP_SLOTTIME  // diagnostic builds only: when each wavefront reaches and leaves each slot's barrier
-    const unsigned long long st_a = wall_clock64();
     __syncthreads();
-    if ((threadIdx.x & 63) == 0 && T < 160) {
-      unsigned long long* w = g_slottime + ((size_t)(blockIdx.x & 3) * 16 + (threadIdx.x >> 6)) * 160 * 2 + 2 * T;
-      w[0] = st_a;
-      w[1] = wall_clock64();
-    }
-#else
-    __syncthreads();
-#endif
   }
   drain_held();
 }
@@ -711,12 +683,7 @@ __device__ __forceinline__ void x_strip(const DevMap& m, Emit& emit_, const Unit
 template <int R, int DX, int DY, typename Emit>
 __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const UnitGeom g, const StripSlot ss, double* ring_base,
                                         const double* diag_ring) {
-#ifdef VHP_EXP_NOSTORE_Y
-  Emit emit = emit_;
-  emit.nx = -12345;
-#else
   Emit& emit = emit_;
-#endif
   const int p = ss.pg, tmax = ss.tmax;
   constexpr int S = 64 * R;
   constexpr int CB = Emit::kCellBytes;
@@ -754,9 +721,6 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const Unit
     ow[r] = 0;
   }
   auto refill = [&](int blk) {
-#ifdef VHP_EXP_NOREFILL
-    if (cur_blk != INT32_MIN) { cur_blk = blk; return; }
-#endif
     cur_blk = blk;
     const int yt = blk * 64 + lane;
     const int jt = DY > 0 ? yt - g.sy : g.sy - yt;
@@ -987,17 +951,7 @@ __device__ __forceinline__ void y_strip(const DevMap& m, Emit& emit_, const Unit
         }
       }
     }
-#ifdef VHP_EXP_SLOTTIME  // diagnostic builds only: when each wavefront reaches and leaves each slot's barrier
-    const unsigned long long st_a = wall_clock64();
     __syncthreads();
-    if ((threadIdx.x & 63) == 0 && T < 160) {
-      unsigned long long* w = g_slottime + ((size_t)(blockIdx.x & 3) * 16 + (threadIdx.x >> 6)) * 160 * 2 + 2 * T;
-      w[0] = st_a;
-      w[1] = wall_clock64();
-    }
-#else
-    __syncthreads();
-#endif
   }
 }
 
@@ -1148,9 +1102,6 @@ __device__ __forceinline__ SubGroup whole_workgroup() {
   return sg;
 }
 
-#ifdef VHP_EXP_WGTIME
-__device__ unsigned long long g_wgtime[3 * 4 * 4096];
-#endif
 // grid = n_src * 4 workgroups of 128*W threads; dynamic LDS = sweep_lds_bytes(R, W)
 // Register budgets: R <= 2 single-round shapes fit 64 VGPRs so two 16-wavefront workgroups share a
 // CU; the R = 2 multi-round shape runs 8-wavefront workgroups, three per CU.
@@ -1204,22 +1155,7 @@ __device__ __forceinline__ void sweep_slot(const DevMap& m, const int32_t* __res
     return;
   }
   StoreEmit<OutT, MULTI> emit(out + (size_t)s * field_stride, m.nx, m.ny);
-#ifdef VHP_EXP_WGTIME  // diagnostic builds only: start/end time (100 MHz) and hardware id of each workgroup
-  const unsigned long long wg_t0 = wall_clock64();
-#endif
   sweep_quadrant<R>(m, emit, sx, sy, q, lds + (size_t)sub * sweep_lds_doubles(R, sg.W, MULTI), sg);
-#ifdef VHP_EXP_WGTIME
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long* w = g_wgtime + 3 * (size_t)(s * kUnitsPerSource + q);
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    w[0] = wg_t0;
-    w[1] = wall_clock64();
-    w[2] = ((unsigned long long)xcc << 32) | hwid;
-  }
-#endif
 }
 
 // grid = slots: workgroup b sweeps slot b; slots are handed out longest first, which with in-order dispatch is LPT
