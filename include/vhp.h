@@ -110,6 +110,19 @@ int vhp_planner_solve_device(vhp_ctx* ctx, int start_x, int start_y, int end_x, 
 int vhp_planner_results_device(vhp_ctx* ctx, const uint32_t** labels, const double** vis_global, const double** vis_local,
                                const int32_t** pivots_xy);
 
+/* The speculative planner (the loop of solver.cpp:127-140 with every sweep launch taking the k - 1 best other candidates of
+ * the last heuristic evaluation along; a launch sweeps k sources in the time it sweeps one).  k = 1, 2, 4 or 8.
+ *   mode 0, exact: the extra fields go into a cache keyed by their source cell, and an iteration whose pivot is cached
+ *     skips its sweep.  Every output equals vhp_planner_solve's bit for bit; only the number of sweep launches differs.
+ *   mode 1, fast, NOT the reference's result: all k candidates of a launch are committed as pivots in that iteration, in
+ *     rank order.  The outputs are a valid planner result (labels index pivots, every pivot was lit by an earlier one, the
+ *     path reconstructs) but not the reference's pivots or path.
+ * stats (may be NULL): [0] iterations whose pivot was cached, [1] iterations that swept, [2] fields swept.
+ * Results stay on the device as with vhp_planner_solve_device (vhp_planner_results_device); host outputs may be NULL. */
+int vhp_planner_solve_speculative(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold, uint64_t max_iter,
+                                  int k, int mode, uint64_t* came_from, double* vis_global, double* vis_local, int32_t* pivots_xy,
+                                  uint32_t* n_pivots, int32_t* stats);
+
 /* Replaces reconstructPath() (solver.cpp:1183-1213): walks came_from -> pivots from
  * `end` until the label repeats; writes the path start-first into path_xy (capacity
  * cap points), its point count into *n_path, the summed eval_d length into *length.

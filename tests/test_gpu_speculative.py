@@ -1,0 +1,124 @@
+"""The speculative planner (vhp_planner_solve_speculative): every sweep launch takes the k - 1 best other
+candidates along.  mode 0 must equal the plain planner -- hence the oracle -- in every output, whatever k; mode 1 commits
+all candidates and must still produce a valid parent table and a path from the end to the start."""
+import numpy as np
+import pytest
+
+import maps
+from test_gpu_planner import _assert_same_solution
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vhp():
+    import torch  # noqa: F401
+    import vhp_amd
+    return vhp_amd
+
+
+def _ctx(vhp, occ):
+    c = vhp.Context(0)
+    c.set_map(occ)
+    return c
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+def test_exact_mode_equals_the_oracle_on_maze6(vhp, oracle, k):
+    occ = maps.maze_6()
+    ny = occ.shape[0]
+    start, end = (345, ny - 1 - 391), (341, ny - 1 - 10)
+    c = _ctx(vhp, occ)
+    got = c.planner_solve_speculative(start, end, 0.1, 250, k=k, mode=0)
+    want = oracle.solve(occ, start, end, 0.1, 250)
+    _assert_same_solution(got, want, "maze_6, k=%d" % k)
+    assert got["n_pivots"] == 64 and got["hits"] + got["sweeps"] == 64
+    plain = c.planner_solve(start, end, 0.1, 250)
+    _assert_same_solution(got, plain, "maze_6 vs vhp_planner_solve, k=%d" % k)
+    if k == 1:
+        assert got["fields_swept"] == got["sweeps"]
+
+
+@pytest.mark.parametrize("seed,thr,k", [(1, 0.25, 4), (2, 0.5, 8), (3, 0.1, 2), (4, 0.25, 8), (5, 0.9, 4)])
+def test_exact_mode_random_maps(vhp, oracle, seed, thr, k):
+    occ = maps.random_rect_map(160, 131, 22, 4, 30, 4, 30, seed)
+    pts = maps.free_sources(occ, 2, seed + 50)
+    start, end = tuple(int(v) for v in pts[0]), tuple(int(v) for v in pts[1])
+    got = _ctx(vhp, occ).planner_solve_speculative(start, end, thr, 60, k=k, mode=0)
+    _assert_same_solution(got, oracle.solve(occ, start, end, thr, 60), "seed %d thr %g k %d" % (seed, thr, k))
+
+
+def test_exact_mode_c1_mask_and_1000(vhp, oracle):
+    occ = maps.c1_rnd1_mask()
+    got = _ctx(vhp, occ).planner_solve_speculative((5, 5), (95, 95), 0.3, 100, k=4, mode=0)
+    _assert_same_solution(got, oracle.solve(occ, (5, 5), (95, 95), 0.3, 100), "C1 mask")
+    occ, _ = maps.config_c3(4)
+    occ = occ.copy()
+    occ[50, 50] = occ[990, 990] = 1
+    got = _ctx(vhp, occ).planner_solve_speculative((50, 50), (990, 990), 0.25, 250, k=8, mode=0)
+    _assert_same_solution(got, oracle.solve(occ, (50, 50), (990, 990), 0.25, 250), "1000^2")
+
+
+def test_exact_mode_livelock_always_hits(vhp, oracle):
+    # thr 0.25 on maze_6 repeats one pivot until max_iter: after its first sweep that pivot's field is cached
+    occ = maps.maze_6()
+    ny = occ.shape[0]
+    start, end = (345, ny - 1 - 391), (341, ny - 1 - 10)
+    got = _ctx(vhp, occ).planner_solve_speculative(start, end, 0.25, 60, k=2, mode=0)
+    want = oracle.solve(occ, start, end, 0.25, 60)
+    _assert_same_solution(got, want, "live-lock")
+    assert got["status"] == vhp.VHP_ERR_MAX_ITER
+    repeats = sum(1 for a, b in zip(want["pivots"][:-1], want["pivots"][1:]) if tuple(a) == tuple(b))
+    assert got["hits"] >= repeats - 1 > 10
+
+
+def test_validation_codes_and_arguments(vhp):
+    occ = np.ones((64, 64), np.uint8)
+    occ[2, 2] = 0
+    c = _ctx(vhp, occ)
+    assert c.planner_solve_speculative((70, 1), (1, 1), 0.5, 5)["status"] == vhp.VHP_ERR_START_OOB
+    assert c.planner_solve_speculative((1, 1), (1, 64), 0.5, 5)["status"] == vhp.VHP_ERR_END_OOB
+    assert c.planner_solve_speculative((2, 2), (1, 1), 0.5, 5)["status"] == vhp.VHP_ERR_START_OCCUPIED
+    assert c.planner_solve_speculative((1, 1), (2, 2), 0.5, 5)["status"] == vhp.VHP_ERR_END_OCCUPIED
+    with pytest.raises(vhp.VhpError):
+        c.planner_solve_speculative((1, 1), (60, 60), 0.5, 5, k=3)
+    with pytest.raises(vhp.VhpError):
+        c.planner_solve_speculative((1, 1), (60, 60), 0.5, 5, mode=2)
+
+
+def _check_valid_plan(vhp, occ, r, start, end, thr):
+    assert r["status"] == vhp.VHP_OK
+    piv, came, vg = r["pivots"], r["came_from"], r["vis_global"]
+    n = r["n_pivots"]
+    assert tuple(piv[0]) == tuple(start) and tuple(piv[n]) == tuple(end)
+    assert vg[end[1], end[0]] > thr
+    lab = came[came != vhp.UNLABELLED]
+    assert lab.max() < n
+    # every pivot but the first was lit by an earlier pivot
+    for k in range(1, n):
+        x, y = int(piv[k][0]), int(piv[k][1])
+        assert came[y, x] < k, "pivot %d at (%d,%d) carries label %d" % (k, x, y, came[y, x])
+        assert occ[y, x] == 1
+    d, path = vhp.reconstruct_path(came, piv, end)
+    assert tuple(path[0]) == tuple(start) and tuple(path[-1]) == tuple(end)
+    return d, path
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_fast_mode_gives_a_valid_plan_in_fewer_launches(vhp, oracle, k):
+    occ = maps.maze_6()
+    ny = occ.shape[0]
+    start, end = (345, ny - 1 - 391), (341, ny - 1 - 10)
+    c = _ctx(vhp, occ)
+    r = c.planner_solve_speculative(start, end, 0.1, 400, k=k, mode=1)
+    d, path = _check_valid_plan(vhp, occ, r, start, end, 0.1)
+    exact = oracle.solve(occ, start, end, 0.1, 250)
+    de, _ = oracle.reconstruct_path(exact["came_from"], exact["pivots"], end)
+    assert r["hits"] == 0 and r["sweeps"] < exact["n_pivots"]      # fewer sweep launches than the reference has iterations
+    assert d < 1.5 * de                                              # and not a wild detour (the exact path: 1529.55)
+    # labels of a lit cell: the cell is visible from its parent pivot in that pivot's own field
+    py, px = np.argwhere((r["came_from"] != vhp.UNLABELLED))[::997].T
+    for x, y in list(zip(px.tolist(), py.tolist()))[:12]:
+        lab = int(r["came_from"][y, x])
+        f = oracle.sweep_full(occ, int(r["pivots"][lab][0]), int(r["pivots"][lab][1]))
+        assert f[y, x] >= 0.1

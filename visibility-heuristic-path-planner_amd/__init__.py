@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
     "vhp_raycast_all", "vhp_timing", "vhp_timing_collect", "vhp_set_option", "vhp_sweep_batch_variant", "vhp_planner_solve_variant",
     "vhp_planner_solve_device", "vhp_planner_results_device", "vhp_last_sweep_kernel",
-    "vhp_last_elapsed_ms", "vhp_version", "vhp_sweep_batch_offset",
+    "vhp_last_elapsed_ms", "vhp_version", "vhp_sweep_batch_offset", "vhp_planner_solve_speculative",
 )
 
 
@@ -84,6 +84,7 @@ def load_library():
     lib.vhp_planner_solve.argtypes = [vp, i32, i32, i32, i32, f64, u64, vp, vp, vp, vp, C.POINTER(u32)]
     lib.vhp_reconstruct_path.argtypes = [vp, vp, u32, i32, i32, i32, i32, vp, u32, C.POINTER(u32), C.POINTER(f64)]
     lib.vhp_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+    lib.vhp_planner_solve_speculative.argtypes = [vp, i32, i32, i32, i32, f64, u64, i32, i32, vp, vp, vp, vp, C.POINTER(u32), vp]
     lib.vhp_planner_solve_device.argtypes = [vp, i32, i32, i32, i32, f64, u64, C.POINTER(u32)]
     lib.vhp_planner_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.vhp_sweep_batch_variant.argtypes = [vp, vp, i32, f64, f64, vp]
@@ -190,6 +191,23 @@ class Context:
             self._check(rc)
         return dict(status=rc, came_from=came, vis_global=vg, vis_local=vl, pivots=piv[: npiv.value + 1].copy(),
                     n_pivots=npiv.value)
+
+    def planner_solve_speculative(self, start, end, threshold, max_iter, k=4, mode=0, outputs=True):
+        """vhp_planner_solve_speculative: mode 0 = exact (same outputs as planner_solve), mode 1 = fast (commits all k).
+        Adds stats: cache hits, sweeping iterations, fields swept."""
+        came = np.empty((self.ny, self.nx), np.uint64) if outputs else None
+        vg = np.empty((self.ny, self.nx), np.float64) if outputs else None
+        vl = np.empty((self.ny, self.nx), np.float64) if outputs else None
+        piv = np.zeros((int(max_iter) + 2 + 8, 2), np.int32)
+        npiv = C.c_uint32(0)
+        st = np.zeros(3, np.int32)
+        rc = self.lib.vhp_planner_solve_speculative(self.h, start[0], start[1], end[0], end[1], float(threshold), int(max_iter), int(k), int(mode),
+                                                    _ptr(came) if outputs else None, _ptr(vg) if outputs else None, _ptr(vl) if outputs else None,
+                                                    _ptr(piv), C.byref(npiv), _ptr(st))
+        if rc in (VHP_ERR_HIP, VHP_ERR_NO_MAP, VHP_ERR_ARG, VHP_ERR_TOO_LARGE):
+            self._check(rc)
+        return dict(status=rc, came_from=came, vis_global=vg, vis_local=vl, pivots=piv[: npiv.value + 1].copy(), n_pivots=npiv.value,
+                    hits=int(st[0]), sweeps=int(st[1]), fields_swept=int(st[2]))
 
     def planner_solve_device(self, start, end, threshold, max_iter):
         """Planner solve with the results left on the device.  Returns (status, n_pivots, dict of raw device pointers:

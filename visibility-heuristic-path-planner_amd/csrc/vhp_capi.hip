@@ -71,6 +71,7 @@ struct vhp_ctx {
   int opt_stream_tile_slots = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
 
   vhp::PlannerState pl;  // device-resident planner state
+  vhp::SpecState spec;   // field cache of the speculative planner
   vhp::QueueScratch qs;  // scratch of the queue-variant sweep
 };
 
@@ -169,6 +170,7 @@ void free_map(vhp_ctx* c) {
   if (c->d_recip) hipFree(c->d_recip);
   c->d_occ = nullptr; c->d_rows = nullptr; c->d_cols = nullptr; c->d_recip = nullptr;
   vhp::planner_free(c->pl);
+  vhp::spec_free(c->spec);
   vhp::queue_scratch_free(c->qs);
   c->nx = c->ny = 0;
 }
@@ -813,6 +815,34 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
   }
   int rc = vhp::planner_solve(ctx->pl, pm, ctx->d_occ, ctx->stream, ctx->ev0, ctx->ev1, start_x, start_y, end_x,
                               end_y, threshold, max_iter, came_from, vis_global, vis_local, pivots_xy, n_pivots, &msg);
+  ctx->timed = true;
+  if (rc != VHP_OK) ctx->err = msg;
+  return rc;
+}
+
+int vhp_planner_solve_speculative(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold, uint64_t max_iter, int k,
+                                  int mode, uint64_t* came_from, double* vis_global, double* vis_local, int32_t* pivots_xy,
+                                  uint32_t* n_pivots, int32_t* stats) {
+  if (!ctx) return VHP_ERR_ARG;
+  if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_planner_solve_speculative: no map set");
+  VHP_ON_DEVICE(ctx);
+  std::string msg;
+  vhp::DevMap pm = dev_map(ctx);
+  {
+    int R, W;
+    bool multi;
+    pick_shape(ctx, std::max(ctx->nx, ctx->ny), &R, &W, &multi);
+    hipError_t eb = vhp::attach_round_scratch(pm, W * 64 * R, (size_t)4 * vhp::kSpecMaxK, &ctx->d_bnd, &ctx->d_bnd_cap);
+    if (eb != hipSuccess) return fail(ctx, VHP_ERR_HIP, std::string("scratch: ") + hipGetErrorString(eb));
+    ctx->pl.R = R;
+    ctx->pl.W = W;
+    ctx->pl.multi = multi;
+    ctx->pl.raise_lds = [ctx](const void* fn, size_t bytes) { return raise_lds_limit(ctx, fn, bytes); };
+  }
+  int st[3] = {0, 0, 0};
+  int rc = vhp::planner_solve_speculative(ctx->pl, ctx->spec, pm, ctx->d_occ, ctx->stream, ctx->ev0, ctx->ev1, start_x, start_y, end_x, end_y,
+                                          threshold, max_iter, k, mode, came_from, vis_global, vis_local, pivots_xy, n_pivots, st, &msg);
+  if (stats) { stats[0] = st[0]; stats[1] = st[1]; stats[2] = st[2]; }
   ctx->timed = true;
   if (rc != VHP_OK) ctx->err = msg;
   return rc;

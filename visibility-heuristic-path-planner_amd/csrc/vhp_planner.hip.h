@@ -410,4 +410,383 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   return ctl.status;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The speculative planner (second half).  The planner loop is sequential in its pivots -- pivot k+1 is the
+// arg-min of a heuristic that needs the union after pivot k -- but a sweep depends on nothing but its pivot, and one
+// launch sweeps K sources in the time it sweeps one (a single-source sweep is latency-bound: 4 workgroups on 256 CUs).
+// So every sweep launch takes the next pivot AND the K-1 best other candidates of the last heuristic evaluation along,
+// into a cache of fields keyed by the source cell:
+//   mode 0 (exact): an iteration whose pivot is already in the cache skips its sweep.  Pivots, labels, union and the
+//     last local field are those of planner_solve bit for bit (the cached field is the same kernel's output from the
+//     same cell); only the number of sweep launches changes.  The gain is the hit rate (reported), which is what the
+//     map makes it: a pivot that repeats always hits.
+//   mode 1 (fast, NOT the reference's result): every candidate that was swept is committed as a pivot in the same
+//     iteration, in rank order -- what the reference would do if its heap handed out its K best entries before it
+//     re-evaluated the heuristic.  Fewer, fatter iterations; the labels still form a valid parent table (every pivot
+//     was lit by an earlier one), the path and the pivot list differ from the reference's.
+// Candidates: the committed pivot is the exact arg-min; the runner-ups are the best cells of the other 255 epilogue
+// workgroups' partial minima (a guess is allowed to be a guess), at least kSpecSep cells apart.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSpecMaxK = 8;
+constexpr int kSpecSlots = 32;  // cached fields (a multiple of every K)
+constexpr int kSpecSep = 8;     // Chebyshev distance between candidates of one launch
+
+struct SpecCtl {
+  int cand[2 * kSpecMaxK];       // sources of the next sweep launch: [0] the pivot, then runner-ups (x < 0: none)
+  int slot_key[2 * kSpecSlots];  // source cell of the field in each cache slot (x < 0: empty)
+  int head;                      // the slot group the next sweep launch overwrites
+  int cur_slot;                  // where the current pivot's field is
+  int sweep;                     // this iteration sweeps (a miss, or mode 1)
+  int n_commit;                  // pivots this iteration commits (1 in mode 0)
+  int hits, misses, fields_swept;
+};
+
+struct SpecDev {
+  SpecCtl* sc;
+  double* cache;  // kSpecSlots fields
+  size_t cells;
+  int K, mode;
+};
+
+__global__ void vhp_spec_init(SpecDev sp, int start_x, int start_y) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  SpecCtl* c = sp.sc;
+  for (int k = 0; k < 2 * kSpecMaxK; ++k) c->cand[k] = -1;
+  for (int k = 0; k < 2 * kSpecSlots; ++k) c->slot_key[k] = -1;
+  c->cand[0] = start_x;
+  c->cand[1] = start_y;
+  c->head = c->cur_slot = c->sweep = 0;
+  c->n_commit = 1;
+  c->hits = c->misses = c->fields_swept = 0;
+}
+
+// Before the sweep of an iteration: is the pivot's field cached?  Otherwise the launch's slots are named after its sources.
+__global__ void vhp_spec_lookup(PlannerDev d, SpecDev sp) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || d.ctl->done) return;
+  SpecCtl* c = sp.sc;
+  const int nb = d.ctl->nb;
+  const int px = d.pivots[2 * nb], py = d.pivots[2 * nb + 1];
+  c->n_commit = 1;
+  if (sp.mode == 0) {
+    for (int s = 0; s < kSpecSlots; ++s)
+      if (c->slot_key[2 * s] == px && c->slot_key[2 * s + 1] == py) {
+        c->cur_slot = s;
+        c->sweep = 0;
+        c->hits += 1;
+        return;
+      }
+  }
+  const int base = c->head;
+  c->head = (base + sp.K) % kSpecSlots;
+  c->cand[0] = px;  // (it is: the pick wrote both)
+  c->cand[1] = py;
+  int n = 0;
+  for (int j = 0; j < sp.K; ++j) {
+    const int x = c->cand[2 * j], y = c->cand[2 * j + 1];
+    c->slot_key[2 * (base + j)] = x;
+    c->slot_key[2 * (base + j) + 1] = y;
+    if (x >= 0) ++n;
+    if (sp.mode == 1 && j > 0 && x >= 0 && (unsigned long long)(nb + j) <= d.max_iter + 1) {
+      // committed in rank order: lightSources_[nb + j]
+      d.pivots[2 * (nb + j)] = x;
+      d.pivots[2 * (nb + j) + 1] = y;
+    }
+  }
+  if (sp.mode == 1) {
+    // the candidates are packed (the pick fills them front to back), so the committed ones are cand[0 .. n)
+    c->n_commit = n;
+  }
+  c->cur_slot = base;
+  c->sweep = 1;
+  c->misses += 1;
+  c->fields_swept += n;
+}
+
+// The sweep launch of an iteration: workgroup b sweeps quadrant b & 3 of candidate b >> 2 into its cache slot.
+template <int R, bool MULTI>
+__global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : ((MULTI && R == 2) ? 6 : 8)) vhp_spec_sweep(DevMap m, PlannerDev d, SpecDev sp) {
+  extern __shared__ double lds[];
+  if (d.ctl->done || !sp.sc->sweep) return;
+  const int j = blockIdx.x >> 2;
+  const int sx = sp.sc->cand[2 * j], sy = sp.sc->cand[2 * j + 1];
+  if (sx < 0) return;
+  StoreEmit<double, MULTI> emit(sp.cache + (size_t)(sp.sc->cur_slot + j) * sp.cells, m.nx, m.ny);
+  sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x & 3, lds, whole_workgroup());
+}
+
+// updateVisibility()'s per-cell body over the committed field(s), the arg-min, and -- in the last workgroup -- the next
+// pivot and the runner-ups.  With one committed field (mode 0) this is vhp_planner_epilogue operation for operation.
+__global__ void __launch_bounds__(256) vhp_spec_epilogue(DevMap m, PlannerDev d, SpecDev sp) {
+  __shared__ PlannerKey slots[4];
+  __shared__ int chosen[2 * kSpecMaxK];
+  if (d.ctl->done) return;
+  const int nb = d.ctl->nb;
+  const int nc = sp.sc->n_commit;
+  const int nx = m.nx, ny = m.ny;
+  const int sx0 = d.pivots[2 * nb], sy0 = d.pivots[2 * nb + 1];
+  const double* field0 = sp.cache + (size_t)sp.sc->cur_slot * sp.cells;
+  PlannerKey best;
+  best.h = ~0ull;
+  best.rank = ~0ull;
+  best.x = best.y = -1;
+  const size_t cells = (size_t)nx * ny;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < cells; k += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(k / nx), x = (int)(k - (size_t)y * nx);
+    double g = d.vis_global[k];
+    uint32_t lab = d.label[k];
+    bool visited = false;
+    for (int j = 0; j < nc; ++j) {
+      const int sx = d.pivots[2 * (nb + j)], sy = d.pivots[2 * (nb + j) + 1];
+      if ((x == 0 && sx > 0) || (y == 0 && sy > 0)) continue;  // not swept from this pivot
+      visited = true;
+      const double v = field0[(size_t)j * sp.cells + k];
+      g = fmax(v, g);  // :417-418
+      if (v >= d.threshold && lab == kUnlabelled32) lab = (uint32_t)(nb + j);  // :419-423
+    }
+    if (!visited) continue;
+    d.vis_global[k] = g;
+    d.label[k] = lab;
+    if (g >= d.threshold) {  // :424-430
+      const int px = d.pivots[2 * lab], py = d.pivots[2 * lab + 1];
+      const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, px, py));
+      PlannerKey c;
+      c.h = (unsigned long long)__double_as_longlong(h);
+      c.rank = push_rank(nx, ny, sx0, sy0, x, y);
+      c.x = x;
+      c.y = y;
+      if (key_less(c, best)) best = c;
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const PlannerKey o = key_shuffle_xor(best, s);
+    if (key_less(o, best)) best = o;
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) slots[wave] = best;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    PlannerKey b = slots[0];
+    for (int w = 1; w < 4; ++w)
+      if (key_less(slots[w], b)) b = slots[w];
+    d.partial[blockIdx.x] = b;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    is_last = __hip_atomic_fetch_add(d.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    if (is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!is_last) return;
+  PlannerKey mine;
+  {
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(d.partial + threadIdx.x);
+    mine.h = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mine.rank = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long xy = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mine.x = (int)(unsigned)xy;
+    mine.y = (int)(unsigned)(xy >> 32);
+  }
+  // round 0: the arg-min (the next pivot, exactly); rounds 1 .. K-1: the best partial minima at least kSpecSep away from
+  // what has been chosen
+  for (int r = 0; r < sp.K; ++r) {
+    PlannerKey k = mine;
+    for (int c = 0; c < r; ++c) {
+      const int cx = chosen[2 * c], cy = chosen[2 * c + 1];
+      if (cx >= 0 && k.x >= 0 && abs(k.x - cx) < kSpecSep && abs(k.y - cy) < kSpecSep) { k.h = ~0ull; k.rank = ~0ull; k.x = k.y = -1; }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      const PlannerKey o = key_shuffle_xor(k, s);
+      if (key_less(o, k)) k = o;
+    }
+    if ((threadIdx.x & 63) == 0) slots[wave] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      PlannerKey bb = slots[0];
+      for (int w = 1; w < 4; ++w)
+        if (key_less(slots[w], bb)) bb = slots[w];
+      chosen[2 * r] = bb.x;
+      chosen[2 * r + 1] = bb.y;
+      if (r == 0) {
+        *d.ticket = 0;
+        d.ctl->nb += nc - 1;  // the runner-ups this iteration committed (mode 1) are pivots nb+1 .. nb+nc-1
+        planner_pick(m, d, bb);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    SpecCtl* c = sp.sc;
+    const int nbn = d.ctl->nb;
+    c->cand[0] = d.pivots[2 * nbn];  // (the end point if the loop is over: nothing sweeps it)
+    c->cand[1] = d.pivots[2 * nbn + 1];
+    int n = 1;
+    for (int r = 1; r < kSpecMaxK; ++r) {
+      const bool ok = r < sp.K && chosen[2 * r] >= 0;
+      if (ok) { c->cand[2 * n] = chosen[2 * r]; c->cand[2 * n + 1] = chosen[2 * r + 1]; ++n; }
+    }
+    for (int r = n; r < kSpecMaxK; ++r) { c->cand[2 * r] = -1; c->cand[2 * r + 1] = -1; }
+  }
+}
+
+// the last committed pivot's field becomes vis_local; cells its sweep does not visit read as zero (visibility_.reset(), :386)
+__global__ void vhp_spec_export_local(DevMap m, PlannerDev d, SpecDev sp) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= sp.cells) return;
+  const int last = d.ctl->iters > 0 ? sp.sc->n_commit - 1 : 0;
+  const double* f = sp.cache + (size_t)(sp.sc->cur_slot + last) * sp.cells;
+  const int sx = sp.sc->slot_key[2 * (sp.sc->cur_slot + last)], sy = sp.sc->slot_key[2 * (sp.sc->cur_slot + last) + 1];
+  const int y = (int)(k / m.nx), x = (int)(k - (size_t)y * m.nx);
+  const bool unvisited = (x == 0 && sx > 0) || (y == 0 && sy > 0);
+  d.vis_local[k] = (d.ctl->iters == 0 || unvisited) ? 0.0 : f[k];
+}
+
+struct SpecState {
+  size_t cells = 0;
+  double* cache = nullptr;
+  SpecCtl* sc = nullptr;
+};
+inline void spec_free(SpecState& s) {
+  if (s.cache) (void)hipFree(s.cache);
+  if (s.sc) (void)hipFree(s.sc);
+  s.cache = nullptr;
+  s.sc = nullptr;
+  s.cells = 0;
+}
+
+template <int R, bool MULTI>
+inline hipError_t launch_spec_fronts(PlannerState& s, const DevMap& m, const PlannerDev& d, const SpecDev& sp, int W, hipStream_t stream) {
+  const size_t lds = sweep_lds_bytes(R, W, MULTI);
+  auto k = vhp_spec_sweep<R, MULTI>;
+  {
+    hipError_t e = s.raise_lds ? s.raise_lds(reinterpret_cast<const void*>(k), lds)
+                               : hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k, dim3(4 * sp.K), dim3(128 * W), lds, stream, m, d, sp);
+  return hipGetLastError();
+}
+
+// The loop of planner_solve with the speculative sweep launches.  stats (3 ints, may be null): iterations whose pivot was
+// cached, iterations that swept, fields swept.  The caller has validated start / end and sized the round scratch for 4 K units.
+inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMap& m, const uint8_t* d_occ, hipStream_t stream, hipEvent_t ev0,
+                                     hipEvent_t ev1, int start_x, int start_y, int end_x, int end_y, double threshold, uint64_t max_iter, int K,
+                                     int mode, uint64_t* came_from, double* vis_global, double* vis_local, int32_t* pivots_xy,
+                                     uint32_t* n_pivots, int* stats, std::string* msg) {
+  const int nx = m.nx, ny = m.ny;
+  // the four validity checks of solve(), in the reference's order (solver.cpp:89-116)
+  auto valid = [&](int x, int y) { return (size_t)x < (size_t)nx && (size_t)y < (size_t)ny; };
+  if (!valid(start_x, start_y)) { *msg = "Start point is out of bounds."; return VHP_ERR_START_OOB; }
+  if (!valid(end_x, end_y)) { *msg = "End point is out of bounds."; return VHP_ERR_END_OOB; }
+  uint8_t occ_s = 0, occ_e = 0;
+  VHP_PL_HIP(hipMemcpyAsync(&occ_s, d_occ + (size_t)start_y * nx + start_x, 1, hipMemcpyDeviceToHost, stream));
+  VHP_PL_HIP(hipMemcpyAsync(&occ_e, d_occ + (size_t)end_y * nx + end_x, 1, hipMemcpyDeviceToHost, stream));
+  VHP_PL_HIP(hipStreamSynchronize(stream));
+  if (!occ_s) { *msg = "Start point is not valid (occupied)"; return VHP_ERR_START_OCCUPIED; }
+  if (!occ_e) { *msg = "End point is not valid (occupied)"; return VHP_ERR_END_OCCUPIED; }
+  if (max_iter > (1u << 24)) { *msg = "max_iter too large"; return VHP_ERR_ARG; }
+  if ((K != 1 && K != 2 && K != 4 && K != 8) || (mode != 0 && mode != 1)) { *msg = "speculative planner: k must be 1, 2, 4 or 8 and mode 0 or 1"; return VHP_ERR_ARG; }
+  const size_t cells = (size_t)nx * ny;
+  const size_t pcap = 2 * (size_t)(max_iter + 2 + kSpecMaxK);
+  if (s.cells != cells) {
+    planner_free(s);
+    VHP_PL_HIP(hipMalloc(&s.vis_global, cells * 8));
+    VHP_PL_HIP(hipMalloc(&s.vis_local, cells * 8));
+    VHP_PL_HIP(hipMalloc(&s.label, cells * 4));
+    VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
+    VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
+    VHP_PL_HIP(hipMalloc(&s.partial, kEpilogueBlocks * sizeof(PlannerKey)));
+    VHP_PL_HIP(hipMalloc(&s.ticket, sizeof(unsigned int)));
+    s.cells = cells;
+  }
+  if (s.pivot_cap < pcap) {
+    if (s.pivots) (void)hipFree(s.pivots);
+    s.pivots = nullptr;
+    VHP_PL_HIP(hipMalloc(&s.pivots, pcap * sizeof(int32_t)));
+    s.pivot_cap = pcap;
+  }
+  if (ss.cells != cells) {
+    spec_free(ss);
+    VHP_PL_HIP(hipMalloc(&ss.cache, (size_t)kSpecSlots * cells * 8));
+    VHP_PL_HIP(hipMalloc(&ss.sc, sizeof(SpecCtl)));
+    ss.cells = cells;
+  }
+  VHP_PL_HIP(hipMemsetAsync(s.vis_global, 0, cells * 8, stream));
+  VHP_PL_HIP(hipMemsetAsync(s.label, 0xff, cells * 4, stream));
+  VHP_PL_HIP(hipMemsetAsync(s.pivots, 0, s.pivot_cap * sizeof(int32_t), stream));
+  VHP_PL_HIP(hipMemsetAsync(s.ticket, 0, sizeof(unsigned int), stream));
+
+  PlannerDev d;
+  d.vis_global = s.vis_global;
+  d.vis_local = s.vis_local;
+  d.label = s.label;
+  d.pivots = s.pivots;
+  d.ctl = s.ctl;
+  d.partial = s.partial;
+  d.ticket = s.ticket;
+  d.threshold = threshold;
+  {
+    volatile double q = (double)((size_t)ny * ny + (size_t)nx * nx);
+    d.scale = std::sqrt(q);  // scale_, solver.cpp:49
+  }
+  d.end_x = end_x;
+  d.end_y = end_y;
+  d.max_iter = max_iter;
+  SpecDev sp;
+  sp.sc = ss.sc;
+  sp.cache = ss.cache;
+  sp.cells = cells;
+  sp.K = K;
+  sp.mode = mode;
+
+  const int R = s.R, W = s.W;
+  const bool multi = s.multi;
+  VHP_PL_HIP(hipEventRecord(ev0, stream));
+  hipLaunchKernelGGL(vhp_planner_init, dim3(1), dim3(64), 0, stream, d, nx, start_x, start_y);
+  hipLaunchKernelGGL(vhp_spec_init, dim3(1), dim3(64), 0, stream, sp, start_x, start_y);
+  VHP_PL_HIP(hipGetLastError());
+  PlannerCtl ctl{};
+  const int batch = 8;
+  for (;;) {
+    for (int b = 0; b < batch; ++b) {
+      hipLaunchKernelGGL(vhp_spec_lookup, dim3(1), dim3(64), 0, stream, d, sp);
+      hipError_t e = R == 1 ? (multi ? launch_spec_fronts<1, true>(s, m, d, sp, W, stream) : launch_spec_fronts<1, false>(s, m, d, sp, W, stream))
+                   : R == 2 ? (multi ? launch_spec_fronts<2, true>(s, m, d, sp, W, stream) : launch_spec_fronts<2, false>(s, m, d, sp, W, stream))
+                            : (multi ? launch_spec_fronts<4, true>(s, m, d, sp, W, stream) : launch_spec_fronts<4, false>(s, m, d, sp, W, stream));
+      if (e != hipSuccess) { *msg = std::string("speculative planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
+      hipLaunchKernelGGL(vhp_spec_epilogue, dim3(kEpilogueBlocks), dim3(256), 0, stream, m, d, sp);
+      VHP_PL_HIP(hipGetLastError());
+    }
+    VHP_PL_HIP(hipMemcpyAsync(&ctl, s.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
+    VHP_PL_HIP(hipStreamSynchronize(stream));
+    if (ctl.done) break;
+  }
+  hipLaunchKernelGGL(vhp_spec_export_local, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, m, d, sp);
+  VHP_PL_HIP(hipGetLastError());
+  VHP_PL_HIP(hipEventRecord(ev1, stream));
+  SpecCtl hc{};
+  VHP_PL_HIP(hipMemcpyAsync(&hc, ss.sc, sizeof(hc), hipMemcpyDeviceToHost, stream));
+
+  const uint32_t nb = (uint32_t)ctl.nb;
+  if (n_pivots) *n_pivots = nb;
+  if (pivots_xy) VHP_PL_HIP(hipMemcpyAsync(pivots_xy, s.pivots, 2 * (size_t)(nb + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  if (came_from) {
+    hipLaunchKernelGGL(vhp_labels_to_u64, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, s.label, s.came64, cells);
+    VHP_PL_HIP(hipGetLastError());
+    VHP_PL_HIP(hipMemcpyAsync(came_from, s.came64, cells * 8, hipMemcpyDeviceToHost, stream));
+  }
+  if (vis_global) VHP_PL_HIP(hipMemcpyAsync(vis_global, s.vis_global, cells * 8, hipMemcpyDeviceToHost, stream));
+  if (vis_local) VHP_PL_HIP(hipMemcpyAsync(vis_local, s.vis_local, cells * 8, hipMemcpyDeviceToHost, stream));
+  VHP_PL_HIP(hipStreamSynchronize(stream));
+  if (stats) { stats[0] = hc.hits; stats[1] = hc.misses; stats[2] = hc.fields_swept; }
+  if (ctl.status == VHP_ERR_MAX_ITER) *msg = "Max iters hit. Solution could not be found. Try lowering visibility threshold.";
+  if (ctl.status == VHP_ERR_NOTHING_LIT) *msg = "no cell reached the visibility threshold";
+  return ctl.status;
+}
+
 }  // namespace vhp
