@@ -7,6 +7,8 @@
 //   VHP_DIAG_NOSTORE    all the work, none of the field stores                        (every batch kernel)
 //   VHP_DIAG_NOXSTORE   no x-major field stores / VHP_DIAG_NOYSTORE no y-major ones      (pool sweep)
 //   VHP_DIAG_NOMATH     the stencil and the ratio return an operand: the traffic without the arithmetic
+//   VHP_DIAG_NOPARTIAL  no predicated field store (the partially written sectors)        (streaming and pool sweep)
+//   VHP_DIAG_NOWAIT     no strip waits for the strip below or for its seeds: the launch's stores at full speed (pool sweep)
 //   VHP_DIAG_WGTIME     per-workgroup times and per-wavefront cycle accounts             (streaming sweep)
 //   VHP_DIAG_POOLPROF   per-wavefront cycle accounts, per-unit install / finish times    (pool sweep)
 //
@@ -22,6 +24,14 @@
 #else
 #define VHP_DIAG_STORE_GUARD(a, b, off)
 #define VHP_DIAG_FRONT_STORE_GUARD
+#endif
+
+// every PREDICATED field store of the lane-vector kernels dropped (wrong results): what the partially written sectors at
+// octant diagonals, quadrant axes and ragged edges cost the memory system
+#ifdef VHP_DIAG_NOPARTIAL
+#define VHP_DIAG_PARTIAL_GUARD(a, b, off) { asm volatile("" :: "v"(a), "v"(b), "v"(off)); return; }
+#else
+#define VHP_DIAG_PARTIAL_GUARD(a, b, off)
 #endif
 
 // back-off of a wavefront that waits (s_sleep units of 64 cycles): measured in round 2, 12 for a hand-off that is not

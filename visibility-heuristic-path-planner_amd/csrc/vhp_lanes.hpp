@@ -252,6 +252,7 @@ template <typename OutT> VHP_LANE_FN void g_store2(OutT* base, vu32 off, vd a, v
 }
 template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p_hi, OutT* base, vu32 off, vd a, vd b) {
   VHP_DIAG_STORE_GUARD(a, b, off)
+  VHP_DIAG_PARTIAL_GUARD(a, b, off)
   vd single = p_lo ? a : b;
   asm volatile("" : "+v"(single));  // keep the compiler from splitting the 16-byte store to share a half with the single
   if (p2) *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};

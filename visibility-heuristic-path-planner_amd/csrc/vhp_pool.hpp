@@ -257,6 +257,10 @@ struct Link {
     VHP_PP_ADDP(pp, 1, tq);
   }
   VHP_FN void fetch_(int ia, int ib, int nb) {
+#ifdef VHP_DIAG_NOWAIT  // diagnostic builds only (WRONG results): no strip waits for another -- the launch's store trace at full speed
+    (void)ia; (void)ib; (void)nb;
+    return;
+#endif
     for (;;) {
       const int h = lds_poll(rd_hdr);
       if ((h >> 14) != rd_tag) break;                 // the writer has finished that strip: its line is (being) stored
@@ -377,8 +381,14 @@ struct XStrip {
         const vd a = lds_load(tile, tix);
         const vd b = lds_load(tile, tix + 1);
         if (!PRED) {
+#ifndef VHP_DIAG_DROP_XRAGGED
           g_store2_if(row_ok, vb(false), vb(false), base, off, a, b);
+#endif
         } else {
+#ifdef VHP_DIAG_DROP_XPRED
+          base += base_step;
+          continue;
+#endif
           const vi jr = r + j0;
           const vb ok0 = row_ok && (i0c >= jr) && (i0c <= i_now);
           const vb ok1 = row_ok && (i1c >= jr) && (i1c <= i_now);
@@ -591,6 +601,10 @@ struct YStrip {
 
   // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below the diagonal
   VHP_FN void store_pred(OutT* row, int j, vd v0, vd v1) {
+#ifdef VHP_DIAG_DROP_YPRED
+    asm volatile("" :: "v"(v0), "v"(v1));
+    return;
+#endif
     const vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
     const vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
     if (DX > 0) g_store2_if(ok0 && ok1, ok0, ok1, row, xoff, v0, v1);
@@ -830,8 +844,10 @@ struct Worker {
       const int qo = unit & 7, sx = sxsy & 0xffff, sy = sxsy >> 16;
       UnitGeo ug;
       ug.init(a.m.nx, a.m.ny, qo, sx, sy);
+#ifndef VHP_DIAG_NOWAIT
       if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_step(p) + 8 + 1) continue;  // the strip below has swept my first window
       if (!ug.x_major && lds_poll(cx + kDiagReady) < ug.diag_need(p)) continue;
+#endif
       best_c = c; best_seq = rank; best_p = p; best_word = word; best_qo = qo; best_sx = sx; best_sy = sy;
     }
     if (best_c >= 0) {
