@@ -1,7 +1,6 @@
 """The streaming sweep kernel (csrc/vhp_stream.hpp, gfx950 build) through the C ABI against the oracle, bit for bit.
-Which batches take this kernel by default is decided in vhp_capi.hip (use_stream_kernel; today sides above 1024 from 96
-sources, from 64 at 3072 and up -- tests/test_gpu_sweep.py::test_config5_the_launch_that_ships checks that launch as it
-ships); here it is selected explicitly (vhp_set_option "kernel" = 2) so that small batches exercise it too.  The same source runs on the CPU simulator in tests/test_stream_sim.py."""
+Since round 3 no batch takes this kernel by default (the pool sweep, tests/test_gpu_pool.py, took its place:
+vhp_capi.hip use_pool_kernel); here it is selected explicitly (vhp_set_option "kernel" = 2) so that small batches exercise it too.  The same source runs on the CPU simulator in tests/test_stream_sim.py."""
 import numpy as np
 import pytest
 
@@ -111,20 +110,31 @@ def test_stream_rejects_bad_source_and_is_idempotent(vhp):
 
 
 def test_kernel_choice_is_reported(vhp):
-    # which kernel a batch takes is the library's decision (vhp_capi.hip use_stream_kernel); it tells through the ABI
+    # which kernel a batch takes is the library's decision (vhp_capi.hip use_pool_kernel / use_stream_kernel); it tells
+    # through the ABI.  1 = front sweep, 2 = streaming sweep, 3 = pool sweep
     occ = np.ones((8, 1104), np.uint8)   # a side above 1024
     src = np.array([[k, 3] for k in range(96)], np.int32)
     c = vhp.Context(0)
     c.set_map(occ)
     assert c.last_sweep_kernel() == 0
     c.sweep_batch(src)
-    assert c.last_sweep_kernel() == 2
+    assert c.last_sweep_kernel() == 3
     c.sweep_batch(src[:95])
     assert c.last_sweep_kernel() == 1
     c.set_option("kernel", 2)
     c.sweep_batch(src[:3])
     assert c.last_sweep_kernel() == 2
-    occ = np.ones((40, 1000), np.uint8)  # up to 1024: the front sweep, whatever the batch
+    c.set_option("kernel", 3)
+    c.sweep_batch(src[:3])
+    assert c.last_sweep_kernel() == 3
+    occ = np.ones((40, 1000), np.uint8)  # up to 1024: the front sweep below 192 sources, the pool sweep from there
+    c = vhp.Context(0)
+    c.set_map(occ)
+    c.sweep_batch(np.array([[k, 3] for k in range(191)], np.int32))
+    assert c.last_sweep_kernel() == 1
+    c.sweep_batch(np.array([[k, 3] for k in range(300)], np.int32))
+    assert c.last_sweep_kernel() == 3
+    occ = np.ones((40, 1001), np.uint8)  # a pitch that is not a multiple of 8 cells: always the front sweep
     c = vhp.Context(0)
     c.set_map(occ)
     c.sweep_batch(np.array([[k, 3] for k in range(300)], np.int32))

@@ -214,11 +214,11 @@ def _device_launch(vhp, c, src, shape, dtype_t, dtype_v):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_config3_all_256_fields_of_the_bench_launch(vhp, oracle, dtype, kernel):
     # the launch bench.py times (256 C3 sources, device-resident, default shape selection): EVERY field against
-    # the oracle, cell by cell.  kernel 0 = what the library picks by itself (the streaming sweep for a batch this
-    # size), 1 = the front sweep in its large-batch shape (one row per lane, line mode, slid grid), 2 = streaming sweep
+    # the oracle, cell by cell.  kernel 0 = what the library picks by itself (the pool sweep for a batch this size),
+    # 1 = the front sweep in its large-batch shape, 2 = streaming sweep, 3 = pool sweep
     import torch
     occ, src = maps.config_c3(256)
     c = _ctx(vhp, occ, kernel=kernel)

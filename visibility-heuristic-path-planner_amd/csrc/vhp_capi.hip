@@ -67,6 +67,7 @@ struct vhp_ctx {
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep, 3 pool sweep
   int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
   int opt_pool_heads = 0;      // pool sweep: contexts that pull the largest units (0 auto)
+  int opt_pool_tail_pct = 0;   // pool sweep: share of the units the filler contexts take from the small end (0 auto)
   int opt_pool_busy_cap = 0;   // pool sweep: no new unit while this many wavefronts of the workgroup are sweeping (0 auto)
   int opt_stream_tile_slots = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
 
@@ -254,13 +255,20 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
 // Which kernel sweeps a batch: the streaming sweep (vhp_stream.hpp) is built for throughput -- many quadrants in
 // flight, whole-line stores, one barrier per 64 steps -- the front sweep (vhp_sweep.hip.h) for the latency of a few.
 bool use_pool_kernel(const vhp_ctx* c, int n_src) {
-  (void)n_src;
-  if (c->opt_kernel != 3) return false;
-  return vhp::pool_supported(c->nx, c->ny);
+  if (c->opt_kernel == 1 || c->opt_kernel == 2) return false;
+  if (!vhp::pool_supported(c->nx, c->ny)) return false;
+  if (c->opt_kernel == 3) return true;
+  // Measured on MI355X (tools/ab_libs.py: the three kernels on one buffer in one process; pool / streaming / front, ms):
+  // 256 sources at 1000^2 0.51-0.55 / 0.61 / 0.56 on one box and 0.67-0.70 / 0.73 / 0.74 on another; 512: 0.96 / - / 1.03;
+  // 128: 0.44-0.46 / - / 0.45; 128 sources at 2048^2 1.25 / 1.42 / -; at 4096^2 3.88 / 4.29 / -.  The pool sweep from 192
+  // sources up to side 1024, and wherever the streaming sweep used to be picked above it.
+  const int maxdim = std::max(c->nx, c->ny);
+  if (maxdim <= 1024) return n_src >= 192;
+  return n_src >= (maxdim >= 3072 ? 64 : 96);
 }
 
 bool use_stream_kernel(const vhp_ctx* c, int n_src) {
-  if (c->opt_kernel == 1) return false;
+  if (c->opt_kernel == 1 || c->opt_kernel == 3) return false;
   if (!vhp::stream_supported(c->nx, c->ny)) return false;
   if (c->opt_kernel == 2) return true;
   // Measured on MI355X (tools/ab_libs.py on one buffer, tools/ab_bench.sh in fresh processes; DESIGN.md "which kernel").
@@ -311,6 +319,7 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.force_tile_slots = c->opt_stream_tile_slots;
   a.pool_contexts = c->opt_pool_contexts;
   a.pool_busy_cap = c->opt_pool_busy_cap;
+  a.pool_tail_pct = c->opt_pool_tail_pct;
   a.pool_heads = c->opt_pool_heads;
   if (c->timing) {
     if (!c->event_pool.empty()) {
@@ -755,6 +764,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3 && v != 4 && v != 6 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2, 3, 4, 6 or 8"); ctx->opt_stream_tile_slots = v; }
   else if (k == "kernel") { if (v < 0 || v > 3) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream, 3 pool"); ctx->opt_kernel = v; }
   else if (k == "pool_heads") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_heads: 0 (automatic) .. 16"); ctx->opt_pool_heads = v; }
+  else if (k == "pool_tail_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_tail_pct: 0 (automatic) .. 100"); ctx->opt_pool_tail_pct = v; }
   else if (k == "pool_busy_cap") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_busy_cap: 0 (automatic) .. 16"); ctx->opt_pool_busy_cap = v; }
   else if (k == "pool_contexts") { if (v < 0 || v > 11) return fail(ctx, VHP_ERR_ARG, "pool_contexts: 0 (automatic) .. 11"); ctx->opt_pool_contexts = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");

@@ -8,6 +8,7 @@
 //   VHP_DIAG_NOXSTORE   no x-major field stores / VHP_DIAG_NOYSTORE no y-major ones      (pool sweep)
 //   VHP_DIAG_NOMATH     the stencil and the ratio return an operand: the traffic without the arithmetic
 //   VHP_DIAG_NOPARTIAL  no predicated field store (the partially written sectors)        (streaming and pool sweep)
+//   VHP_DIAG_DROP_XPRED / _YPRED / _XRAGGED   the predicated x-major flushes / y-major stores / ragged x-major rows only (pool sweep)
 //   VHP_DIAG_NOWAIT     no strip waits for the strip below or for its seeds: the launch's stores at full speed (pool sweep)
 //   VHP_DIAG_WGTIME     per-workgroup times and per-wavefront cycle accounts             (streaming sweep)
 //   VHP_DIAG_POOLPROF   per-wavefront cycle accounts, per-unit install / finish times    (pool sweep)

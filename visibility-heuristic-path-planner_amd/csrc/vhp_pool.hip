@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, i
 #endif
 }
 
-// Launch order: one workgroup counting-sorts the 8 n_src units by cell count, largest first, zeroes the pull queue, and
+// Launch order: one workgroup counting-sorts the 8 n_src units by the length of their march (then by cell count), longest first,
+// zeroes the pull queue, and
 // lays the units' boundary lines out in the scratch (line_base[u]: first 64-entry block of unit u; exclusive prefix sum
 // of UnitGeo::line_blocks in unit order).  Units of out-of-range sources weigh nothing and sort last (they are rejected
 // when they are installed).  If the lines do not fit `capacity_blocks` (the launcher sizes the scratch by an upper
@@ -112,7 +113,11 @@ __global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict
       if (g.x_major) { const double r = g.rows_total; cells = r * g.ni - r * (r - 1) * 0.5; }
       else { const double c = g.cols_total; cells = c * (g.nj - 1) - c * (c - 1) * 0.5; }
     }
-    double f = cells * inv_area * 1.6;  // an octant holds at most ~5/8 of the grid's cells
+    // Launch order = how early a unit has to start, not how large it is: a unit is as long as its march (a thin octant along
+    // an axis is one strip, i.e. one wavefront, for 15 blocks: sorted by cells it started last and the launch ended on it),
+    // so the key is mostly the march length; among equally long ones the larger first.
+    const double march = (double)(g.x_major ? g.ni : g.nj) / (double)(nx > ny ? nx : ny);
+    double f = 0.8 * march + 0.2 * (cells * inv_area * 1.6 > 1.0 ? 1.0 : cells * inv_area * 1.6);
     if (f > 1.0) f = 1.0;
     return (kBuckets - 1) - (int)(f * (kBuckets - 1));
   };
@@ -141,9 +146,9 @@ long long line_blocks_per_source(int nx, int ny) { return (3LL * nx * ny) / 8192
 
 struct PoolShape { int n_ctx; size_t lds; };
 // as many contexts (units a workgroup holds at once) as asked for (default 4) that fit the LDS
-// Measured (tools/ab_libs.py, 256 sources at 1000^2 on one buffer): 1 / 2 / 3 / 4 / 6 / 8 contexts 1.20 / 0.78 / 0.75-0.77 /
-// 0.77-0.82 / 0.83 / 0.80 ms; 128 sources at 4096^2: 4.44 / 4.68 / - / 4.50-4.95 ms -- units that large (a 4096^2 octant is
-// 67 MB, 64 strips) keep every wavefront busy by themselves and only lose to a neighbour.
+// Measured (tools/ab_libs.py on one buffer, final launch order): 256 sources at 1000^2, 2 / 3 / 4 / 5 contexts 0.69 / 0.67-0.70 /
+// 0.74 / 0.77 ms; 128 sources at 2048^2, 1 / 2 / 3 contexts 1.25 / 1.38 / 1.41 ms; at 4096^2 1 / 2: 3.88 / 4.80 ms -- units that
+// large (a 4096^2 octant is 67 MB, 64 strips) keep every wavefront busy by themselves and only lose to a neighbour.
 PoolShape pool_shape(int nx, int ny, int force_ctx) {
   PoolShape s;
   s.n_ctx = force_ctx > 0 ? force_ctx : ((nx > ny ? nx : ny) > 2048 ? 1 : 3);
@@ -185,7 +190,8 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   g.epoch = a.pool_epoch;
   g.busy_cap = a.pool_busy_cap > 0 ? a.pool_busy_cap : kWaves;
   // two contexts take the largest units left, the others the smallest (0.75 against 0.78 ms with one head at 1000^2)
-  g.n_head = a.pool_heads > 0 ? a.pool_heads : (sh.n_ctx >= 3 ? 2 : 1);
+  g.n_head = a.pool_heads > 0 ? a.pool_heads : (sh.n_ctx >= 3 ? 2 : 1);  // (all three from the head: 0.51 / 0.70 ms on two boxes, this: 0.53 / 0.67)
+  g.tail_limit = (int)((long long)g.n_units * (a.pool_tail_pct > 0 ? a.pool_tail_pct : 15) / 100);  // (100 / 50 / 25 / 15 %: 0.56 / 0.55 / 0.53 / - and - / - / - / 0.67 ms on two boxes)
   g.unit_times = nullptr;
 #ifdef VHP_DIAG_POOLPROF
   if (a.n_src <= 1024) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_unit_times)) == hipSuccess) g.unit_times = static_cast<unsigned long long*>(p); }

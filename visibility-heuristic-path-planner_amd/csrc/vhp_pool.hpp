@@ -136,7 +136,8 @@ struct Args {
   const int* line_base;
   uint64_t epoch;     // the tag of this launch (never 0, never repeated on this scratch)
   int busy_cap;       // a workgroup takes another unit only while fewer than this many of its wavefronts are sweeping
-  int n_head;         // contexts 0 .. n_head-1 take the largest unit left, the others the smallest
+  int n_head;         // contexts 0 .. n_head-1 take the largest unit left, the others the smallest ...
+  int tail_limit;     // ... while fewer than this many units have been taken from the small end; then the largest left, too
   unsigned long long* unit_times;  // diagnostic builds: when unit u was installed / finished (wall clock), or nullptr
 };
 
@@ -344,7 +345,7 @@ struct XStrip {
   // Emits one line of the rows r = r_first, r_first + r_stride, ... of this strip from the tile, 8 rows per store instruction.
   // (PRED: only the cells with step index j <= i' <= i_now.)
   template <bool PRED>
-  VHP_FN void flush(int xa, int r_first, int i_now) {
+  VHP_FN void flush(int xa, int r_first, int i_now, int i_extra = 0) {
 #ifdef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
     return;
 #endif
@@ -390,8 +391,9 @@ struct XStrip {
           continue;
 #endif
           const vi jr = r + j0;
-          const vb ok0 = row_ok && (i0c >= jr) && (i0c <= i_now);
-          const vb ok1 = row_ok && (i1c >= jr) && (i1c <= i_now);
+          const vi jlo = jr;
+          const vb ok0 = row_ok && (i0c >= jlo) && (i0c <= i_now + i_extra);
+          const vb ok1 = row_ok && (i1c >= jlo) && (i1c <= i_now + i_extra);
           g_store2_if(ok0 && ok1, ok0, ok1, base, off, a, b);
         }
         base += base_step;
@@ -420,12 +422,20 @@ struct XStrip {
   VHP_FN void end_of_march() {
     const int i_now = g.ni - 1;
     const int xe = g.X(i_now);
+    // Marching down, the march ends at x = 1: column 0 is never swept and reads as zero.  The zero leaves with
+    // the last line of every row (one step "past" the march) instead of as a lone 8-byte store some other time.
+    const int extra = DX < 0 ? 1 : 0;
+    if (DX < 0) {
+      wave_sync();
+      lds_store(tile, tile_l, vd(0.0));  // x = 0: slot 0, column 0 of every row's ring
+      wave_sync();
+    }
     if (r_stride == 1) {
-      flush<true>(xe & ~15, 0, i_now);
+      flush<true>(xe & ~15, 0, i_now, extra);
     } else {
       for (int ph = 0; ph < 2; ++ph) {  // rows whose lines start at x % 16 == 8*ph
         const int xa = 8 * ph + (((xe - 8 * ph) >> 4) << 4);
-        flush<true>(xa, (ph ^ g.sy ^ j0) & 1, i_now);
+        flush<true>(xa, (ph ^ g.sy ^ j0) & 1, i_now, extra);
       }
     }
   }
@@ -605,8 +615,15 @@ struct YStrip {
     asm volatile("" :: "v"(v0), "v"(v1));
     return;
 #endif
-    const vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
-    const vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
+    vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
+    vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
+    if (DX < 0) {
+      // Column 0 is never swept (the march stops at x = 1) and reads as zero.  Whoever stores x = 1 stores
+      // that zero with it: one 16-byte store instead of an 8-byte one here and another somewhere else, some other time.
+      const vb col0 = (ib == g.ni) && ok0;
+      v1 = select(col0, vd(0.0), v1);
+      ok1 = ok1 || col0;
+    }
     if (DX > 0) g_store2_if(ok0 && ok1, ok0, ok1, row, xoff, v0, v1);
     else g_store2_if(ok0 && ok1, ok1, ok0, row, xoff, v1, v0);
   }
@@ -880,7 +897,10 @@ struct Worker {
   VHP_FN void install(int c) {
     int* sc = sh.sched();
     int* cx = sh.ctx(c);
-    const bool from_tail = c >= a.n_head;
+    // (the small end only feeds the gaps beside the large units: once its share is gone, what is left leaves in size order,
+    // largest first, so that the launch ends on its smallest units and not on whatever the two ends met at)
+    bool from_tail = c >= a.n_head;
+    if (from_tail && (int)(g_add_u64(a.queue, 0ull) >> 32) >= a.tail_limit) from_tail = false;
     const unsigned long long old = g_add_u64(a.queue, from_tail ? (1ull << 32) : 1ull);
     const unsigned taken_head = (unsigned)old, taken_tail = (unsigned)(old >> 32);
     const int idx = from_tail ? a.n_units - 1 - (int)taken_tail : (int)taken_head;
@@ -903,8 +923,7 @@ struct Worker {
     OutT* field = a.out + (size_t)s * a.field_stride;
     if (qo == 0) {
       // rows/columns no quadrant covers read as zero; the x-major unit of quadrant 1 always exists
-      if (sx > 0)
-        for (int y0 = 0; y0 < a.m.ny; y0 += kLanes) g_store_scalar_if(lane + y0 < a.m.ny, field, (lane + y0) * a.m.nx, OutT(0));
+      // (column 0, x = 0, y >= 1: written as zero by the units that march down to x = 1, with their last store of the row)
       if (sy > 0)
         for (int x0 = 0; x0 < a.m.nx; x0 += kLanes) g_store_scalar_if(lane + x0 < a.m.nx, field, lane + x0, OutT(0));
     }

@@ -30,6 +30,7 @@ struct StreamArgs {
   int force_tile_slots;   // 0: automatic; 2 / 3: windows per staging tile (tuning, vhp_set_option "stream_tile_slots")
   int pool_contexts = 0;  // pool sweep: units a workgroup holds at once (0: automatic; vhp_set_option "pool_contexts")
   int pool_heads = 0;     // pool sweep: contexts that pull from the head of the size-sorted queue (0: one)
+  int pool_tail_pct = 0;  // pool sweep: share of the units (by count, smallest first) that the filler contexts may take from the small end (0: 50)
   int pool_busy_cap = 0;  // pool sweep: a workgroup takes another unit only while fewer wavefronts than this are sweeping (0: no cap)
   unsigned long long pool_epoch = 0;  // pool sweep: the tag of this launch's boundary-line entries: never 0, never reused on this scratch
 };
