@@ -68,6 +68,7 @@ struct vhp_ctx {
   int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
   int opt_pool_heads = 0;      // pool sweep: contexts that pull the largest units (0 auto)
   int opt_pool_tail_pct = 0;   // pool sweep: share of the units the filler contexts take from the small end (0 auto)
+  int opt_pool_early_ctx = 0, opt_pool_late_pct = 0;  // pool sweep: late contexts (0 auto)
   int opt_pool_busy_cap = 0;   // pool sweep: no new unit while this many wavefronts of the workgroup are sweeping (0 auto)
   int opt_stream_tile_slots = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
 
@@ -319,6 +320,8 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.force_tile_slots = c->opt_stream_tile_slots;
   a.pool_contexts = c->opt_pool_contexts;
   a.pool_busy_cap = c->opt_pool_busy_cap;
+  a.pool_early_ctx = c->opt_pool_early_ctx;
+  a.pool_late_pct = c->opt_pool_late_pct;
   a.pool_tail_pct = c->opt_pool_tail_pct;
   a.pool_heads = c->opt_pool_heads;
   if (c->timing) {
@@ -765,6 +768,8 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "kernel") { if (v < 0 || v > 3) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream, 3 pool"); ctx->opt_kernel = v; }
   else if (k == "pool_heads") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_heads: 0 (automatic) .. 16"); ctx->opt_pool_heads = v; }
   else if (k == "pool_tail_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_tail_pct: 0 (automatic) .. 100"); ctx->opt_pool_tail_pct = v; }
+  else if (k == "pool_early_ctx") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_early_ctx: 0 (automatic) .. 16"); ctx->opt_pool_early_ctx = v; }
+  else if (k == "pool_late_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_late_pct: 0 (automatic) .. 100"); ctx->opt_pool_late_pct = v; }
   else if (k == "pool_busy_cap") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_busy_cap: 0 (automatic) .. 16"); ctx->opt_pool_busy_cap = v; }
   else if (k == "pool_contexts") { if (v < 0 || v > 11) return fail(ctx, VHP_ERR_ARG, "pool_contexts: 0 (automatic) .. 11"); ctx->opt_pool_contexts = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");

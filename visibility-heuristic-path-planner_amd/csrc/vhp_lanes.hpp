@@ -173,6 +173,7 @@ inline int lds_and(int* p, int v) { const int old = *p; *p = old & v; return old
 // global memory: one atomic add per wavefront; a lane vector stored / loaded as 64 consecutive doubles
 inline int g_add(int* p, int v) { const int old = *p; *p = old + v; return old; }
 inline unsigned long long g_add_u64(unsigned long long* p, unsigned long long v) { const unsigned long long old = *p; *p = old + v; return old; }
+inline unsigned long long g_peek_u64(const unsigned long long* p) { return *p; }
 inline void g_store_f64(double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) base[idx.v[l]] = v.v[l]; }
 inline void g_store_f64_if(const vb& p, double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v.v[l]; }
 template <typename T> inline void g_store_scalar_if(const vb& p, T* base, const vi& idx, T v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v; }
@@ -357,6 +358,12 @@ VHP_LANE_FN unsigned long long g_add_u64(unsigned long long* p, unsigned long lo
   unsigned long long old = 0;
   if ((threadIdx.x & 63u) == 0) old = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)old), hi = __builtin_amdgcn_readfirstlane((unsigned)(old >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+// a word that other workgroups update with atomics, read (not modified) as a uniform: an agent-scope load, no atomic
+VHP_LANE_FN unsigned long long g_peek_u64(const unsigned long long* p) {
+  const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
 }
 VHP_LANE_FN void g_store_f64(double* base, vi idx, vd v) { base[idx] = v; }

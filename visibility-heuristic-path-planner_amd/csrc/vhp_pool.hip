@@ -192,6 +192,8 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   // two contexts take the largest units left, the others the smallest (0.75 against 0.78 ms with one head at 1000^2)
   g.n_head = a.pool_heads > 0 ? a.pool_heads : (sh.n_ctx >= 3 ? 2 : 1);  // (all three from the head: 0.51 / 0.70 ms on two boxes, this: 0.53 / 0.67)
   g.tail_limit = (int)((long long)g.n_units * (a.pool_tail_pct > 0 ? a.pool_tail_pct : 15) / 100);  // (100 / 50 / 25 / 15 %: 0.56 / 0.55 / 0.53 / - and - / - / - / 0.67 ms on two boxes)
+  g.early_ctx = a.pool_early_ctx > 0 ? a.pool_early_ctx : sh.n_ctx;
+  g.late_after = (int)((long long)g.n_units * (a.pool_late_pct > 0 ? a.pool_late_pct : 50) / 100);
   g.unit_times = nullptr;
 #ifdef VHP_DIAG_POOLPROF
   if (a.n_src <= 1024) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_unit_times)) == hipSuccess) g.unit_times = static_cast<unsigned long long*>(p); }

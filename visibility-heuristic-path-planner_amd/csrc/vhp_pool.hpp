@@ -76,6 +76,7 @@ constexpr int kUnits = 8;     // units per source: 4 quadrants x {x-major, y-maj
 // block (66 entries: the block's 64 and the neighbour of its first step on either side), the ring of the boundary values
 // this strip produces (its last 256 steps), a dummy slot; then the scheduler's ints:
 //   [0] queue empty   [2] units installed so far (sequence numbers)   [3] wavefronts sweeping a strip right now
+//   [4] the late contexts are open
 //   [8 + w] header of wavefront w's ring: tag of the strip it belongs to << 14 | steps of it that are in the ring
 //   per context: state (0 free, 1 being installed, 2 active), claim word (seq << 8 | next strip; -1 while not active),
 //   unit, strips, strips not yet finished, sx | sy << 16, diagonal entries ready, (pad), then progress[strip] (steps
@@ -85,7 +86,7 @@ constexpr int kHdr = 8;
 constexpr int kBin = 72;   // doubles of a boundary-in slab (66 used)
 constexpr int kRing = 256; // entries of a wavefront's boundary ring, indexed by the marching coordinate & 255
 constexpr int kRingSafe = 232;  // a reader trusts ring entries only while the writer is at most this many steps past them
-enum { kQEmpty = 0, kSeq = 2, kBusy = 3 };
+enum { kQEmpty = 0, kSeq = 2, kBusy = 3, kLateOpen = 4 };
 enum { kState = 0, kWord = 1, kUnit = 2, kNStrips = 3, kLeft = 4, kSxSy = 5, kDiagReady = 6 };
 struct Layout {
   int W, C, S;
@@ -138,6 +139,8 @@ struct Args {
   int busy_cap;       // a workgroup takes another unit only while fewer than this many of its wavefronts are sweeping
   int n_head;         // contexts 0 .. n_head-1 take the largest unit left, the others the smallest ...
   int tail_limit;     // ... while fewer than this many units have been taken from the small end; then the largest left, too
+  int early_ctx;      // contexts >= this one open only once `late_after` units have been taken: towards the end of a launch a
+  int late_after;     // workgroup holds more, shorter units at once (what is left then has nothing large to get in the way of)
   unsigned long long* unit_times;  // diagnostic builds: when unit u was installed / finished (wall clock), or nullptr
 };
 
@@ -844,10 +847,11 @@ struct Worker {
     int best_c = -1, best_seq = 0x7fffffff, best_p = 0, best_word = 0, best_qo = 0, best_sx = 0, best_sy = 0;
     int free_c = -1;
     bool unclaimed = false, installing = false;
+    const bool late_open = a.early_ctx >= sh.L.C || lds_poll(sc + kLateOpen) != 0;  // (raised by this workgroup's own pulls: install)
     for (int c = 0; c < sh.L.C; ++c) {
       int* cx = sh.ctx(c);
       const int st = lds_poll(cx + kState);
-      if (st == 0) { free_c = c; continue; }
+      if (st == 0) { if (c < a.early_ctx || late_open) free_c = c; continue; }
       if (st == 1) { installing = true; continue; }
       const int word = lds_poll(cx + kWord);
       if (word < 0) continue;  // being recycled
@@ -900,10 +904,11 @@ struct Worker {
     // (the small end only feeds the gaps beside the large units: once its share is gone, what is left leaves in size order,
     // largest first, so that the launch ends on its smallest units and not on whatever the two ends met at)
     bool from_tail = c >= a.n_head;
-    if (from_tail && (int)(g_add_u64(a.queue, 0ull) >> 32) >= a.tail_limit) from_tail = false;
+    if (from_tail && (int)(g_peek_u64(a.queue) >> 32) >= a.tail_limit) from_tail = false;
     const unsigned long long old = g_add_u64(a.queue, from_tail ? (1ull << 32) : 1ull);
     const unsigned taken_head = (unsigned)old, taken_tail = (unsigned)(old >> 32);
     const int idx = from_tail ? a.n_units - 1 - (int)taken_tail : (int)taken_head;
+    if ((int)(taken_head + taken_tail) >= a.late_after) lds_publish(sc + kLateOpen, 1);
     sim_progress();
     if (taken_head + taken_tail >= (unsigned)a.n_units) {
       lds_publish(sc + kQEmpty, 1);
