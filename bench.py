@@ -53,7 +53,7 @@ def parse():
                     help="diagnostic: allocate this many candidate outputs and time each with a few launches before the timed "
                          "region.  The timed region ALWAYS runs on the first allocation; the probe times (and their median / "
                          "best) are only reported, in config.output_placement")
-    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2, 3],
+    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="0 = the library's own choice, 1 = front sweep, 2 = streaming sweep, 3 = pool sweep (vhp_set_option \"kernel\")")
     ap.add_argument("--pool-contexts", type=int, default=0, help="pool sweep: units a workgroup holds at once (0 = automatic)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo only with --dry-run)")
@@ -413,7 +413,7 @@ def main():
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this
         # command): collected by tools/collect_profiles.sh into profiles/, not measured inside this run
         traffic, traffic_src = None, None
-        kname = {1: "vhp_sweep_fronts", 2: "vhp_stream_sweep", 3: "vhp_pool_sweep"}.get(ctx.last_sweep_kernel(), "unknown")  # what the library launched
+        kname = {1: "vhp_sweep_fronts", 2: "vhp_stream_sweep", 3: "vhp_pool_sweep", 4: "vhp_lat_sweep"}.get(ctx.last_sweep_kernel(), "unknown")  # what the library launched
         tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s_%s.json" % (args.workload, args.dtype, kname))
         if os.path.exists(tpath):
             try:

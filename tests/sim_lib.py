@@ -50,6 +50,8 @@ def load_pool():
         lib = C.CDLL(os.path.join(SIM_DIR, "libvhp_pool_sim.so"))
         lib.vhp_sim_pool_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_uint, C.c_void_p]
+        lib.vhp_sim_lat_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint,
+                                          C.c_void_p]
         _pool = lib
     return _pool
 
@@ -73,6 +75,21 @@ def pool_sweep(occ, sources, dtype=np.float64, W=12, C=4, G=1, policy=0, seed=1)
     return out, dict(switches=int(stats[0]), progress=int(stats[1]), deadlock=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]),
                      err=int(stats[5]), pulled=int(stats[6]), from_ring=int(stats[7]), from_global=int(stats[8]), too_far=int(stats[9]),
                      overwritten=int(stats[10]))
+
+
+def lat_sweep(occ, sources, dtype=np.float64, W=12, policy=0, seed=1):
+    """Fields [n, ny, nx] of the simulated latency sweep (csrc/vhp_lat.hpp: a workgroup of W wavefronts per unit) and the stats dict."""
+    lib = load_pool()
+    occ = np.ascontiguousarray(occ, np.uint8)
+    ny, nx = occ.shape
+    src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
+    out = np.full((len(src), ny, nx), np.nan, dtype)
+    stats = np.zeros(11, np.int64)
+    rc = lib.vhp_sim_lat_sweep(occ.ctypes.data, nx, ny, src.ctypes.data, len(src), 0 if dtype == np.float64 else 1, out.ctypes.data,
+                               W, policy, seed, stats.ctypes.data)
+    assert rc == 0, rc
+    return out, dict(switches=int(stats[0]), progress=int(stats[1]), deadlock=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]),
+                     err=int(stats[5]), from_ring=int(stats[7]), from_global=int(stats[8]), too_far=int(stats[9]), overwritten=int(stats[10]))
 
 
 LAZY_FLUSH = 8   # order flag: the flushers of x-major strips run as late as the hand-off allows

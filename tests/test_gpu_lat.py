@@ -1,0 +1,95 @@
+"""The latency sweep (csrc/vhp_lat.hpp, gfx950 build) through the C ABI against the oracle, bit for bit.
+Selected explicitly (vhp_set_option "kernel" = 4) on every grid it supports; the same source runs on the CPU simulator in
+tests/test_lat_sim.py."""
+import numpy as np
+import pytest
+
+import maps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vhp():
+    import torch  # noqa: F401
+    import vhp_amd
+    return vhp_amd
+
+
+def _ctx(vhp, occ):
+    c = vhp.Context(0)
+    c.set_map(occ)
+    c.set_option("kernel", 4)
+    return c
+
+
+def _assert_same(got, want, what):
+    if got.tobytes() != want.tobytes():
+        bad = np.argwhere(~((got == want) | (np.isnan(got) & np.isnan(want))))
+        y, x = bad[0][-2:]
+        raise AssertionError("%s: %d cells differ, first at (x=%d,y=%d): got %r want %r" % (what, len(bad), x, y, got[tuple(bad[0])], want[tuple(bad[0])]))
+
+
+def _sources(occ, n, seed):
+    ny, nx = occ.shape
+    src = list(map(tuple, maps.free_sources(occ, n, seed)))
+    src += [(0, 0), (nx - 1, ny - 1), (nx - 1, 0), (0, ny - 1), (min(1, nx - 1), max(ny - 2, 0)), (nx // 2, 0), (0, ny // 2)]
+    src = np.array(sorted(set(src)), np.int32)
+    occ[src[:, 1], src[:, 0]] = 1
+    return src
+
+
+@pytest.mark.parametrize("nx,ny", [(8, 8), (8, 1), (16, 3), (8, 200), (264, 9), (104, 77), (96, 96), (200, 163), (328, 300),
+                                   (640, 603), (72, 1100), (1104, 72), (1000, 1000), (1024, 700), (1016, 520), (2, 5), (10, 9), (106, 77), (130, 131), (690, 402)])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_lat_kernel_bit_exact(vhp, oracle, nx, ny, dtype):
+    nb = max(3, min(40, nx * ny // 400))
+    occ = maps.random_rect_map(nx, ny, nb, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 7 + ny)
+    src = _sources(occ, 4, nx + ny)
+    c = _ctx(vhp, occ)
+    got = c.sweep_batch(src, dtype=vhp.F64 if dtype == "f64" else vhp.F32)
+    assert c.last_sweep_kernel() == 4
+    for k, (sx, sy) in enumerate(src):
+        want = oracle.sweep_full(occ, int(sx), int(sy))
+        _assert_same(got[k], want if dtype == "f64" else want.astype(np.float32), "%dx%d %s latency sweep, source (%d,%d)" % (nx, ny, dtype, sx, sy))
+
+
+def test_lat_kernel_config2_and_again(vhp, oracle):
+    # the C2 launch (1000 x 1000, empty, centre source) into a NaN-filled buffer, twice on one context (the scratch of the first
+    # launch holds valid-looking entries of an older epoch for the second), then after a pool-sweep launch on the same scratch
+    import torch
+    occ = np.ones((1000, 1000), np.uint8)
+    c = _ctx(vhp, occ)
+    src = np.array([[500, 500]], np.int32)
+    want = oracle.sweep_full(occ, 500, 500)
+    d_src = torch.from_numpy(src).cuda()
+    out = torch.full((1, 1000, 1000), float("nan"), dtype=torch.float64, device="cuda")
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        out.fill_(float("nan"))
+        if rep == 2:
+            c.set_option("kernel", 3)
+            c.sweep_batch_device(d_src.data_ptr(), 1, out.data_ptr())
+            c.set_option("kernel", 4)
+            out.fill_(float("nan"))
+        c.sweep_batch_device(d_src.data_ptr(), 1, out.data_ptr())
+        torch.cuda.synchronize()
+        assert c.last_sweep_kernel() == 4
+        _assert_same(out[0].cpu().numpy(), want, "C2, launch %d" % rep)
+
+
+@pytest.mark.parametrize("nx,ny", [(2048, 1500), (1536, 2600), (4096, 4096), (8192, 24), (24, 8192)])
+def test_lat_kernel_large_grids_in_rounds(vhp, oracle, nx, ny):
+    # more strips than wavefronts: a wavefront sweeps its strips one after the other
+    occ = maps.random_rect_map(nx, ny, 40, min(10, ny // 6 - 1, nx // 6 - 1) if min(nx, ny) < 64 else 10, max(nx // 6, 2), 1 if min(nx, ny) < 64 else 10, max(ny // 6, 2), nx + 3)
+    src = _sources(occ, 1, ny)[:3]
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d latency sweep, source (%d,%d)" % (nx, ny, sx, sy))
+
+
+def test_lat_kernel_bad_source_is_reported(vhp):
+    occ = np.zeros((64, 64), np.uint8)
+    c = _ctx(vhp, occ)
+    with pytest.raises(Exception):
+        c.sweep_batch(np.array([[5, 5], [64, 3]], np.int32))

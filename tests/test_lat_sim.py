@@ -1,0 +1,73 @@
+"""The latency sweep (csrc/vhp_lat.hpp) on the CPU simulator against the oracle, bit for bit.
+
+Same unit code as the pool sweep, another schedule: one workgroup per octant, strip p bound to wavefront p mod W (the last
+wavefront of a y-major workgroup runs the diagonal).  The simulator (tests/sim/vhp_pool_sim.cpp) runs every wavefront as a
+coroutine under several scheduling policies; the fields must equal the oracle's in every cell (output, LDS and scratch
+start as NaN or as entries of "an earlier launch"), and no run may end with every wavefront waiting -- including the runs with
+fewer wavefronts than strips, where a wavefront sweeps several strips one after the other.  No GPU needed; the gfx950 build of
+the same source is checked in tests/test_gpu_lat.py.
+"""
+import numpy as np
+import pytest
+
+import maps
+import sim_lib
+from sim_lib import POOL_BACKWARD, POOL_BURSTS, POOL_GREEDY, POOL_POINTS_ALWAYS, POOL_POINTS_RANDOM, POOL_RANDOM, POOL_ROUND_ROBIN
+
+
+def _check(oracle, occ, src, what, dtype=np.float64, **kw):
+    got, st = sim_lib.lat_sweep(occ, src, dtype, **kw)
+    assert st["deadlock"] == 0, "%s: every wavefront waiting %r" % (what, st)
+    assert st["err"] == 0
+    for k, (sx, sy) in enumerate(src):
+        want = oracle.sweep_full(occ, int(sx), int(sy)).astype(dtype)
+        if got[k].tobytes() != want.tobytes():
+            bad = np.argwhere(~((got[k] == want) | (np.isnan(got[k]) & np.isnan(want))))
+            y, x = bad[0]
+            raise AssertionError("%s, source (%d,%d): %d cells differ, first at (x=%d,y=%d): got %r want %r" % (
+                what, sx, sy, len(bad), x, y, got[k][y, x], want[y, x]))
+    return st
+
+
+def _sources(occ, n, seed):
+    ny, nx = occ.shape
+    src = list(map(tuple, maps.free_sources(occ, n, seed)))
+    src += [(0, 0), (nx - 1, ny - 1), (nx - 1, 0), (0, ny - 1), (min(1, nx - 1), max(ny - 2, 0)), (nx // 2, 0), (0, ny // 2)]
+    src = np.array(sorted(set(src)), np.int32)
+    occ[src[:, 1], src[:, 0]] = 1
+    return src
+
+
+SIZES = [(8, 8), (8, 1), (16, 3), (8, 200), (264, 9), (104, 77), (96, 96), (200, 163), (328, 300), (640, 603), (72, 1100), (1104, 72),
+         (2, 5), (10, 9), (106, 77), (130, 131), (690, 402)]  # (any even width: the planner's maze is 690 wide)
+SHAPES = [  # W wavefronts per workgroup, policy, dtype
+    (12, POOL_ROUND_ROBIN | POOL_POINTS_ALWAYS, np.float64),
+    (12, POOL_RANDOM | POOL_POINTS_RANDOM, np.float32),
+    (4, POOL_GREEDY | POOL_POINTS_ALWAYS, np.float64),     # fewer wavefronts than strips on the larger grids: rounds
+    (2, POOL_BACKWARD | POOL_POINTS_ALWAYS, np.float64),   # one strip wavefront + the diagonal's in a y-major workgroup
+    (3, POOL_BURSTS | POOL_POINTS_RANDOM, np.float64),
+]
+
+
+@pytest.mark.parametrize("nx,ny", SIZES)
+def test_lat_sim_small_and_ragged_grids(oracle, nx, ny):
+    nb = max(3, min(40, nx * ny // 400))
+    occ = maps.random_rect_map(nx, ny, nb, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 7 + ny)
+    src = _sources(occ, 4, nx + ny)
+    for W, policy, dtype in SHAPES:
+        _check(oracle, occ, src, "%dx%d W=%d policy=%d" % (nx, ny, W, policy), dtype, W=W, policy=policy, seed=nx + W)
+
+
+def test_lat_sim_config2_shape(oracle):
+    """The C2 launch itself: 1000 x 1000, empty, one source in the centre; every hand-off of the static schedule comes out of the
+    writer's ring when the wavefronts run in lockstep."""
+    occ = np.ones((1000, 1000), np.uint8)
+    st = _check(oracle, occ, np.array([[500, 500]], np.int32), "C2", W=12, policy=POOL_ROUND_ROBIN)
+    assert st["from_ring"] > 0
+
+
+def test_lat_sim_config3_map_three_sources(oracle):
+    occ = maps.random_rect_map(1000, 1000, 50, 20, 100, 20, 100, 1)
+    src = maps.free_sources(occ, 3, 11)
+    _check(oracle, occ, src, "C3 map", W=12, policy=POOL_RANDOM | POOL_POINTS_RANDOM, seed=5)
+    _check(oracle, occ, src, "C3 map, rounds", W=5, policy=POOL_GREEDY, seed=6)

@@ -255,8 +255,13 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
 
 // Which kernel sweeps a batch: the streaming sweep (vhp_stream.hpp) is built for throughput -- many quadrants in
 // flight, whole-line stores, one barrier per 64 steps -- the front sweep (vhp_sweep.hip.h) for the latency of a few.
+bool use_lat_kernel(const vhp_ctx* c, int n_src) {
+  if (c->opt_kernel != 4) return false;
+  return vhp::lat_supported(c->nx, c->ny) && n_src <= 64;
+}
+
 bool use_pool_kernel(const vhp_ctx* c, int n_src) {
-  if (c->opt_kernel == 1 || c->opt_kernel == 2) return false;
+  if (c->opt_kernel == 1 || c->opt_kernel == 2 || c->opt_kernel == 4) return false;
   if (!vhp::pool_supported(c->nx, c->ny)) return false;
   if (c->opt_kernel == 3) return true;
   // Measured on MI355X (tools/ab_libs.py: the three kernels on one buffer in one process; pool / streaming / front, ms):
@@ -269,7 +274,7 @@ bool use_pool_kernel(const vhp_ctx* c, int n_src) {
 }
 
 bool use_stream_kernel(const vhp_ctx* c, int n_src) {
-  if (c->opt_kernel == 1 || c->opt_kernel == 3) return false;
+  if (c->opt_kernel == 1 || c->opt_kernel == 3 || c->opt_kernel == 4) return false;
   if (!vhp::stream_supported(c->nx, c->ny)) return false;
   if (c->opt_kernel == 2) return true;
   // Measured on MI355X (tools/ab_libs.py on one buffer, tools/ab_bench.sh in fresh processes; DESIGN.md "which kernel").
@@ -299,9 +304,10 @@ hipError_t ensure_pool_scratch(vhp_ctx* c, size_t bytes) {
 }
 
 template <typename OutT>
-hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, bool pool = false) {
+hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, bool pool = false, bool lat = false) {
   {
-    hipError_t eo = pool ? ensure_pool_scratch(c, vhp::pool_scratch_bytes(n_src, c->nx, c->ny)) : ensure_queue_scratch(c, vhp::stream_queue_bytes(n_src));
+    hipError_t eo = lat ? ensure_pool_scratch(c, vhp::lat_scratch_bytes(n_src, c->nx, c->ny))
+                  : pool ? ensure_pool_scratch(c, vhp::pool_scratch_bytes(n_src, c->nx, c->ny)) : ensure_queue_scratch(c, vhp::stream_queue_bytes(n_src));
     if (eo != hipSuccess) return eo;
   }
   vhp::StreamArgs a;
@@ -311,8 +317,8 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.dtype = sizeof(OutT) == 8 ? VHP_F64 : VHP_F32;
   a.field_stride = (long long)c->nx * c->ny;
   a.d_err = c->d_err;
-  a.d_queue = pool ? c->d_pool : c->d_queue;
-  a.pool_epoch = pool ? ++c->pool_epoch : 0;
+  a.d_queue = (pool || lat) ? c->d_pool : c->d_queue;
+  a.pool_epoch = (pool || lat) ? ++c->pool_epoch : 0;
   a.n_cus = c->n_cus;
   a.stream = c->stream;
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
@@ -334,7 +340,7 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
       if (hipEventCreate(&a.ev_end) != hipSuccess) { (void)hipEventDestroy(a.ev_begin); return hipErrorOutOfMemory; }
     }
   }
-  const hipError_t e = pool ? vhp::launch_pool(a) : vhp::launch_stream(a);
+  const hipError_t e = lat ? vhp::launch_lat(a) : pool ? vhp::launch_pool(a) : vhp::launch_stream(a);
   if (c->timing) {
     // (a launch that failed before its events were recorded must not leave a pair that can never be waited for)
     if (e == hipSuccess) c->timed_launches.push_back({a.ev_begin, a.ev_end});
@@ -345,6 +351,10 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
 
 template <typename OutT>
 hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
+  if (use_lat_kernel(c, n_src)) {
+    c->last_kernel = 4;
+    return launch_stream_sweep<OutT>(c, d_src, n_src, d_out, false, true);
+  }
   if (use_pool_kernel(c, n_src)) {
     c->last_kernel = 3;
     return launch_stream_sweep<OutT>(c, d_src, n_src, d_out, true);
@@ -765,7 +775,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
   else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3 && v != 4 && v != 6 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2, 3, 4, 6 or 8"); ctx->opt_stream_tile_slots = v; }
-  else if (k == "kernel") { if (v < 0 || v > 3) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream, 3 pool"); ctx->opt_kernel = v; }
+  else if (k == "kernel") { if (v < 0 || v > 4) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream, 3 pool, 4 latency"); ctx->opt_kernel = v; }
   else if (k == "pool_heads") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_heads: 0 (automatic) .. 16"); ctx->opt_pool_heads = v; }
   else if (k == "pool_tail_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_tail_pct: 0 (automatic) .. 100"); ctx->opt_pool_tail_pct = v; }
   else if (k == "pool_early_ctx") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_early_ctx: 0 (automatic) .. 16"); ctx->opt_pool_early_ctx = v; }

@@ -144,6 +144,7 @@ inline int uniform(int x) { return x; }
 // release: everything this wavefront has written to LDS becomes visible, then the progress word
 inline void lds_publish(volatile int* word, int value) { *word = value; }
 inline int lds_poll(const volatile int* word) { return *word; }
+inline int lds_peek(const volatile int* word) { return *word; }
 inline int lds_int_at(const int* p) { return *p; }
 inline void lds_set_int(int* p, int v) { *p = v; }
 inline void lds_acquire() {}
@@ -294,6 +295,15 @@ VHP_LANE_FN int lds_int_at(const int* p) { return __builtin_amdgcn_readfirstlane
 VHP_LANE_FN void lds_set_int(int* p, int v) { *(lds_int*)p = v; }
 // a progress word of another wavefront, read afresh, as a uniform value (a DS read: see lds_publish)
 VHP_LANE_FN int lds_poll(const volatile int* word) { return __builtin_amdgcn_readfirstlane(*(const volatile lds_int*)word); }
+// The same read without waiting for it: the value (the same in every lane) stays in a vector register until uniform() is
+// taken of it, so that the read joins a batch of LDS reads issued around it -- the LDS serves one wavefront's reads in the
+// order they were issued, which is what a "header, data, header again" check needs; only the compiler must keep that order.
+VHP_LANE_FN int lds_peek(const volatile int* word) {
+  asm volatile("" ::: "memory");
+  const int v = *(const volatile lds_int*)word;
+  asm volatile("" ::: "memory");
+  return v;
+}
 // Four uniform words for another wavefront, as ONE 16-byte LDS write (d is 16-byte aligned): every lane writes the same
 // values to the same address, so there is no exec masking, and a reader sees all four words or none.  Ordered after
 // this wavefront's earlier LDS writes like lds_publish.

@@ -1,0 +1,695 @@
+// vhp_lat.hpp -- the latency sweep: a FEW sources (one, in the planner's loop) as fast as their dependency chain allows.
+//
+// Replaces computeVisibility() (/root/reference/src/visibilityBasedSolver.cpp:570-696) for launches too small to fill the
+// chip.  There the time of a launch is the time of its longest chain -- the ni steps of a quadrant's march, one after the
+// other, each of them in the strip that is just growing along the diagonal -- and a wavefront that runs alone on its SIMD
+// pays for every instruction it issues (4-5 cycles whatever its kind, ~250 cycles for a round trip to the LDS, ~11 per
+// dependent fp64 operation: tools/ldsbench.hip).  So this kernel is built around instruction count per step:
+//   * ONE workgroup per unit (octant), strips bound to wavefronts statically (strip p to wavefront p mod W);
+//   * windows of 16 steps, aligned to 16 cells of the marching coordinate: an x-major window is 16 adjacent cells of every
+//     row, so the tile is 16 columns, flushed by its own wavefront right after the window -- no pending lines, no line
+//     phases; heads, tails and ragged ends are the same window with some steps switched off, not a step-by-step path;
+//   * the operands of window n+1 (the boundary values of the strip below STRAIGHT OUT OF ITS WRITER'S RING, the writer's
+//     header read before and after them; the reciprocals of the step indices) are requested while window n's cells leave,
+//     and checked when they are needed;
+//   * the boundary values an x-major strip produces go to its ring once per window (out of the tile's last row);
+//   * y-major strips own one column per lane (64 columns), and the diagonal they start from comes from a wavefront of
+//     their workgroup that runs the two-term recurrence ahead of them into LDS (and then sweeps strips like the others).
+// The boundary protocol is the pool sweep's (vhp_pool.hpp Link: LDS ring of the writing wavefront first, tagged lines in
+// global memory as the durable copy), so a strip waits only for the strip below it and a wavefront sweeps its strips in
+// rising order: whatever the number of strips and wavefronts, the lowest unfinished strip can always run.
+// Grids: any height, an even width (the x-major cells leave in pairs of 16 bytes).
+//
+// Written against vhp_lanes.hpp: compiled for gfx950 (vhp_lat.hip) and for the CPU simulator (tests/sim), bit-exact against
+// the oracle in both (tests/test_lat_sim.py, tests/test_gpu_lat.py).
+#pragma once
+#include "vhp_pool.hpp"
+
+namespace vhp {
+namespace pool {
+
+constexpr int kLW = 16;      // steps per window
+constexpr int kLatDummy = 16;  // doubles of a wavefront's dummy slots (Layout::dummies holds 16 per wavefront)
+
+template <typename OutT>
+struct LatArgs {
+  Map m;
+  const int32_t* src_xy;
+  OutT* out;
+  long long field_stride;
+  int* err_flag;
+  Tagged* lines;       // scratch: the boundary lines; strip p of unit u at 64 * (u * unit_blocks + p * blocks of the march)
+  long long unit_blocks;
+  uint64_t epoch;      // the tag of this launch (never 0, never repeated on this scratch)
+  unsigned long long* strip_times;  // diagnostic builds (tools/lat_timeline.py): [unit][48][4] wall-clock stamps, or nullptr
+};
+
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
+#define VHP_LAT_STAMP(unit, p, k) do { if (a.strip_times && (p) < 48 && (unit) < 64 && (threadIdx.x & 63) == 0) a.strip_times[(((unit) * 48) + (p)) * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define VHP_LAT_STAMP(unit, p, k)
+#endif
+
+// 64-entry blocks of boundary-line scratch a unit can need on an nx * ny grid (an upper bound: the sources are device data)
+VHP_HD long long lat_unit_blocks(int nx, int ny) {
+  const int side = imax(nx, ny);
+  return (long long)((side + 63) / 64 + 2) * ((side + 63) / 64 + 2);
+}
+
+// What the strips of both kinds read from the strip below for one window.  D = direction of the marching coordinate;
+// v[0] = the strip below at the coordinate one step BEFORE the window's first-marched cell, v[k] (k >= 1) at the cell of
+// step k - 1 of the window.
+template <int D, int NB>
+struct Below {
+  bool ring;   // the values came out of the writer's ring and are still to be checked against h1 / h2
+  int h1, h2;
+  vd v[NB];
+
+  // cw = lowest coordinate of the window, c_first = its first-marched coordinate (cw marching up, cw + 15 marching down)
+  VHP_FN void from_ring(const Link<D>& lk, int cw, int c_first) {
+    h1 = lds_peek(lk.rd_hdr);
+    sim_point();
+    v[0] = lds_bcast(lk.rd_ring, (c_first - D) & (kRing - 1));
+    const int rw = cw & (kRing - 1);
+#pragma unroll
+    for (int k = 1; k < NB; ++k) v[k] = lds_bcast(lk.rd_ring, rw + (D > 0 ? k - 1 : kLW - k));
+    sim_point();
+    h2 = lds_peek(lk.rd_hdr);
+    ring = true;
+  }
+  VHP_FN void from_slab(const double* bin, int cw, int c_first) {
+    v[0] = lds_bcast(bin, 1 + (c_first & 63) - D);
+    const int b = 1 + (cw & 63);
+#pragma unroll
+    for (int k = 1; k < NB; ++k) v[k] = lds_bcast(bin, b + (D > 0 ? k - 1 : kLW - k));
+    ring = false;
+  }
+  VHP_FN void request(const Link<D>& lk, const double* bin, int cw, int c_first, int nb) {
+    if (lk.bin_block == nb) from_slab(bin, cw, c_first); else from_ring(lk, cw, c_first);
+  }
+  // Makes sure the values are those of steps ia - 1 .. last_needed of the strip below: waits for the writer (asking again), or
+  // takes the block from global memory if the writer is gone or too far ahead for its ring.
+  VHP_FN void accept(Link<D>& lk, const double* bin, int cw, int c_first, int ia, int last_needed, int nb) {
+    if (!ring) return;
+    for (;;) {
+      const int ha = uniform(h1), hb = uniform(h2);
+      if ((ha >> 14) != lk.rd_tag) break;                                                            // the writer has finished that strip: its line is (being) stored
+      if ((ha & 0x3fff) <= last_needed) { ready_backoff(); from_ring(lk, cw, c_first); continue; }  // not swept yet
+      // (a writer is at most one window past what it has published: an entry of step s is safe while published - s <= kRingSafe)
+      if ((hb >> 14) != lk.rd_tag || (hb & 0x3fff) - (ia - 1) > kRingSafe) { sim_count(3); break; }
+      sim_count(0);
+      ring = false;
+      return;
+    }
+    lk.fetch(ia, last_needed, nb);
+    from_slab(bin, cw, c_first);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// x-major strip p of a unit: rows j = 64 p + lane; steps i = 64 p .. ni - 1; cells (i, j), j <= i.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY, typename OutT>
+struct LatX {
+  static constexpr int CB = sizeof(OutT);
+  Map m;
+  Quad<DX, DY> g;
+  OutT* out;
+  double* tile;   // 64 rows x 16 columns (pitch kTStride): column c = x - (lowest x of the window)
+  double* slab;   // reciprocals of the current block's 64 coordinates, indexed by x & 63
+  double* bin;    // = lk.bin
+  Link<DX> lk;
+  int p, j0, rows_here, i_first, i_last;
+  bool below, has_consumer;
+  int pf_blk;     // the block (x >> 6) whose operands wait in ow_nx / rv_nx, or -1
+  vi lane, tile_l, fl_t;
+  vu32 fl_off;
+  vd prev, jd;
+  vu64 ow, ow_nx;
+  vd rv_nx;
+  Below<DX, kLW + 1> nx;   // the next window's operands from the strip below ...
+  vd nx_rr[kLW];           // ... and the reciprocals of its step indices
+  int nx_ia;               // that window's lowest step (-0x7fffffff: none)
+
+  // (the caller has initialised lk)
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int p_) {
+    m = m_; out = out_;
+    g.init(m.nx, m.ny, sx, sy);
+    tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
+    slab = sh.lds + sh.L.slabs + w * kBlock;
+    bin = lk.bin;
+    lane = lane_id();
+    tile_l = lane * kTStride;
+    {
+      // flush geometry: lane -> (row slot = lane >> 3, piece = lane & 7 = cells 2 * piece, + 1 of the window's 16); the row slots
+      // of a store instruction are counted upward in y, so that byte offsets from its lowest row are never negative
+      const vi rslot = lane >> 3, pc = lane & 7;
+      const vi rs = DY > 0 ? rslot : 7 - rslot;
+      fl_t = rslot * kTStride + pc * 2;
+      fl_off = to_u32((rs * m.nx + pc * 2) * CB);
+    }
+    p = p_;
+    j0 = kXRows * p;
+    rows_here = imin(kXRows, g.rows_total - j0);
+    i_first = j0;
+    i_last = g.ni - 1;
+    below = p > 0;
+    has_consumer = p + 1 < g.Px;
+    prev = vd(0.0);
+    jd = to_f64(lane + j0);
+    pf_blk = -1;
+    nx_ia = -0x7fffffff;
+  }
+
+  // the occupancy word of every lane's row and the reciprocals of the step indices of the 64 coordinates of block blk (x >> 6)
+  VHP_FN void load_ops(int blk, vu64& o, vd& rv) {
+    const vi yl = (vmin(lane + j0, g.rows_total - 1)) * DY + g.sy;
+    o = g_load_u64(m.rows, yl * m.wpr + (1 + blk));
+    const vi it = (lane + (blk * 64 - g.sx)) * DX;
+    const vb ok = (it >= 0) && (it < g.ni);
+    rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
+  }
+  VHP_FN bool block_in_march(int blk) const { const int xe = g.X(i_last); return DX > 0 ? 64 * blk <= xe : 64 * blk + 63 >= xe; }
+  VHP_FN void prefetch_ops(int blk) { pf_blk = blk; load_ops(blk, ow_nx, rv_nx); }
+  VHP_FN void begin_block(int blk) {
+    vd rv;
+    if (pf_blk == blk) { ow = ow_nx; rv = rv_nx; } else { load_ops(blk, ow, rv); }
+    pin(ow);
+    pin(rv);
+    wave_sync();
+    lds_store(slab, lane, rv);
+    wave_sync();
+    if (block_in_march(blk + DX)) prefetch_ops(blk + DX); else pf_blk = -1;
+  }
+
+  // requests the operands of the window whose lowest x is xw (lowest step ia) in block nb; nothing is waited for
+  VHP_FN void request(int ia, int xw, int nb) {
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (xw & 63) + (DX > 0 ? k : kLW - 1 - k));
+    if (below) {
+#ifndef VHP_DIAG_NOWAIT
+      nx.request(lk, bin, xw, DX > 0 ? xw : xw + kLW - 1, nb);
+#else
+      nx.ring = false;
+#endif
+    }
+    nx_ia = ia;
+  }
+
+  // One window: steps ia + k, k = k_lo .. k_hi (all 16 unless GUARD), at x = xw + (k marching up, 15 - k marching down).
+  // DIAG: the strip's diagonal may fall into it (rows switch on one by one: the diagonal cell of row j takes the NEW value of
+  // the row below it times its own occupancy).  more: the next window belongs to the same block (its operands are
+  // requested while this one's cells leave).
+  template <bool DIAG, bool GUARD>
+  VHP_FN void window(int ia, int xw, int nb, int k_lo, int k_hi, bool more) {
+    if (nx_ia != ia) request(ia, xw, nb);
+    nx_ia = -0x7fffffff;
+    if (below) nx.accept(lk, bin, xw, DX > 0 ? xw : xw + kLW - 1, imax(ia, i_first), ia + k_hi, nb);
+    const vu32 hs = half_shifted(ow, xw & 63, xw & 31);  // the window's 16 occupancy bits: bit c = the cell at x = xw + c
+    vd di = vd((double)ia);
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) {
+      const int c = DX > 0 ? k : kLW - 1 - k;
+      if (!GUARD || (k >= k_lo && k <= k_hi)) {
+        if (GUARD) di = vd((double)(ia + k));
+        // nx.v[k] = the row below at x(step k) - DX, the OLD neighbour of lane 0 (nx.v[k + 1] the NEW one); strip 0 has none
+        const vd b = shift_up(prev, below ? nx.v[k] : vd(0.0));
+        const vi mk = sbfe1(hs, c);
+        vd v = and_mask(stencil(prev, b, ratio(jd, di, nx_rr[k])), mk);
+        if (DIAG) {
+          const vd up = shift_up(v, below ? nx.v[k + 1] : vd(1.0));  // strip 0: 1.0 = light strength at the origin
+          const vb isd = lane == (ia + k - j0);
+          const vd dcell = and_mask(up, mk);
+          v = select(isd, dcell, v);
+        }
+        prev = v;
+        lds_store(tile, tile_l + c, v);
+        if (!GUARD) di = di + 1.0;
+      }
+    }
+    // ---- the window's 16 cells of every row leave; its boundary values go to the ring ----
+    int lim = i_last;
+    if (DX < 0 && xw == 0) {
+      // Marching down, the march ends at x = 1: column 0 is never swept and reads as zero.  The zero leaves with
+      // the last cells of every row (one step "past" the march) instead of as a lone 8-byte store some other time.
+      wave_sync();
+      lds_store(tile, tile_l, vd(0.0));
+      lim = i_last + 1;
+    }
+    wave_sync();
+    vd fa[8], fb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { fa[u] = lds_load(tile, fl_t + u * (8 * kTStride)); fb[u] = lds_load(tile, fl_t + (u * (8 * kTStride) + 1)); }
+    vd bv = vd(0.0);
+    if (has_consumer) bv = lds_load(tile, (lane & (kLW - 1)) + (kXRows - 1) * kTStride);  // the last row: what the strip above reads
+    wave_sync();
+    if (more) request(ia + kLW, xw + kLW * DX, nb);
+#ifndef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
+    {
+      // Groups of 8 rows (u): whole (every cell a computed cell of a row of this strip: 16-byte stores), none (skipped), or cell
+      // by cell.  A cell (i', j) exists for j <= i' <= lim; the window's steps are ia .. ia + 15.
+      OutT* base = out + (long)(DY > 0 ? g.Y(j0) : g.Y(j0 + 7)) * (long)m.nx + xw;
+      const long base_step = (long)(8 * DY) * m.nx;
+      if (!DIAG && !GUARD && rows_here == kXRows) {  // past the diagonal, inside the march, all 64 rows: every group whole
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { g_store2(base, fl_off, fa[u], fb[u]); base += base_step; }
+      } else {
+      const int top = imin(ia + kLW - 1, lim) - j0;                      // rows up to j0 + top have cells in this window
+      const int u_end = top >= 0 ? imin(top / 8 + 1, (rows_here + 7) >> 3) : 0;
+      int u_full = 0;
+      if (ia + kLW - 1 <= lim && ia - j0 >= 7) u_full = imin((ia - j0 - 7) / 8 + 1, rows_here >> 3);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u < u_full) {
+          g_store2(base, fl_off, fa[u], fb[u]);
+        } else if (u < u_end) {
+          const vi cc = (lane & 7) * 2;
+          const vi s0 = DX > 0 ? cc + ia : (-cc) + (kLW - 1 + ia), s1 = s0 + DX;  // step indices of the pair's two cells
+          const vi r = (lane >> 3) + 8 * u;
+          const vb row_ok = r < rows_here;
+          const vi jr = r + j0;
+          const vb ok0 = row_ok && (s0 >= jr) && (s0 <= lim);
+          const vb ok1 = row_ok && (s1 >= jr) && (s1 <= lim);
+          g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, fa[u], fb[u]);
+        }
+        base += base_step;
+      }
+      }
+    }
+#endif
+    if (has_consumer) {
+      lds_store(lk.ring, (lane & (kLW - 1)) + (xw & (kRing - 1)), bv);  // (every lane: the four lanes of an entry write the same value)
+      lk.publish(ia + k_hi + 1);
+    }
+  }
+
+  VHP_FN void run() {
+    int xw = g.X(i_first) & ~(kLW - 1);
+    int ia = DX > 0 ? xw - g.sx : g.sx - (xw + kLW - 1);
+    int blk = xw >> 6;
+    begin_block(blk);
+    for (; ia <= i_last; ia += kLW, xw += kLW * DX) {
+      const int b = xw >> 6;
+      if (b != blk) {
+        if (has_consumer) lk.store_block(g.nbx(ia - 1), blk);
+        begin_block(b);
+        blk = b;
+      }
+      const int nb = DX > 0 ? b - g.bx0 : g.bx0 - b;
+      const int k_lo = imax(i_first - ia, 0), k_hi = imin(kLW - 1, i_last - ia);
+      if (k_lo > 0 || k_hi < kLW - 1) {
+        window<true, true>(ia, xw, nb, k_lo, k_hi, false);
+      } else {
+        // a run of whole windows of one kind inside this block: each requests the next one's operands (a loop of its own per
+        // kind, so that those operands stay where they are from one window to the next)
+        const bool diag = ia <= j0 + kXRows - 1;
+        int n = 1;
+        while (ia + kLW * (n + 1) - 1 <= i_last && ((xw + kLW * n * DX) >> 6) == b && (ia + kLW * n <= j0 + kXRows - 1) == diag) ++n;
+        if (diag) {
+          for (int t = 0; t < n; ++t) {
+            window<true, false>(ia, xw, nb, 0, kLW - 1, t + 1 < n);
+            if (t + 1 < n) { ia += kLW; xw += kLW * DX; sim_progress(); sim_point(); }
+          }
+        } else {
+          for (int t = 0; t < n; ++t) {
+            window<false, false>(ia, xw, nb, 0, kLW - 1, t + 1 < n);
+            if (t + 1 < n) { ia += kLW; xw += kLW * DX; sim_progress(); sim_point(); }
+          }
+        }
+      }
+      sim_progress();
+      sim_point();
+    }
+    if (has_consumer) lk.store_block(g.nbx(i_last), blk);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// y-major strip q of a unit: columns i = 64 q + lane; steps j = 64 q .. nj - 1; cells (i, j), i <= j (the diagonal cell is
+// the seed diag(i), stored again with its row).  Marching down in x, the lane of "column ni" (x = 0, never swept: SURVEY
+// Q2) stores the zero that column reads as, with every row that stores x = 1.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX>
+VHP_HD int lat_ycols(int ni, int nj) {
+  const int cols = imax(imin(ni, nj - 1), 0);  // columns with computed cells (j > i)
+  return cols + ((DX < 0 && cols == ni && cols > 0) ? 1 : 0);
+}
+
+template <int DX, int DY, typename OutT>
+struct LatY {
+  static constexpr int CB = sizeof(OutT);
+  Map m;
+  Quad<DX, DY> g;
+  OutT* out;
+  double* slab;   // reciprocals of the current block's 64 coordinates, indexed by y & 63
+  double* bin;
+  double* dummy;
+  Link<DY> lk;
+  int q, i0, j_first, j_last;
+  bool below, has_consumer, interior;
+  int pf_blk;
+  vi lane, ic;
+  vb col_ok, zero_lane;
+  vu32 xoff;
+  vd prev, id, dg;
+  vu64 ow, ow_nx;
+  vd rv_nx;
+  Below<DY, kLW> nx;
+  vd nx_rr[kLW];
+  int nx_ja;
+
+  // (the caller has initialised lk; the seeds of the strip's columns are in diag_lds)
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, int n_strips, const double* diag_lds) {
+    m = m_; out = out_;
+    g.init(m.nx, m.ny, sx, sy);
+    slab = sh.lds + sh.L.slabs + w * kBlock;
+    bin = lk.bin;
+    dummy = sh.lds + sh.L.dummies + w * kLatDummy;
+    lane = lane_id();
+    q = q_;
+    i0 = kBlock * q;
+    j_first = i0;
+    j_last = g.nj - 1;
+    below = q > 0;
+    has_consumer = q + 1 < n_strips;
+    ic = lane + i0;
+    col_ok = ic < g.ni;
+    zero_lane = (ic == g.ni) && (DX < 0);
+    interior = i0 + kBlock - 1 < g.ni;  // every lane a column of the quadrant
+    prev = vd(0.0);
+    id = to_f64(ic);
+    dg = lds_load(diag_lds, vmin(ic, g.rows_total - 1));
+    pin(dg);
+    xoff = to_u32((vmin(ic, g.ni) * DX + g.sx) * CB);  // (lanes past "column ni" store nothing)
+    pf_blk = -1;
+    nx_ja = -0x7fffffff;
+  }
+
+  VHP_FN void load_ops(int blk, vu64& o, vd& rv) {
+    const vi xl = vmin(ic, DX < 0 ? g.ni : g.ni - 1) * DX + g.sx;
+    o = g_load_u64(m.cols, xl * m.wpc + (1 + blk));
+    const vi jt = (lane + (blk * 64 - g.sy)) * DY;
+    const vb ok = (jt >= 0) && (jt < g.nj);
+    rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
+  }
+  VHP_FN bool block_in_march(int blk) const { const int ye = g.Y(j_last); return DY > 0 ? 64 * blk <= ye : 64 * blk + 63 >= ye; }
+  VHP_FN void prefetch_ops(int blk) { pf_blk = blk; load_ops(blk, ow_nx, rv_nx); }
+  VHP_FN void begin_block(int blk) {
+    vd rv;
+    if (pf_blk == blk) { ow = ow_nx; rv = rv_nx; } else { load_ops(blk, ow, rv); }
+    pin(ow);
+    pin(rv);
+    wave_sync();
+    lds_store(slab, lane, rv);
+    wave_sync();
+    if (block_in_march(blk + DY)) prefetch_ops(blk + DY); else pf_blk = -1;
+  }
+  VHP_FN void request(int ja, int yw, int nb) {
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (yw & 63) + (DY > 0 ? k : kLW - 1 - k));
+    if (below) {
+#ifndef VHP_DIAG_NOWAIT
+      nx.request(lk, bin, yw, DY > 0 ? yw : yw + kLW - 1, nb);
+#else
+      nx.ring = false;
+#endif
+    }
+    nx_ja = ja;
+  }
+
+  // One window: steps ja + k, k = k_lo .. k_hi (all 16 unless GUARD), at y = yw + (k marching up, 15 - k marching down).
+  // DIAG: columns may be seeded in it (implies PRED); PRED: predicated stores (columns that do not exist, or not yet).
+  template <bool DIAG, bool PRED, bool GUARD>
+  VHP_FN void window(int ja, int yw, int nb, int k_lo, int k_hi, bool more) {
+    if (nx_ja != ja) request(ja, yw, nb);
+    nx_ja = -0x7fffffff;
+    if (below) nx.accept(lk, bin, yw, DY > 0 ? yw : yw + kLW - 1, imax(ja, j_first), ja + k_hi - 1, nb);
+    const vu32 hs = half_shifted(ow, yw & 63, yw & 31);
+    double* wbase = has_consumer ? lk.ring + (yw & (kRing - 1)) : dummy;
+    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
+    vd dj = vd((double)ja);
+    const long rowstep = (long)DY * m.nx;
+    OutT* row = out + (long)g.Y(ja) * (long)m.nx;
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) {
+      const int c = DY > 0 ? k : kLW - 1 - k;
+      if (!GUARD || (k >= k_lo && k <= k_hi)) {
+        if (GUARD) dj = vd((double)(ja + k));
+        const vd b = shift_up(prev, below ? nx.v[k] : vd(0.0));
+        vd v = and_mask(stencil(prev, b, ratio(id, dj, nx_rr[k])), sbfe1(hs, c));
+        if (DIAG) v = select(ic == ja + k, dg, v);
+#ifndef VHP_DIAG_NOYSTORE  // diagnostic builds only: what the y-major stores cost
+        if (PRED) {
+          const int j = ja + k;
+          const vb ok = (col_ok && (ic <= j)) || (zero_lane && (j >= g.ni - 1));
+          g_store1_if(ok, row, xoff, select(zero_lane, vd(0.0), v));
+        } else {
+          g_store1_if(vb(true), row, xoff, v);
+        }
+#endif
+        prev = v;
+        lds_store(wbase, widx + c, v);
+        if (!GUARD) dj = dj + 1.0;
+      }
+      row += rowstep;
+    }
+    if (more) request(ja + kLW, yw + kLW * DY, nb);
+    if (has_consumer) lk.publish(ja + k_hi + 1);
+  }
+
+  VHP_FN void run() {
+    int yw = g.Y(j_first) & ~(kLW - 1);
+    int ja = DY > 0 ? yw - g.sy : g.sy - (yw + kLW - 1);
+    int blk = yw >> 6;
+    begin_block(blk);
+    for (; ja <= j_last; ja += kLW, yw += kLW * DY) {
+      const int b = yw >> 6;
+      if (b != blk) {
+        if (has_consumer) lk.store_block(g.nby(ja - 1), blk);
+        begin_block(b);
+        blk = b;
+      }
+      const int nb = DY > 0 ? b - g.by0 : g.by0 - b;
+      const int k_lo = imax(j_first - ja, 0), k_hi = imin(kLW - 1, j_last - ja);
+      if (k_lo > 0 || k_hi < kLW - 1) {
+        window<true, true, true>(ja, yw, nb, k_lo, k_hi, false);
+      } else {
+        // a run of whole windows of one kind inside this block (see LatX::run)
+        const bool diag = ja <= i0 + kBlock - 1;
+        int n = 1;
+        while (ja + kLW * (n + 1) - 1 <= j_last && ((yw + kLW * n * DY) >> 6) == b && (ja + kLW * n <= i0 + kBlock - 1) == diag) ++n;
+        if (diag) {
+          for (int t = 0; t < n; ++t) {
+            window<true, true, false>(ja, yw, nb, 0, kLW - 1, t + 1 < n);
+            if (t + 1 < n) { ja += kLW; yw += kLW * DY; sim_progress(); sim_point(); }
+          }
+        } else if (!interior) {
+          for (int t = 0; t < n; ++t) {
+            window<false, true, false>(ja, yw, nb, 0, kLW - 1, t + 1 < n);
+            if (t + 1 < n) { ja += kLW; yw += kLW * DY; sim_progress(); sim_point(); }
+          }
+        } else {
+          for (int t = 0; t < n; ++t) {
+            window<false, false, false>(ja, yw, nb, 0, kLW - 1, t + 1 < n);
+            if (t + 1 < n) { ja += kLW; yw += kLW * DY; sim_progress(); sim_point(); }
+          }
+        }
+      }
+      sim_progress();
+      sim_point();
+    }
+    if (has_consumer) lk.store_block(g.nby(j_last), blk);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// The diagonal of a quadrant for its y-major unit, into LDS, 64 entries per call.  diag(0) = occ(source); for k >= 1:
+//   sub(k)  = V(k, k-1) = (a - c*(a - b)) * occ(k, k-1),  a = diag(k-1), b = sub(k-1), c = (k-1)/k
+//   diag(k) = sub(k) * occ(k, k)                                            (the stale diagonal)
+// The ratios and the occupancy bits of a chunk are lane work; the chain is one value after the other.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY>
+struct LatDiag {
+  Map m;
+  Quad<DX, DY> g;
+  double* diag;
+  int k;
+  vi lane;
+  vd dprev, sprev;
+
+  VHP_FN void init(const Map& m_, int sx, int sy, double* diag_lds) {
+    m = m_;
+    g.init(m.nx, m.ny, sx, sy);
+    diag = diag_lds;
+    lane = lane_id();
+    k = 0;
+    dprev = vd(0.0);
+    sprev = vd(0.0);
+  }
+  VHP_FN bool done() const { return k >= g.rows_total; }
+  // entries k .. k+63; returns the number of entries ready afterwards
+  VHP_FN int run_chunk() {
+    const int k0 = k, k1 = imin(k0 + kBlock, g.rows_total);
+    const vi kk = vmin(lane + k0, g.rows_total - 1);
+    const vi x = kk * DX + g.sx;
+    const vi ya = vmax(kk - 1, 0) * DY + g.sy, yb = kk * DY + g.sy;
+    const vu64 wa = g_load_u64(m.rows, ya * m.wpr + ((x >> 6) + 1));
+    const vu64 wb = g_load_u64(m.rows, yb * m.wpr + ((x >> 6) + 1));
+    const vd rk = g_load_f64(m.recip, kk);
+    const vi ma = bit_mask_lane(wa, x & 63), mb = bit_mask_lane(wb, x & 63);
+    const vd cv = ratio(to_f64(vmax(kk - 1, 0)), to_f64(kk), rk);  // (k-1)/k of every entry of the chunk
+    vd acc = vd(0.0);
+    for (int kq = k0; kq < k1; ++kq) {
+      const int l = kq - k0;
+      vd dcur;
+      if (kq == 0) {
+        dcur = and_mask(vd(1.0), vi(read_lane_i(mb, l)));  // the origin: light strength 1 times its occupancy
+        sprev = vd(0.0);
+      } else {
+        const vd sub = and_mask(stencil(dprev, sprev, vd(read_lane(cv, l))), vi(read_lane_i(ma, l)));
+        dcur = and_mask(sub, vi(read_lane_i(mb, l)));
+        sprev = sub;
+      }
+      dprev = dcur;
+      acc = select(lane == l, dcur, acc);
+    }
+    wave_sync();
+    lds_store_if(lane < (k1 - k0), diag, lane + k0, acc);
+    k = k1;
+    return k1;
+  }
+};
+
+template <typename OutT>
+struct LatWorker {
+  LatArgs<OutT> a;
+  Shared sh;
+  int w, W;
+  vi lane;
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
+  unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (Worker::prof: [1] waiting for / copying boundary values, [4] block-start loads)
+#endif
+
+  VHP_FN void init(const LatArgs<OutT>& a_, double* lds, const Layout& L, int w_) {
+    a = a_;
+    sh.lds = lds;
+    sh.L = L;
+    w = w_;
+    W = L.W;
+    lane = lane_id();
+  }
+  // Before any wavefront runs: every thread of the workgroup calls this (tid of nthreads), then a barrier.
+  static VHP_FN void clear(double* lds, const Layout& L, int tid, int nthreads) { Worker<OutT>::clear(lds, L, tid, nthreads); }
+
+  VHP_FN Tagged* line_of(int unit, int p, int nb) const { return a.lines + (size_t)64 * ((size_t)unit * (size_t)a.unit_blocks + (size_t)p * nb); }
+  static VHP_FN int tag_of(int p) { return (1 << 8) | p; }  // (never 0: a cleared header belongs to no strip)
+
+  // a coarse gate ahead of a strip's first window (which then checks exactly what it reads): one word per poll
+  VHP_FN void wait_for(const int* word, int at_least) {
+    while (lds_poll(word) < at_least) { ready_backoff(); sim_point(); }
+    lds_acquire();
+  }
+
+  template <int DX, int DY>
+  VHP_FN void run_x(int unit, int sx, int sy, OutT* field) {
+    Quad<DX, DY> g;
+    g.init(a.m.nx, a.m.ny, sx, sy);
+    int* prog = sh.prog(0);
+    for (int p = w; p < g.Px; p += W) {
+      LatX<DX, DY, OutT> xs;
+      xs.lk.init(sh, w, sx, kXRows * p, tag_of(p), prog + p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr,
+                 a.epoch, p > 0 ? (p - 1) % W : -1, p > 0 ? tag_of(p - 1) : 0);
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
+      xs.lk.pp = prof;
+#endif
+      xs.init(a.m, sx, sy, field, sh, w, p);
+      xs.prefetch_ops(g.X(xs.i_first) >> 6);
+      VHP_LAT_STAMP(unit, p, 0);
+#ifndef VHP_DIAG_NOWAIT
+      if (p > 0) wait_for(prog + (p - 1), imin(kXRows * p + 2, g.ni));  // the strip below has got to my rows
+#endif
+      VHP_LAT_STAMP(unit, p, 1);
+      xs.run();
+      VHP_LAT_STAMP(unit, p, 3);
+      lds_publish(prog + p, 0x3fff);  // finished (a march can end before the first window of the strip above does)
+      sim_progress();
+    }
+  }
+
+  template <int DX, int DY>
+  VHP_FN void run_y(int unit, int sx, int sy, OutT* field) {
+    Quad<DX, DY> g;
+    g.init(a.m.nx, a.m.ny, sx, sy);
+    int* prog = sh.prog(0);
+    int* cx = sh.ctx(0);
+    double* diag_lds = sh.lds + sh.L.tiles;  // (a y-major workgroup stages nothing: the tiles' space holds the diagonal)
+    const int n_strips = (lat_ycols<DX>(g.ni, g.nj) + kBlock - 1) / kBlock;
+    if (n_strips == 0) return;
+    if (w == W - 1) {  // the last wavefront runs the diagonal ahead of the strips, then takes its share of them
+      LatDiag<DX, DY> dt;
+      dt.init(a.m, sx, sy, diag_lds);
+      VHP_LAT_STAMP(unit, 47, 0);
+      while (!dt.done()) {
+        const int ready = dt.run_chunk();
+        lds_publish(cx + kDiagReady, ready);
+        if (ready <= kBlock) VHP_LAT_STAMP(unit, 47, 1);
+        if (ready <= 2 * kBlock) VHP_LAT_STAMP(unit, 47, 2);
+        sim_progress();
+        sim_point();
+      }
+      VHP_LAT_STAMP(unit, 47, 3);
+    }
+    const int Nby = g.Nby;
+    for (int q = w; q < n_strips; q += W) {
+      LatY<DX, DY, OutT> ys;
+      ys.lk.init(sh, w, sy, kBlock * q, tag_of(q), prog + q, q > 0 ? line_of(unit, q - 1, Nby) : nullptr, q + 1 < n_strips ? line_of(unit, q, Nby) : nullptr,
+                 a.epoch, q > 0 ? (q - 1) % W : -1, q > 0 ? tag_of(q - 1) : 0);
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
+      ys.lk.pp = prof;
+#endif
+      VHP_LAT_STAMP(unit, q, 0);
+#ifndef VHP_DIAG_NOWAIT
+      wait_for(cx + kDiagReady, imin(kBlock * q + kBlock, g.rows_total));  // my columns' seeds
+#endif
+      ys.init(a.m, sx, sy, field, sh, w, q, n_strips, diag_lds);
+      ys.prefetch_ops(g.Y(ys.j_first) >> 6);
+#ifndef VHP_DIAG_NOWAIT
+      if (q > 0) wait_for(prog + (q - 1), imin(kBlock * q + 1, g.nj));
+#endif
+      VHP_LAT_STAMP(unit, q, 1);
+      ys.run();
+      VHP_LAT_STAMP(unit, q, 3);
+      lds_publish(prog + q, 0x3fff);
+      sim_progress();
+    }
+  }
+
+  // the whole life of this wavefront: its strips of unit `unit` (8 * source + 2 * quadrant + {0: x-major, 1: y-major})
+  VHP_FN void run(int unit) {
+    const int s = unit / kUnits, qo = unit - s * kUnits;
+    const int sx = uniform(a.src_xy[2 * s]), sy = uniform(a.src_xy[2 * s + 1]);
+    if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
+      if (qo == 0 && w == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
+      return;
+    }
+    OutT* field = a.out + (size_t)s * a.field_stride;
+    if (qo == 0 && w == W - 1 && sy > 0) {
+      // rows/columns no quadrant covers read as zero; the x-major unit of quadrant 0 always exists
+      // (column 0, x = 0, y >= 1: written as zero by the units that march down to x = 1, with their last store of the row)
+      for (int x0 = 0; x0 < a.m.nx; x0 += kLanes) g_store_scalar_if(lane + x0 < a.m.nx, field, lane + x0, OutT(0));
+    }
+    switch (qo) {
+      case 0: run_x<+1, +1>(unit, sx, sy, field); break;
+      case 1: run_y<+1, +1>(unit, sx, sy, field); break;
+      case 2: run_x<-1, +1>(unit, sx, sy, field); break;
+      case 3: run_y<-1, +1>(unit, sx, sy, field); break;
+      case 4: run_x<-1, -1>(unit, sx, sy, field); break;
+      case 5: run_y<-1, -1>(unit, sx, sy, field); break;
+      case 6: run_x<+1, -1>(unit, sx, sy, field); break;
+      default: run_y<+1, -1>(unit, sx, sy, field); break;
+    }
+  }
+};
+
+}  // namespace pool
+}  // namespace vhp

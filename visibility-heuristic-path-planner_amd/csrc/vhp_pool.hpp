@@ -101,7 +101,7 @@ VHP_HD Layout make_layout(int W, int C, int nx, int ny) {
   L.slabs = o; o += W * kBlock;
   L.bins = o; o += W * kBin;
   L.rings = o; o += W * kRing;
-  L.dummies = o; o += W * 8;
+  L.dummies = o; o += W * 16;  // (8 per wavefront here; the latency sweep, vhp_lat.hpp, uses 16)
   L.sched = o;
   L.ctx_stride = kCtxHead + 2 * L.S;
   o += (kSchedHead + C * L.ctx_stride + 1) / 2;
@@ -186,7 +186,6 @@ struct Link {
   int rd_tag;
   const Tagged* line_in;   // the strip below's line in global memory: entry of x in block n at 64 n + (x & 63)
   int bin_block;           // the block that is in `bin` as a whole (from global memory), or -1
-  bool primed;
   int first_step;
   // writing side
   double* ring;            // mine: entry of x at x & 255
@@ -213,7 +212,6 @@ struct Link {
     c0 = c0_;
     first_step = first_step_;
     bin_block = -1;
-    primed = false;
     lane = lane_id();
     rd_ring = below_w >= 0 ? sh.ring(below_w) : nullptr;
     rd_hdr = below_w >= 0 ? sh.hdr(below_w) : nullptr;
@@ -231,23 +229,20 @@ struct Link {
     g_store_tagged(line_out, lane + 64 * nb, lds_load(ring, lane + 64 * (blk & 3)), epoch);
   }
   // block nb of the strip below from global memory into the slab (it has been stored, or is about to be; the tag tells)
+  // step index of the first coordinate of block nb >= 1
+  VHP_FN int block_first_step(int nb) const { return D > 0 ? 64 * ((c0 >> 6) + nb) - c0 : c0 - (64 * ((c0 >> 6) - nb) + 63); }
   VHP_FN void load_block(int nb) {
-    if (!primed) {
-      primed = true;
-      const int ic = first_step - 1;
-      if (ic >= 0 && block_of(ic) != nb) {
-        vd c;
-        while (!wave_all(g_load_tagged(line_in, vi(64 * block_of(ic) + (coord(ic) & 63)), epoch, c))) backoff();
-        lds_store(bin, vi(D > 0 ? 64 : 1), c);
-        wave_sync();
-      }
-    }
-    const double carry = D > 0 ? bin[64] : bin[1];
+    // the neighbour of the block's first step is the last entry of the line's previous block -- wanted (and written by the strip
+    // below) if that step is one of mine.  (Out of memory, not out of what the slab held before: the latency sweep's windows
+    // read the writer's ring directly and leave the slab alone.)
+    vd carry = vd(0.0);
+    if (nb >= 1 && block_first_step(nb) >= imax(first_step, 1))
+      while (!wave_all(g_load_tagged(line_in, vi(64 * (nb - 1) + (D > 0 ? 63 : 0)), epoch, carry))) backoff();
     vd v;
     while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) backoff();
     wave_sync();
     lds_store(bin, lane + 1, v);
-    lds_store(bin, vi(D > 0 ? 0 : 65), vd(carry));
+    lds_store(bin, vi(D > 0 ? 0 : 65), carry);
     wave_sync();
     bin_block = nb;
   }
@@ -273,7 +268,6 @@ struct Link {
       if (steps - (ia - 1) > kRingSafe) { sim_count(2); break; }  // far ahead: the ring may be overwritten any moment, the block is stored
       lds_acquire();
       sim_point();
-      primed = true;
       const vi st = vmin(lane + (ia - 1), ib);        // lane l: step ia - 1 + l (clamped: the same entry again)
       const vi x = st * D + c0;
       const vd v = lds_load(rd_ring, x & (kRing - 1));

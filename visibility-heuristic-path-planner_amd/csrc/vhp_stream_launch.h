@@ -50,4 +50,11 @@ bool pool_supported(int nx, int ny);
 hipError_t launch_pool(const StreamArgs& a);
 size_t pool_scratch_bytes(int n_src, int nx, int ny);
 
+// The latency sweep (vhp_lat.hip): one workgroup per octant, for launches of a few sources.  d_queue is scratch of
+// lat_scratch_bytes with the pool sweep's rules (zero when first used, written by nothing but these two kernels; the two
+// share the epoch counter, so either may follow the other on one allocation).
+bool lat_supported(int nx, int ny);
+hipError_t launch_lat(const StreamArgs& a);
+size_t lat_scratch_bytes(int n_src, int nx, int ny);
+
 }  // namespace vhp
