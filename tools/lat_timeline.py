@@ -41,10 +41,10 @@ for u in range(8):
     if u % 2 == 0:
         for v in range(12):
             r = w[u, v]
-            if r[12] > 0:
-                nw = r[12] + r[13]
-                print("   wave %2d: %3d steady windows of %5.0f cycles, %2d diagonal windows of %5.0f (of which predicated flush %5.0f); all: LDS batch %5.0f stores %5.0f compute %5.0f | polling the strip below (whole strip) %7.0f; %d blocks, outside the windows %6.0f cycles per block (block-start loads %5.0f)" % (
-                    v, r[12], r[11] / max(r[12], 1), r[13], r[14] / max(r[13], 1), r[15] / max(r[13], 1), r[8] / nw, r[9] / nw, r[10] / nw, r[1], r[6], (r[2] - r[11] - r[14]) / max(r[6], 1), r[4] / max(r[6], 1)))
+            nw = r[12] + r[13]
+            if nw > 0:
+                print("   wave %2d: %3d steady windows of %5.0f cycles, %2d diagonal of %5.0f; all: operands %5.0f compute %5.0f tile reads + next request %5.0f stores %5.0f | whole strip %7.0f cycles, outside the windows %6.0f" % (
+                    v, r[12], r[15] / max(r[12], 1), r[13], r[14] / max(r[13], 1), r[8] / nw, r[9] / nw, r[10] / nw, r[11] / nw, r[2], r[2] - r[15] - r[14]))
     for p in range(48):
         if st[u, p, 3] == 0:
             continue

@@ -83,6 +83,8 @@ inline vd vfma(const vd& a, const vd& b, const vd& c) { vd r; for (int l = 0; l 
 
 // lane l <- lane l-1; lane 0 <- fill's lane 0
 inline vd shift_up(const vd& v, const vd& fill) { vd r; r.v[0] = fill.v[0]; for (int l = 1; l < kLanes; ++l) r.v[l] = v.v[l - 1]; return r; }
+// lane l <- lane l+1; lane 63 <- fill's lane 63
+inline vd shift_down(const vd& v, const vd& fill) { vd r; r.v[kLanes - 1] = fill.v[kLanes - 1]; for (int l = 0; l + 1 < kLanes; ++l) r.v[l] = v.v[l + 1]; return r; }
 // lane l <- lane l+1; lane 63 <- lane 0
 inline vd rotate_down(const vd& v) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = v.v[(l + 1) & 63]; return r; }
 inline double read_lane(const vd& v, int l) { return v.v[l & 63]; }
@@ -213,6 +215,14 @@ VHP_LANE_FN vd shift_up(vd v, vd fill) {
   const int flo = __double2loint(fill), fhi = __double2hiint(fill);
   lo = __builtin_amdgcn_update_dpp(flo, lo, 0x138, 0xf, 0xf, false);
   hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// lane l <- lane l+1, lane 63 keeps `fill`'s lane 63: DPP wave_shl:1 (0x130)
+VHP_LANE_FN vd shift_down(vd v, vd fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  const int flo = __double2loint(fill), fhi = __double2hiint(fill);
+  lo = __builtin_amdgcn_update_dpp(flo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x130, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 // lane l <- lane l+1 (lane 63 <- lane 0): DPP wave_rol:1 (0x134).  Every lane has a source, so the destination needs

@@ -44,6 +44,13 @@ struct LatArgs {
   unsigned long long* strip_times;  // diagnostic builds (tools/lat_timeline.py): [unit][48][4] wall-clock stamps, or nullptr
 };
 
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)  // diagnostic builds only: cycle accounts inside the x-major windows (they cost a few hundred cycles per window themselves)
+#define VHP_WP_T0(var) const unsigned long long var = __builtin_readcyclecounter()
+#define VHP_WP_ADDP(pp, slot, var) (pp)[slot] += __builtin_readcyclecounter() - var
+#else
+#define VHP_WP_T0(var)
+#define VHP_WP_ADDP(pp, slot, var)
+#endif
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
 #define VHP_LAT_STAMP(unit, p, k) do { if (a.strip_times && (p) < 48 && (unit) < 64 && (threadIdx.x & 63) == 0) a.strip_times[(((unit) * 48) + (p)) * 4 + (k)] = wall_clock64(); } while (0)
 #else
@@ -196,22 +203,31 @@ struct LatX {
     nx_ia = ia;
   }
 
-  // One window: steps ia + k, k = k_lo .. k_hi (all 16 unless GUARD), at x = xw + (k marching up, 15 - k marching down).
-  // DIAG: the strip's diagonal may fall into it (rows switch on one by one: the diagonal cell of row j takes the NEW value of
-  // the row below it times its own occupancy).  more: the next window belongs to the same block (its operands are
-  // requested while this one's cells leave).
-  template <bool DIAG, bool GUARD>
-  VHP_FN void window(int ia, int xw, int nb, int k_lo, int k_hi, bool more) {
+  // One window: steps ia + k, k = 0 .. 15, at x = xw + (k marching up, 15 - k marching down).  DIAG: the strip's diagonal may fall
+  // into it (rows switch on one by one: the diagonal cell of row j takes the NEW value of the row below it times its own
+  // occupancy).  A window that sticks out of the march (before the strip's first step, past the last) is swept
+  // like any other: the steps that do not exist leave garbage where garbage does no harm -- a row is garbage until its diagonal
+  // cell switches it on, cells of steps outside j <= i <= i_last are never stored, and no strip reads another's values of such
+  // steps (reciprocal 0 for a step that does not exist: the ratio is 0 and nothing overflows).  more: the next window belongs
+  // to the same block (its operands are requested while this one's cells leave).
+  template <bool DIAG>
+  VHP_FN void window(int ia, int xw, int nb, bool more) {
+    const int k_hi = imin(kLW - 1, i_last - ia);
+    VHP_WP_T0(tw0);
     if (nx_ia != ia) request(ia, xw, nb);
     nx_ia = -0x7fffffff;
     if (below) nx.accept(lk, bin, xw, DX > 0 ? xw : xw + kLW - 1, imax(ia, i_first), ia + k_hi, nb);
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+    pin(nx_rr[kLW - 1]);
+#endif
+    VHP_WP_ADDP(lk.pp, 8, tw0);
+    VHP_WP_T0(tw1);
     const vu32 hs = half_shifted(ow, xw & 63, xw & 31);  // the window's 16 occupancy bits: bit c = the cell at x = xw + c
     vd di = vd((double)ia);
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DX > 0 ? k : kLW - 1 - k;
-      if (!GUARD || (k >= k_lo && k <= k_hi)) {
-        if (GUARD) di = vd((double)(ia + k));
+      {
         // nx.v[k] = the row below at x(step k) - DX, the OLD neighbour of lane 0 (nx.v[k + 1] the NEW one); strip 0 has none
         const vd b = shift_up(prev, below ? nx.v[k] : vd(0.0));
         const vi mk = sbfe1(hs, c);
@@ -224,9 +240,14 @@ struct LatX {
         }
         prev = v;
         lds_store(tile, tile_l + c, v);
-        if (!GUARD) di = di + 1.0;
+        di = di + 1.0;
       }
     }
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+    pin(prev);
+#endif
+    VHP_WP_ADDP(lk.pp, 9, tw1);
+    VHP_WP_T0(tw2);
     // ---- the window's 16 cells of every row leave; its boundary values go to the ring ----
     int lim = i_last;
     if (DX < 0 && xw == 0) {
@@ -244,13 +265,18 @@ struct LatX {
     if (has_consumer) bv = lds_load(tile, (lane & (kLW - 1)) + (kXRows - 1) * kTStride);  // the last row: what the strip above reads
     wave_sync();
     if (more) request(ia + kLW, xw + kLW * DX, nb);
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+    pin(fa[7]);
+#endif
+    VHP_WP_ADDP(lk.pp, 10, tw2);
+    VHP_WP_T0(tw3);
 #ifndef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
     {
       // Groups of 8 rows (u): whole (every cell a computed cell of a row of this strip: 16-byte stores), none (skipped), or cell
       // by cell.  A cell (i', j) exists for j <= i' <= lim; the window's steps are ia .. ia + 15.
       OutT* base = out + (long)(DY > 0 ? g.Y(j0) : g.Y(j0 + 7)) * (long)m.nx + xw;
       const long base_step = (long)(8 * DY) * m.nx;
-      if (!DIAG && !GUARD && rows_here == kXRows) {  // past the diagonal, inside the march, all 64 rows: every group whole
+      if (!DIAG && rows_here == kXRows && ia + kLW - 1 <= i_last) {  // past the diagonal, inside the march, all 64 rows: every group whole
 #pragma unroll
         for (int u = 0; u < 8; ++u) { g_store2(base, fl_off, fa[u], fb[u]); base += base_step; }
       } else {
@@ -277,10 +303,14 @@ struct LatX {
       }
     }
 #endif
+    VHP_WP_ADDP(lk.pp, 11, tw3);
     if (has_consumer) {
       lds_store(lk.ring, (lane & (kLW - 1)) + (xw & (kRing - 1)), bv);  // (every lane: the four lanes of an entry write the same value)
       lk.publish(ia + k_hi + 1);
     }
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+    if (DIAG) { VHP_WP_ADDP(lk.pp, 14, tw0); lk.pp[13] += 1; } else { VHP_WP_ADDP(lk.pp, 15, tw0); lk.pp[12] += 1; }
+#endif
   }
 
   VHP_FN void run() {
@@ -296,23 +326,20 @@ struct LatX {
         blk = b;
       }
       const int nb = DX > 0 ? b - g.bx0 : g.bx0 - b;
-      const int k_lo = imax(i_first - ia, 0), k_hi = imin(kLW - 1, i_last - ia);
-      if (k_lo > 0 || k_hi < kLW - 1) {
-        window<true, true>(ia, xw, nb, k_lo, k_hi, false);
-      } else {
-        // a run of whole windows of one kind inside this block: each requests the next one's operands (a loop of its own per
-        // kind, so that those operands stay where they are from one window to the next)
+      {
+        // a run of windows of one kind inside this block: each requests the next one's operands (a loop of its own per kind,
+        // so that those operands stay where they are from one window to the next)
         const bool diag = ia <= j0 + kXRows - 1;
         int n = 1;
-        while (ia + kLW * (n + 1) - 1 <= i_last && ((xw + kLW * n * DX) >> 6) == b && (ia + kLW * n <= j0 + kXRows - 1) == diag) ++n;
+        while (ia + kLW * n <= i_last && ((xw + kLW * n * DX) >> 6) == b && (ia + kLW * n <= j0 + kXRows - 1) == diag) ++n;
         if (diag) {
           for (int t = 0; t < n; ++t) {
-            window<true, false>(ia, xw, nb, 0, kLW - 1, t + 1 < n);
+            window<true>(ia, xw, nb, t + 1 < n);
             if (t + 1 < n) { ia += kLW; xw += kLW * DX; sim_progress(); sim_point(); }
           }
         } else {
           for (int t = 0; t < n; ++t) {
-            window<false, false>(ia, xw, nb, 0, kLW - 1, t + 1 < n);
+            window<false>(ia, xw, nb, t + 1 < n);
             if (t + 1 < n) { ia += kLW; xw += kLW * DX; sim_progress(); sim_point(); }
           }
         }
@@ -338,6 +365,10 @@ VHP_HD int lat_ycols(int ni, int nj) {
 template <int DX, int DY, typename OutT>
 struct LatY {
   static constexpr int CB = sizeof(OutT);
+  // Lanes are laid along x, lowest x in lane 0 (a row's 64 cells leave as one ascending 512-byte piece whatever the marching
+  // direction): marching down in x the columns run against the lanes, REV, and the neighbour of a column sits one lane up.
+  static constexpr bool REV = DX < 0;
+  static constexpr int kEdge = REV ? 0 : kLanes - 1;  // the lane of the strip's last column: what the strip above reads
   Map m;
   Quad<DX, DY> g;
   OutT* out;
@@ -349,7 +380,8 @@ struct LatY {
   bool below, has_consumer, interior;
   int pf_blk;
   vi lane, ic;
-  vb col_ok, zero_lane;
+  vi first_j;     // the first step at which the lane stores its cell of the row (0x7fffffff: never)
+  vb zero_lane;
   vu32 xoff;
   vd prev, id, dg;
   vu64 ow, ow_nx;
@@ -372,13 +404,14 @@ struct LatY {
     j_last = g.nj - 1;
     below = q > 0;
     has_consumer = q + 1 < n_strips;
-    ic = lane + i0;
-    col_ok = ic < g.ni;
+    ic = REV ? (-lane) + (i0 + kLanes - 1) : lane + i0;
     zero_lane = (ic == g.ni) && (DX < 0);
+    // a column stores from its seed on (i <= j); the lane of "column ni" stores its zero with every row that stores x = 1
+    first_j = select(ic < g.ni, ic, select(zero_lane, vi(g.ni - 1), vi(0x7fffffff)));
     interior = i0 + kBlock - 1 < g.ni;  // every lane a column of the quadrant
     prev = vd(0.0);
     id = to_f64(ic);
-    dg = lds_load(diag_lds, vmin(ic, g.rows_total - 1));
+    dg = select(zero_lane, vd(0.0), lds_load(diag_lds, vmin(ic, g.rows_total - 1)));
     pin(dg);
     xoff = to_u32((vmin(ic, g.ni) * DX + g.sx) * CB);  // (lanes past "column ni" store nothing)
     pf_blk = -1;
@@ -388,6 +421,7 @@ struct LatY {
   VHP_FN void load_ops(int blk, vu64& o, vd& rv) {
     const vi xl = vmin(ic, DX < 0 ? g.ni : g.ni - 1) * DX + g.sx;
     o = g_load_u64(m.cols, xl * m.wpc + (1 + blk));
+    if (DX < 0) o = select(zero_lane, vu64(0), o);  // ("column ni" computes zeros: blocked all the way)
     const vi jt = (lane + (blk * 64 - g.sy)) * DY;
     const vb ok = (jt >= 0) && (jt < g.nj);
     rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
@@ -417,39 +451,40 @@ struct LatY {
     nx_ja = ja;
   }
 
-  // One window: steps ja + k, k = k_lo .. k_hi (all 16 unless GUARD), at y = yw + (k marching up, 15 - k marching down).
-  // DIAG: columns may be seeded in it (implies PRED); PRED: predicated stores (columns that do not exist, or not yet).
-  template <bool DIAG, bool PRED, bool GUARD>
-  VHP_FN void window(int ja, int yw, int nb, int k_lo, int k_hi, bool more) {
+  // One window: steps ja + k, k = 0 .. 15, at y = yw + (k marching up, 15 - k marching down).  DIAG: columns may be seeded in it
+  // (implies PRED); PRED: predicated stores (columns that do not exist, or not yet; steps past the march).  Windows that stick
+  // out of the march are swept like the others (see LatX::window).
+  template <bool DIAG, bool PRED>
+  VHP_FN void window(int ja, int yw, int nb, bool more) {
+    const int k_hi = imin(kLW - 1, j_last - ja);
     if (nx_ja != ja) request(ja, yw, nb);
     nx_ja = -0x7fffffff;
     if (below) nx.accept(lk, bin, yw, DY > 0 ? yw : yw + kLW - 1, imax(ja, j_first), ja + k_hi - 1, nb);
     const vu32 hs = half_shifted(ow, yw & 63, yw & 31);
     double* wbase = has_consumer ? lk.ring + (yw & (kRing - 1)) : dummy;
-    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
+    const vi widx = select(lane == kEdge, vi(0), vi((int)(dummy - wbase)));
     vd dj = vd((double)ja);
     const long rowstep = (long)DY * m.nx;
     OutT* row = out + (long)g.Y(ja) * (long)m.nx;
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DY > 0 ? k : kLW - 1 - k;
-      if (!GUARD || (k >= k_lo && k <= k_hi)) {
-        if (GUARD) dj = vd((double)(ja + k));
-        const vd b = shift_up(prev, below ? nx.v[k] : vd(0.0));
+      {
+        const vd fill = below ? nx.v[k] : vd(0.0);
+        const vd b = REV ? shift_down(prev, fill) : shift_up(prev, fill);
         vd v = and_mask(stencil(prev, b, ratio(id, dj, nx_rr[k])), sbfe1(hs, c));
         if (DIAG) v = select(ic == ja + k, dg, v);
 #ifndef VHP_DIAG_NOYSTORE  // diagnostic builds only: what the y-major stores cost
         if (PRED) {
           const int j = ja + k;
-          const vb ok = (col_ok && (ic <= j)) || (zero_lane && (j >= g.ni - 1));
-          g_store1_if(ok, row, xoff, select(zero_lane, vd(0.0), v));
+          g_store1_if(first_j <= (j <= j_last ? j : -1), row, xoff, v);
         } else {
           g_store1_if(vb(true), row, xoff, v);
         }
 #endif
         prev = v;
         lds_store(wbase, widx + c, v);
-        if (!GUARD) dj = dj + 1.0;
+        dj = dj + 1.0;
       }
       row += rowstep;
     }
@@ -470,27 +505,30 @@ struct LatY {
         blk = b;
       }
       const int nb = DY > 0 ? b - g.by0 : g.by0 - b;
-      const int k_lo = imax(j_first - ja, 0), k_hi = imin(kLW - 1, j_last - ja);
-      if (k_lo > 0 || k_hi < kLW - 1) {
-        window<true, true, true>(ja, yw, nb, k_lo, k_hi, false);
-      } else {
-        // a run of whole windows of one kind inside this block (see LatX::run)
-        const bool diag = ja <= i0 + kBlock - 1;
+      {
+        // a run of windows of one kind inside this block (see LatX::run)
+        const int kind = ja <= i0 + kBlock - 1 ? 0 : (!interior || ja + kLW - 1 > j_last) ? 1 : 2;
         int n = 1;
-        while (ja + kLW * (n + 1) - 1 <= j_last && ((yw + kLW * n * DY) >> 6) == b && (ja + kLW * n <= i0 + kBlock - 1) == diag) ++n;
-        if (diag) {
+        for (;;) {
+          const int jn = ja + kLW * n;
+          if (jn > j_last || ((yw + kLW * n * DY) >> 6) != b) break;
+          const int kn = jn <= i0 + kBlock - 1 ? 0 : (!interior || jn + kLW - 1 > j_last) ? 1 : 2;
+          if (kn != kind) break;
+          ++n;
+        }
+        if (kind == 0) {
           for (int t = 0; t < n; ++t) {
-            window<true, true, false>(ja, yw, nb, 0, kLW - 1, t + 1 < n);
+            window<true, true>(ja, yw, nb, t + 1 < n);
             if (t + 1 < n) { ja += kLW; yw += kLW * DY; sim_progress(); sim_point(); }
           }
-        } else if (!interior) {
+        } else if (kind == 1) {
           for (int t = 0; t < n; ++t) {
-            window<false, true, false>(ja, yw, nb, 0, kLW - 1, t + 1 < n);
+            window<false, true>(ja, yw, nb, t + 1 < n);
             if (t + 1 < n) { ja += kLW; yw += kLW * DY; sim_progress(); sim_point(); }
           }
         } else {
           for (int t = 0; t < n; ++t) {
-            window<false, false, false>(ja, yw, nb, 0, kLW - 1, t + 1 < n);
+            window<false, false>(ja, yw, nb, t + 1 < n);
             if (t + 1 < n) { ja += kLW; yw += kLW * DY; sim_progress(); sim_point(); }
           }
         }
@@ -609,7 +647,9 @@ struct LatWorker {
       if (p > 0) wait_for(prog + (p - 1), imin(kXRows * p + 2, g.ni));  // the strip below has got to my rows
 #endif
       VHP_LAT_STAMP(unit, p, 1);
+      VHP_PP_T0(tsb);
       xs.run();
+      VHP_PP_ADD(2, tsb);
       VHP_LAT_STAMP(unit, p, 3);
       lds_publish(prog + p, 0x3fff);  // finished (a march can end before the first window of the strip above does)
       sim_progress();
