@@ -110,8 +110,9 @@ def test_stream_rejects_bad_source_and_is_idempotent(vhp):
 
 
 def test_kernel_choice_is_reported(vhp):
-    # which kernel a batch takes is the library's decision (vhp_capi.hip use_pool_kernel / use_stream_kernel); it tells
-    # through the ABI.  1 = front sweep, 2 = streaming sweep, 3 = pool sweep
+    # which kernel a batch takes is the library's decision (vhp_capi.hip use_lat_kernel / use_pool_kernel / use_stream_kernel); it
+    # tells through the ABI.  1 = front sweep, 2 = streaming sweep, 3 = pool sweep, 4 = latency sweep (up to 32 sources: an octant
+    # per CU)
     occ = np.ones((8, 1104), np.uint8)   # a side above 1024
     src = np.array([[k, 3] for k in range(96)], np.int32)
     c = vhp.Context(0)
@@ -120,6 +121,10 @@ def test_kernel_choice_is_reported(vhp):
     c.sweep_batch(src)
     assert c.last_sweep_kernel() == 3
     c.sweep_batch(src[:95])
+    assert c.last_sweep_kernel() == 1
+    c.sweep_batch(src[:32])
+    assert c.last_sweep_kernel() == 4
+    c.sweep_batch(src[:33])
     assert c.last_sweep_kernel() == 1
     c.set_option("kernel", 2)
     c.sweep_batch(src[:3])
@@ -138,4 +143,6 @@ def test_kernel_choice_is_reported(vhp):
     c = vhp.Context(0)
     c.set_map(occ)
     c.sweep_batch(np.array([[k, 3] for k in range(300)], np.int32))
+    assert c.last_sweep_kernel() == 1
+    c.sweep_batch(np.array([[5, 3]], np.int32))  # (an odd width: no latency sweep either)
     assert c.last_sweep_kernel() == 1

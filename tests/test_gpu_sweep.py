@@ -77,12 +77,14 @@ def test_border_blocked_and_thin(vhp, oracle):
             _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d source (%d,%d)" % (nx, ny, sx, sy))
 
 
+# (batches of up to 32 sources on even widths take the latency sweep by default: kernel = 1 keeps the front sweep's default shapes covered)
+@pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("side", [200, 300, 640])
-def test_multi_strip_sizes(vhp, oracle, side):
+def test_multi_strip_sizes(vhp, oracle, side, kernel):
     # sides that need 1, several and many wavefront strips per octant
     occ = maps.random_rect_map(side, side - 37, 30, 3, side // 8, 3, side // 8, side)
     src = maps.free_sources(occ, 6, side)
-    got = _ctx(vhp, occ).sweep_batch(src)
+    got = _ctx(vhp, occ, kernel=kernel).sweep_batch(src)
     for k, (sx, sy) in enumerate(src):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "side %d source %d" % (side, k))
 
@@ -112,26 +114,28 @@ def test_line_mode_shape_bit_exact(vhp, oracle, nx, ny):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d line mode, source (%d,%d)" % (nx, ny, sx, sy))
 
 
-def test_config3_1000x1000_subset(vhp, oracle):
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_config3_1000x1000_subset(vhp, oracle, kernel):
     occ, src = maps.config_c3(256)
     pick = src[[0, 17, 101, 255]]
     extra = np.array([[0, 0], [999, 999], [999, 0], [500, 500]], np.int32)
     extra = extra[[bool(occ[y, x]) for x, y in extra]]
     pick = np.concatenate([pick, extra])
-    got = _ctx(vhp, occ).sweep_batch(pick)
+    got = _ctx(vhp, occ, kernel=kernel).sweep_batch(pick)
     for k, (sx, sy) in enumerate(pick):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "C3 source (%d,%d)" % (sx, sy))
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("nx,ny", [(1500, 1100), (2500, 2300), (2049, 700)])
-def test_large_grids_multi_round(vhp, oracle, nx, ny):
+def test_large_grids_multi_round(vhp, oracle, nx, ny, kernel):
     # sides above 1024 use 4 rows per lane; above 2048 the strips of an octant are swept in rounds
     occ = maps.random_rect_map(nx, ny, 40, 10, nx // 6, 10, ny // 6, nx)
     src = maps.free_sources(occ, 3, ny)
     corner = np.array([[0, 0], [nx - 1, ny - 1], [nx - 1, 0]], np.int32)
     corner = corner[[bool(occ[y, x]) for x, y in corner]]
     src = np.concatenate([src, corner])
-    got = _ctx(vhp, occ).sweep_batch(src)
+    got = _ctx(vhp, occ, kernel=kernel).sweep_batch(src)
     for k, (sx, sy) in enumerate(src):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d source (%d,%d)" % (nx, ny, sx, sy))
 
@@ -146,18 +150,20 @@ def test_config5_4096_subset(vhp, oracle):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "C5 source (%d,%d)" % (sx, sy))
 
 
-def test_config2_empty_1000(vhp):
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_config2_empty_1000(vhp, kernel):
     # README benchmark case: empty grid, centre source -> everything visible, except the
     # never-swept row 0 / column 0
     occ = np.ones((1000, 1000), np.uint8)
-    got = _ctx(vhp, occ).sweep_batch(np.array([[500, 500]], np.int32))[0]
+    got = _ctx(vhp, occ, kernel=kernel).sweep_batch(np.array([[500, 500]], np.int32))[0]
     assert (got[1:, 1:] == 1.0).all() and not got[0].any() and not got[:, 0].any()
 
 
-def test_fp32_storage_is_rounded_fp64(vhp, oracle):
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_fp32_storage_is_rounded_fp64(vhp, oracle, kernel):
     occ = maps.random_rect_map(300, 257, 30, 3, 40, 3, 40, 9)
     src = maps.free_sources(occ, 5, 9)
-    got = _ctx(vhp, occ).sweep_batch(src, dtype=vhp.F32)
+    got = _ctx(vhp, occ, kernel=kernel).sweep_batch(src, dtype=vhp.F32)
     assert got.dtype == np.float32
     for k, (sx, sy) in enumerate(src):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)).astype(np.float32), "fp32 source %d" % k)

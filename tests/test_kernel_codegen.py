@@ -34,7 +34,7 @@ def _kernels(asm, name):
     return out
 
 
-@pytest.mark.parametrize("src,kernel", [("vhp_stream.hip", "vhp_stream_sweep"), ("vhp_pool.hip", "vhp_pool_sweep")])
+@pytest.mark.parametrize("src,kernel", [("vhp_stream.hip", "vhp_stream_sweep"), ("vhp_pool.hip", "vhp_pool_sweep"), ("vhp_lat.hip", "vhp_lat_sweep")])
 def test_no_flat_and_no_scratch_instructions(tmp_path, src, kernel):
     asm = _asm(src, tmp_path)
     ks = _kernels(asm, kernel)

@@ -46,10 +46,10 @@ struct LatArgs {
 
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)  // diagnostic builds only: cycle accounts inside the x-major windows (they cost a few hundred cycles per window themselves)
 #define VHP_WP_T0(var) const unsigned long long var = __builtin_readcyclecounter()
-#define VHP_WP_ADDP(pp, slot, var) (pp)[slot] += __builtin_readcyclecounter() - var
+#define VHP_WP_ADDP(pp, slot, var) { (pp)[slot] += __builtin_readcyclecounter() - var; }
 #else
 #define VHP_WP_T0(var)
-#define VHP_WP_ADDP(pp, slot, var)
+#define VHP_WP_ADDP(pp, slot, var) {}
 #endif
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
 #define VHP_LAT_STAMP(unit, p, k) do { if (a.strip_times && (p) < 48 && (unit) < 64 && (threadIdx.x & 63) == 0) a.strip_times[(((unit) * 48) + (p)) * 4 + (k)] = wall_clock64(); } while (0)
@@ -220,7 +220,7 @@ struct LatX {
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
     pin(nx_rr[kLW - 1]);
 #endif
-    VHP_WP_ADDP(lk.pp, 8, tw0);
+    if (DIAG) VHP_WP_ADDP(lk.pp, 8, tw0);
     VHP_WP_T0(tw1);
     const vu32 hs = half_shifted(ow, xw & 63, xw & 31);  // the window's 16 occupancy bits: bit c = the cell at x = xw + c
     vd di = vd((double)ia);
@@ -246,7 +246,7 @@ struct LatX {
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
     pin(prev);
 #endif
-    VHP_WP_ADDP(lk.pp, 9, tw1);
+    if (DIAG) VHP_WP_ADDP(lk.pp, 9, tw1);
     VHP_WP_T0(tw2);
     // ---- the window's 16 cells of every row leave; its boundary values go to the ring ----
     int lim = i_last;
@@ -268,7 +268,7 @@ struct LatX {
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
     pin(fa[7]);
 #endif
-    VHP_WP_ADDP(lk.pp, 10, tw2);
+    if (DIAG) VHP_WP_ADDP(lk.pp, 10, tw2);
     VHP_WP_T0(tw3);
 #ifndef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
     {
@@ -303,7 +303,7 @@ struct LatX {
       }
     }
 #endif
-    VHP_WP_ADDP(lk.pp, 11, tw3);
+    if (DIAG) VHP_WP_ADDP(lk.pp, 11, tw3);
     if (has_consumer) {
       lds_store(lk.ring, (lane & (kLW - 1)) + (xw & (kRing - 1)), bv);  // (every lane: the four lanes of an entry write the same value)
       lk.publish(ia + k_hi + 1);
