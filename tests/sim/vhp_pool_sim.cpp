@@ -251,6 +251,8 @@ int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, O
   for (size_t k = 0; k < lines.size(); ++k) { lines[k].v = std::numeric_limits<double>::quiet_NaN(); lines[k].tag = (k % 5 == 0) ? 0 : epoch - 1 - (k % 3); }
   a.lines = lines.data();
   a.epoch = epoch;
+  a.src_index = nullptr;
+  a.skip = nullptr;
   a.strip_times = nullptr;
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
   std::vector<LatCo<OutT>> workers((size_t)G * W);

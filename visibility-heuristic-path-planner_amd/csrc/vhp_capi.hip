@@ -63,6 +63,8 @@ struct vhp_ctx {
   int opt_multi = 0;          // 1: force the multi-round build
   int opt_slide = -1;         // 0 / 1: y-major column grid slid onto 128-byte lines
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
+  const int* lat_src_index = nullptr;  // set around a latency-sweep launch of the planner's loop (vhp_planner_solve)
+  const int* lat_skip = nullptr;
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream), 3 pool sweep (vhp_pool)
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep, 3 pool sweep
   int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
@@ -328,6 +330,8 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.d_err = c->d_err;
   a.d_queue = (pool || lat) ? c->d_pool : c->d_queue;
   a.pool_epoch = (pool || lat) ? ++c->pool_epoch : 0;
+  a.d_src_index = lat ? c->lat_src_index : nullptr;
+  a.d_skip = lat ? c->lat_skip : nullptr;
   a.n_cus = c->n_cus;
   a.stream = c->stream;
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
@@ -846,6 +850,16 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
     ctx->pl.W = W;
     ctx->pl.multi = multi;
     ctx->pl.raise_lds = [ctx](const void* fn, size_t bytes) { return raise_lds_limit(ctx, fn, bytes); };
+    // one source per sweep: the latency sweep wherever a batch of one would take it (94 against 67 us per sweep at 690^2)
+    ctx->pl.lat_sweep = nullptr;
+    if (use_lat_kernel(ctx, 1))
+      ctx->pl.lat_sweep = [ctx](const int32_t* pivots, const int* nb, const int* done, double* out) {
+        ctx->lat_src_index = nb;
+        ctx->lat_skip = done;
+        const hipError_t e = launch_stream_sweep<double>(ctx, pivots, 1, out, false, true);
+        ctx->lat_src_index = ctx->lat_skip = nullptr;
+        return e;
+      };
   }
   int rc = vhp::planner_solve(ctx->pl, pm, ctx->d_occ, ctx->stream, ctx->ev0, ctx->ev1, start_x, start_y, end_x,
                               end_y, threshold, max_iter, came_from, vis_global, vis_local, pivots_xy, n_pivots, &msg);

@@ -69,6 +69,8 @@ hipError_t launch_lat_t(const StreamArgs& a) {
   g.lines = reinterpret_cast<vhp::lanes::Tagged*>(a.d_queue);
   g.unit_blocks = lat_unit_blocks(a.nx, a.ny);
   g.epoch = a.pool_epoch;
+  g.src_index = a.d_src_index;
+  g.skip = a.d_skip;
   g.strip_times = nullptr;
 #ifdef VHP_DIAG_POOLPROF
   { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_lat_strip_times)) == hipSuccess) g.strip_times = static_cast<unsigned long long*>(p); }

@@ -41,6 +41,10 @@ struct LatArgs {
   Tagged* lines;       // scratch: the boundary lines; strip p of unit u at 64 * (u * unit_blocks + p * blocks of the march)
   long long unit_blocks;
   uint64_t epoch;      // the tag of this launch (never 0, never repeated on this scratch)
+  // the planner's loop (vhp_planner.hip.h): the launch sweeps source number *src_index of src_xy (the current pivot) into field 0,
+  // or nothing at all if *skip is set (the loop has ended: launches are enqueued ahead of the host's polls); both may be null
+  const int* src_index;
+  const int* skip;
   unsigned long long* strip_times;  // diagnostic builds (tools/lat_timeline.py): [unit][48][4] wall-clock stamps, or nullptr
 };
 
@@ -707,7 +711,9 @@ struct LatWorker {
   // the whole life of this wavefront: its strips of unit `unit` (8 * source + 2 * quadrant + {0: x-major, 1: y-major})
   VHP_FN void run(int unit) {
     const int s = unit / kUnits, qo = unit - s * kUnits;
-    const int sx = uniform(a.src_xy[2 * s]), sy = uniform(a.src_xy[2 * s + 1]);
+    if (a.skip && uniform(*a.skip) != 0) return;
+    const int si = a.src_index ? uniform(*a.src_index) : s;
+    const int sx = uniform(a.src_xy[2 * si]), sy = uniform(a.src_xy[2 * si + 1]);
     if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
       if (qo == 0 && w == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
       return;

@@ -268,6 +268,9 @@ struct PlannerState {
   int R = 2, W = 8;
   bool multi = false;
   std::function<hipError_t(const void*, size_t)> raise_lds;
+  // set by the caller when the latency sweep (vhp_lat.hpp) can sweep this grid: launches it for source number *nb of pivots into
+  // out unless *done is set (the same contract as vhp_planner_sweep: everything read on the device when the launch runs)
+  std::function<hipError_t(const int32_t* pivots, const int* nb, const int* done, double* out)> lat_sweep;
 };
 
 inline void planner_free(PlannerState& s) {
@@ -381,7 +384,8 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   const int batch = 8;  // iterations enqueued per host poll (those past the end see `done` and return at once)
   for (;;) {
     for (int b = 0; b < batch; ++b) {
-      hipError_t e = R == 1 ? (multi ? launch_planner_fronts<1, true>(s, m, d, W, stream) : launch_planner_fronts<1, false>(s, m, d, W, stream))
+      hipError_t e = s.lat_sweep ? s.lat_sweep(d.pivots, &s.ctl->nb, &s.ctl->done, d.vis_local)
+                   : R == 1 ? (multi ? launch_planner_fronts<1, true>(s, m, d, W, stream) : launch_planner_fronts<1, false>(s, m, d, W, stream))
                    : R == 2 ? (multi ? launch_planner_fronts<2, true>(s, m, d, W, stream) : launch_planner_fronts<2, false>(s, m, d, W, stream))
                             : (multi ? launch_planner_fronts<4, true>(s, m, d, W, stream) : launch_planner_fronts<4, false>(s, m, d, W, stream));
       if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }

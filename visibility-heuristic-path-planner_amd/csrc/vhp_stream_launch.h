@@ -33,6 +33,8 @@ struct StreamArgs {
   int pool_tail_pct = 0;  // pool sweep: share of the units (by count, smallest first) that the filler contexts may take from the small end (0: 50)
   int pool_early_ctx = 0, pool_late_pct = 0;  // pool sweep: contexts >= early_ctx open once late_pct % of the units are taken (0: all open)
   int pool_busy_cap = 0;  // pool sweep: a workgroup takes another unit only while fewer wavefronts than this are sweeping (0: no cap)
+  const int* d_src_index = nullptr;  // latency sweep in the planner's loop: sweep source number *d_src_index of d_src (n_src = 1) ...
+  const int* d_skip = nullptr;       // ... and nothing at all if *d_skip is set
   unsigned long long pool_epoch = 0;  // pool sweep: the tag of this launch's boundary-line entries: never 0, never reused on this scratch
 };
 
