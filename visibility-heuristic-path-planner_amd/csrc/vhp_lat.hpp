@@ -105,7 +105,14 @@ struct Below {
     for (;;) {
       const int ha = uniform(h1), hb = uniform(h2);
       if ((ha >> 14) != lk.rd_tag) break;                                                            // the writer has finished that strip: its line is (being) stored
-      if ((ha & 0x3fff) <= last_needed) { ready_backoff(); from_ring(lk, cw, c_first); continue; }  // not swept yet
+      if ((ha & 0x3fff) <= last_needed) {  // not swept yet
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+        lk.pp[7] += 1;
+#endif
+        ready_backoff();
+        from_ring(lk, cw, c_first);
+        continue;
+      }
       // (a writer is at most one window past what it has published: an entry of step s is safe while published - s <= kRingSafe)
       if ((hb >> 14) != lk.rd_tag || (hb & 0x3fff) - (ia - 1) > kRingSafe) { sim_count(3); break; }
       sim_count(0);
@@ -127,12 +134,15 @@ struct LatX {
   Quad<DX, DY> g;
   OutT* out;
   double* tile;   // 64 rows x 16 columns (pitch kTStride): column c = x - (lowest x of the window)
-  double* slab;   // reciprocals of the current block's 64 coordinates, indexed by x & 63
+  double* slab;   // reciprocals of the step indices of two blocks of 64 coordinates (the current one and the next), indexed by x & 127
   double* bin;    // = lk.bin
   Link<DX> lk;
   int p, j0, rows_here, i_first, i_last;
   bool below, has_consumer;
-  int pf_blk;     // the block (x >> 6) whose operands wait in ow_nx / rv_nx, or -1
+  int blk;        // the current block (x >> 6): its occupancy words are in ow
+  int pf_blk;     // the block whose operands wait in ow_nx / rv_nx (requested when the current block began), or -1 ...
+  int staged_blk; // ... and the block whose reciprocals were put into the slab last
+  bool pf_wait;   // the loads of ow_nx / rv_nx have not been waited for yet
   vi lane, tile_l, fl_t;
   vu32 fl_off;
   vd prev, jd;
@@ -147,7 +157,7 @@ struct LatX {
     m = m_; out = out_;
     g.init(m.nx, m.ny, sx, sy);
     tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
-    slab = sh.lds + sh.L.slabs + w * kBlock;
+    slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
     bin = lk.bin;
     lane = lane_id();
     tile_l = lane * kTStride;
@@ -169,6 +179,9 @@ struct LatX {
     prev = vd(0.0);
     jd = to_f64(lane + j0);
     pf_blk = -1;
+    pf_wait = false;
+    staged_blk = -0x7fffffff;
+    blk = -0x7fffffff;
     nx_ia = -0x7fffffff;
   }
 
@@ -180,23 +193,36 @@ struct LatX {
     const vb ok = (it >= 0) && (it < g.ni);
     rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
   }
-  VHP_FN bool block_in_march(int blk) const { const int xe = g.X(i_last); return DX > 0 ? 64 * blk <= xe : 64 * blk + 63 >= xe; }
-  VHP_FN void prefetch_ops(int blk) { pf_blk = blk; load_ops(blk, ow_nx, rv_nx); }
-  VHP_FN void begin_block(int blk) {
-    vd rv;
-    if (pf_blk == blk) { ow = ow_nx; rv = rv_nx; } else { load_ops(blk, ow, rv); }
-    pin(ow);
-    pin(rv);
+  VHP_FN bool block_in_march(int b) const { const int xe = g.X(i_last); return DX > 0 ? 64 * b <= xe : 64 * b + 63 >= xe; }
+  VHP_FN void prefetch_ops(int b) { pf_blk = b; pf_wait = true; load_ops(b, ow_nx, rv_nx); }
+  VHP_FN void stage(int b, vd rv) {
     wave_sync();
-    lds_store(slab, lane, rv);
+    lds_store(slab, lane + kBlock * (b & 1), rv);
     wave_sync();
-    if (block_in_march(blk + DX)) prefetch_ops(blk + DX); else pf_blk = -1;
+    staged_blk = b;
+  }
+  // the reciprocals of the block after the current one into the other half of the slab (its loads were issued when the current
+  // block began: a window ago at the least), so that the windows of that block can be requested before it begins
+  // (waiting for a global load waits for every global store issued before it as well: one counter, out of order between the two
+  // kinds.  Settling the next block's loads right after a window's compute, when the last stores are oldest, was measured: +3 %)
+  VHP_FN void settle() {
+    if (pf_wait) { pin(ow_nx); pin(rv_nx); pf_wait = false; }
+  }
+  VHP_FN void stage_next() {
+    if (pf_blk != -1 && staged_blk != pf_blk) { settle(); stage(pf_blk, rv_nx); }
+  }
+  // block b becomes the current one (the first block of the strip, or the one after the current)
+  VHP_FN void enter_block(int b) {
+    if (pf_blk == b) { stage_next(); ow = ow_nx; }
+    else { vd rv; load_ops(b, ow, rv); pin(ow); pin(rv); stage(b, rv); }
+    blk = b;
+    if (block_in_march(b + DX)) prefetch_ops(b + DX); else pf_blk = -1;
   }
 
   // requests the operands of the window whose lowest x is xw (lowest step ia) in block nb; nothing is waited for
   VHP_FN void request(int ia, int xw, int nb) {
 #pragma unroll
-    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (xw & 63) + (DX > 0 ? k : kLW - 1 - k));
+    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (xw & (2 * kBlock - 1)) + (DX > 0 ? k : kLW - 1 - k));
     if (below) {
 #ifndef VHP_DIAG_NOWAIT
       nx.request(lk, bin, xw, DX > 0 ? xw : xw + kLW - 1, nb);
@@ -268,7 +294,12 @@ struct LatX {
     vd bv = vd(0.0);
     if (has_consumer) bv = lds_load(tile, (lane & (kLW - 1)) + (kXRows - 1) * kTStride);  // the last row: what the strip above reads
     wave_sync();
-    if (more) request(ia + kLW, xw + kLW * DX, nb);
+    if (more) {
+      const int xn = xw + kLW * DX;
+      const bool other = (xn >> 6) != (xw >> 6);  // the next window opens the next block
+      if (other) stage_next();
+      request(ia + kLW, xn, other ? nb + 1 : nb);
+    }
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
     pin(fa[7]);
 #endif
@@ -317,39 +348,37 @@ struct LatX {
 #endif
   }
 
+  // the window at xw (lowest step ia) is next: if it opens a block, that block's operands become the current ones
+  VHP_FN void open_block(int xw, int ia) {
+    const int b = xw >> 6;
+    if (b == blk) return;
+    if (has_consumer) lk.store_block(g.nbx(ia - 1), blk);
+    enter_block(b);
+  }
   VHP_FN void run() {
     int xw = g.X(i_first) & ~(kLW - 1);
     int ia = DX > 0 ? xw - g.sx : g.sx - (xw + kLW - 1);
-    int blk = xw >> 6;
-    begin_block(blk);
-    for (; ia <= i_last; ia += kLW, xw += kLW * DX) {
-      const int b = xw >> 6;
-      if (b != blk) {
-        if (has_consumer) lk.store_block(g.nbx(ia - 1), blk);
-        begin_block(b);
-        blk = b;
+    enter_block(xw >> 6);
+    // runs of windows of one kind (a loop of its own per kind, so that the operands requested for the next window stay where
+    // they are from one window to the next); every window requests the next one's operands, whatever its kind and block
+    while (ia <= i_last) {
+      if (ia <= j0 + kXRows - 1) {
+        do {
+          open_block(xw, ia);
+          window<true>(ia, xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk, ia + kLW <= i_last);
+          ia += kLW; xw += kLW * DX;
+          sim_progress();
+          sim_point();
+        } while (ia <= i_last && ia <= j0 + kXRows - 1);
+      } else {
+        do {
+          open_block(xw, ia);
+          window<false>(ia, xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk, ia + kLW <= i_last);
+          ia += kLW; xw += kLW * DX;
+          sim_progress();
+          sim_point();
+        } while (ia <= i_last);
       }
-      const int nb = DX > 0 ? b - g.bx0 : g.bx0 - b;
-      {
-        // a run of windows of one kind inside this block: each requests the next one's operands (a loop of its own per kind,
-        // so that those operands stay where they are from one window to the next)
-        const bool diag = ia <= j0 + kXRows - 1;
-        int n = 1;
-        while (ia + kLW * n <= i_last && ((xw + kLW * n * DX) >> 6) == b && (ia + kLW * n <= j0 + kXRows - 1) == diag) ++n;
-        if (diag) {
-          for (int t = 0; t < n; ++t) {
-            window<true>(ia, xw, nb, t + 1 < n);
-            if (t + 1 < n) { ia += kLW; xw += kLW * DX; sim_progress(); sim_point(); }
-          }
-        } else {
-          for (int t = 0; t < n; ++t) {
-            window<false>(ia, xw, nb, t + 1 < n);
-            if (t + 1 < n) { ia += kLW; xw += kLW * DX; sim_progress(); sim_point(); }
-          }
-        }
-      }
-      sim_progress();
-      sim_point();
     }
     if (has_consumer) lk.store_block(g.nbx(i_last), blk);
   }
@@ -376,13 +405,14 @@ struct LatY {
   Map m;
   Quad<DX, DY> g;
   OutT* out;
-  double* slab;   // reciprocals of the current block's 64 coordinates, indexed by y & 63
+  double* slab;   // reciprocals of the step indices of two blocks of 64 coordinates (the current one and the next), indexed by y & 127
   double* bin;
   double* dummy;
   Link<DY> lk;
   int q, i0, j_first, j_last;
   bool below, has_consumer, interior;
-  int pf_blk;
+  int blk, pf_blk, staged_blk;  // (as in LatX)
+  bool pf_wait;
   vi lane, ic;
   vi first_j;     // the first step at which the lane stores its cell of the row (0x7fffffff: never)
   vb zero_lane;
@@ -398,7 +428,7 @@ struct LatY {
   VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, int n_strips, const double* diag_lds) {
     m = m_; out = out_;
     g.init(m.nx, m.ny, sx, sy);
-    slab = sh.lds + sh.L.slabs + w * kBlock;
+    slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
     bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * kLatDummy;
     lane = lane_id();
@@ -419,6 +449,9 @@ struct LatY {
     pin(dg);
     xoff = to_u32((vmin(ic, g.ni) * DX + g.sx) * CB);  // (lanes past "column ni" store nothing)
     pf_blk = -1;
+    pf_wait = false;
+    staged_blk = -0x7fffffff;
+    blk = -0x7fffffff;
     nx_ja = -0x7fffffff;
   }
 
@@ -430,21 +463,31 @@ struct LatY {
     const vb ok = (jt >= 0) && (jt < g.nj);
     rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
   }
-  VHP_FN bool block_in_march(int blk) const { const int ye = g.Y(j_last); return DY > 0 ? 64 * blk <= ye : 64 * blk + 63 >= ye; }
-  VHP_FN void prefetch_ops(int blk) { pf_blk = blk; load_ops(blk, ow_nx, rv_nx); }
-  VHP_FN void begin_block(int blk) {
-    vd rv;
-    if (pf_blk == blk) { ow = ow_nx; rv = rv_nx; } else { load_ops(blk, ow, rv); }
-    pin(ow);
-    pin(rv);
+  VHP_FN bool block_in_march(int b) const { const int ye = g.Y(j_last); return DY > 0 ? 64 * b <= ye : 64 * b + 63 >= ye; }
+  VHP_FN void prefetch_ops(int b) { pf_blk = b; pf_wait = true; load_ops(b, ow_nx, rv_nx); }
+  VHP_FN void stage(int b, vd rv) {
     wave_sync();
-    lds_store(slab, lane, rv);
+    lds_store(slab, lane + kBlock * (b & 1), rv);
     wave_sync();
-    if (block_in_march(blk + DY)) prefetch_ops(blk + DY); else pf_blk = -1;
+    staged_blk = b;
+  }
+  // (waiting for a global load waits for every global store issued before it as well: one counter, out of order between the two
+  // kinds.  Settling the next block's loads right after a window's compute, when the last stores are oldest, was measured: +3 %)
+  VHP_FN void settle() {
+    if (pf_wait) { pin(ow_nx); pin(rv_nx); pf_wait = false; }
+  }
+  VHP_FN void stage_next() {
+    if (pf_blk != -1 && staged_blk != pf_blk) { settle(); stage(pf_blk, rv_nx); }
+  }
+  VHP_FN void enter_block(int b) {
+    if (pf_blk == b) { stage_next(); ow = ow_nx; }
+    else { vd rv; load_ops(b, ow, rv); pin(ow); pin(rv); stage(b, rv); }
+    blk = b;
+    if (block_in_march(b + DY)) prefetch_ops(b + DY); else pf_blk = -1;
   }
   VHP_FN void request(int ja, int yw, int nb) {
 #pragma unroll
-    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (yw & 63) + (DY > 0 ? k : kLW - 1 - k));
+    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (yw & (2 * kBlock - 1)) + (DY > 0 ? k : kLW - 1 - k));
     if (below) {
 #ifndef VHP_DIAG_NOWAIT
       nx.request(lk, bin, yw, DY > 0 ? yw : yw + kLW - 1, nb);
@@ -492,53 +535,54 @@ struct LatY {
       }
       row += rowstep;
     }
-    if (more) request(ja + kLW, yw + kLW * DY, nb);
+    if (more) {
+      const int yn = yw + kLW * DY;
+      const bool other = (yn >> 6) != (yw >> 6);
+      if (other) stage_next();
+      request(ja + kLW, yn, other ? nb + 1 : nb);
+    }
     if (has_consumer) lk.publish(ja + k_hi + 1);
   }
 
+  VHP_FN void open_block(int yw, int ja) {
+    const int b = yw >> 6;
+    if (b == blk) return;
+    if (has_consumer) lk.store_block(g.nby(ja - 1), blk);
+    enter_block(b);
+  }
+  VHP_FN int kind_of(int ja) const { return ja <= i0 + kBlock - 1 ? 0 : (!interior || ja + kLW - 1 > j_last) ? 1 : 2; }
   VHP_FN void run() {
     int yw = g.Y(j_first) & ~(kLW - 1);
     int ja = DY > 0 ? yw - g.sy : g.sy - (yw + kLW - 1);
-    int blk = yw >> 6;
-    begin_block(blk);
-    for (; ja <= j_last; ja += kLW, yw += kLW * DY) {
-      const int b = yw >> 6;
-      if (b != blk) {
-        if (has_consumer) lk.store_block(g.nby(ja - 1), blk);
-        begin_block(b);
-        blk = b;
+    enter_block(yw >> 6);
+    // runs of windows of one kind (see LatX::run)
+    while (ja <= j_last) {
+      const int kind = kind_of(ja);
+      if (kind == 0) {
+        do {
+          open_block(yw, ja);
+          window<true, true>(ja, yw, DY > 0 ? blk - g.by0 : g.by0 - blk, ja + kLW <= j_last);
+          ja += kLW; yw += kLW * DY;
+          sim_progress();
+          sim_point();
+        } while (ja <= j_last && kind_of(ja) == 0);
+      } else if (kind == 1) {
+        do {
+          open_block(yw, ja);
+          window<false, true>(ja, yw, DY > 0 ? blk - g.by0 : g.by0 - blk, ja + kLW <= j_last);
+          ja += kLW; yw += kLW * DY;
+          sim_progress();
+          sim_point();
+        } while (ja <= j_last && kind_of(ja) == 1);
+      } else {
+        do {
+          open_block(yw, ja);
+          window<false, false>(ja, yw, DY > 0 ? blk - g.by0 : g.by0 - blk, ja + kLW <= j_last);
+          ja += kLW; yw += kLW * DY;
+          sim_progress();
+          sim_point();
+        } while (ja <= j_last && kind_of(ja) == 2);
       }
-      const int nb = DY > 0 ? b - g.by0 : g.by0 - b;
-      {
-        // a run of windows of one kind inside this block (see LatX::run)
-        const int kind = ja <= i0 + kBlock - 1 ? 0 : (!interior || ja + kLW - 1 > j_last) ? 1 : 2;
-        int n = 1;
-        for (;;) {
-          const int jn = ja + kLW * n;
-          if (jn > j_last || ((yw + kLW * n * DY) >> 6) != b) break;
-          const int kn = jn <= i0 + kBlock - 1 ? 0 : (!interior || jn + kLW - 1 > j_last) ? 1 : 2;
-          if (kn != kind) break;
-          ++n;
-        }
-        if (kind == 0) {
-          for (int t = 0; t < n; ++t) {
-            window<true, true>(ja, yw, nb, t + 1 < n);
-            if (t + 1 < n) { ja += kLW; yw += kLW * DY; sim_progress(); sim_point(); }
-          }
-        } else if (kind == 1) {
-          for (int t = 0; t < n; ++t) {
-            window<false, true>(ja, yw, nb, t + 1 < n);
-            if (t + 1 < n) { ja += kLW; yw += kLW * DY; sim_progress(); sim_point(); }
-          }
-        } else {
-          for (int t = 0; t < n; ++t) {
-            window<false, false>(ja, yw, nb, t + 1 < n);
-            if (t + 1 < n) { ja += kLW; yw += kLW * DY; sim_progress(); sim_point(); }
-          }
-        }
-      }
-      sim_progress();
-      sim_point();
     }
     if (has_consumer) lk.store_block(g.nby(j_last), blk);
   }

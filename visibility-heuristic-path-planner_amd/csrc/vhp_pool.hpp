@@ -98,7 +98,7 @@ VHP_HD Layout make_layout(int W, int C, int nx, int ny) {
   L.S = ((imax(nx, ny) + 63) / 64 + 2 + 3) & ~3;  // most strips a unit can have (+ slack)
   int o = 0;
   L.tiles = o; o += W * kXRows * kTStride;
-  L.slabs = o; o += W * kBlock;
+  L.slabs = o; o += W * 2 * kBlock;  // (64 per wavefront here; the latency sweep, vhp_lat.hpp, keeps two blocks per wavefront)
   L.bins = o; o += W * kBin;
   L.rings = o; o += W * kRing;
   L.dummies = o; o += W * 16;  // (8 per wavefront here; the latency sweep, vhp_lat.hpp, uses 16)
