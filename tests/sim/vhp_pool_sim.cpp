@@ -323,7 +323,7 @@ int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, O
     stats[3] = vhp::lanes::store_stats().n16;
     stats[4] = vhp::lanes::store_stats().n8;
     stats[5] = err;
-    stats[6] = G;
+    stats[6] = vhp::lanes::sim_counts().c[4];  // strips that died (stopped sweeping: all zeros from there on)
     for (int k = 0; k < 4; ++k) stats[7 + k] = vhp::lanes::sim_counts().c[k];
   }
   return 0;

@@ -89,7 +89,8 @@ def lat_sweep(occ, sources, dtype=np.float64, W=12, policy=0, seed=1):
                                W, policy, seed, stats.ctypes.data)
     assert rc == 0, rc
     return out, dict(switches=int(stats[0]), progress=int(stats[1]), deadlock=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]),
-                     err=int(stats[5]), from_ring=int(stats[7]), from_global=int(stats[8]), too_far=int(stats[9]), overwritten=int(stats[10]))
+                     err=int(stats[5]), died=int(stats[6]), from_ring=int(stats[7]), from_global=int(stats[8]), too_far=int(stats[9]),
+                     overwritten=int(stats[10]))
 
 
 LAZY_FLUSH = 8   # order flag: the flushers of x-major strips run as late as the hand-off allows

@@ -93,3 +93,44 @@ def test_lat_kernel_bad_source_is_reported(vhp):
     c = _ctx(vhp, occ)
     with pytest.raises(Exception):
         c.sweep_batch(np.array([[5, 5], [64, 3]], np.int32))
+
+
+def _walled(nx, ny, seed, density):
+    rng = np.random.RandomState(seed)
+    occ = (rng.rand(ny, nx) >= density).astype(np.uint8)
+    for k in range(3):
+        occ[rng.randint(0, ny), :] = 0
+        occ[:, rng.randint(0, nx)] = 0
+    return occ
+
+
+@pytest.mark.parametrize("nx,ny,density", [(200, 163, 0.5), (328, 300, 0.2), (640, 603, 0.08), (1104, 72, 0.3), (72, 1100, 0.3), (130, 131, 0.95),
+                                           (1000, 1000, 0.05), (2048, 1500, 0.02)])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_lat_kernel_strips_that_die(vhp, oracle, nx, ny, density, dtype):
+    # maps where the light dies early: dead strips stop sweeping and store zeros; NaN-filled output, every cell against the oracle
+    import torch
+    occ = _walled(nx, ny, nx + ny, density)
+    src = _sources(occ, 5, nx * 3 + ny)
+    c = _ctx(vhp, occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    out = torch.full((len(src), ny, nx), float("nan"), dtype=tdt, device="cuda")
+    c.sweep_batch_device(d_src.data_ptr(), len(src), out.data_ptr(), dtype=vhp.F64 if dtype == "f64" else vhp.F32)
+    torch.cuda.synchronize()
+    assert c.last_sweep_kernel() == 4
+    got = out.cpu().numpy()
+    for k, (sx, sy) in enumerate(src):
+        want = oracle.sweep_full(occ, int(sx), int(sy))
+        _assert_same(got[k], want if dtype == "f64" else want.astype(np.float32), "%dx%d density %.2f %s, source (%d,%d)" % (nx, ny, density, dtype, sx, sy))
+
+
+def test_lat_kernel_maze_6_pivots(vhp, oracle):
+    occ = maps.maze_6()
+    res = oracle.solve(occ, (345, 391), (341, 10), 0.1, 1000)
+    piv = res["pivots"][: res["n_pivots"] + 1]
+    src = np.array([p for p in piv if occ[p[1], p[0]]], np.int32)[:24]
+    got = _ctx(vhp, occ).sweep_batch(src)
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "maze_6 pivot %d (%d,%d)" % (k, sx, sy))

@@ -71,3 +71,43 @@ def test_lat_sim_config3_map_three_sources(oracle):
     src = maps.free_sources(occ, 3, 11)
     _check(oracle, occ, src, "C3 map", W=12, policy=POOL_RANDOM | POOL_POINTS_RANDOM, seed=5)
     _check(oracle, occ, src, "C3 map, rounds", W=5, policy=POOL_GREEDY, seed=6)
+
+
+def _walled(nx, ny, seed, density):
+    """A map where light dies early: random cells blocked with the given density, plus a few full walls."""
+    rng = np.random.RandomState(seed)
+    occ = (rng.rand(ny, nx) >= density).astype(np.uint8)
+    for k in range(3):
+        occ[rng.randint(0, ny), :] = 0
+        occ[:, rng.randint(0, nx)] = 0
+    return occ
+
+
+@pytest.mark.parametrize("nx,ny,density", [(200, 163, 0.5), (328, 300, 0.2), (640, 603, 0.08), (1104, 72, 0.3), (72, 1100, 0.3), (130, 131, 0.95)])
+def test_lat_sim_strips_that_die(oracle, nx, ny, density):
+    """Maps where every strip's values turn +0.0 long before its march ends (a strip that is dead, below a dead strip, stops sweeping
+    and stores zeros): the fields must still equal the oracle's bit for bit, whatever the order the wavefronts run in."""
+    occ = _walled(nx, ny, nx + ny, density)
+    src = _sources(occ, 5, nx * 3 + ny)
+    for W, policy, dtype in SHAPES:
+        _check(oracle, occ, src, "%dx%d density %.2f W=%d policy=%d" % (nx, ny, density, W, policy), dtype, W=W, policy=policy, seed=ny + W)
+
+
+def test_lat_sim_source_in_a_box(oracle):
+    # the source walled in: everything outside the box is dark, and so is every strip that starts outside it
+    occ = np.ones((300, 328), np.uint8)
+    occ[100:141, 150] = 0; occ[100:141, 190] = 0; occ[100, 150:191] = 0; occ[140, 150:191] = 0
+    src = np.array([[170, 120], [151, 101], [189, 139], [10, 10]], np.int32)
+    st = _check(oracle, occ, src, "box", W=8, policy=POOL_RANDOM | POOL_POINTS_RANDOM, seed=3)
+    assert st["died"] > 0, st
+    _check(oracle, occ, src, "box, rounds", W=3, policy=POOL_BACKWARD | POOL_POINTS_ALWAYS, seed=4)
+
+
+def test_lat_sim_maze_6_pivots(oracle):
+    # the planner's map (690 x 402) from a few of the pivots of its reference run: the light is gone after ~60 steps of marches of ~550
+    occ = maps.maze_6()
+    src = np.array([[345, 391], [341, 10], [112, 201], [600, 60], [689, 401], [0, 0]], np.int32)
+    src = src[[bool(occ[y, x]) for x, y in src]]
+    st = _check(oracle, occ, src, "maze_6", W=8, policy=POOL_ROUND_ROBIN | POOL_POINTS_ALWAYS, seed=1)
+    assert st["died"] > 20 * len(src), st   # (most of the ~60 strips of a source die)
+    _check(oracle, occ, src, "maze_6", W=8, policy=POOL_BURSTS | POOL_POINTS_RANDOM, seed=2)

@@ -83,6 +83,8 @@ inline vd vfma(const vd& a, const vd& b, const vd& c) { vd r; for (int l = 0; l 
 
 // lane l <- lane l-1; lane 0 <- fill's lane 0
 inline vd shift_up(const vd& v, const vd& fill) { vd r; r.v[0] = fill.v[0]; for (int l = 1; l < kLanes; ++l) r.v[l] = v.v[l - 1]; return r; }
+// the value is +0.0, bit for bit
+inline vb is_pos_zero(const vd& v) { vb r; for (int l = 0; l < kLanes; ++l) { uint64_t u; std::memcpy(&u, &v.v[l], 8); r.v[l] = u == 0; } return r; }
 // lane l <- lane l+1; lane 63 <- fill's lane 63
 inline vd shift_down(const vd& v, const vd& fill) { vd r; r.v[kLanes - 1] = fill.v[kLanes - 1]; for (int l = 0; l + 1 < kLanes; ++l) r.v[l] = v.v[l + 1]; return r; }
 // lane l <- lane l+1; lane 63 <- lane 0
@@ -217,6 +219,8 @@ VHP_LANE_FN vd shift_up(vd v, vd fill) {
   hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// the value is +0.0, bit for bit
+VHP_LANE_FN vb is_pos_zero(vd v) { return __double_as_longlong(v) == 0; }
 // lane l <- lane l+1, lane 63 keeps `fill`'s lane 63: DPP wave_shl:1 (0x130)
 VHP_LANE_FN vd shift_down(vd v, vd fill) {
   int lo = __double2loint(v), hi = __double2hiint(v);

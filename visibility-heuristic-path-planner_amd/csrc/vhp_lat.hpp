@@ -15,6 +15,10 @@
 //   * the boundary values an x-major strip produces go to its ring once per window (out of the tile's last row);
 //   * y-major strips own one column per lane (64 columns), and the diagonal they start from comes from a wavefront of
 //     their workgroup that runs the two-term recurrence ahead of them into LDS (and then sweeps strips like the others).
+//   * a strip whose values are all +0.0, below a strip that has said the same, is DEAD: everything it would still compute is
+//     +0.0 (the stencil of zeros, times an occupancy), so it says so, stops sweeping and stores the zeros of its remaining
+//     cells.  In a maze that is most of a sweep: from the pivots of the reference's maze_6 run the light of the longest-lived
+//     octant is gone after 59 steps on average, of marches of 551.
 // The boundary protocol is the pool sweep's (vhp_pool.hpp Link: LDS ring of the writing wavefront first, tagged lines in
 // global memory as the durable copy), so a strip waits only for the strip below it and a wavefront sweeps its strips in
 // rising order: whatever the number of strips and wavefronts, the lowest unfinished strip can always run.
@@ -74,10 +78,11 @@ template <int D, int NB>
 struct Below {
   bool ring;   // the values came out of the writer's ring and are still to be checked against h1 / h2
   int h1, h2;
+  int hd;      // the strip below's word of death, read with the values: 0 alive, else 1 + the step from which all its values are +0.0
   vd v[NB];
 
   // cw = lowest coordinate of the window, c_first = its first-marched coordinate (cw marching up, cw + 15 marching down)
-  VHP_FN void from_ring(const Link<D>& lk, int cw, int c_first) {
+  VHP_FN void from_ring(const Link<D>& lk, const int* dead_below, int cw, int c_first) {
     h1 = lds_peek(lk.rd_hdr);
     sim_point();
     v[0] = lds_bcast(lk.rd_ring, (c_first - D) & (kRing - 1));
@@ -86,6 +91,7 @@ struct Below {
     for (int k = 1; k < NB; ++k) v[k] = lds_bcast(lk.rd_ring, rw + (D > 0 ? k - 1 : kLW - k));
     sim_point();
     h2 = lds_peek(lk.rd_hdr);
+    hd = lds_peek(dead_below);
     ring = true;
   }
   VHP_FN void from_slab(const double* bin, int cw, int c_first) {
@@ -95,14 +101,24 @@ struct Below {
     for (int k = 1; k < NB; ++k) v[k] = lds_bcast(bin, b + (D > 0 ? k - 1 : kLW - k));
     ring = false;
   }
-  VHP_FN void request(const Link<D>& lk, const double* bin, int cw, int c_first, int nb) {
-    if (lk.bin_block == nb) from_slab(bin, cw, c_first); else from_ring(lk, cw, c_first);
+  VHP_FN void request(const Link<D>& lk, const int* dead_below, const double* bin, int cw, int c_first, int nb) {
+    if (lk.bin_block == nb) { from_slab(bin, cw, c_first); hd = lds_peek(dead_below); } else from_ring(lk, dead_below, cw, c_first);
   }
+  // the step from which the strip below is dead, as of the last request (0x7fffffff: alive)
+  VHP_FN int dead_from() const { const int d = uniform(hd); return d != 0 ? d - 1 : 0x7fffffff; }
   // Makes sure the values are those of steps ia - 1 .. last_needed of the strip below: waits for the writer (asking again), or
   // takes the block from global memory if the writer is gone or too far ahead for its ring.
-  VHP_FN void accept(Link<D>& lk, const double* bin, int cw, int c_first, int ia, int last_needed, int nb) {
-    if (!ring) return;
+  VHP_FN void accept(Link<D>& lk, const int* dead_below, const double* bin, int cw, int c_first, int ia, int last_needed, int nb) {
     for (;;) {
+      // (a strip dies at the end of a window, and all strips cut their windows alike: a window is before the death of the strip
+      // below or after it, never across)
+      if (dead_from() <= ia - 1) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v[k] = vd(0.0);
+        ring = false;
+        return;
+      }
+      if (!ring) return;
       const int ha = uniform(h1), hb = uniform(h2);
       if ((ha >> 14) != lk.rd_tag) break;                                                            // the writer has finished that strip: its line is (being) stored
       if ((ha & 0x3fff) <= last_needed) {  // not swept yet
@@ -110,7 +126,7 @@ struct Below {
         lk.pp[7] += 1;
 #endif
         ready_backoff();
-        from_ring(lk, cw, c_first);
+        from_ring(lk, dead_below, cw, c_first);
         continue;
       }
       // (a writer is at most one window past what it has published: an entry of step s is safe while published - s <= kRingSafe)
@@ -143,6 +159,8 @@ struct LatX {
   int pf_blk;     // the block whose operands wait in ow_nx / rv_nx (requested when the current block began), or -1 ...
   int staged_blk; // ... and the block whose reciprocals were put into the slab last
   bool pf_wait;   // the loads of ow_nx / rv_nx have not been waited for yet
+  int* dead_mine;          // my word of death (0: alive; else 1 + the step from which every value of the strip is +0.0) ...
+  const int* dead_below;   // ... and the strip below's
   vi lane, tile_l, fl_t;
   vu32 fl_off;
   vd prev, jd;
@@ -176,6 +194,9 @@ struct LatX {
     i_last = g.ni - 1;
     below = p > 0;
     has_consumer = p + 1 < g.Px;
+    dead_mine = sh.owner(0) + p;
+    dead_below = sh.owner(0) + (p > 0 ? p - 1 : p);
+    nx.hd = 0;
     prev = vd(0.0);
     jd = to_f64(lane + j0);
     pf_blk = -1;
@@ -225,12 +246,51 @@ struct LatX {
     for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (xw & (2 * kBlock - 1)) + (DX > 0 ? k : kLW - 1 - k));
     if (below) {
 #ifndef VHP_DIAG_NOWAIT
-      nx.request(lk, bin, xw, DX > 0 ? xw : xw + kLW - 1, nb);
+      nx.request(lk, dead_below, bin, xw, DX > 0 ? xw : xw + kLW - 1, nb);
 #else
       nx.ring = false;
 #endif
     }
     nx_ia = ia;
+  }
+
+  // The 16 cells of every row of the window at xw (lowest step ia) leave: fa[u], fb[u] = the lane's pair of cells of the rows of
+  // group u (8 rows).  A cell (i', j) exists for j <= i' <= lim.
+  template <bool DIAG>
+  VHP_FN void store_window(int ia, int xw, int lim, const vd (&fa)[8], const vd (&fb)[8]) {
+#ifndef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
+    {
+      // Groups of 8 rows (u): whole (every cell a computed cell of a row of this strip: 16-byte stores), none (skipped), or cell
+      // by cell.  A cell (i', j) exists for j <= i' <= lim; the window's steps are ia .. ia + 15.
+      OutT* base = out + (long)(DY > 0 ? g.Y(j0) : g.Y(j0 + 7)) * (long)m.nx + xw;
+      const long base_step = (long)(8 * DY) * m.nx;
+      if (!DIAG && rows_here == kXRows && ia + kLW - 1 <= i_last) {  // past the diagonal, inside the march, all 64 rows: every group whole
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { g_store2(base, fl_off, fa[u], fb[u]); base += base_step; }
+      } else {
+      const int top = imin(ia + kLW - 1, lim) - j0;                      // rows up to j0 + top have cells in this window
+      const int u_end = top >= 0 ? imin(top / 8 + 1, (rows_here + 7) >> 3) : 0;
+      int u_full = 0;
+      if (ia + kLW - 1 <= lim && ia - j0 >= 7) u_full = imin((ia - j0 - 7) / 8 + 1, rows_here >> 3);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u < u_full) {
+          g_store2(base, fl_off, fa[u], fb[u]);
+        } else if (u < u_end) {
+          const vi cc = (lane & 7) * 2;
+          const vi s0 = DX > 0 ? cc + ia : (-cc) + (kLW - 1 + ia), s1 = s0 + DX;  // step indices of the pair's two cells
+          const vi r = (lane >> 3) + 8 * u;
+          const vb row_ok = r < rows_here;
+          const vi jr = r + j0;
+          const vb ok0 = row_ok && (s0 >= jr) && (s0 <= lim);
+          const vb ok1 = row_ok && (s1 >= jr) && (s1 <= lim);
+          g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, fa[u], fb[u]);
+        }
+        base += base_step;
+      }
+      }
+    }
+#endif
   }
 
   // One window: steps ia + k, k = 0 .. 15, at x = xw + (k marching up, 15 - k marching down).  DIAG: the strip's diagonal may fall
@@ -246,7 +306,7 @@ struct LatX {
     VHP_WP_T0(tw0);
     if (nx_ia != ia) request(ia, xw, nb);
     nx_ia = -0x7fffffff;
-    if (below) nx.accept(lk, bin, xw, DX > 0 ? xw : xw + kLW - 1, imax(ia, i_first), ia + k_hi, nb);
+    if (below) nx.accept(lk, dead_below, bin, xw, DX > 0 ? xw : xw + kLW - 1, imax(ia, i_first), ia + k_hi, nb);
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
     pin(nx_rr[kLW - 1]);
 #endif
@@ -305,39 +365,7 @@ struct LatX {
 #endif
     if (DIAG) VHP_WP_ADDP(lk.pp, 10, tw2);
     VHP_WP_T0(tw3);
-#ifndef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
-    {
-      // Groups of 8 rows (u): whole (every cell a computed cell of a row of this strip: 16-byte stores), none (skipped), or cell
-      // by cell.  A cell (i', j) exists for j <= i' <= lim; the window's steps are ia .. ia + 15.
-      OutT* base = out + (long)(DY > 0 ? g.Y(j0) : g.Y(j0 + 7)) * (long)m.nx + xw;
-      const long base_step = (long)(8 * DY) * m.nx;
-      if (!DIAG && rows_here == kXRows && ia + kLW - 1 <= i_last) {  // past the diagonal, inside the march, all 64 rows: every group whole
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { g_store2(base, fl_off, fa[u], fb[u]); base += base_step; }
-      } else {
-      const int top = imin(ia + kLW - 1, lim) - j0;                      // rows up to j0 + top have cells in this window
-      const int u_end = top >= 0 ? imin(top / 8 + 1, (rows_here + 7) >> 3) : 0;
-      int u_full = 0;
-      if (ia + kLW - 1 <= lim && ia - j0 >= 7) u_full = imin((ia - j0 - 7) / 8 + 1, rows_here >> 3);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (u < u_full) {
-          g_store2(base, fl_off, fa[u], fb[u]);
-        } else if (u < u_end) {
-          const vi cc = (lane & 7) * 2;
-          const vi s0 = DX > 0 ? cc + ia : (-cc) + (kLW - 1 + ia), s1 = s0 + DX;  // step indices of the pair's two cells
-          const vi r = (lane >> 3) + 8 * u;
-          const vb row_ok = r < rows_here;
-          const vi jr = r + j0;
-          const vb ok0 = row_ok && (s0 >= jr) && (s0 <= lim);
-          const vb ok1 = row_ok && (s1 >= jr) && (s1 <= lim);
-          g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, fa[u], fb[u]);
-        }
-        base += base_step;
-      }
-      }
-    }
-#endif
+    store_window<DIAG>(ia, xw, lim, fa, fb);
     if (DIAG) VHP_WP_ADDP(lk.pp, 11, tw3);
     if (has_consumer) {
       lds_store(lk.ring, (lane & (kLW - 1)) + (xw & (kRing - 1)), bv);  // (every lane: the four lanes of an entry write the same value)
@@ -361,9 +389,11 @@ struct LatX {
     enter_block(xw >> 6);
     // runs of windows of one kind (a loop of its own per kind, so that the operands requested for the next window stay where
     // they are from one window to the next); every window requests the next one's operands, whatever its kind and block
-    while (ia <= i_last) {
+    bool dead = false;
+    while (ia <= i_last && !dead) {
       if (ia <= j0 + kXRows - 1) {
         do {
+          if (dies_at(ia - 1)) { dead = true; break; }
           open_block(xw, ia);
           window<true>(ia, xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk, ia + kLW <= i_last);
           ia += kLW; xw += kLW * DX;
@@ -372,6 +402,7 @@ struct LatX {
         } while (ia <= i_last && ia <= j0 + kXRows - 1);
       } else {
         do {
+          if (dies_at(ia - 1)) { dead = true; break; }
           open_block(xw, ia);
           window<false>(ia, xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk, ia + kLW <= i_last);
           ia += kLW; xw += kLW * DX;
@@ -380,7 +411,34 @@ struct LatX {
         } while (ia <= i_last);
       }
     }
-    if (has_consumer) lk.store_block(g.nbx(i_last), blk);
+    if (has_consumer) lk.store_block(imax(g.nbx(imin(imax(ia - 1, 0), i_last)), 0), blk);
+    if (dead) {
+      // Everything from step ia - 1 on is +0.0, in this strip and below it: say so (the word of death first, then the progress
+      // word that lets the strip above past its gate), then store the zeros of what is left of the march.
+      lds_publish(dead_mine, ia);
+      lds_publish(lk.prog, 0x3fff);
+      sim_progress();
+      sim_count(4);
+      vd z[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = vd(0.0);
+      for (; ia <= i_last; ia += kLW, xw += kLW * DX) {
+        store_window<true>(ia, xw, (DX < 0 && xw == 0) ? i_last + 1 : i_last, z, z);
+        sim_point();
+      }
+    }
+  }
+  // Is the strip dead from step ie on?  (Asked between windows, ie = the last step swept.)  Its rows that are switched on hold
+  // +0.0 -- the others are switched on by the row below them, with its value -- and the strip below has been dead since ie or
+  // before: then all this strip will ever compute is the stencil of zeros.  (The strip below's word is as old as the last
+  // request: a window late at most.)
+  VHP_FN bool dies_at(int ie) {
+#ifdef VHP_DIAG_NODEATH  // diagnostic builds only: what the early exits are worth
+    return false;
+#endif
+    if (ie < 0) return false;
+    if (below && nx.dead_from() > ie) return false;
+    return wave_all(!((lane < rows_here) && ((lane + j0) <= ie)) || is_pos_zero(prev));
   }
 };
 
@@ -413,6 +471,8 @@ struct LatY {
   bool below, has_consumer, interior;
   int blk, pf_blk, staged_blk;  // (as in LatX)
   bool pf_wait;
+  int* dead_mine;
+  const int* dead_below;
   vi lane, ic;
   vi first_j;     // the first step at which the lane stores its cell of the row (0x7fffffff: never)
   vb zero_lane;
@@ -438,6 +498,9 @@ struct LatY {
     j_last = g.nj - 1;
     below = q > 0;
     has_consumer = q + 1 < n_strips;
+    dead_mine = sh.owner(0) + q;
+    dead_below = sh.owner(0) + (q > 0 ? q - 1 : q);
+    nx.hd = 0;
     ic = REV ? (-lane) + (i0 + kLanes - 1) : lane + i0;
     zero_lane = (ic == g.ni) && (DX < 0);
     // a column stores from its seed on (i <= j); the lane of "column ni" stores its zero with every row that stores x = 1
@@ -490,7 +553,7 @@ struct LatY {
     for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (yw & (2 * kBlock - 1)) + (DY > 0 ? k : kLW - 1 - k));
     if (below) {
 #ifndef VHP_DIAG_NOWAIT
-      nx.request(lk, bin, yw, DY > 0 ? yw : yw + kLW - 1, nb);
+      nx.request(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, nb);
 #else
       nx.ring = false;
 #endif
@@ -506,7 +569,7 @@ struct LatY {
     const int k_hi = imin(kLW - 1, j_last - ja);
     if (nx_ja != ja) request(ja, yw, nb);
     nx_ja = -0x7fffffff;
-    if (below) nx.accept(lk, bin, yw, DY > 0 ? yw : yw + kLW - 1, imax(ja, j_first), ja + k_hi - 1, nb);
+    if (below) nx.accept(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, imax(ja, j_first), ja + k_hi - 1, nb);
     const vu32 hs = half_shifted(ow, yw & 63, yw & 31);
     double* wbase = has_consumer ? lk.ring + (yw & (kRing - 1)) : dummy;
     const vi widx = select(lane == kEdge, vi(0), vi((int)(dummy - wbase)));
@@ -556,10 +619,12 @@ struct LatY {
     int ja = DY > 0 ? yw - g.sy : g.sy - (yw + kLW - 1);
     enter_block(yw >> 6);
     // runs of windows of one kind (see LatX::run)
-    while (ja <= j_last) {
+    bool dead = false;
+    while (ja <= j_last && !dead) {
       const int kind = kind_of(ja);
       if (kind == 0) {
         do {
+          if (dies_at(ja - 1)) { dead = true; break; }
           open_block(yw, ja);
           window<true, true>(ja, yw, DY > 0 ? blk - g.by0 : g.by0 - blk, ja + kLW <= j_last);
           ja += kLW; yw += kLW * DY;
@@ -568,6 +633,7 @@ struct LatY {
         } while (ja <= j_last && kind_of(ja) == 0);
       } else if (kind == 1) {
         do {
+          if (dies_at(ja - 1)) { dead = true; break; }
           open_block(yw, ja);
           window<false, true>(ja, yw, DY > 0 ? blk - g.by0 : g.by0 - blk, ja + kLW <= j_last);
           ja += kLW; yw += kLW * DY;
@@ -576,6 +642,7 @@ struct LatY {
         } while (ja <= j_last && kind_of(ja) == 1);
       } else {
         do {
+          if (dies_at(ja - 1)) { dead = true; break; }
           open_block(yw, ja);
           window<false, false>(ja, yw, DY > 0 ? blk - g.by0 : g.by0 - blk, ja + kLW <= j_last);
           ja += kLW; yw += kLW * DY;
@@ -584,7 +651,30 @@ struct LatY {
         } while (ja <= j_last && kind_of(ja) == 2);
       }
     }
-    if (has_consumer) lk.store_block(g.nby(j_last), blk);
+    if (has_consumer) lk.store_block(imax(g.nby(imin(imax(ja - 1, 0), j_last)), 0), blk);
+    if (dead) {  // (see LatX::run)
+      lds_publish(dead_mine, ja);
+      lds_publish(lk.prog, 0x3fff);
+      sim_progress();
+      sim_count(4);
+      const long rowstep = (long)DY * m.nx;
+      OutT* row = out + (long)g.Y(ja) * (long)m.nx;
+      for (int j = ja; j <= j_last; ++j) {
+        g_store1_if(first_j <= j, row, xoff, vd(0.0));
+        row += rowstep;
+        if (((j - ja) & (kLW - 1)) == kLW - 1) sim_point();
+      }
+    }
+  }
+  // Is the strip dead from step je on?  Its columns that have been seeded hold +0.0, the seeds of the others are +0.0, and the
+  // strip below has been dead since je or before.
+  VHP_FN bool dies_at(int je) {
+#ifdef VHP_DIAG_NODEATH
+    return false;
+#endif
+    if (je < 0) return false;
+    if (below && nx.dead_from() > je) return false;
+    return wave_all((first_j == 0x7fffffff) || is_pos_zero(select(ic <= je, prev, dg)));
   }
 };
 
@@ -602,12 +692,14 @@ struct LatDiag {
   int k;
   vi lane;
   vd dprev, sprev;
+  bool zero_rest;  // diag(k-1) and sub(k-1) are +0.0: so is everything after them
 
   VHP_FN void init(const Map& m_, int sx, int sy, double* diag_lds) {
     m = m_;
     g.init(m.nx, m.ny, sx, sy);
     diag = diag_lds;
     lane = lane_id();
+    zero_rest = false;
     k = 0;
     dprev = vd(0.0);
     sprev = vd(0.0);
@@ -616,6 +708,12 @@ struct LatDiag {
   // entries k .. k+63; returns the number of entries ready afterwards
   VHP_FN int run_chunk() {
     const int k0 = k, k1 = imin(k0 + kBlock, g.rows_total);
+    if (zero_rest) {
+      wave_sync();
+      lds_store_if(lane < (k1 - k0), diag, lane + k0, vd(0.0));
+      k = k1;
+      return k1;
+    }
     const vi kk = vmin(lane + k0, g.rows_total - 1);
     const vi x = kk * DX + g.sx;
     const vi ya = vmax(kk - 1, 0) * DY + g.sy, yb = kk * DY + g.sy;
@@ -642,6 +740,9 @@ struct LatDiag {
     wave_sync();
     lds_store_if(lane < (k1 - k0), diag, lane + k0, acc);
     k = k1;
+#ifndef VHP_DIAG_NODEATH
+    zero_rest = k1 > 0 && wave_all(is_pos_zero(dprev) && is_pos_zero(sprev));
+#endif
     return k1;
   }
 };
