@@ -33,7 +33,8 @@ namespace vhp {
 namespace pool {
 
 constexpr int kLW = 16;      // steps per window
-constexpr int kLatDummy = 16;  // doubles of a wavefront's dummy slots (Layout::dummies holds 16 per wavefront)
+constexpr int kLatDummy = 16;
+constexpr int kDiagZero = 7;   // (a free word of the context's head, vhp_pool.hpp kCtxHead = 8)  // doubles of a wavefront's dummy slots (Layout::dummies holds 16 per wavefront)
 
 template <typename OutT>
 struct LatArgs {
@@ -139,6 +140,34 @@ struct Below {
     from_slab(bin, cw, c_first);
   }
 };
+
+// +0.0 into the cells [x0, x1] x [y0, y1] of a field of even pitch nx (what a dead strip leaves behind): pairs of cells as 16-byte
+// stores, two rows of 64 columns per instruction; an odd first or last column as 8-byte stores, 64 rows per instruction.
+template <typename OutT>
+VHP_FN void lat_zero_rect(OutT* out, int nx, int x0, int x1, int y0, int y1) {
+  if (x0 > x1 || y0 > y1) return;
+  constexpr int CB = sizeof(OutT);
+  const vi lane = lane_id();
+  const int xe = x0 + (x0 & 1);            // the first even column: (y * nx + x) is even there, whatever the row
+  const int np = (x1 + 1 - xe) >> 1;       // whole pairs
+  const vi pi = lane & 31, ro = lane >> 5;
+  for (int pc = 0; pc < np; pc += 32) {
+    const vb col_ok = (pi + pc) < np;
+    const vu32 off = to_u32((ro * nx + (pi + pc) * 2 + xe) * CB);
+    OutT* row = out + (long)y0 * (long)nx;
+    for (int y = y0; y <= y1; y += 2) {
+      const vb ok = col_ok && ((ro + y) <= y1);
+      g_store2_if(ok, vb(false), vb(false), row, off, vd(0.0), vd(0.0));
+      row += 2 * (long)nx;
+      if (((y - y0) & 62) == 62) sim_point();
+    }
+  }
+  for (int e = 0; e < 2; ++e) {
+    const int x = e == 0 ? x0 : x1;
+    if (e == 0 ? (x0 & 1) == 0 : ((x1 & 1) != 0 || (x1 == x0 && (x0 & 1) != 0))) continue;  // (part of a pair; or the same odd column twice)
+    for (int y = y0; y <= y1; y += kLanes) g_store_scalar_if((lane + y) <= y1, out, (lane + y) * nx + x, OutT(0));
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // x-major strip p of a unit: rows j = 64 p + lane; steps i = 64 p .. ni - 1; cells (i, j), j <= i.
@@ -386,10 +415,11 @@ struct LatX {
   VHP_FN void run() {
     int xw = g.X(i_first) & ~(kLW - 1);
     int ia = DX > 0 ? xw - g.sx : g.sx - (xw + kLW - 1);
+    if (below) nx.hd = lds_poll(dead_below);  // (a strip that starts below a dead strip need not sweep a window to find out)
     enter_block(xw >> 6);
     // runs of windows of one kind (a loop of its own per kind, so that the operands requested for the next window stay where
     // they are from one window to the next); every window requests the next one's operands, whatever its kind and block
-    bool dead = false;
+    bool dead = below && lds_poll(dead_mine) != 0;  // (a strip below died before this one could start, and said so for it)
     while (ia <= i_last && !dead) {
       if (ia <= j0 + kXRows - 1) {
         do {
@@ -417,16 +447,39 @@ struct LatX {
       // word that lets the strip above past its gate), then store the zeros of what is left of the march.
       lds_publish(dead_mine, ia);
       lds_publish(lk.prog, 0x3fff);
+      announce_death(ia - 1, g.Px);
       sim_progress();
       sim_count(4);
       vd z[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) z[u] = vd(0.0);
-      for (; ia <= i_last; ia += kLW, xw += kLW * DX) {
+      // the windows that the strip's diagonal runs through cell by cell as usual; what lies past it is a rectangle
+      for (; ia <= i_last && ia <= j0 + kXRows - 1; ia += kLW, xw += kLW * DX) {
         store_window<true>(ia, xw, (DX < 0 && xw == 0) ? i_last + 1 : i_last, z, z);
         sim_point();
       }
+      if (ia <= i_last) {
+        const int xa = DX > 0 ? xw : 0, xb = DX > 0 ? g.X(i_last) : xw + kLW - 1;  // (marching down, column 0 -- never swept, SURVEY Q2 -- with it)
+        const int ya = DY > 0 ? g.Y(j0) : g.Y(j0 + rows_here - 1), yb = DY > 0 ? g.Y(j0 + rows_here - 1) : g.Y(j0);
+        lat_zero_rect(out, m.nx, xa, xb, ya, yb);
+      }
     }
+  }
+  // If the strip above cannot have started yet (its first step lies past s + 1: this strip has not got there), neither has any
+  // strip above that one, and all of them are dead from their first step on: they are told at once, instead of one waking the
+  // next.  (A strip above that HAS started may still hold light of its own, and so may every strip above it.)
+  VHP_FN void announce_death(int s, int n_strips) {
+    if ((p + 1) * kXRows <= s + 1) return;
+    int* dead_base = dead_mine - p;
+    int* prog_base = lk.prog - p;
+    for (int q0 = p + 1; q0 < n_strips; q0 += kLanes) {
+      const vi q = lane + q0;
+      const vb up = q < n_strips;
+      lds_store_i_if(up, dead_base, q, s + 1);
+      lds_acquire();
+      lds_store_i_if(up, prog_base, q, 0x3fff);
+    }
+    lds_acquire();
   }
   // Is the strip dead from step ie on?  (Asked between windows, ie = the last step swept.)  Its rows that are switched on hold
   // +0.0 -- the others are switched on by the row below them, with its value -- and the strip below has been dead since ie or
@@ -467,12 +520,13 @@ struct LatY {
   double* bin;
   double* dummy;
   Link<DY> lk;
-  int q, i0, j_first, j_last;
+  int q, n_q, i0, j_first, j_last;
   bool below, has_consumer, interior;
   int blk, pf_blk, staged_blk;  // (as in LatX)
   bool pf_wait;
   int* dead_mine;
   const int* dead_below;
+  const int* diag_zero;  // the diagonal's word: 0 unknown, else 1 + the entry from which all of it is +0.0
   vi lane, ic;
   vi first_j;     // the first step at which the lane stores its cell of the row (0x7fffffff: never)
   vb zero_lane;
@@ -493,6 +547,7 @@ struct LatY {
     dummy = sh.lds + sh.L.dummies + w * kLatDummy;
     lane = lane_id();
     q = q_;
+    n_q = n_strips;
     i0 = kBlock * q;
     j_first = i0;
     j_last = g.nj - 1;
@@ -500,6 +555,7 @@ struct LatY {
     has_consumer = q + 1 < n_strips;
     dead_mine = sh.owner(0) + q;
     dead_below = sh.owner(0) + (q > 0 ? q - 1 : q);
+    diag_zero = sh.ctx(0) + kDiagZero;
     nx.hd = 0;
     ic = REV ? (-lane) + (i0 + kLanes - 1) : lane + i0;
     zero_lane = (ic == g.ni) && (DX < 0);
@@ -617,9 +673,10 @@ struct LatY {
   VHP_FN void run() {
     int yw = g.Y(j_first) & ~(kLW - 1);
     int ja = DY > 0 ? yw - g.sy : g.sy - (yw + kLW - 1);
+    if (below) nx.hd = lds_poll(dead_below);
     enter_block(yw >> 6);
     // runs of windows of one kind (see LatX::run)
-    bool dead = false;
+    bool dead = below && lds_poll(dead_mine) != 0;
     while (ja <= j_last && !dead) {
       const int kind = kind_of(ja);
       if (kind == 0) {
@@ -655,16 +712,41 @@ struct LatY {
     if (dead) {  // (see LatX::run)
       lds_publish(dead_mine, ja);
       lds_publish(lk.prog, 0x3fff);
+      announce_death(ja - 1);
       sim_progress();
       sim_count(4);
       const long rowstep = (long)DY * m.nx;
       OutT* row = out + (long)g.Y(ja) * (long)m.nx;
-      for (int j = ja; j <= j_last; ++j) {
+      int j = ja;
+      // row by row while columns are still being seeded; below that every column of the strip is stored in every row: a rectangle
+      for (; j <= j_last && j <= i0 + kBlock - 1; ++j) {
         g_store1_if(first_j <= j, row, xoff, vd(0.0));
         row += rowstep;
         if (((j - ja) & (kLW - 1)) == kLW - 1) sim_point();
       }
+      if (j <= j_last) {
+        const int c_hi = imin(i0 + kBlock - 1, DX < 0 ? g.ni : g.ni - 1);  // the strip's last column (marching down: "column ni", x = 0, if it is here)
+        const int xa = DX > 0 ? g.X(i0) : g.sx - c_hi, xb = DX > 0 ? g.X(c_hi) : g.X(i0);
+        const int ya = DY > 0 ? g.Y(j) : g.Y(j_last), yb = DY > 0 ? g.Y(j_last) : g.Y(j);
+        lat_zero_rect(out, m.nx, xa, xb, ya, yb);
+      }
     }
+  }
+  // (see LatX::announce_death; a y-major strip is seeded by the diagonal as well: only strips whose every seed is +0.0 -- the
+  // diagonal's wavefront says from where on, if it has found out -- are dead before they start)
+  VHP_FN void announce_death(int s) {
+    int* dead_base = dead_mine - q;
+    int* prog_base = lk.prog - q;
+    const int dz = lds_poll(diag_zero);
+    if (dz == 0 || (q + 1) * kBlock <= s + 1 || (q + 1) * kBlock < dz - 1) return;
+    for (int q0 = q + 1; q0 < n_q; q0 += kLanes) {
+      const vi qq = lane + q0;
+      const vb up = qq < n_q;
+      lds_store_i_if(up, dead_base, qq, s + 1);
+      lds_acquire();
+      lds_store_i_if(up, prog_base, qq, 0x3fff);
+    }
+    lds_acquire();
   }
   // Is the strip dead from step je on?  Its columns that have been seeded hold +0.0, the seeds of the others are +0.0, and the
   // strip below has been dead since je or before.
@@ -692,7 +774,8 @@ struct LatDiag {
   int k;
   vi lane;
   vd dprev, sprev;
-  bool zero_rest;  // diag(k-1) and sub(k-1) are +0.0: so is everything after them
+  bool zero_rest;  // diag(k-1) and sub(k-1) are +0.0: so is everything after them ...
+  int zero_from;   // ... i.e. the entries from this one on
 
   VHP_FN void init(const Map& m_, int sx, int sy, double* diag_lds) {
     m = m_;
@@ -700,6 +783,7 @@ struct LatDiag {
     diag = diag_lds;
     lane = lane_id();
     zero_rest = false;
+    zero_from = 0;
     k = 0;
     dprev = vd(0.0);
     sprev = vd(0.0);
@@ -741,7 +825,10 @@ struct LatDiag {
     lds_store_if(lane < (k1 - k0), diag, lane + k0, acc);
     k = k1;
 #ifndef VHP_DIAG_NODEATH
-    zero_rest = k1 > 0 && wave_all(is_pos_zero(dprev) && is_pos_zero(sprev));
+    if (!zero_rest && k1 > 0 && wave_all(is_pos_zero(dprev) && is_pos_zero(sprev))) {
+      zero_rest = true;
+      zero_from = k1;
+    }
 #endif
     return k1;
   }
@@ -820,6 +907,7 @@ struct LatWorker {
       VHP_LAT_STAMP(unit, 47, 0);
       while (!dt.done()) {
         const int ready = dt.run_chunk();
+        if (dt.zero_rest) lds_publish(cx + kDiagZero, dt.zero_from + 1);
         lds_publish(cx + kDiagReady, ready);
         if (ready <= kBlock) VHP_LAT_STAMP(unit, 47, 1);
         if (ready <= 2 * kBlock) VHP_LAT_STAMP(unit, 47, 2);
