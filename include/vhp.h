@@ -180,13 +180,13 @@ int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n);
  * (0 / -1 = automatic, the default).  Keys: "rows_per_lane" (1, 2, 4), "strips" (1..8 wavefront
  * strips per octant), "multi_round" (1 = force the multi-round build), "slide" (0 / 1: y-major
  * column grid slid onto 128-byte lines), "pack" (1 = pack short quadrants), "kernel" (1 = front
- * sweep, 2 = streaming sweep, 3 = pool sweep), "stream_tile_slots" (2, 3, 4, 6, 8: staging-tile
+ * sweep, 2 = streaming sweep, 3 = pool sweep, 4 = latency sweep), "stream_tile_slots" (2, 3, 4, 6, 8: staging-tile
  * depth of the streaming sweep), "pool_contexts" (1..11: units a workgroup of the pool sweep holds
  * at once).  The results never depend on these; only the schedule does. */
 int vhp_set_option(vhp_ctx* ctx, const char* key, long long value);
 /* Which kernel the last batch sweep of this context launched: 1 = front sweep (vhp_sweep_fronts),
- * 2 = streaming sweep (vhp_stream_sweep), 3 = pool sweep (vhp_pool_sweep), 0 = none yet.  For
- * benchmarks and profiles. */
+ * 2 = streaming sweep (vhp_stream_sweep), 3 = pool sweep (vhp_pool_sweep), 4 = latency sweep
+ * (vhp_lat_sweep), 0 = none yet.  For benchmarks and profiles. */
 int vhp_last_sweep_kernel(const vhp_ctx* ctx);
 
 /* Library / build identification: "vhp-hip <version> gfx950". */

@@ -6,7 +6,8 @@
 #   2. the command under rocprofv3 --kernel-trace --stats  -> <tag>_kernel_stats_<w>.csv + the JSON line of that same run
 #   3. the command under --pmc FETCH_SIZE / --pmc WRITE_SIZE (one pass each, no trace domain besides kernel-trace; the
 #      program directly after `--`)                        -> <tag>_pmc_*_<w>.csv and traffic_<w>_f64_<kernel>.json
-#   4. the other workloads (fp32, C2, C4 planner, each batch kernel forced on C3) as plain bench lines
+#   4. the other workloads (fp32, C2, C4 planner, each batch kernel forced on C3) as plain bench lines; C2 and C4 also under
+#      rocprofv3 --kernel-trace --stats; the latency sweep against the front sweep by grid side and source count
 tag=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles_$tag
@@ -32,5 +33,13 @@ for k in 1 2 3; do python3 $R/bench.py $DRV --kernel $k > $O/${tag}_bench_c3_ker
 python3 $R/bench.py --steps 300 --no-cpu-baseline > $O/${tag}_bench_c3_300steps.json 2>/dev/null
 python3 $R/bench.py --dtype f32 --steps 100 --no-cpu-baseline > $O/${tag}_bench_c3_f32.json 2>/dev/null
 python3 $R/bench.py --workload c2 --steps 300 --no-cpu-baseline > $O/${tag}_bench_c2.json 2>/dev/null
-python3 $R/bench.py --workload c4 --steps 5 --warmup 1 > $O/${tag}_bench_c4_planner.json 2>/dev/null
+python3 $R/bench.py --workload c2 --steps 300 --no-cpu-baseline --kernel 1 > $O/${tag}_bench_c2_kernel1.json 2>/dev/null
+python3 $R/bench.py --workload c4 --steps 20 --warmup 2 > $O/${tag}_bench_c4_planner.json 2>/dev/null
+# the latency cases under rocprofv3 --kernel-trace --stats (C2: vhp_lat_sweep; C4: vhp_lat_sweep + vhp_planner_epilogue)
+for w in c2 c4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o kt -- python3 $R/bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline > $O/${tag}_bench_${w}_same_run_as_kernel_stats.json 2> $O/kt_$w.err
+  find $O/kt_$w -name "*kernel_stats.csv" -exec cp {} $O/${tag}_kernel_stats_${w}.csv \;
+  rm -rf $O/kt_$w
+done
+python3 $R/tools/lat_vs_front.py 256 512 690 1000 1536 2048 > $O/${tag}_lat_vs_front.txt 2>/dev/null
 ls -la $O
