@@ -187,7 +187,7 @@ def bench_planner(args):
         "config": {"workload": "C4: maze_6, start {345,391}, end {341,10}, visibilityThreshold 0.1: %d pivots per solve, results device-resident" % n_piv,
                    "us_per_pivot_device_loop": round(loop_ms * 1e3 / n_piv, 2), "us_per_pivot_wall": round(elapsed / args.steps * 1e6 / n_piv, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": None, "kernel": "vhp_planner_sweep + vhp_planner_epilogue", "kernel_ms": round(loop_ms, 4),
+                     "traffic": None, "kernel": "sweep of the iteration (vhp_lat_sweep where a batch of one takes it, else vhp_planner_sweep) + vhp_planner_epilogue", "kernel_ms": round(loop_ms, 4),
                      "note": "latency case by construction: one source per pivot, pivots are sequential (SURVEY 8d expectation management)"},
     }
     # the speculative planner (vhp_planner_solve_speculative): exact mode (same pivots, cached fields) and fast mode (all k
