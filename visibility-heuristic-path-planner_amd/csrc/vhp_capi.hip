@@ -261,14 +261,15 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
 // kernel time in us, front / latency sweep): one source at 256^2 33 / 28, 512^2 70 / 55, 690^2 94 / 67, 1000^2 132 / 96, 1536^2
 // 291 / 176, 2048^2 380 / 244; 8 sources 65 / 47, 123 / 88, 176 / 130, 244 / 177, 607 / 362, 844 / 559; 32 sources 67 / 48, 138 / 92,
 // 178 / 131, 296 / 196, 644 / 377, 866 / 604; 64 sources (two workgroups per CU wanted, one fits) 68 / 85, 139 / 153, 187 / 213,
-// 300 / 317, 664 / 559, 999 / 1015.  So: every launch whose octants have a CU each.
+// 300 / 317, 664 / 559, 999 / 1015; 3072^2: 1 / 8 / 32 sources 649 / 413, 1661 / 1171, 1771 / 1351; 4096^2: 8 / 32 sources 2543 / 1800,
+// 2886 / 2554.  So: every launch whose octants have a CU each.
 bool use_lat_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel != 0 && c->opt_kernel != 4) return false;
   if (!vhp::lat_supported(c->nx, c->ny)) return false;
   if (c->opt_kernel == 4) return n_src <= 64;
   // (a caller that sets a launch shape of the front sweep is asking for the front sweep)
   if (c->opt_rows_per_lane || c->opt_strips || c->opt_multi || c->opt_slide >= 0 || c->opt_pack) return false;
-  return 8 * n_src <= c->n_cus && std::max(c->nx, c->ny) <= 2048;
+  return 8 * n_src <= c->n_cus;
 }
 
 bool use_pool_kernel(const vhp_ctx* c, int n_src) {
