@@ -1,7 +1,7 @@
 // vhp_diag.h -- every diagnostic build switch of the kernels, in one place.
 //
 // The product is built with NONE of these defined, and then this header defines empty macros only.  tools/build_exp.sh
-// builds exp/libvhp_<NAME>.so with one of them for tools/ab_libs.py, tools/stream_timeline.py and tools/pool_timeline.py.
+// builds exp/libvhp_<NAME>.so with one of them for tools/ab_libs.py, tools/stream_timeline.py, tools/pool_timeline.py and tools/lat_timeline.py.
 // Several produce WRONG results on purpose (they take a cost away to measure it); none is reachable from the C ABI.
 //
 //   VHP_DIAG_NOSTORE    all the work, none of the field stores                        (every batch kernel)
@@ -11,7 +11,9 @@
 //   VHP_DIAG_DROP_XPRED / _YPRED / _XRAGGED   the predicated x-major flushes / y-major stores / ragged x-major rows only (pool sweep)
 //   VHP_DIAG_NOWAIT     no strip waits for the strip below or for its seeds: the launch's stores at full speed (pool sweep)
 //   VHP_DIAG_WGTIME     per-workgroup times and per-wavefront cycle accounts             (streaming sweep)
-//   VHP_DIAG_POOLPROF   per-wavefront cycle accounts, per-unit install / finish times    (pool sweep)
+//   VHP_DIAG_POOLPROF   per-wavefront cycle accounts, per-unit install / finish times    (pool sweep); per-strip stamps (latency sweep)
+//   VHP_DIAG_WINPROF    cycle accounts inside the x-major windows (with POOLPROF; ~250 cycles per probe)   (latency sweep)
+//   VHP_DIAG_NODEATH    no strip ever declares itself dead: what the early exits are worth                  (latency sweep)
 //
 // Experiments that are over were deleted together with their switches (round 3): FLATPOLL, MASKPUB, HEAVYSYNC, NOLOAD,
 // YDRAIN, NOREFILL, SLOTTIME, SMALLSTORE, NOSTORE_X/_Y of the front sweep, PRIO, the back-off lengths as -D values.
