@@ -8,13 +8,14 @@
 //   * ONE workgroup per unit (octant), strips bound to wavefronts statically (strip p to wavefront p mod W);
 //   * windows of 16 steps, aligned to 16 cells of the marching coordinate: an x-major window is 16 adjacent cells of every
 //     row, so the tile is 16 columns, flushed by its own wavefront right after the window -- no pending lines, no line
-//     phases; heads, tails and ragged ends are the same window with some steps switched off, not a step-by-step path;
+//     phases; heads, tails and ragged ends are the same window (steps that do not exist leave garbage where it does no harm),
+//     not a step-by-step path;
 //   * the operands of window n+1 (the boundary values of the strip below STRAIGHT OUT OF ITS WRITER'S RING, the writer's
 //     header read before and after them; the reciprocals of the step indices) are requested while window n's cells leave,
 //     and checked when they are needed;
 //   * the boundary values an x-major strip produces go to its ring once per window (out of the tile's last row);
 //   * y-major strips own one column per lane (64 columns), and the diagonal they start from comes from a wavefront of
-//     their workgroup that runs the two-term recurrence ahead of them into LDS (and then sweeps strips like the others).
+//     their workgroup that runs the two-term recurrence ahead of them into LDS (and then sweeps strips like the others);
 //   * a strip whose values are all +0.0, below a strip that has said the same, is DEAD: everything it would still compute is
 //     +0.0 (the stencil of zeros, times an occupancy), so it says so, stops sweeping and stores the zeros of its remaining
 //     cells.  In a maze that is most of a sweep: from the pivots of the reference's maze_6 run the light of the longest-lived
@@ -32,9 +33,9 @@
 namespace vhp {
 namespace pool {
 
-constexpr int kLW = 16;      // steps per window
-constexpr int kLatDummy = 16;
-constexpr int kDiagZero = 7;   // (a free word of the context's head, vhp_pool.hpp kCtxHead = 8)  // doubles of a wavefront's dummy slots (Layout::dummies holds 16 per wavefront)
+constexpr int kLW = 16;        // steps per window
+constexpr int kLatDummy = 16;  // doubles of a wavefront's dummy slots (Layout::dummies holds 16 per wavefront)
+constexpr int kDiagZero = 7;   // the diagonal's "all +0.0 from here" word: a free word of the context's head (vhp_pool.hpp kCtxHead = 8)
 
 template <typename OutT>
 struct LatArgs {
