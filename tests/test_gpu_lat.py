@@ -134,3 +134,17 @@ def test_lat_kernel_maze_6_pivots(vhp, oracle):
     got = _ctx(vhp, occ).sweep_batch(src)
     for k, (sx, sy) in enumerate(src):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "maze_6 pivot %d (%d,%d)" % (k, sx, sy))
+
+
+def test_lat_kernel_thirty_two_sources_by_default(vhp, oracle):
+    # the largest launch the library gives to the latency sweep by itself: 32 sources = 256 workgroups, an octant per CU
+    occ = maps.random_rect_map(328, 300, 30, 3, 40, 3, 40, 77)
+    src = maps.free_sources(occ, 32, 5)
+    c = vhp.Context(0)
+    c.set_map(occ)
+    got = c.sweep_batch(src)
+    assert c.last_sweep_kernel() == 4
+    for k, (sx, sy) in enumerate(src):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "32 sources, source %d (%d,%d)" % (k, sx, sy))
+    got = c.sweep_batch(np.concatenate([src, src[:1]]))   # 33: the front sweep again
+    assert c.last_sweep_kernel() == 1
