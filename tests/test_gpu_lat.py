@@ -148,3 +148,24 @@ def test_lat_kernel_thirty_two_sources_by_default(vhp, oracle):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "32 sources, source %d (%d,%d)" % (k, sx, sy))
     got = c.sweep_batch(np.concatenate([src, src[:1]]))   # 33: the front sweep again
     assert c.last_sweep_kernel() == 1
+
+
+def test_lat_kernel_random_campaign(vhp, oracle):
+    # a fixed pseudo-random campaign: sizes, obstacle kinds (rectangles / salt of three densities with walls), source counts
+    rng = np.random.RandomState(20261003)
+    for case in range(60):
+        nx = int(rng.choice([8, 16, 40, 72, 104, 130, 200, 264, 328, 520, 690, 1000]))
+        ny = int(rng.randint(1, 900))
+        if rng.randint(0, 3) == 0:
+            occ = maps.random_rect_map(nx, ny, int(rng.randint(1, 40)), 1, max(nx // 6, 2), 1, max(ny // 6, 2), int(rng.randint(1, 1 << 20)))
+        else:
+            occ = (rng.rand(ny, nx) >= [0.03, 0.15, 0.5][rng.randint(0, 3)]).astype(np.uint8)
+            for k in range(rng.randint(0, 4)):
+                occ[rng.randint(0, ny), :] = 0
+                occ[:, rng.randint(0, nx)] = 0
+        ns = int(rng.randint(1, 9))
+        src = np.stack([rng.randint(0, nx, ns), rng.randint(0, ny, ns)], 1).astype(np.int32)
+        occ[src[:, 1], src[:, 0]] = 1
+        got = _ctx(vhp, occ).sweep_batch(src)
+        for k, (sx, sy) in enumerate(src):
+            _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "case %d: %dx%d, source (%d,%d)" % (case, nx, ny, sx, sy))
