@@ -156,14 +156,15 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
     // neither united, labelled nor pushed
     if ((x == 0 && sx > 0) || (y == 0 && sy > 0)) continue;
     const double v = d.vis_local[k];
-    const double g = fmax(v, d.vis_global[k]);  // :417-418
-    d.vis_global[k] = g;
-    uint32_t lab = d.label[k];
-    if (v >= d.threshold && lab == kUnlabelled32) {  // :419-423
-      lab = (uint32_t)nb;
-      d.label[k] = lab;
-    }
-    if (g >= d.threshold) {  // :424-430
+    const double old = d.vis_global[k];
+    const double g = fmax(v, old);  // :417-418
+    if (g != old) d.vis_global[k] = g;  // (most cells of most iterations are dark: nothing to write, no label to read)
+    if (g >= d.threshold) {  // :424-430 (v >= threshold implies g >= threshold)
+      uint32_t lab = d.label[k];
+      if (v >= d.threshold && lab == kUnlabelled32) {  // :419-423
+        lab = (uint32_t)nb;
+        d.label[k] = lab;
+      }
       const int px = d.pivots[2 * lab], py = d.pivots[2 * lab + 1];
       const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, px, py));
       PlannerKey c;
