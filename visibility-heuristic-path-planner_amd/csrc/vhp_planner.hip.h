@@ -150,29 +150,44 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
   best.rank = ~0ull;
   best.x = best.y = -1;
   const size_t cells = (size_t)nx * ny;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < cells; k += (size_t)gridDim.x * blockDim.x) {
-    const int y = (int)(k / nx), x = (int)(k - (size_t)y * nx);
-    // column 0 / row 0 are swept only when the pivot lies on them: unvisited cells are
-    // neither united, labelled nor pushed
-    if ((x == 0 && sx > 0) || (y == 0 && sy > 0)) continue;
-    const double v = d.vis_local[k];
-    const double old = d.vis_global[k];
-    const double g = fmax(v, old);  // :417-418
-    if (g != old) d.vis_global[k] = g;  // (most cells of most iterations are dark: nothing to write, no label to read)
-    if (g >= d.threshold) {  // :424-430 (v >= threshold implies g >= threshold)
-      uint32_t lab = d.label[k];
-      if (v >= d.threshold && lab == kUnlabelled32) {  // :419-423
-        lab = (uint32_t)nb;
-        d.label[k] = lab;
+  // Four cells of a thread at a time, their loads issued together: the kernel is a chain of memory latencies, not of bytes.
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k0 < cells; k0 += 4 * stride) {
+    double vv[4], oo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t k = k0 + u * stride;
+      const bool in = k < cells;
+      vv[u] = in ? d.vis_local[k] : 0.0;
+      oo[u] = in ? d.vis_global[k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t k = k0 + u * stride;
+      if (k >= cells) continue;
+      const int y = (int)((unsigned)k / (unsigned)nx), x = (int)((unsigned)k - (unsigned)y * (unsigned)nx);  // (cells < 2^31: VHP_MAX_SIDE^2)
+      // column 0 / row 0 are swept only when the pivot lies on them: unvisited cells are
+      // neither united, labelled nor pushed
+      if ((x == 0 && sx > 0) || (y == 0 && sy > 0)) continue;
+      const double v = vv[u];
+      const double old = oo[u];
+      const double g = fmax(v, old);  // :417-418
+      if (g != old) d.vis_global[k] = g;  // (most cells of most iterations are dark: nothing to write, no label to read)
+      if (g >= d.threshold) {  // :424-430 (v >= threshold implies g >= threshold)
+        uint32_t lab = d.label[k];
+        if (v >= d.threshold && lab == kUnlabelled32) {  // :419-423
+          lab = (uint32_t)nb;
+          d.label[k] = lab;
+        }
+        const int px = d.pivots[2 * lab], py = d.pivots[2 * lab + 1];
+        const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, px, py));
+        PlannerKey c;
+        c.h = (unsigned long long)__double_as_longlong(h);
+        c.rank = push_rank(nx, ny, sx, sy, x, y);
+        c.x = x;
+        c.y = y;
+        if (key_less(c, best)) best = c;
       }
-      const int px = d.pivots[2 * lab], py = d.pivots[2 * lab + 1];
-      const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, px, py));
-      PlannerKey c;
-      c.h = (unsigned long long)__double_as_longlong(h);
-      c.rank = push_rank(nx, ny, sx, sy, x, y);
-      c.x = x;
-      c.y = y;
-      if (key_less(c, best)) best = c;
     }
   }
 #pragma unroll
