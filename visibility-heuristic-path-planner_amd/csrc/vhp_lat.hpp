@@ -528,6 +528,10 @@ struct LatY {
   int* dead_mine;
   const int* dead_below;
   const int* diag_zero;  // the diagonal's word: 0 unknown, else 1 + the entry from which all of it is +0.0
+  const int* diag_ready; // entries of the diagonal that are in diag_lds ...
+  int diag_seen;         // ... as of the last look
+  int seeds_total;       // entries the diagonal has in all
+  const double* diag_lds;
   vi lane, ic;
   vi first_j;     // the first step at which the lane stores its cell of the row (0x7fffffff: never)
   vb zero_lane;
@@ -540,7 +544,7 @@ struct LatY {
   int nx_ja;
 
   // (the caller has initialised lk; the seeds of the strip's columns are in diag_lds)
-  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, int n_strips, const double* diag_lds) {
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, int n_strips, const double* diag_lds_) {
     m = m_; out = out_;
     g.init(m.nx, m.ny, sx, sy);
     slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
@@ -557,6 +561,9 @@ struct LatY {
     dead_mine = sh.owner(0) + q;
     dead_below = sh.owner(0) + (q > 0 ? q - 1 : q);
     diag_zero = sh.ctx(0) + kDiagZero;
+    diag_ready = sh.ctx(0) + kDiagReady;
+    diag_seen = 0;
+    diag_lds = diag_lds_;
     nx.hd = 0;
     ic = REV ? (-lane) + (i0 + kLanes - 1) : lane + i0;
     zero_lane = (ic == g.ni) && (DX < 0);
@@ -565,8 +572,8 @@ struct LatY {
     interior = i0 + kBlock - 1 < g.ni;  // every lane a column of the quadrant
     prev = vd(0.0);
     id = to_f64(ic);
-    dg = select(zero_lane, vd(0.0), lds_load(diag_lds, vmin(ic, g.rows_total - 1)));
-    pin(dg);
+    seeds_total = g.rows_total;
+    dg = vd(0.0);  // (the seeds are taken window by window, as the diagonal's wavefront delivers them: seeds_through)
     xoff = to_u32((vmin(ic, g.ni) * DX + g.sx) * CB);  // (lanes past "column ni" store nothing)
     pf_blk = -1;
     pf_wait = false;
@@ -618,12 +625,26 @@ struct LatY {
     nx_ja = ja;
   }
 
+  // The seeds of the columns i <= upto are wanted: waits for the diagonal's wavefront if it has not got there, and takes every
+  // lane's seed afresh (lanes whose seed is not there yet get whatever the LDS holds; they are not seeded before a later call).
+  VHP_FN void seeds_through(int upto) {
+    const int need = imin(upto + 1, seeds_total);
+    if (diag_seen < need) {
+      int have = lds_poll(diag_ready);
+      while (have < need) { ready_backoff(); sim_point(); have = lds_poll(diag_ready); }
+      lds_acquire();
+      diag_seen = have;
+    }
+    dg = select(zero_lane, vd(0.0), lds_load(diag_lds, vmin(ic, seeds_total - 1)));
+  }
+
   // One window: steps ja + k, k = 0 .. 15, at y = yw + (k marching up, 15 - k marching down).  DIAG: columns may be seeded in it
   // (implies PRED); PRED: predicated stores (columns that do not exist, or not yet; steps past the march).  Windows that stick
   // out of the march are swept like the others (see LatX::window).
   template <bool DIAG, bool PRED>
   VHP_FN void window(int ja, int yw, int nb, bool more) {
     const int k_hi = imin(kLW - 1, j_last - ja);
+    if (DIAG) seeds_through(ja + kLW - 1);
     if (nx_ja != ja) request(ja, yw, nb);
     nx_ja = -0x7fffffff;
     if (below) nx.accept(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, imax(ja, j_first), ja + k_hi - 1, nb);
@@ -757,6 +778,10 @@ struct LatY {
 #endif
     if (je < 0) return false;
     if (below && nx.dead_from() > je) return false;
+    if (je < i0 + kBlock - 1) {  // columns still to be seeded: their seeds have to be there, and +0.0
+      if (lds_poll(diag_ready) < imin(i0 + kBlock, seeds_total)) return false;
+      seeds_through(i0 + kBlock - 1);
+    }
     return wave_all((first_j == 0x7fffffff) || is_pos_zero(select(ic <= je, prev, dg)));
   }
 };
@@ -791,7 +816,7 @@ struct LatDiag {
   }
   VHP_FN bool done() const { return k >= g.rows_total; }
   // entries k .. k+63; returns the number of entries ready afterwards
-  VHP_FN int run_chunk() {
+  VHP_FN int run_chunk(int* ready_word) {
     const int k0 = k, k1 = imin(k0 + kBlock, g.rows_total);
     if (zero_rest) {
       wave_sync();
@@ -821,9 +846,15 @@ struct LatDiag {
       }
       dprev = dcur;
       acc = select(lane == l, dcur, acc);
+      if ((l & (kLW - 1)) == kLW - 1 && kq + 1 < k1) {  // a window's worth of seeds: the strips need not wait for the whole chunk
+        wave_sync();
+        lds_store_if((lane <= l) && (lane > l - kLW), diag, lane + k0, acc);
+        lds_publish(ready_word, kq + 1);
+        sim_progress();
+      }
     }
     wave_sync();
-    lds_store_if(lane < (k1 - k0), diag, lane + k0, acc);
+    lds_store_if((lane < (k1 - k0)) && (lane >= ((k1 - k0 - 1) & ~(kLW - 1))), diag, lane + k0, acc);
     k = k1;
 #ifndef VHP_DIAG_NODEATH
     if (!zero_rest && k1 > 0 && wave_all(is_pos_zero(dprev) && is_pos_zero(sprev))) {
@@ -907,7 +938,7 @@ struct LatWorker {
       dt.init(a.m, sx, sy, diag_lds);
       VHP_LAT_STAMP(unit, 47, 0);
       while (!dt.done()) {
-        const int ready = dt.run_chunk();
+        const int ready = dt.run_chunk(cx + kDiagReady);
         if (dt.zero_rest) lds_publish(cx + kDiagZero, dt.zero_from + 1);
         lds_publish(cx + kDiagReady, ready);
         if (ready <= kBlock) VHP_LAT_STAMP(unit, 47, 1);
@@ -926,9 +957,6 @@ struct LatWorker {
       ys.lk.pp = prof;
 #endif
       VHP_LAT_STAMP(unit, q, 0);
-#ifndef VHP_DIAG_NOWAIT
-      wait_for(cx + kDiagReady, imin(kBlock * q + kBlock, g.rows_total));  // my columns' seeds
-#endif
       ys.init(a.m, sx, sy, field, sh, w, q, n_strips, diag_lds);
       ys.prefetch_ops(g.Y(ys.j_first) >> 6);
 #ifndef VHP_DIAG_NOWAIT
