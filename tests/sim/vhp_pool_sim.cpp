@@ -253,6 +253,7 @@ int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, O
   a.epoch = epoch;
   a.src_index = nullptr;
   a.skip = nullptr;
+  a.dead_cells_are_zero = false;
   a.strip_times = nullptr;
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
   std::vector<LatCo<OutT>> workers((size_t)G * W);

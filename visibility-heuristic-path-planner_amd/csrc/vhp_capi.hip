@@ -65,6 +65,7 @@ struct vhp_ctx {
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
   const int* lat_src_index = nullptr;  // set around a latency-sweep launch of the planner's loop (vhp_planner_solve)
   const int* lat_skip = nullptr;
+  bool lat_dark_unwritten = false;
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream), 3 pool sweep (vhp_pool)
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep, 3 pool sweep
   int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
@@ -333,6 +334,7 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.pool_epoch = (pool || lat) ? ++c->pool_epoch : 0;
   a.d_src_index = lat ? c->lat_src_index : nullptr;
   a.d_skip = lat ? c->lat_skip : nullptr;
+  a.lat_dead_cells_are_zero = lat && c->lat_dark_unwritten;
   a.n_cus = c->n_cus;
   a.stream = c->stream;
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
@@ -854,11 +856,13 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
     // one source per sweep: the latency sweep wherever a batch of one would take it (94 against 67 us per sweep at 690^2)
     ctx->pl.lat_sweep = nullptr;
     if (use_lat_kernel(ctx, 1))
-      ctx->pl.lat_sweep = [ctx](const int32_t* pivots, const int* nb, const int* done, double* out) {
+      ctx->pl.lat_sweep = [ctx](const int32_t* pivots, const int* nb, const int* done, double* out, bool dark_unwritten) {
         ctx->lat_src_index = nb;
         ctx->lat_skip = done;
+        ctx->lat_dark_unwritten = dark_unwritten;
         const hipError_t e = launch_stream_sweep<double>(ctx, pivots, 1, out, false, true);
         ctx->lat_src_index = ctx->lat_skip = nullptr;
+        ctx->lat_dark_unwritten = false;
         return e;
       };
   }
@@ -908,7 +912,7 @@ int vhp_planner_results_device(vhp_ctx* ctx, const uint32_t** labels, const doub
   if (!ctx->pl.vis_global) return fail(ctx, VHP_ERR_ARG, "vhp_planner_results_device: no planner solve has run on this map");
   if (labels) *labels = ctx->pl.label;
   if (vis_global) *vis_global = ctx->pl.vis_global;
-  if (vis_local) *vis_local = ctx->pl.vis_local;
+  if (vis_local) *vis_local = ctx->pl.vis_local_out ? ctx->pl.vis_local_out : ctx->pl.vis_local;
   if (pivots_xy) *pivots_xy = ctx->pl.pivots;
   return VHP_OK;
 }

@@ -71,6 +71,7 @@ hipError_t launch_lat_t(const StreamArgs& a) {
   g.epoch = a.pool_epoch;
   g.src_index = a.d_src_index;
   g.skip = a.d_skip;
+  g.dead_cells_are_zero = a.lat_dead_cells_are_zero;
   g.strip_times = nullptr;
 #ifdef VHP_DIAG_POOLPROF
   { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_lat_strip_times)) == hipSuccess) g.strip_times = static_cast<unsigned long long*>(p); }

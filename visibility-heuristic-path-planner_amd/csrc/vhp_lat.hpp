@@ -51,6 +51,9 @@ struct LatArgs {
   // or nothing at all if *skip is set (the loop has ended: launches are enqueued ahead of the host's polls); both may be null
   const int* src_index;
   const int* skip;
+  // the field is known to hold +0.0 wherever this launch does not write: dead strips store nothing (the planner's loop keeps two
+  // local fields and clears the one that is not in use while it reads the other: vhp_planner.hip.h)
+  bool dead_cells_are_zero;
   unsigned long long* strip_times;  // diagnostic builds (tools/lat_timeline.py): [unit][48][4] wall-clock stamps, or nullptr
 };
 
@@ -191,6 +194,7 @@ struct LatX {
   bool pf_wait;   // the loads of ow_nx / rv_nx have not been waited for yet
   int* dead_mine;          // my word of death (0: alive; else 1 + the step from which every value of the strip is +0.0) ...
   const int* dead_below;   // ... and the strip below's
+  bool skip_fill;          // a dead strip stores nothing (LatArgs::dead_cells_are_zero)
   vi lane, tile_l, fl_t;
   vu32 fl_off;
   vd prev, jd;
@@ -226,6 +230,7 @@ struct LatX {
     has_consumer = p + 1 < g.Px;
     dead_mine = sh.owner(0) + p;
     dead_below = sh.owner(0) + (p > 0 ? p - 1 : p);
+    skip_fill = false;
     nx.hd = 0;
     prev = vd(0.0);
     jd = to_f64(lane + j0);
@@ -451,6 +456,7 @@ struct LatX {
       announce_death(ia - 1, g.Px);
       sim_progress();
       sim_count(4);
+      if (skip_fill) return;
       vd z[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) z[u] = vd(0.0);
@@ -527,6 +533,7 @@ struct LatY {
   bool pf_wait;
   int* dead_mine;
   const int* dead_below;
+  bool skip_fill;
   const int* diag_zero;  // the diagonal's word: 0 unknown, else 1 + the entry from which all of it is +0.0
   const int* diag_ready; // entries of the diagonal that are in diag_lds ...
   int diag_seen;         // ... as of the last look
@@ -562,6 +569,7 @@ struct LatY {
     dead_below = sh.owner(0) + (q > 0 ? q - 1 : q);
     diag_zero = sh.ctx(0) + kDiagZero;
     diag_ready = sh.ctx(0) + kDiagReady;
+    skip_fill = false;
     diag_seen = 0;
     diag_lds = diag_lds_;
     nx.hd = 0;
@@ -737,6 +745,7 @@ struct LatY {
       announce_death(ja - 1);
       sim_progress();
       sim_count(4);
+      if (skip_fill) return;
       const long rowstep = (long)DY * m.nx;
       OutT* row = out + (long)g.Y(ja) * (long)m.nx;
       int j = ja;
@@ -909,6 +918,7 @@ struct LatWorker {
       xs.lk.pp = prof;
 #endif
       xs.init(a.m, sx, sy, field, sh, w, p);
+      xs.skip_fill = a.dead_cells_are_zero;
       xs.prefetch_ops(g.X(xs.i_first) >> 6);
       VHP_LAT_STAMP(unit, p, 0);
 #ifndef VHP_DIAG_NOWAIT
@@ -958,6 +968,7 @@ struct LatWorker {
 #endif
       VHP_LAT_STAMP(unit, q, 0);
       ys.init(a.m, sx, sy, field, sh, w, q, n_strips, diag_lds);
+      ys.skip_fill = a.dead_cells_are_zero;
       ys.prefetch_ops(g.Y(ys.j_first) >> 6);
 #ifndef VHP_DIAG_NOWAIT
       if (q > 0) wait_for(prog + (q - 1), imin(kBlock * q + 1, g.nj));

@@ -52,6 +52,8 @@ struct PlannerKey {
 struct PlannerDev {
   double* vis_global;
   double* vis_local;
+  double* vis_other;    // the local field that is NOT in use this iteration (two take turns when the sweep leaves dark cells
+                        // unwritten): the epilogue clears it for the next sweep; nullptr: one local field, fully written by every sweep
   uint32_t* label;
   int32_t* pivots;      // (x, y) pairs, lightSources_
   PlannerCtl* ctl;
@@ -160,6 +162,7 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
       const bool in = k < cells;
       vv[u] = in ? d.vis_local[k] : 0.0;
       oo[u] = in ? d.vis_global[k] : 0.0;
+      if (d.vis_other && in && d.vis_other[k] != 0.0) d.vis_other[k] = 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -274,6 +277,8 @@ struct PlannerState {
   size_t pivot_cap = 0;
   double* vis_global = nullptr;
   double* vis_local = nullptr;
+  double* vis_local2 = nullptr;      // the second local field of the plain solve (see PlannerDev::vis_other)
+  double* vis_local_out = nullptr;   // where the last solve left its local field (one of the two)
   uint32_t* label = nullptr;
   unsigned long long* came64 = nullptr;
   int32_t* pivots = nullptr;
@@ -286,12 +291,15 @@ struct PlannerState {
   std::function<hipError_t(const void*, size_t)> raise_lds;
   // set by the caller when the latency sweep (vhp_lat.hpp) can sweep this grid: launches it for source number *nb of pivots into
   // out unless *done is set (the same contract as vhp_planner_sweep: everything read on the device when the launch runs)
-  std::function<hipError_t(const int32_t* pivots, const int* nb, const int* done, double* out)> lat_sweep;
+  // (dark_unwritten: the field holds +0.0 wherever the sweep does not write, dead strips store nothing)
+  std::function<hipError_t(const int32_t* pivots, const int* nb, const int* done, double* out, bool dark_unwritten)> lat_sweep;
 };
 
 inline void planner_free(PlannerState& s) {
   if (s.vis_global) (void)hipFree(s.vis_global);
   if (s.vis_local) (void)hipFree(s.vis_local);
+  if (s.vis_local2) (void)hipFree(s.vis_local2);
+  s.vis_local2 = s.vis_local_out = nullptr;
   if (s.label) (void)hipFree(s.label);
   if (s.came64) (void)hipFree(s.came64);
   if (s.pivots) (void)hipFree(s.pivots);
@@ -367,9 +375,11 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
     VHP_PL_HIP(hipMalloc(&s.pivots, pcap * sizeof(int32_t)));
     s.pivot_cap = pcap;
   }
+  if (!s.vis_local2) VHP_PL_HIP(hipMalloc(&s.vis_local2, cells * 8));  // (the speculative solve, which shares this state, has one local field)
   // reset(): visibility_global_ = 0, visibility_ = 0, cameFrom_ = 1e15   (solver.cpp:42-47)
   VHP_PL_HIP(hipMemsetAsync(s.vis_global, 0, cells * 8, stream));
   VHP_PL_HIP(hipMemsetAsync(s.vis_local, 0, cells * 8, stream));
+  VHP_PL_HIP(hipMemsetAsync(s.vis_local2, 0, cells * 8, stream));
   VHP_PL_HIP(hipMemsetAsync(s.label, 0xff, cells * 4, stream));
   VHP_PL_HIP(hipMemsetAsync(s.pivots, 0, pcap * sizeof(int32_t), stream));
   VHP_PL_HIP(hipMemsetAsync(s.ticket, 0, sizeof(unsigned int), stream));
@@ -377,6 +387,11 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   PlannerDev d;
   d.vis_global = s.vis_global;
   d.vis_local = s.vis_local;
+  d.vis_other = nullptr;
+  // With the latency sweep the dark part of a field -- most of it, in a maze -- is not written at all: two local fields take
+  // turns, and the epilogue that reads one clears what the sweep before last left in the other.
+  const bool two_fields = (bool)s.lat_sweep;
+  size_t launches = 0;
   d.label = s.label;
   d.pivots = s.pivots;
   d.ctl = s.ctl;
@@ -399,8 +414,12 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   PlannerCtl ctl{};
   const int batch = 8;  // iterations enqueued per host poll (those past the end see `done` and return at once)
   for (;;) {
-    for (int b = 0; b < batch; ++b) {
-      hipError_t e = s.lat_sweep ? s.lat_sweep(d.pivots, &s.ctl->nb, &s.ctl->done, d.vis_local)
+    for (int b = 0; b < batch; ++b, ++launches) {
+      if (two_fields) {
+        d.vis_local = (launches & 1) ? s.vis_local2 : s.vis_local;
+        d.vis_other = (launches & 1) ? s.vis_local : s.vis_local2;
+      }
+      hipError_t e = s.lat_sweep ? s.lat_sweep(d.pivots, &s.ctl->nb, &s.ctl->done, d.vis_local, true)
                    : R == 1 ? (multi ? launch_planner_fronts<1, true>(s, m, d, W, stream) : launch_planner_fronts<1, false>(s, m, d, W, stream))
                    : R == 2 ? (multi ? launch_planner_fronts<2, true>(s, m, d, W, stream) : launch_planner_fronts<2, false>(s, m, d, W, stream))
                             : (multi ? launch_planner_fronts<4, true>(s, m, d, W, stream) : launch_planner_fronts<4, false>(s, m, d, W, stream));
@@ -414,6 +433,8 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   }
   VHP_PL_HIP(hipEventRecord(ev1, stream));
 
+  // (launch number n is iteration number n while the loop runs; the last iteration that ran is number iters - 1)
+  s.vis_local_out = (two_fields && ctl.iters > 0 && ((ctl.iters - 1) & 1)) ? s.vis_local2 : s.vis_local;
   const uint32_t nb = (uint32_t)ctl.nb;
   if (n_pivots) *n_pivots = nb;
   if (pivots_xy) VHP_PL_HIP(hipMemcpyAsync(pivots_xy, s.pivots, 2 * (size_t)(nb + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -423,7 +444,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
     VHP_PL_HIP(hipMemcpyAsync(came_from, s.came64, cells * 8, hipMemcpyDeviceToHost, stream));
   }
   if (vis_global) VHP_PL_HIP(hipMemcpyAsync(vis_global, s.vis_global, cells * 8, hipMemcpyDeviceToHost, stream));
-  if (vis_local) VHP_PL_HIP(hipMemcpyAsync(vis_local, s.vis_local, cells * 8, hipMemcpyDeviceToHost, stream));
+  if (vis_local) VHP_PL_HIP(hipMemcpyAsync(vis_local, s.vis_local_out, cells * 8, hipMemcpyDeviceToHost, stream));
   VHP_PL_HIP(hipStreamSynchronize(stream));
   if (ctl.status == VHP_ERR_MAX_ITER) *msg = "Max iters hit. Solution could not be found. Try lowering visibility threshold.";
   if (ctl.status == VHP_ERR_NOTHING_LIT) *msg = "no cell reached the visibility threshold";
@@ -744,6 +765,8 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
   PlannerDev d;
   d.vis_global = s.vis_global;
   d.vis_local = s.vis_local;
+  d.vis_other = nullptr;
+  s.vis_local_out = s.vis_local;
   d.label = s.label;
   d.pivots = s.pivots;
   d.ctl = s.ctl;

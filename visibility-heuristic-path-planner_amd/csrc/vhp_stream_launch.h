@@ -35,6 +35,7 @@ struct StreamArgs {
   int pool_busy_cap = 0;  // pool sweep: a workgroup takes another unit only while fewer wavefronts than this are sweeping (0: no cap)
   const int* d_src_index = nullptr;  // latency sweep in the planner's loop: sweep source number *d_src_index of d_src (n_src = 1) ...
   const int* d_skip = nullptr;       // ... and nothing at all if *d_skip is set
+  bool lat_dead_cells_are_zero = false;  // ... and dead strips store nothing: the field holds +0.0 wherever the launch does not write
   unsigned long long pool_epoch = 0;  // pool sweep: the tag of this launch's boundary-line entries: never 0, never reused on this scratch
 };
 
