@@ -179,3 +179,23 @@ def test_queue_variant_small(vhp, oracle):
     got = c.sweep_batch(src, variant=vhp.SWEEP_QUEUE)
     for k, (sx, sy) in enumerate(src):
         assert got[k].tobytes() == oracle.sweep_queue(occ, int(sx), int(sy)).tobytes()
+
+
+def test_plain_speculative_plain_on_one_context(vhp, oracle):
+    # The plain solve keeps two local fields that take turns (dark cells of a sweep stay unwritten; vhp_planner.hip.h), the
+    # speculative solve one, and both share the context's planner state: alternate them, with solves of an odd and of an even
+    # number of iterations, and compare everything -- the local field, wherever it ended up, included.
+    occ = maps.random_rect_map(160, 132, 22, 4, 30, 4, 30, 7)
+    pts = maps.free_sources(occ, 6, 57)
+    c = vhp.Context(0)
+    c.set_map(occ)
+    seen = set()
+    for k in range(5):
+        start, end = tuple(int(v) for v in pts[k]), tuple(int(v) for v in pts[k + 1])
+        want = oracle.solve(occ, start, end, 0.3, 80)
+        got = c.planner_solve(start, end, 0.3, 80)
+        _assert_same_solution(got, want, "plain solve %d" % k)
+        seen.add(want["n_pivots"] & 1)
+        spec = c.planner_solve_speculative(start, end, 0.3, 80, 4, 0)
+        _assert_same_solution(spec, want, "speculative solve %d" % k)
+    assert seen == {0, 1}, "pick sources that give solves of both parities (%r)" % seen
