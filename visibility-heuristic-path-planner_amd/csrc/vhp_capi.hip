@@ -270,7 +270,8 @@ bool use_lat_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel == 4) return n_src <= 64;
   // (a caller that sets a launch shape of the front sweep is asking for the front sweep)
   if (c->opt_rows_per_lane || c->opt_strips || c->opt_multi || c->opt_slide >= 0 || c->opt_pack) return false;
-  return 8 * n_src <= c->n_cus;
+  // (the boundary lines of a launch -- 16 bytes per strip and step -- stay below two gigabytes: 32 sources at 8192^2 would take four)
+  return 8 * n_src <= c->n_cus && vhp::lat_scratch_bytes(n_src, c->nx, c->ny) <= ((size_t)2 << 30);
 }
 
 bool use_pool_kernel(const vhp_ctx* c, int n_src) {
