@@ -14,6 +14,8 @@
 //   VHP_DIAG_POOLPROF   per-wavefront cycle accounts, per-unit install / finish times    (pool sweep); per-strip stamps (latency sweep)
 //   VHP_DIAG_WINPROF    cycle accounts inside the x-major windows (with POOLPROF; ~250 cycles per probe)   (latency sweep)
 //   VHP_DIAG_NODEATH    no strip ever declares itself dead: what the early exits are worth                  (latency sweep)
+//   VHP_DIAG_NODIAGSTORE  a strip that is growing along its diagonal stores nothing: the bound on what handing its stores to
+//                       another wavefront could buy (C2: 98.8 -> 79 us)                                     (latency sweep)
 //
 // Experiments that are over were deleted together with their switches (round 3): FLATPOLL, MASKPUB, HEAVYSYNC, NOLOAD,
 // YDRAIN, NOREFILL, SLOTTIME, SMALLSTORE, NOSTORE_X/_Y of the front sweep, PRIO, the back-off lengths as -D values.

@@ -400,6 +400,9 @@ struct LatX {
 #endif
     if (DIAG) VHP_WP_ADDP(lk.pp, 10, tw2);
     VHP_WP_T0(tw3);
+#ifdef VHP_DIAG_NODIAGSTORE  // diagnostic builds only (WRONG results): what the stores of a strip that is growing cost its chain
+    if (!DIAG)
+#endif
     store_window<DIAG>(ia, xw, lim, fa, fb);
     if (DIAG) VHP_WP_ADDP(lk.pp, 11, tw3);
     if (has_consumer) {
@@ -670,6 +673,9 @@ struct LatY {
         const vd b = REV ? shift_down(prev, fill) : shift_up(prev, fill);
         vd v = and_mask(stencil(prev, b, ratio(id, dj, nx_rr[k])), sbfe1(hs, c));
         if (DIAG) v = select(ic == ja + k, dg, v);
+#ifdef VHP_DIAG_NODIAGSTORE
+        if (!DIAG)
+#endif
 #ifndef VHP_DIAG_NOYSTORE  // diagnostic builds only: what the y-major stores cost
         if (PRED) {
           const int j = ja + k;
