@@ -68,6 +68,7 @@ struct vhp_ctx {
   bool lat_dark_unwritten = false;
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream), 3 pool sweep (vhp_pool)
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep, 3 pool sweep
+  long long opt_field_stride = 0;  // device-pointer batch sweeps: elements from one field to the next (0: nx * ny, packed)
   int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
   int opt_pool_heads = 0;      // pool sweep: contexts that pull the largest units (0 auto)
   int opt_pool_tail_pct = 0;   // pool sweep: share of the units the filler contexts take from the small end (0 auto)
@@ -201,7 +202,7 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     hipError_t e = raise_lds_limit(c, reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return e;
   }
-  const long long stride = (long long)c->nx * c->ny;
+  const long long stride = c->opt_field_stride > 0 ? c->opt_field_stride : (long long)c->nx * c->ny;
   vhp::DevMap m = dev_map(c);
   // Sliding the y-major column grid onto 128-byte lines pays in the store-bound regime (many quadrants in flight:
   // +1 % at 1000^2, +3.5 % at 4096^2); a lone quadrant is latency-bound, and there the predicated stores of the
@@ -329,7 +330,7 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.wpr = c->wpr; a.wpc = c->wpc; a.nx = c->nx; a.ny = c->ny;
   a.d_src = d_src; a.n_src = n_src; a.d_out = d_out;
   a.dtype = sizeof(OutT) == 8 ? VHP_F64 : VHP_F32;
-  a.field_stride = (long long)c->nx * c->ny;
+  a.field_stride = c->opt_field_stride > 0 ? c->opt_field_stride : (long long)c->nx * c->ny;
   a.d_err = c->d_err;
   a.d_queue = (pool || lat) ? c->d_pool : c->d_queue;
   a.pool_epoch = (pool || lat) ? ++c->pool_epoch : 0;
@@ -793,6 +794,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "pack") { ctx->opt_pack = v != 0; }
   else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3 && v != 4 && v != 6 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2, 3, 4, 6 or 8"); ctx->opt_stream_tile_slots = v; }
   else if (k == "kernel") { if (v < 0 || v > 4) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream, 3 pool, 4 latency"); ctx->opt_kernel = v; }
+  else if (k == "field_stride") { if (value < 0) return fail(ctx, VHP_ERR_ARG, "field_stride: 0 (packed) or elements per field"); ctx->opt_field_stride = value; }
   else if (k == "pool_heads") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_heads: 0 (automatic) .. 16"); ctx->opt_pool_heads = v; }
   else if (k == "pool_tail_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_tail_pct: 0 (automatic) .. 100"); ctx->opt_pool_tail_pct = v; }
   else if (k == "pool_early_ctx") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_early_ctx: 0 (automatic) .. 16"); ctx->opt_pool_early_ctx = v; }

@@ -262,13 +262,43 @@ VHP_LANE_FN vu64 g_load_u64(const uint64_t* base, vi idx) { return base[idx]; }
 VHP_LANE_FN vd g_load_f64(const double* base, vi idx) { return base[idx]; }
 
 template <typename OutT> struct alignas(2 * sizeof(OutT)) Pair { OutT a, b; };
+#ifdef VHP_DIAG_WHOLELINES
+// diagnostic builds only (WRONG results): a 16-byte store leaves only as part of a whole 128-byte line that this instruction writes
+// (fp64: 8 consecutive lanes, all storing, the first on a line) -- the bound on what a launch without partially written lines takes
+VHP_LANE_FN bool diag_whole_line(bool active, const void* addr) {
+  // lanes are laid along the addresses, 16 bytes apart, upward or downward: the lane with the line's first 16 bytes is k lanes away
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(active);
+  const int lane = (int)(threadIdx.x & 63u);
+  const unsigned long long a = (unsigned long long)addr;
+  const int k = (int)((a >> 4) & 7u);
+  bool whole = false;
+  for (int dir = -1; dir <= 1; dir += 2) {
+    const int l0 = lane + dir * k;                 // holds the first piece if the addresses rise (dir = -1) / fall (dir = +1) with the lane
+    const int lo = dir < 0 ? l0 : l0 - 7;
+    const bool in = lo >= 0 && lo + 7 <= 63;
+    const int src = in ? l0 : lane;
+    const unsigned lo32 = (unsigned)__shfl((int)(unsigned)a, src), hi32 = (unsigned)__shfl((int)(unsigned)(a >> 32), src);
+    const unsigned long long a0 = ((unsigned long long)hi32 << 32) | lo32;
+    const bool ok = in && ((m >> (lo & 63)) & 0xffull) == 0xffull && a0 == a - 16ull * (unsigned long long)k;
+    whole = whole || ok;
+  }
+  return active && whole;
+}
+#endif
 template <typename OutT> VHP_LANE_FN void g_store2(OutT* base, vu32 off, vd a, vd b) {
   VHP_DIAG_STORE_GUARD(a, b, off)
+#ifdef VHP_DIAG_WHOLELINES
+  if (!diag_whole_line(true, reinterpret_cast<char*>(base) + off)) return;
+#endif
   *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
 }
 template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p_hi, OutT* base, vu32 off, vd a, vd b) {
   VHP_DIAG_STORE_GUARD(a, b, off)
   VHP_DIAG_PARTIAL_GUARD(a, b, off)
+#ifdef VHP_DIAG_WHOLELINES
+  if (diag_whole_line(p2, reinterpret_cast<char*>(base) + off)) *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
+  return;
+#endif
   vd single = p_lo ? a : b;
   asm volatile("" : "+v"(single));  // keep the compiler from splitting the 16-byte store to share a half with the single
   if (p2) *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};

@@ -78,6 +78,10 @@ __global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict
   __shared__ int start[kBuckets];
   __shared__ int wave_tot[16];
   const int n_units = n_src * kUnits;
+#ifdef VHP_DIAG_TIMELINE
+  for (int k = threadIdx.x; k < 256 * 2 * kPpBins; k += blockDim.x) g_pp_hist[k] = 0;
+  if (threadIdx.x == 0) g_pp_t0 = wall_clock64();
+#endif
   {
     // boundary lines: thread t lays out the units [t * per, (t + 1) * per)
     auto blocks_of = [&](int u) {
@@ -223,6 +227,12 @@ extern "C" int vhp_debug_read_poolprof(unsigned long long* dst, int n_words) {
 }
 extern "C" int vhp_debug_read_unit_times(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_unit_times), (size_t)n_words * 8);
+}
+#endif
+
+#ifdef VHP_DIAG_TIMELINE
+extern "C" int vhp_debug_read_hist(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_pp_hist), (size_t)n_words * 8);
 }
 #endif
 

@@ -70,6 +70,23 @@ constexpr int kUnits = 8;     // units per source: 4 quadrants x {x-major, y-maj
 #define VHP_PP_ADDP(pp, slot, var)
 #define VHP_PP_COUNT(slot)
 #endif
+#if defined(VHP_DIAG_TIMELINE) && !defined(VHP_SIM)
+// the launch's timeline: cells swept (= bytes stored, one window late) and strips running, per 10 us of wall clock since the
+// order pre-kernel (g_pp_t0); one atomic per 64-step block of a strip, into the histogram of the wavefront's own workgroup
+// (one histogram for the chip was 3000 wavefronts adding to one address: +30 % launch time)
+constexpr int kPpBins = 256;
+static __device__ unsigned long long g_pp_hist[256 * 2 * kPpBins];
+static __device__ unsigned long long g_pp_t0;
+static __device__ __forceinline__ unsigned long long* pp_slot(int which) {
+  const unsigned long long b_ = (wall_clock64() - g_pp_t0) / 1000;
+  return g_pp_hist + ((size_t)(blockIdx.x & 255) * 2 + which) * kPpBins + (b_ < kPpBins - 1 ? b_ : kPpBins - 1);
+}
+#define VHP_PP_BYTES(n) do { if ((threadIdx.x & 63) == 0) atomicAdd(pp_slot(0), (unsigned long long)(n)); } while (0)
+#define VHP_PP_STRIPS(d) do { if ((threadIdx.x & 63) == 0) atomicAdd(pp_slot(1), (unsigned long long)(long long)(d)); } while (0)
+#else
+#define VHP_PP_BYTES(n)
+#define VHP_PP_STRIPS(d)
+#endif
 
 // ---- LDS of a workgroup -------------------------------------------------------------------------------------------
 // doubles per wavefront: the staging tile, the reciprocal slab, the boundary line of the strip below for the current
@@ -553,6 +570,9 @@ struct XStrip {
       if (boundary && i_last != g.ni - 1) flush_completed(xl, i_last);  // (the last step of the march is end_of_march's)
     }
     if (has_consumer) lk.store_block(nb, blk);
+#if defined(VHP_DIAG_TIMELINE) && !defined(VHP_SIM)
+    { long cells = 0; for (int ii = lo; ii <= hi; ++ii) cells += imin(rows_here, ii - j0 + 1); VHP_PP_BYTES(cells * CB); }
+#endif
   }
 };
 
@@ -736,6 +756,9 @@ struct YStrip {
       if (has_consumer) lk.publish(j);
     }
     if (has_consumer) lk.store_block(nb, blk);
+#if defined(VHP_DIAG_TIMELINE) && !defined(VHP_SIM)
+    { long cells = 0; for (int jj = lo; jj <= hi; ++jj) cells += imax(imin(imin(i0 + kYCols - 1, g.ni - 1), jj) - imax(i0, 0) + 1, 0); VHP_PP_BYTES(cells * CB); }
+#endif
   }
 };
 
@@ -997,6 +1020,7 @@ struct Worker {
     xs.lk.pp = prof;
 #endif
     VHP_PP_COUNT(5);
+    VHP_PP_STRIPS(1);
     for (int n = p; n < xs.g.Nbx; ++n) {
       VHP_PP_T0(ts);
       xs.sweep_block(n);
@@ -1007,6 +1031,7 @@ struct Worker {
       sim_point();
     }
     lds_publish(mine, 0x3fff);  // finished: whatever the strip above needs to start is there (a march can end before its first window does)
+    VHP_PP_STRIPS(-1);
     strip_done(c);
   }
 
@@ -1023,6 +1048,7 @@ struct Worker {
     ys.lk.pp = prof;
 #endif
     VHP_PP_COUNT(5);
+    VHP_PP_STRIPS(1);
     for (int n = ys.g.nby(ys.jstart); n < ys.g.Nby; ++n) {
       VHP_PP_T0(ts);
       ys.sweep_block(n);
@@ -1032,6 +1058,7 @@ struct Worker {
       sim_point();
     }
     lds_publish(mine, 0x3fff);
+    VHP_PP_STRIPS(-1);
     strip_done(c);
   }
 
