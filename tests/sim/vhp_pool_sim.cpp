@@ -111,7 +111,7 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
     const int s = u / kUnits, qo = u % kUnits, sx = src[2 * s], sy = src[2 * s + 1];
     if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) continue;
     UnitGeo g;
-    g.init(nx, ny, qo, sx, sy);
+    g.init(nx, ny, qo, sx, sy, vhp::pool::y_pitch(nx, (int)sizeof(OutT)));
     line_blocks += g.line_blocks();
     if (g.n_strips > 0) weight[u] = g.x_major ? (double)g.rows_total * g.ni - 0.5 * g.rows_total * (g.rows_total - 1.0)
                                               : (double)g.cols_total * (g.nj - 1) - 0.5 * g.cols_total * (g.cols_total - 1.0);
@@ -171,6 +171,8 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   vhp::lanes::sim_hooks().progress = hook_progress;
   vhp::lanes::sim_hooks().point = hook_point;
   vhp::lanes::store_stats() = vhp::lanes::StoreStats();
+  vhp::lanes::store_stats().base = reinterpret_cast<const char*>(out);
+  vhp::lanes::store_stats().bytes = (size_t)n_src * nx * ny * sizeof(OutT);
   vhp::lanes::sim_counts() = vhp::lanes::SimCounts();
   g_point_mode = (policy & 8) ? 1 : (policy & 16) ? 2 : 0;
   g_progress = g_switches = 0;
@@ -219,6 +221,8 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
     stats[5] = err;
     stats[6] = (long long)((queue & 0xffffffffull) + (queue >> 32));
     for (int k = 0; k < 4; ++k) stats[7 + k] = vhp::lanes::sim_counts().c[k];  // hand-offs: from the ring, from global memory, "too far ahead", "overwritten while copying"
+    stats[11] = vhp::lanes::store_stats().lines_whole;
+    stats[12] = vhp::lanes::store_stats().lines_part;
   }
   return 0;
 }
@@ -309,7 +313,7 @@ int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, O
       sh.L = L;
       const int s_ = gI / kUnits, qo = gI % kUnits;
       UnitGeo ug;
-      ug.init(nx, ny, qo, src[2 * s_], src[2 * s_ + 1]);
+      ug.init(nx, ny, qo, src[2 * s_], src[2 * s_ + 1], vhp::pool::y_pitch(nx, (int)sizeof(OutT)));
       fprintf(stderr, "unit %d (source %d,%d qo %d): strips %d diag ready %d\n   prog:", gI, src[2 * s_], src[2 * s_ + 1], qo, ug.n_strips, sh.ctx(0)[kDiagReady]);
       for (int p = 0; p < ug.n_strips && p < L.S; ++p) fprintf(stderr, " %d", sh.prog(0)[p]);
       fprintf(stderr, "\n   alive:");

@@ -30,7 +30,15 @@ __global__ void __launch_bounds__(256) shapes(char* out, int pattern, int n_task
     if (t >= (unsigned)n_tasks) break;
     const int f = t % NF, k = t / NF;
     char* field = out + (size_t)f * FIELD;
-    if (pattern >= 14 && pattern <= 19) {
+    if (pattern == 20 || pattern == 21) {
+      // 20: y1k_mixed without its half lines, the whole lines of the odd rows issued by lanes 4..59 (8-lane groups that straddle lines)
+      // 21: all rows aligned, but issued by lanes 4..59 of a rotated wavefront: lane m stores 16 bytes at 16 (m - 4)
+      for (int row = 0; row < NY; ++row) {
+        char* p = field + (size_t)row * PITCH + (pattern == 21 ? ((row & 1) ? 64 : 0) : 0) + (size_t)k * 1024;
+        if (pattern == 20) { if (!(row & 1) || (lane >= 4 && lane < 60)) *reinterpret_cast<double2*>(p + (size_t)lane * 16) = val; }
+        else { if (lane >= 4 && lane < 60) *reinterpret_cast<double2*>(p + (size_t)(lane - 4) * 16) = val; }
+      }
+    } else if (pattern >= 14 && pattern <= 19) {
       // 14..17: y1k with 1 / 2 / 4 / 8 rows of every 16 off the lines by 64 B; 18: y1k_mixed without the half lines (odd rows store their
       // 7 whole lines only); 19: y1k_mixed with the half lines as a separate, later instruction of the same wavefront
       for (int row = 0; row < NY; ++row) {

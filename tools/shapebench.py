@@ -28,7 +28,7 @@ for i in range(ncand):
 t0 = [run(p) for p in bufs]
 print("C3 launch ms per candidate:", " ".join("%.3f" % t for t in t0), flush=True)
 slow, fast = bufs[int(np.argmax(t0))], bufs[int(np.argmin(t0))]
-names = ["y1k", "y1k_half", "y1k_mixed", "x128", "x64", "x256", "x512", "fill", "rand128", "rand1k", "y1k_8B", "x128_rows2", "y2k", "y1k_rot", "y1k_off1of16", "y1k_off2of16", "y1k_off4of16", "y1k_off8of16", "y1k_nohalves", "y1k_halveslater"]
+names = ["y1k", "y1k_half", "y1k_mixed", "x128", "x64", "x256", "x512", "fill", "rand128", "rand1k", "y1k_8B", "x128_rows2", "y2k", "y1k_rot", "y1k_off1of16", "y1k_off2of16", "y1k_off4of16", "y1k_off8of16", "y1k_nohalves", "y1k_halveslater", "y1k_mis_nohalves", "y1k_lanes4to59"]
 print("%-12s %4s | %9s %9s %6s" % ("pattern", "wpc", "slow TB/s", "fast TB/s", "ratio"))
 for pat, nm in enumerate(names):
     if len(sys.argv) > 2 and pat < int(sys.argv[2]) and pat not in (0, 2): continue

@@ -117,7 +117,35 @@ inline vd g_load_f64(const double* base, const vi& idx) { vd r; for (int l = 0; 
 
 // The simulator records every global store (how many, how wide, which 64-byte sectors) for the tests' coverage
 // and store-shape checks.
-struct StoreStats { long long n16 = 0, n8 = 0, n4 = 0; };
+// ... and, for stores into the registered output [base, base + bytes), how many 128-byte lines an instruction wrote whole and
+// how many only in part (a line that leaves in pieces costs the memory several whole ones: DESIGN.md section 7).
+struct StoreStats {
+  long long n16 = 0, n8 = 0, n4 = 0, lines_whole = 0, lines_part = 0;
+  const char* base = nullptr;
+  size_t bytes = 0;
+  // one store instruction: byte ranges [p, p + n) of its active lanes
+  long long tmp_line[2 * kLanes];
+  int tmp_bytes[2 * kLanes];
+  int tmp_n = 0;
+  void add(const void* p, int n) {
+    const char* c = static_cast<const char*>(p);
+    if (!base || c < base || c >= base + bytes) return;
+    const long long off = c - base;
+    for (long long o = off; o < off + n;) {  // (a lane's piece may straddle a line only if it is misaligned; split it)
+      const long long line = o >> 7;
+      const int take = (int)((((line + 1) << 7) < off + n ? ((line + 1) << 7) : off + n) - o);
+      int k = 0;
+      while (k < tmp_n && tmp_line[k] != line) ++k;
+      if (k == tmp_n) { if (tmp_n == 2 * kLanes) return; tmp_line[k] = line; tmp_bytes[k] = 0; ++tmp_n; }
+      tmp_bytes[k] += take;
+      o += take;
+    }
+  }
+  void end_instruction() {
+    for (int k = 0; k < tmp_n; ++k) (tmp_bytes[k] >= 128 ? lines_whole : lines_part) += 1;
+    tmp_n = 0;
+  }
+};
 inline StoreStats& store_stats() { static StoreStats s; return s; }
 
 // two adjacent cells at byte offset off (16-byte aligned for double, 8 for float)
@@ -125,22 +153,26 @@ template <typename OutT> inline void g_store2(OutT* base, const vu32& off, const
   for (int l = 0; l < kLanes; ++l) {
     OutT* p = reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]);
     p[0] = (OutT)a.v[l]; p[1] = (OutT)b.v[l];
+    store_stats().add(p, 2 * (int)sizeof(OutT));
   }
   store_stats().n16 += 1;
+  store_stats().end_instruction();
 }
 template <typename OutT> inline void g_store2_if(const vb& p2, const vb& p_lo, const vb& p_hi, OutT* base, const vu32& off, const vd& a, const vd& b) {
   // p2: both cells; else p_lo: only the first; else p_hi: only the second
   for (int l = 0; l < kLanes; ++l) {
     OutT* p = reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]);
-    if (p2.v[l]) { p[0] = (OutT)a.v[l]; p[1] = (OutT)b.v[l]; }
-    else if (p_lo.v[l]) p[0] = (OutT)a.v[l];
-    else if (p_hi.v[l]) p[1] = (OutT)b.v[l];
+    if (p2.v[l]) { p[0] = (OutT)a.v[l]; p[1] = (OutT)b.v[l]; store_stats().add(p, 2 * (int)sizeof(OutT)); }
+    else if (p_lo.v[l]) { p[0] = (OutT)a.v[l]; store_stats().add(p, (int)sizeof(OutT)); }
+    else if (p_hi.v[l]) { p[1] = (OutT)b.v[l]; store_stats().add(p + 1, (int)sizeof(OutT)); }
   }
   store_stats().n16 += 1;
+  store_stats().end_instruction();
 }
 template <typename OutT> inline void g_store1_if(const vb& p1, OutT* base, const vu32& off, const vd& a) {
-  for (int l = 0; l < kLanes; ++l) if (p1.v[l]) *reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]) = (OutT)a.v[l];
+  for (int l = 0; l < kLanes; ++l) if (p1.v[l]) { OutT* p = reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]); *p = (OutT)a.v[l]; store_stats().add(p, (int)sizeof(OutT)); }
   store_stats().n8 += 1;
+  store_stats().end_instruction();
 }
 inline void wave_sync() {}
 template <typename T> inline void pin(T&) {}
@@ -181,7 +213,10 @@ inline unsigned long long g_add_u64(unsigned long long* p, unsigned long long v)
 inline unsigned long long g_peek_u64(const unsigned long long* p) { return *p; }
 inline void g_store_f64(double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) base[idx.v[l]] = v.v[l]; }
 inline void g_store_f64_if(const vb& p, double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v.v[l]; }
-template <typename T> inline void g_store_scalar_if(const vb& p, T* base, const vi& idx, T v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v; }
+template <typename T> inline void g_store_scalar_if(const vb& p, T* base, const vi& idx, T v) {
+  for (int l = 0; l < kLanes; ++l) if (p.v[l]) { base[idx.v[l]] = v; store_stats().add(&base[idx.v[l]], (int)sizeof(T)); }
+  store_stats().end_instruction();
+}
 inline int ffs_u32(uint32_t v) { return v ? __builtin_ctz(v) : -1; }
 // Tagged 16-byte entries in global memory ({value, tag}): how a strip hands its boundary line to the strip that reads it
 // (vhp_pool.hpp).  The store writes both words at once; the load tells, per lane, whether the entry carries `tag`.

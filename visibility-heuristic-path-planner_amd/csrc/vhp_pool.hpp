@@ -138,6 +138,16 @@ struct Shared {
   VHP_FN double* bin(int w) const { return lds + L.bins + w * kBin; }
 };
 
+// Columns from one y-major strip to the next.  Where the rows of the output alternate between starting on a 128-byte line and
+// half a line off (a row pitch that is an odd multiple of 64 bytes: nx = 8 mod 16 in fp64 -- the 1000-wide grid), strips of 128
+// columns side by side would split a line of every other row between two wavefronts, and a line that leaves in two pieces costs
+// the memory system several whole ones (y1k_mixed 3.7 TB/s, the same bytes in whole lines 5.0).  So
+// neighbouring strips overlap by one line's worth of columns there (16 in fp64, 32 in fp32): a strip still sweeps 128 columns,
+// but of a row whose lines start `o` columns into the strip it stores the columns o .. o + pitch - 1 -- whole lines, its
+// neighbour goes on where it ends -- (strip 0: from its first column; the last strip: to its last), and the columns it shares
+// with its neighbour are computed twice, bit for bit the same.  `cb` = bytes per cell.
+VHP_HD int y_pitch(int nx, int cb) { const int lc = 128 / cb; return (nx % lc) ? kYCols - lc : kYCols; }
+
 template <typename OutT>
 struct Args {
   Map m;
@@ -159,13 +169,15 @@ struct Args {
   int early_ctx;      // contexts >= this one open only once `late_after` units have been taken: towards the end of a launch a
   int late_after;     // workgroup holds more, shorter units at once (what is left then has nothing large to get in the way of)
   unsigned long long* unit_times;  // diagnostic builds: when unit u was installed / finished (wall clock), or nullptr
+  VHP_HD int yp() const { return y_pitch(m.nx, (int)sizeof(OutT)); }  // columns from one y-major strip to the next
 };
 
 // Geometry of a unit without the direction templates: what the scheduler needs to tell whether a strip may start.
 struct UnitGeo {
-  int ni, nj, rows_total, cols_total, ya, n_strips, ph, nb;
+  int ni, nj, rows_total, cols_total, ya, n_strips, ph, nb, yp;
   bool x_major;
-  VHP_FN void init(int nx, int ny, int qo, int sx, int sy) {
+  VHP_FN void init(int nx, int ny, int qo, int sx, int sy, int yp_) {
+    yp = yp_;
     const int q = qo >> 1;
     const int dx = (q == 0 || q == 3) ? 1 : -1, dy = q < 2 ? 1 : -1;
     x_major = (qo & 1) == 0;
@@ -179,12 +191,12 @@ struct UnitGeo {
     nb = x_major ? (ni > 0 ? ((phx + ni - 1) >> 6) + 1 : 0) : (nj > 0 ? ((ph + nj - 1) >> 6) + 1 : 0);  // blocks of the march (Quad::Nbx / Nby)
     if (ni <= 0 || nj <= 0) n_strips = 0;
     else if (x_major) n_strips = (rows_total + kXRows - 1) / kXRows;
-    else n_strips = cols_total > 0 ? (cols_total + ya + kYCols - 1) / kYCols : 0;
+    else n_strips = cols_total > 0 ? imax((cols_total + ya - (kYCols - yp) + yp - 1) / yp, 1) : 0;
   }
   // first step of strip p
-  VHP_FN int first_step(int p) const { return x_major ? kXRows * p : imax(kYCols * p - ya, 0); }
+  VHP_FN int first_step(int p) const { return x_major ? kXRows * p : imax(yp * p - ya, 0); }
   // diagonal entries a y-major strip needs before it starts
-  VHP_FN int diag_need(int p) const { return x_major ? 0 : imin(kYCols * p - ya + kYCols, rows_total); }
+  VHP_FN int diag_need(int p) const { return x_major ? 0 : imin(yp * p - ya + kYCols, rows_total); }
   // 64-entry blocks of boundary-line scratch: one line of nb blocks per strip that has a reader
   VHP_FN int line_blocks() const { return n_strips > 1 ? (n_strips - 1) * nb : 0; }
 };
@@ -242,6 +254,9 @@ struct Link {
   }
   // the whole block nb (coordinate block blk = x >> 6) goes to my line in global memory, out of the ring
   VHP_FN void store_block(int nb, int blk) {
+#ifdef VHP_DIAG_NOLINES  // diagnostic builds only (with NOWAIT): no boundary line leaves for global memory
+    return;
+#endif
     wave_sync();
     g_store_tagged(line_out, lane + 64 * nb, lds_load(ring, lane + 64 * (blk & 3)), epoch);
   }
@@ -597,11 +612,16 @@ struct YStrip {
   vd prev0, prev1, id0, id1, dg0, dg1;
   vu64 ow0, ow1;
   vu32 xoff;  // byte offset of the lane's pair inside a row
+  // overlapping strips (y_pitch): the lanes that store a row are sl_lo + o/2 .. sl_hi + o/2, o = the columns from the strip's
+  // first to the row's first line start inside it (0 <= o < lc, even); bl = the lane whose second column is the left
+  // neighbour of the next strip's first
+  bool ovl;
+  int bl, lc, o_c0, o_c1, sl_lo, sl_hi;
 
   // (the caller has initialised lk)
   VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const double* diag) {
     m = m_; out = out_;
-    g.init(m.nx, m.ny, sx, sy);
+    g.init(m.nx, m.ny, sx, sy, y_pitch(m.nx, CB));
     slab = sh.lds + sh.L.slabs + w * kBlock;
     bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * 8;
@@ -611,6 +631,20 @@ struct YStrip {
     jstart = g.ystart(q);
     has_consumer = q + 1 < g.Py;
     interior = i0 >= 0 && i0 + kYCols - 1 < g.ni;  // every column of the strip is a column of the grid
+    ovl = g.yp != kYCols;
+    bl = g.yp / 2 - 1;
+    lc = 128 / CB;
+    {
+      // the strip's lowest x and, from it, the row phase: row y's lines start o(y) = (o_c0 - y * o_c1) mod lc columns into the strip
+      const int x_low = DX > 0 ? g.sx + i0 : g.sx - (i0 + kYCols - 1);
+      o_c0 = (lc - (x_low & (lc - 1))) & (lc - 1);
+      o_c1 = m.nx & (lc - 1);
+      // places are counted from the strip's lowest x (marching down, lane 0 holds the HIGHEST x: store_lanes).  The strip next
+      // to the axis also stores what lies between the axis and its first whole line, the last strip what lies beyond its last.
+      const bool first = q == 0, last = !has_consumer;
+      sl_lo = (DX > 0 ? first : last) ? -64 : 0;
+      sl_hi = (DX > 0 ? last : first) ? 128 : g.yp / 2 - 1;
+    }
     ia = lane * 2 + i0;
     ib = ia + 1;
     prev0 = vd(0.0);
@@ -627,6 +661,12 @@ struct YStrip {
   }
 
   // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below the diagonal
+  // the lanes that store row y (overlapping strips only; see y_pitch)
+  VHP_FN vb store_lanes(int y) const {
+    const int o2 = ((o_c0 - y * o_c1) & (lc - 1)) >> 1;
+    const vi pos = DX > 0 ? lane : 63 - lane;  // the lane's place counted from the strip's lowest x
+    return (pos >= sl_lo + o2) && (pos <= sl_hi + o2);
+  }
   VHP_FN void store_pred(OutT* row, int j, vd v0, vd v1) {
 #ifdef VHP_DIAG_DROP_YPRED
     asm volatile("" :: "v"(v0), "v"(v1));
@@ -634,6 +674,11 @@ struct YStrip {
 #endif
     vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
     vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
+    if (ovl) {
+      const vb mine = store_lanes(g.Y(j));
+      ok0 = ok0 && mine;
+      ok1 = ok1 && mine;
+    }
     if (DX < 0) {
       // Column 0 is never swept (the march stops at x = 1) and reads as zero.  Whoever stores x = 1 stores
       // that zero with it: one 16-byte store instead of an 8-byte one here and another somewhere else, some other time.
@@ -644,7 +689,11 @@ struct YStrip {
     if (DX > 0) g_store2_if(ok0 && ok1, ok0, ok1, row, xoff, v0, v1);
     else g_store2_if(ok0 && ok1, ok1, ok0, row, xoff, v1, v0);
   }
+#ifdef VHP_DIAG_YALIGNED  // diagnostic builds only (WRONG results): every row of a y-major strip starts on a line (rows off a line are moved by half a line)
+  VHP_FN OutT* row_ptr(int y) const { return out + (size_t)y * (size_t)m.nx - (((size_t)y * (size_t)m.nx) & 15); }
+#else
   VHP_FN OutT* row_ptr(int y) const { return out + (size_t)y * (size_t)m.nx; }
+#endif
 
   VHP_FN void step1(int j) {
     const int y = g.Y(j);
@@ -663,11 +712,11 @@ struct YStrip {
     store_pred(row_ptr(y), j, v0, v1);
     prev0 = v0;
     prev1 = v1;
-    if (has_consumer) lds_store_if(lane == 63, lk.ring, vi(y & (kRing - 1)), v1);
+    if (has_consumer) lds_store_if(lane == bl, lk.ring, vi(y & (kRing - 1)), v1);
   }
 
   // eight steps covering one aligned window of y.  DIAG: seeding may happen (implies PRED); PRED: predicated stores
-  template <bool DIAG, bool PRED>
+  template <bool DIAG, bool PRED, bool OVL = false>
   VHP_FN void window8(int j0w) {
     const int y0 = g.Y(j0w);
     const int t0 = y0 & 63;
@@ -687,7 +736,7 @@ struct YStrip {
     const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
     const vu32 hs0 = half_shifted(ow0, t0, sh), hs1 = half_shifted(ow1, t0, sh);
     double* wbase = has_consumer ? lk.ring + (yb & (kRing - 1)) : dummy;
-    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
+    const vi widx = select(lane == bl, vi(0), vi((int)(dummy - wbase)));
     vd dj = vd((double)j0w);
     OutT* row = row_ptr(y0);
     const long rowstep = (long)DY * m.nx;
@@ -703,6 +752,11 @@ struct YStrip {
       }
 #ifndef VHP_DIAG_NOYSTORE  // diagnostic builds only: what the y-major stores cost
       if (PRED) store_pred(row, j0w + k, v0, v1);
+      else if (OVL) {
+        const vb mine = store_lanes(yb + bit);
+        if (DX > 0) g_store2_if(mine, vb(false), vb(false), row, xoff, v0, v1);
+        else g_store2_if(mine, vb(false), vb(false), row, xoff, v1, v0);
+      }
       else if (DX > 0) g_store2(row, xoff, v0, v1);
       else g_store2(row, xoff, v1, v0);
 #else
@@ -712,7 +766,11 @@ struct YStrip {
       prev1 = v1;
       lds_store(wbase, widx + bit, v1);
       dj = dj + 1.0;
+#ifdef VHP_DIAG_YALIGNED
+      row = row_ptr(y0 + DY * (k + 1));
+#else
       row += rowstep;
+#endif
     }
   }
 
@@ -746,6 +804,7 @@ struct YStrip {
         if (q > 0) lk.fetch(j, j + 7, nb);
         if (j <= i0 + kYCols - 1) window8<true, true>(j);
         else if (!interior) window8<false, true>(j);
+        else if (ovl) window8<false, false, true>(j);
         else window8<false, false>(j);
         j += 8;
       } else {
@@ -813,7 +872,9 @@ struct DiagTask {
       dprev = dcur;
       acc = select(lane == l, dcur, acc);
     }
+#ifndef VHP_DIAG_NOLINES
     g_store_f64_if(lane < (k1 - k0), diag, lane + k0, acc);
+#endif
     k = k1;
     return k1;
   }
@@ -881,7 +942,7 @@ struct Worker {
       const int unit = lds_poll(cx + kUnit), sxsy = lds_poll(cx + kSxSy);
       const int qo = unit & 7, sx = sxsy & 0xffff, sy = sxsy >> 16;
       UnitGeo ug;
-      ug.init(a.m.nx, a.m.ny, qo, sx, sy);
+      ug.init(a.m.nx, a.m.ny, qo, sx, sy, a.yp());
 #ifndef VHP_DIAG_NOWAIT
       if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_step(p) + 8 + 1) continue;  // the strip below has swept my first window
       if (!ug.x_major && lds_poll(cx + kDiagReady) < ug.diag_need(p)) continue;
@@ -941,7 +1002,7 @@ struct Worker {
       return;
     }
     UnitGeo ug;
-    ug.init(a.m.nx, a.m.ny, qo, sx, sy);
+    ug.init(a.m.nx, a.m.ny, qo, sx, sy, a.yp());
     OutT* field = a.out + (size_t)s * a.field_stride;
     if (qo == 0) {
       // rows/columns no quadrant covers read as zero; the x-major unit of quadrant 1 always exists
@@ -1039,7 +1100,7 @@ struct Worker {
   VHP_FN void run_y(int c, int unit, int q, int sx, int sy, OutT* field, const double* dline) {
     YStrip<DX, DY, OutT> ys;
     Quad<DX, DY> g;
-    g.init(a.m.nx, a.m.ny, sx, sy);
+    g.init(a.m.nx, a.m.ny, sx, sy, a.yp());
     int* mine = sh.prog(c) + q;
     ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr,
                a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
