@@ -101,6 +101,7 @@ inline vi bit_mask(const vu64& w, int b) { vi r; for (int l = 0; l < kLanes; ++l
 // bit b (per lane, 0..63) of a lane-private word as 0 / ~0
 inline vi bit_mask_lane(const vu64& w, const vi& b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = ((w.v[l] >> (b.v[l] & 63)) & 1ull) ? -1 : 0; return r; }
 inline int read_lane_i(const vi& v, int l) { return v.v[l & 63]; }
+inline uint64_t read_lane_u64(const vu64& v, int l) { return v.v[l & 63]; }
 // the 32-bit half of w that holds bit t (uniform), shifted right by sh (uniform, 0..31)
 inline vu32 half_shifted(const vu64& w, int t, int sh) {
   vu32 r; for (int l = 0; l < kLanes; ++l) r.v[l] = (uint32_t)((t & 32) ? (w.v[l] >> 32) : w.v[l]) >> sh; return r; }
@@ -114,6 +115,8 @@ inline void lds_store(double* base, const vi& idx, const vd& v) { for (int l = 0
 inline void lds_store_if(const vb& p, double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v.v[l]; }
 inline vu64 g_load_u64(const uint64_t* base, const vi& idx) { vu64 r; for (int l = 0; l < kLanes; ++l) r.v[l] = base[idx.v[l]]; return r; }
 inline vd g_load_f64(const double* base, const vi& idx) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = base[idx.v[l]]; return r; }
+// two adjacent doubles at an even index (one 16-byte load per lane)
+inline void g_load2_f64(const double* base, const vi& idx, vd& a, vd& b) { for (int l = 0; l < kLanes; ++l) { a.v[l] = base[idx.v[l]]; b.v[l] = base[idx.v[l] + 1]; } }
 
 // The simulator records every global store (how many, how wide, which 64-byte sectors) for the tests' coverage
 // and store-shape checks.
@@ -168,6 +171,10 @@ template <typename OutT> inline void g_store2_if(const vb& p2, const vb& p_lo, c
   }
   store_stats().n16 += 1;
   store_stats().end_instruction();
+}
+// the pair, from the lanes of p only (nothing of a pair is ever split)
+template <typename OutT> inline void g_store2_mask(const vb& p, OutT* base, const vu32& off, const vd& a, const vd& b) {
+  g_store2_if(p, vb(false), vb(false), base, off, a, b);
 }
 template <typename OutT> inline void g_store1_if(const vb& p1, OutT* base, const vu32& off, const vd& a) {
   for (int l = 0; l < kLanes; ++l) if (p1.v[l]) { OutT* p = reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]); *p = (OutT)a.v[l]; store_stats().add(p, (int)sizeof(OutT)); }
@@ -285,6 +292,10 @@ VHP_LANE_FN vi bit_mask(vu64 w, int b) {
 }
 VHP_LANE_FN vi bit_mask_lane(vu64 w, vi b) { return ((w >> (b & 63)) & 1ull) ? -1 : 0; }
 VHP_LANE_FN int read_lane_i(vi v, int l) { return __builtin_amdgcn_readlane(v, l); }
+VHP_LANE_FN uint64_t read_lane_u64(vu64 v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
 VHP_LANE_FN vu32 half_shifted(vu64 w, int t, int sh) { return ((t & 32) ? (uint32_t)(w >> 32) : (uint32_t)w) >> sh; }
 VHP_LANE_FN vi sbfe1(vu32 hs, int b) { return __builtin_amdgcn_sbfe(hs, b, 1); }
 
@@ -295,8 +306,19 @@ VHP_LANE_FN void lds_store(double* base, vi idx, vd v) { base[idx] = v; }
 VHP_LANE_FN void lds_store_if(bool p, double* base, vi idx, vd v) { if (p) base[idx] = v; }
 VHP_LANE_FN vu64 g_load_u64(const uint64_t* base, vi idx) { return base[idx]; }
 VHP_LANE_FN vd g_load_f64(const double* base, vi idx) { return base[idx]; }
+VHP_LANE_FN void g_load2_f64(const double* base, vi idx, vd& a, vd& b) { const double2 v = *reinterpret_cast<const double2*>(base + idx); a = v.x; b = v.y; }
 
-template <typename OutT> struct alignas(2 * sizeof(OutT)) Pair { OutT a, b; };
+// Field stores are NON-TEMPORAL (the nt bit of global_store).  A field is written once and never read by the launch, and --
+// measured, DESIGN.md section 7 -- the memory side charges a plain store that covers only part of a 128-byte line (the two ends
+// of a row piece that is half a line off the line grid, the cells next to a diagonal or an axis) several whole lines' worth on
+// two thirds of the device's memory; with nt a partially written line costs what it weighs (tools/policybench.hip: the same
+// bytes, every other row half a line off: 3.65 -> 4.81 TB/s on a slow buffer, 5.27 -> 5.96 on a fast one).
+#ifdef VHP_DIAG_PLAINSTORE  // diagnostic builds only: the stores without the nt bit (what the launch took until round 4)
+#define VHP_FIELD_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define VHP_FIELD_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+template <typename OutT> using Pair = OutT __attribute__((ext_vector_type(2)));
 #ifdef VHP_DIAG_WHOLELINES
 // diagnostic builds only (WRONG results): a 16-byte store leaves only as part of a whole 128-byte line that this instruction writes
 // (fp64: 8 consecutive lanes, all storing, the first on a line) -- the bound on what a launch without partially written lines takes
@@ -325,23 +347,27 @@ template <typename OutT> VHP_LANE_FN void g_store2(OutT* base, vu32 off, vd a, v
 #ifdef VHP_DIAG_WHOLELINES
   if (!diag_whole_line(true, reinterpret_cast<char*>(base) + off)) return;
 #endif
-  *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
+  VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
 }
 template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p_hi, OutT* base, vu32 off, vd a, vd b) {
   VHP_DIAG_STORE_GUARD(a, b, off)
   VHP_DIAG_PARTIAL_GUARD(a, b, off)
 #ifdef VHP_DIAG_WHOLELINES
-  if (diag_whole_line(p2, reinterpret_cast<char*>(base) + off)) *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
+  if (diag_whole_line(p2, reinterpret_cast<char*>(base) + off)) VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
   return;
 #endif
   vd single = p_lo ? a : b;
   asm volatile("" : "+v"(single));  // keep the compiler from splitting the 16-byte store to share a half with the single
-  if (p2) *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
+  if (p2) VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
   else if (p_lo || p_hi)
-    *reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off + (p_lo ? 0u : (uint32_t)sizeof(OutT))) = static_cast<OutT>(single);
+    VHP_FIELD_STORE(reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off + (p_lo ? 0u : (uint32_t)sizeof(OutT))), static_cast<OutT>(single));
+}
+template <typename OutT> VHP_LANE_FN void g_store2_mask(bool p, OutT* base, vu32 off, vd a, vd b) {
+  VHP_DIAG_STORE_GUARD(a, b, off)
+  if (p) VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
 }
 template <typename OutT> VHP_LANE_FN void g_store1_if(bool p1, OutT* base, vu32 off, vd a) {
-  if (p1) *reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off) = static_cast<OutT>(a);
+  if (p1) VHP_FIELD_STORE(reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off), static_cast<OutT>(a));
 }
 // Orders this wavefront's LDS writes before its later LDS reads of other lanes' data.  The LDS executes the DS
 // instructions of one wavefront in issue order, so a read issued after a write sees it without an s_waitcnt in between:

@@ -144,6 +144,8 @@ constexpr int kQueueInts = 16;  // the pull counter (and padding) ahead of the o
 int diag_stride_of(int nx, int ny) { return ((nx < ny ? nx : ny) + 64 + 15) & ~15; }
 size_t head_bytes(int n_src) { return (((size_t)(kQueueInts + 2 * pool::kUnits * (size_t)n_src) * sizeof(int)) + 255) & ~(size_t)255; }
 size_t diag_bytes(int n_src, int nx, int ny) { return (((size_t)n_src * 4 * (size_t)diag_stride_of(nx, ny) * sizeof(double)) + 255) & ~(size_t)255; }
+// the seam bands (fp64 fields): a 128-byte line per row of the diagonal of every quadrant
+size_t band_bytes(int n_src, int nx, int ny) { return (size_t)n_src * 4 * (size_t)diag_stride_of(nx, ny) * pool::kLineCells * sizeof(double); }
 // 64-entry blocks of boundary lines a source can need, an upper bound: over its four quadrants ni * nj sums to nx * ny;
 // an x-major unit takes at most (min(ni,nj)/64) * (ni/64 + 2) blocks, a y-major one (ni/96 + 2) * (nj/64 + 2) (strips of 96
 // columns at the least: y_pitch)
@@ -191,7 +193,11 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   g.line_base = line_base;
   g.diag = reinterpret_cast<double*>(scratch + head_bytes(a.n_src));
   g.diag_stride = diag_stride_of(a.nx, a.ny);
-  g.lines = reinterpret_cast<vhp::lanes::Tagged*>(scratch + head_bytes(a.n_src) + diag_bytes(a.n_src, a.nx, a.ny));
+  char* after_diag = scratch + head_bytes(a.n_src) + diag_bytes(a.n_src, a.nx, a.ny);
+  g.band = nullptr;
+  g.overlap = a.pool_no_overlap ? 0 : 1;
+  if (sizeof(OutT) == 8 && !a.pool_no_seam) { g.band = reinterpret_cast<double*>(after_diag); after_diag += band_bytes(a.n_src, a.nx, a.ny); }
+  g.lines = reinterpret_cast<vhp::lanes::Tagged*>(after_diag);
   g.epoch = a.pool_epoch;
   g.busy_cap = a.pool_busy_cap > 0 ? a.pool_busy_cap : kWaves;
   // two contexts take the largest units left, the others the smallest (0.75 against 0.78 ms with one head at 1000^2)
@@ -214,7 +220,8 @@ hipError_t launch_pool_t(const StreamArgs& a) {
 }  // namespace
 
 size_t pool_scratch_bytes(int n_src, int nx, int ny) {
-  return head_bytes(n_src) + diag_bytes(n_src, nx, ny) + (size_t)line_blocks_per_source(nx, ny) * (size_t)n_src * 64 * sizeof(vhp::lanes::Tagged);
+  return head_bytes(n_src) + diag_bytes(n_src, nx, ny) + band_bytes(n_src, nx, ny) +
+         (size_t)line_blocks_per_source(nx, ny) * (size_t)n_src * 64 * sizeof(vhp::lanes::Tagged);
 }
 
 bool pool_supported(int nx, int ny) {

@@ -160,6 +160,7 @@ struct Args {
   int n_units;
   double* diag;       // scratch: diag(k) of the y-major unit of (source s, quadrant q) at (4 s + q) * diag_stride + k
   int diag_stride;
+  double* band;       // scratch (fp64 fields; else nullptr): the seam band of (source s, quadrant q), row j at ((4 s + q) * diag_stride + j) * 16
   Tagged* lines;      // scratch: the boundary lines; strip p of unit u at 64 * (line_base[u] + p * blocks(u)) entries
   const int* line_base;
   uint64_t epoch;     // the tag of this launch (never 0, never repeated on this scratch)
@@ -169,7 +170,8 @@ struct Args {
   int early_ctx;      // contexts >= this one open only once `late_after` units have been taken: towards the end of a launch a
   int late_after;     // workgroup holds more, shorter units at once (what is left then has nothing large to get in the way of)
   unsigned long long* unit_times;  // diagnostic builds: when unit u was installed / finished (wall clock), or nullptr
-  VHP_HD int yp() const { return y_pitch(m.nx, (int)sizeof(OutT)); }  // columns from one y-major strip to the next
+  int overlap;        // 1: neighbouring y-major strips overlap where rows are off the line grid (y_pitch); 0: strips of 128 columns side by side
+  VHP_HD int yp() const { return overlap ? y_pitch(m.nx, (int)sizeof(OutT)) : kYCols; }  // columns from one y-major strip to the next
 };
 
 // Geometry of a unit without the direction templates: what the scheduler needs to tell whether a strip may start.
@@ -196,10 +198,41 @@ struct UnitGeo {
   // first step of strip p
   VHP_FN int first_step(int p) const { return x_major ? kXRows * p : imax(yp * p - ya, 0); }
   // diagonal entries a y-major strip needs before it starts
-  VHP_FN int diag_need(int p) const { return x_major ? 0 : imin(yp * p - ya + kYCols, rows_total); }
+  // (an x-major strip needs the seam band of its own rows: BandTask)
+  VHP_FN int diag_need(int p, bool seam) const { return x_major ? (seam ? imin(kXRows * p + kXRows, rows_total) : 0) : imin(yp * p - ya + kYCols, rows_total); }
   // 64-entry blocks of boundary-line scratch: one line of nb blocks per strip that has a reader
   VHP_FN int line_blocks() const { return n_strips > 1 ? (n_strips - 1) * nb : 0; }
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// The seam of a quadrant (fp64 fields).  In row j the x-major octant owns the cells i >= j and the y-major octant the cells
+// i < j, so the 128-byte line of the output that holds the diagonal cell is written in part by a strip of each -- and a line that
+// reaches the memory in two pieces costs it several whole ones.  Instead the x-major strip stores that line
+// WHOLE: its own cells out of its tile, the <= 15 cells of the y-major side out of the quadrant's seam BAND, which the wavefront
+// that installs the x-major unit recomputes (BandTask: the y-major stencil needs only the row above, so the 15 cells next to the
+// diagonal of every row follow from the diagonal itself, 16 lanes wide, bit for bit what the y-major strips compute); and the
+// y-major strips store nothing of that line.  Rows whose seam line would reach across the source's column or out of the row
+// (the first <= 16 rows, the last few) keep the cell-wise split.
+//   phi = place of the diagonal cell in its line, A = the line's first x, cnt = cells of the y-major side in it
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kLineCells = 16;  // fp64 cells per 128-byte line
+template <int DX, int DY>
+VHP_FN bool seam_regular(const Quad<DX, DY>& g, int nx, int j, int& A, int& cnt) {
+  const int y = g.Y(j), xd = g.X(j);
+  const int phi = (y * nx + xd) & (kLineCells - 1);
+  A = xd - phi;
+  cnt = DX > 0 ? phi : kLineCells - 1 - phi;
+  return j < g.rows_total && j > cnt && (DX > 0 ? A + kLineCells <= nx : A >= 0);
+}
+template <int DX, int DY>
+VHP_FN vb seam_regular_v(const Quad<DX, DY>& g, int nx, const vi& j, vi& A, vi& cnt) {
+  const vi y = j * DY + g.sy, xd = j * DX + g.sx;
+  const vi phi = (y * nx + xd) & (kLineCells - 1);
+  A = xd - phi;
+  cnt = DX > 0 ? phi : vi(kLineCells - 1) - phi;
+  const vb inside = DX > 0 ? (A + kLineCells <= nx) : (A >= 0);
+  return (j < g.rows_total) && (j > cnt) && inside;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // The boundary line between a strip and its neighbours: what a strip reads from the strip below it and what it hands to
@@ -333,6 +366,7 @@ struct XStrip {
   int r_stride;   // 2: the row pitch is an odd multiple of 64 bytes, odd and even rows are half a line apart; else 1
   int p, j0, rows_here;
   bool has_consumer;
+  const double* band; // the quadrant's seam band (BandTask), or nullptr: the cell-wise split at the diagonal
   Link<DX> lk;        // the boundary lines: strip p-1's (read) and mine (written)
   double* bin;        // = lk.bin
   int pf_blk;         // the block (x >> 6) whose operands wait in ow_nx / rv_nx, or -1
@@ -369,6 +403,36 @@ struct XStrip {
     prev = vd(0.0);
     jd = to_f64(lane + j0);
     pf_blk = -1;
+    band = nullptr;
+    band_pending = false;
+  }
+
+  // The band cells this strip will store go into its tile when the strip starts -- a load inside a flush would wait for every
+  // store the wavefront has in flight (one counter for loads and stores, in order; measured: +0.15 ms on a 0.7 ms launch).  Lane =
+  // row: the row's band line (16 cells in the order of the output line that holds its diagonal cell) goes to the 16 column slots
+  // of its tile row.  Until the row's diagonal cell switches it on, the march leaves the row's slots alone (window8<true> / step1
+  // write the tile only for rows that are on), and after that it overwrites exactly the cells of its own side; when the seam line
+  // is complete, the tile holds all of it.  The pad slot of the row (column 16) takes the first x of the row's seam line for the
+  // flush (kNoSeam where the row keeps the cell-wise split).  The loads are issued before the strip's first block loads its
+  // operands and are written to the tile behind the wait those need anyway.
+  static constexpr double kNoSeam = -1.0e9;
+  vd bandc[kLineCells];
+  bool band_pending;
+  VHP_FN void prefill_issue() {
+    const vi jr = vmin(lane + j0, g.rows_total - 1);
+#pragma unroll
+    for (int k = 0; k < kLineCells; k += 2) g_load2_f64(band, jr * kLineCells + k, bandc[k], bandc[k + 1]);
+    band_pending = true;
+  }
+  VHP_FN void prefill_commit() {
+    const vi jr = vmin(lane + j0, g.rows_total - 1);
+    vi A, cnt;
+    const vb reg = seam_regular_v(g, m.nx, jr, A, cnt);
+#pragma unroll
+    for (int k = 0; k < kLineCells; ++k) lds_store(tile, tile_l + ((A + k) & (kLineCells - 1)), bandc[k]);
+    lds_store(tile, tile_l + kLineCells, select(reg, to_f64(A), vd(kNoSeam)));
+    wave_sync();
+    band_pending = false;
   }
 
   // Emits one line of the rows r = r_first, r_first + r_stride, ... of this strip from the tile, 8 rows per store instruction.
@@ -420,10 +484,20 @@ struct XStrip {
           continue;
 #endif
           const vi jr = r + j0;
-          const vi jlo = jr;
-          const vb ok0 = row_ok && (i0c >= jlo) && (i0c <= i_now + i_extra);
-          const vb ok1 = row_ok && (i1c >= jlo) && (i1c <= i_now + i_extra);
-          g_store2_if(ok0 && ok1, ok0, ok1, base, off, a, b);
+          const vb in0 = row_ok && (i0c <= i_now + i_extra), in1 = row_ok && (i1c <= i_now + i_extra);
+          if (band) {
+            // rows with a regular seam: the line is stored whole where it holds the diagonal cell (the y-major side's cells are
+            // in the tile since prefill_band) or lies beyond it, and not at all where it lies on the y-major side
+            const vd A = lds_load(tile, select(row_ok, r, vi(0)) * kTStride + kLineCells);  // the row's seam line (prefill_commit)
+            const vb reg = A > vd(-1.0e8);
+            const vb mine = DX > 0 ? (A <= vd((double)xa)) : (A >= vd((double)xa));
+            const vb ok0 = in0 && select(reg, mine, i0c >= jr);
+            const vb ok1 = in1 && select(reg, mine, i1c >= jr);
+            g_store2_if(ok0 && ok1, ok0, ok1, base, off, a, b);
+          } else {
+            const vb ok0 = in0 && (i0c >= jr), ok1 = in1 && (i1c >= jr);
+            g_store2_if(ok0 && ok1, ok0, ok1, base, off, a, b);
+          }
         }
         base += base_step;
       }
@@ -488,7 +562,8 @@ struct XStrip {
       v = select(isd, dcell, v);
     }
     prev = v;
-    lds_store(tile, tile_l + (((x >> 3) & 1) * 8 + (x & 7)), v);
+    if (band) lds_store_if(lane <= i - j0, tile, tile_l + (((x >> 3) & 1) * 8 + (x & 7)), v);  // (a row that is not on yet keeps its band cells)
+    else lds_store(tile, tile_l + (((x >> 3) & 1) * 8 + (x & 7)), v);
     if (has_consumer) lds_store_if(lane == 63, lk.ring, vi(x & (kRing - 1)), v);
   }
 
@@ -532,7 +607,8 @@ struct XStrip {
         v = select(isd, dcell, v);
       }
       prev = v;
-      lds_store(tile, tidx + col, v);
+      if (DIAG && band) lds_store_if(lane <= i0 + k - j0, tile, tidx + col, v);  // (a row that is not on yet keeps its band cells)
+      else lds_store(tile, tidx + col, v);
       lds_store(wbase, widx + col, v);
       di = di + 1.0;
     }
@@ -561,6 +637,7 @@ struct XStrip {
       pin(rv);
       lds_store(slab, lane, rv);
       wave_sync();
+      if (band_pending) prefill_commit();
       if (nb + 1 < g.Nbx) { pf_blk = blk + DX; load_block(pf_blk, ow_nx, rv_nx); } else { pf_blk = -1; }
       VHP_PP_ADDP(lk.pp, 4, tl);
     }
@@ -617,11 +694,13 @@ struct YStrip {
   // neighbour of the next strip's first
   bool ovl;
   int bl, lc, o_c0, o_c1, sl_lo, sl_hi;
+  vb mk[4];           // store_lanes(y) for y & 3 = 0 .. 3 (the row phases repeat every 2 or 4 rows: nx is a multiple of 8)
+  bool seam;          // the x-major strips store the line that holds the diagonal cell whole (BandTask): nothing of it leaves here
 
   // (the caller has initialised lk)
-  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const double* diag) {
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const double* diag, int yp_) {
     m = m_; out = out_;
-    g.init(m.nx, m.ny, sx, sy, y_pitch(m.nx, CB));
+    g.init(m.nx, m.ny, sx, sy, yp_);
     slab = sh.lds + sh.L.slabs + w * kBlock;
     bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * 8;
@@ -631,6 +710,7 @@ struct YStrip {
     jstart = g.ystart(q);
     has_consumer = q + 1 < g.Py;
     interior = i0 >= 0 && i0 + kYCols - 1 < g.ni;  // every column of the strip is a column of the grid
+    seam = false;
     ovl = g.yp != kYCols;
     bl = g.yp / 2 - 1;
     lc = 128 / CB;
@@ -644,6 +724,8 @@ struct YStrip {
       const bool first = q == 0, last = !has_consumer;
       sl_lo = (DX > 0 ? first : last) ? -64 : 0;
       sl_hi = (DX > 0 ? last : first) ? 128 : g.yp / 2 - 1;
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) mk[ph] = store_lanes_of(ph);
     }
     ia = lane * 2 + i0;
     ib = ia + 1;
@@ -662,18 +744,27 @@ struct YStrip {
 
   // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below the diagonal
   // the lanes that store row y (overlapping strips only; see y_pitch)
-  VHP_FN vb store_lanes(int y) const {
+  VHP_FN vb store_lanes_of(int y) const {
     const int o2 = ((o_c0 - y * o_c1) & (lc - 1)) >> 1;
-    const vi pos = DX > 0 ? lane : 63 - lane;  // the lane's place counted from the strip's lowest x
+    const vi pos = DX > 0 ? lane : vi(63) - lane;  // the lane's place counted from the strip's lowest x
     return (pos >= sl_lo + o2) && (pos <= sl_hi + o2);
+  }
+  VHP_FN vb store_lanes(int y) const {
+    const int ph = y & 3;
+    return ph == 0 ? mk[0] : ph == 1 ? mk[1] : ph == 2 ? mk[2] : mk[3];
   }
   VHP_FN void store_pred(OutT* row, int j, vd v0, vd v1) {
 #ifdef VHP_DIAG_DROP_YPRED
     asm volatile("" :: "v"(v0), "v"(v1));
     return;
 #endif
-    vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
-    vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
+    int lim = j + 1;  // the columns below this one are stored: up to the diagonal cell, or up to the line that holds it
+    if (seam) {
+      int A, cnt;
+      if (seam_regular(g, m.nx, j, A, cnt)) lim = j - cnt;
+    }
+    vb ok0 = (ia >= 0) && (ia < g.ni) && (ia < lim);
+    vb ok1 = (ib >= 0) && (ib < g.ni) && (ib < lim);
     if (ovl) {
       const vb mine = store_lanes(g.Y(j));
       ok0 = ok0 && mine;
@@ -753,9 +844,9 @@ struct YStrip {
 #ifndef VHP_DIAG_NOYSTORE  // diagnostic builds only: what the y-major stores cost
       if (PRED) store_pred(row, j0w + k, v0, v1);
       else if (OVL) {
-        const vb mine = store_lanes(yb + bit);
-        if (DX > 0) g_store2_if(mine, vb(false), vb(false), row, xoff, v0, v1);
-        else g_store2_if(mine, vb(false), vb(false), row, xoff, v1, v0);
+        const vb mine = mk[bit & 3];  // (yb is a multiple of 8)
+        if (DX > 0) g_store2_mask(mine, row, xoff, v0, v1);
+        else g_store2_mask(mine, row, xoff, v1, v0);
       }
       else if (DX > 0) g_store2(row, xoff, v0, v1);
       else g_store2(row, xoff, v1, v0);
@@ -802,7 +893,7 @@ struct YStrip {
       const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
       if (aligned && j + 7 <= hi) {
         if (q > 0) lk.fetch(j, j + 7, nb);
-        if (j <= i0 + kYCols - 1) window8<true, true>(j);
+        if (j <= i0 + kYCols - 1 + (seam ? kLineCells : 0)) window8<true, true>(j);  // (the seam line may reach 15 columns back)
         else if (!interior) window8<false, true>(j);
         else if (ovl) window8<false, false, true>(j);
         else window8<false, false>(j);
@@ -880,6 +971,77 @@ struct DiagTask {
   }
 };
 
+// The band of a quadrant, 64 rows per call, into its scratch: row j as one whole line of 16 doubles in the ORDER OF THE OUTPUT
+// LINE (the cell at x = A + c in place c), so that an x-major strip loads the pair it is about to store with one 16-byte load.
+//   lane m (0 .. 15) holds c(m, j) = V(j - m, j):  c(0, j) = diag(j) (DiagTask's two-term recurrence),
+//   c(m, j) = (a - r (a - b)) occ(j - m, j),  a = c(m - 1, j - 1),  b = c(m, j - 1),  r = (j - m) / j        (m >= 1; 0 where j < m)
+template <int DX, int DY>
+struct BandTask {
+  Map m;
+  Quad<DX, DY> g;
+  double* band;
+  int k;
+  vi lane;
+  vd cprev, sprev;
+
+  VHP_FN void init(const Map& m_, int sx, int sy, double* band_) {
+    m = m_;
+    g.init(m.nx, m.ny, sx, sy);
+    band = band_;
+    lane = lane_id();
+    k = 0;
+    cprev = vd(0.0);
+    sprev = vd(0.0);
+  }
+  VHP_FN bool done() const { return k >= g.rows_total; }
+  VHP_FN int run_chunk() {
+    const int k0 = k, k1 = imin(k0 + kBlock, g.rows_total);
+    // operands of row k0 + lane, fetched once per chunk
+    const vi kk = vmin(lane + k0, g.rows_total - 1);
+    const vi x = kk * DX + g.sx;
+    const vi ya = vmax(kk - 1, 0) * DY + g.sy, yb = kk * DY + g.sy;
+    const vu64 wa = g_load_u64(m.rows, ya * m.wpr + ((x >> 6) + 1));
+    const vu64 wb = g_load_u64(m.rows, yb * m.wpr + ((x >> 6) + 1));
+    const vd rk = g_load_f64(m.recip, kk);
+    const vi ma = bit_mask_lane(wa, x & 63), mb = bit_mask_lane(wb, x & 63);
+    // the 128 occupancy bits of row yb from the word that holds the band's lowest x (x - 15 marching up, x marching down; the pad
+    // word on either side of a row reads as blocked, and so does what lies left of the grid)
+    const vi w0 = (DX > 0 ? x - (kLineCells - 1) : x) >> 6;
+    const vu64 b0 = g_load_u64(m.rows, yb * m.wpr + (w0 + 1));
+    const vu64 b1 = g_load_u64(m.rows, yb * m.wpr + (w0 + 2));
+    for (int kq = k0; kq < k1; ++kq) {
+      const int l = kq - k0;
+      const double rkl = read_lane(rk, l);
+      vd dcur;
+      if (kq == 0) {
+        dcur = and_mask(vd(1.0), vi(read_lane_i(mb, l)));
+        sprev = vd(0.0);
+      } else {
+        const vd c = ratio(vd((double)(kq - 1)), (double)kq, rkl);
+        const vd sub = and_mask(stencil(cprev, sprev, c), vi(read_lane_i(ma, l)));  // (lane 0: a = diag(kq - 1), b = sub(kq - 1))
+        dcur = and_mask(sub, vi(read_lane_i(mb, l)));
+        sprev = sub;
+      }
+      // the band cells of this row
+      const uint64_t wA = read_lane_u64(b0, l), wB = read_lane_u64(b1, l);
+      const int wbase = read_lane_i(w0, l) * 64;
+      const int xk = g.X(kq);
+      const vi i = vi(kq) - lane;
+      const vi pos = (vi(xk) - lane * DX) - wbase;
+      const vb exists = (lane >= 1) && (lane < kLineCells) && (i >= 0);
+      const vi occ = bit_mask_lane(select(pos < 64, vu64(wA), vu64(wB)), pos & 63);
+      const vd a = shift_up(cprev, vd(0.0));
+      const vd bnd = and_mask(stencil(a, cprev, ratio(to_f64(vmax(i, 0)), (double)kq, rkl)), occ);
+      const vd cnew = select(lane == 0, dcur, select(exists, bnd, vd(0.0)));
+      const int phi = (g.Y(kq) * m.nx + xk) & (kLineCells - 1);
+      g_store_f64_if(lane < kLineCells, band + (size_t)kLineCells * kq, (vi(phi) - lane * DX) & (kLineCells - 1), cnew);
+      cprev = cnew;
+    }
+    k = k1;
+    return k1;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // One wavefront of the pool.
 // ---------------------------------------------------------------------------------------------------------------
@@ -945,7 +1107,7 @@ struct Worker {
       ug.init(a.m.nx, a.m.ny, qo, sx, sy, a.yp());
 #ifndef VHP_DIAG_NOWAIT
       if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_step(p) + 8 + 1) continue;  // the strip below has swept my first window
-      if (!ug.x_major && lds_poll(cx + kDiagReady) < ug.diag_need(p)) continue;
+      if ((!ug.x_major || a.band) && lds_poll(cx + kDiagReady) < ug.diag_need(p, a.band != nullptr)) continue;
 #endif
       best_c = c; best_seq = rank; best_p = p; best_word = word; best_qo = qo; best_sx = sx; best_sy = sy;
     }
@@ -1034,6 +1196,32 @@ struct Worker {
         case 2: run_diag<-1, -1>(cx, sx, sy, dline); break;
         default: run_diag<+1, -1>(cx, sx, sy, dline); break;
       }
+    } else if (a.band) {
+      double* bline = band_of(s, qo);
+      switch (qo >> 1) {
+        case 0: run_band<+1, +1>(cx, sx, sy, bline); break;
+        case 1: run_band<-1, +1>(cx, sx, sy, bline); break;
+        case 2: run_band<-1, -1>(cx, sx, sy, bline); break;
+        default: run_band<+1, -1>(cx, sx, sy, bline); break;
+      }
+    }
+  }
+  VHP_FN double* band_of(int s, int qo) const { return a.band + (size_t)(4 * s + (qo >> 1)) * (size_t)a.diag_stride * kLineCells; }
+
+  template <int DX, int DY>
+  VHP_FN void run_band(int* cx, int sx, int sy, double* bline) {
+    BandTask<DX, DY> bt;
+    bt.init(a.m, sx, sy, bline);
+#ifdef VHP_DIAG_NOBANDTASK  // diagnostic builds only (WRONG results): what computing the band costs the launch
+    lds_publish(cx + kDiagReady, bt.g.rows_total);
+    return;
+#endif
+    while (!bt.done()) {
+      const int ready = bt.run_chunk();
+      stores_done();  // the rows are in memory (L2) before the count says so: the strips that load them run on this CU
+      lds_publish(cx + kDiagReady, ready);
+      sim_progress();
+      sim_point();
     }
   }
 
@@ -1077,6 +1265,7 @@ struct Worker {
     xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr,
                a.epoch, p > 0 ? lds_int_at(sh.owner(c) + (p - 1)) : -1, p > 0 ? tag_of(c, p - 1) : 0);
     xs.init(a.m, sx, sy, field, sh, w, p);
+    if (a.band) { xs.band = band_of(unit / kUnits, unit % kUnits); xs.prefill_issue(); }
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
     xs.lk.pp = prof;
 #endif
@@ -1104,7 +1293,8 @@ struct Worker {
     int* mine = sh.prog(c) + q;
     ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr,
                a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
-    ys.init(a.m, sx, sy, field, sh, w, q, dline);
+    ys.init(a.m, sx, sy, field, sh, w, q, dline, a.yp());
+    ys.seam = a.band != nullptr;
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
     ys.lk.pp = prof;
 #endif
