@@ -111,7 +111,7 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
     const int s = u / kUnits, qo = u % kUnits, sx = src[2 * s], sy = src[2 * s + 1];
     if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) continue;
     UnitGeo g;
-    g.init(nx, ny, qo, sx, sy, getenv("VHP_SIM_NO_OVERLAP") ? vhp::pool::kYCols : vhp::pool::y_pitch(nx, (int)sizeof(OutT)));
+    g.init(nx, ny, qo, sx, sy);
     line_blocks += g.line_blocks();
     if (g.n_strips > 0) weight[u] = g.x_major ? (double)g.rows_total * g.ni - 0.5 * g.rows_total * (g.rows_total - 1.0)
                                               : (double)g.cols_total * (g.nj - 1) - 0.5 * g.cols_total * (g.cols_total - 1.0);
@@ -134,9 +134,6 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   a.n_units = n_units;
   a.diag = diag.data();
   a.diag_stride = dstride;
-  a.overlap = getenv("VHP_SIM_NO_OVERLAP") ? 0 : 1;
-  std::vector<double> band(sizeof(OutT) == 8 ? (size_t)n_src * 4 * dstride * vhp::pool::kLineCells : 0, std::numeric_limits<double>::quiet_NaN());
-  a.band = band.empty() || getenv("VHP_SIM_NO_SEAM") ? nullptr : band.data();
   // The boundary lines start with entries of an EARLIER launch (same values poisoned, tag epoch - 1) and, here and there,
   // with a tag from the future of the same scratch region laid out differently: only this launch's tag may be taken.
   const uint64_t epoch = 0x5A17000000000000ull + 7 + seed;
@@ -316,7 +313,7 @@ int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, O
       sh.L = L;
       const int s_ = gI / kUnits, qo = gI % kUnits;
       UnitGeo ug;
-      ug.init(nx, ny, qo, src[2 * s_], src[2 * s_ + 1], vhp::pool::y_pitch(nx, (int)sizeof(OutT)));
+      ug.init(nx, ny, qo, src[2 * s_], src[2 * s_ + 1]);
       fprintf(stderr, "unit %d (source %d,%d qo %d): strips %d diag ready %d\n   prog:", gI, src[2 * s_], src[2 * s_ + 1], qo, ug.n_strips, sh.ctx(0)[kDiagReady]);
       for (int p = 0; p < ug.n_strips && p < L.S; ++p) fprintf(stderr, " %d", sh.prog(0)[p]);
       fprintf(stderr, "\n   alive:");

@@ -69,8 +69,6 @@ struct vhp_ctx {
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream), 3 pool sweep (vhp_pool)
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep, 3 pool sweep
   long long opt_field_stride = 0;  // device-pointer batch sweeps: elements from one field to the next (0: nx * ny, packed)
-  int opt_pool_overlap = 1;    // pool sweep: 1 = overlapping y-major strips where rows are off the line grid
-  int opt_pool_seam = 1;       // pool sweep: 1 = seam lines stored whole by the x-major strips (BandTask), 0 = the cell-wise split
   int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
   int opt_pool_heads = 0;      // pool sweep: contexts that pull the largest units (0 auto)
   int opt_pool_tail_pct = 0;   // pool sweep: share of the units the filler contexts take from the small end (0 auto)
@@ -345,8 +343,6 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.ev_begin = a.ev_end = nullptr;
   a.force_tile_slots = c->opt_stream_tile_slots;
   a.pool_contexts = c->opt_pool_contexts;
-  a.pool_no_seam = c->opt_pool_seam ? 0 : 1;
-  a.pool_no_overlap = c->opt_pool_overlap ? 0 : 1;
   a.pool_busy_cap = c->opt_pool_busy_cap;
   a.pool_early_ctx = c->opt_pool_early_ctx;
   a.pool_late_pct = c->opt_pool_late_pct;
@@ -799,8 +795,6 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3 && v != 4 && v != 6 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2, 3, 4, 6 or 8"); ctx->opt_stream_tile_slots = v; }
   else if (k == "kernel") { if (v < 0 || v > 4) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream, 3 pool, 4 latency"); ctx->opt_kernel = v; }
   else if (k == "field_stride") { if (value < 0) return fail(ctx, VHP_ERR_ARG, "field_stride: 0 (packed) or elements per field"); ctx->opt_field_stride = value; }
-  else if (k == "pool_seam") { ctx->opt_pool_seam = v != 0; }
-  else if (k == "pool_overlap") { ctx->opt_pool_overlap = v != 0; }
   else if (k == "pool_heads") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_heads: 0 (automatic) .. 16"); ctx->opt_pool_heads = v; }
   else if (k == "pool_tail_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_tail_pct: 0 (automatic) .. 100"); ctx->opt_pool_tail_pct = v; }
   else if (k == "pool_early_ctx") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_early_ctx: 0 (automatic) .. 16"); ctx->opt_pool_early_ctx = v; }

@@ -313,7 +313,7 @@ VHP_LANE_FN void g_load2_f64(const double* base, vi idx, vd& a, vd& b) { const d
 // of a row piece that is half a line off the line grid, the cells next to a diagonal or an axis) several whole lines' worth on
 // two thirds of the device's memory; with nt a partially written line costs what it weighs (tools/policybench.hip: the same
 // bytes, every other row half a line off: 3.65 -> 4.81 TB/s on a slow buffer, 5.27 -> 5.96 on a fast one).
-#ifdef VHP_DIAG_PLAINSTORE  // diagnostic builds only: the stores without the nt bit (what the launch took until round 4)
+#if defined(VHP_DIAG_PLAINSTORE) || defined(VHP_FIELD_STORE_PLAIN)  // the latency sweep (vhp_lat.hip); diagnostic builds: what a launch took until round 4
 #define VHP_FIELD_STORE(ptr, val) (*(ptr) = (val))
 #else
 #define VHP_FIELD_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))

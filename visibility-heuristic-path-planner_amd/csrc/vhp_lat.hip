@@ -1,4 +1,7 @@
 // vhp_lat.hip -- gfx950 build of the latency sweep (vhp_lat.hpp) and its launcher.
+// Plain field stores here (not the batch kernels' non-temporal ones, vhp_lanes.hpp): a launch of this kernel writes a few fields
+// that its caller reads right away -- the planner's epilogue, the host copy of a small batch -- out of the caches.
+#define VHP_FIELD_STORE_PLAIN 1
 #include "vhp_stream_launch.h"
 
 #include <hip/hip_runtime.h>

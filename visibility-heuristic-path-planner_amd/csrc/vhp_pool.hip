@@ -71,7 +71,7 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* wave_tot, i
   if (total) *total = all;
   return before + inc - v;
 }
-__global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int yp, int* __restrict__ order,
+__global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order,
                                                        int* __restrict__ line_base, long long capacity_blocks,
                                                        unsigned long long* __restrict__ queue, int* __restrict__ err_flag) {
   __shared__ int hist[kBuckets];
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict
       const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
       if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return 0;
       UnitGeo g;
-      g.init(nx, ny, qo, sx, sy, yp);
+      g.init(nx, ny, qo, sx, sy);
       return g.line_blocks();
     };
     const int per = (n_units + 1023) / 1024;
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict
     const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
     if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return kBuckets - 1;
     UnitGeo g;
-    g.init(nx, ny, qo, sx, sy, yp);
+    g.init(nx, ny, qo, sx, sy);
     double cells = 0.0;
     if (g.n_strips > 0) {
       if (g.x_major) { const double r = g.rows_total; cells = r * g.ni - r * (r - 1) * 0.5; }
@@ -144,12 +144,9 @@ constexpr int kQueueInts = 16;  // the pull counter (and padding) ahead of the o
 int diag_stride_of(int nx, int ny) { return ((nx < ny ? nx : ny) + 64 + 15) & ~15; }
 size_t head_bytes(int n_src) { return (((size_t)(kQueueInts + 2 * pool::kUnits * (size_t)n_src) * sizeof(int)) + 255) & ~(size_t)255; }
 size_t diag_bytes(int n_src, int nx, int ny) { return (((size_t)n_src * 4 * (size_t)diag_stride_of(nx, ny) * sizeof(double)) + 255) & ~(size_t)255; }
-// the seam bands (fp64 fields): a 128-byte line per row of the diagonal of every quadrant
-size_t band_bytes(int n_src, int nx, int ny) { return (size_t)n_src * 4 * (size_t)diag_stride_of(nx, ny) * pool::kLineCells * sizeof(double); }
 // 64-entry blocks of boundary lines a source can need, an upper bound: over its four quadrants ni * nj sums to nx * ny;
-// an x-major unit takes at most (min(ni,nj)/64) * (ni/64 + 2) blocks, a y-major one (ni/96 + 2) * (nj/64 + 2) (strips of 96
-// columns at the least: y_pitch)
-long long line_blocks_per_source(int nx, int ny) { return (7LL * nx * ny) / 16384 + (nx + ny) / 2 + 128; }
+// an x-major unit takes at most (min(ni,nj)/64) * (ni/64 + 2) blocks, a y-major one (ni/128 + 1) * (nj/64 + 2)
+long long line_blocks_per_source(int nx, int ny) { return (3LL * nx * ny) / 8192 + (nx + ny) / 4 + 64; }
 
 struct PoolShape { int n_ctx; size_t lds; };
 // as many contexts (units a workgroup holds at once) as asked for (default 4) that fit the LDS
@@ -193,11 +190,7 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   g.line_base = line_base;
   g.diag = reinterpret_cast<double*>(scratch + head_bytes(a.n_src));
   g.diag_stride = diag_stride_of(a.nx, a.ny);
-  char* after_diag = scratch + head_bytes(a.n_src) + diag_bytes(a.n_src, a.nx, a.ny);
-  g.band = nullptr;
-  g.overlap = a.pool_no_overlap ? 0 : 1;
-  if (sizeof(OutT) == 8 && !a.pool_no_seam) { g.band = reinterpret_cast<double*>(after_diag); after_diag += band_bytes(a.n_src, a.nx, a.ny); }
-  g.lines = reinterpret_cast<vhp::lanes::Tagged*>(after_diag);
+  g.lines = reinterpret_cast<vhp::lanes::Tagged*>(scratch + head_bytes(a.n_src) + diag_bytes(a.n_src, a.nx, a.ny));
   g.epoch = a.pool_epoch;
   g.busy_cap = a.pool_busy_cap > 0 ? a.pool_busy_cap : kWaves;
   // two contexts take the largest units left, the others the smallest (0.75 against 0.78 ms with one head at 1000^2)
@@ -210,7 +203,7 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   if (a.n_src <= 1024) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_unit_times)) == hipSuccess) g.unit_times = static_cast<unsigned long long*>(p); }
 #endif
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs
-  hipLaunchKernelGGL(vhp_pool_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, g.yp(), order, line_base,
+  hipLaunchKernelGGL(vhp_pool_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, order, line_base,
                      line_blocks_per_source(a.nx, a.ny) * a.n_src, reinterpret_cast<unsigned long long*>(a.d_queue), a.d_err);
   hipLaunchKernelGGL(k, dim3((unsigned)a.n_cus), dim3(64 * kWaves), sh.lds, a.stream, g, sh.n_ctx);
   const hipError_t e = hipGetLastError();
@@ -220,8 +213,7 @@ hipError_t launch_pool_t(const StreamArgs& a) {
 }  // namespace
 
 size_t pool_scratch_bytes(int n_src, int nx, int ny) {
-  return head_bytes(n_src) + diag_bytes(n_src, nx, ny) + band_bytes(n_src, nx, ny) +
-         (size_t)line_blocks_per_source(nx, ny) * (size_t)n_src * 64 * sizeof(vhp::lanes::Tagged);
+  return head_bytes(n_src) + diag_bytes(n_src, nx, ny) + (size_t)line_blocks_per_source(nx, ny) * (size_t)n_src * 64 * sizeof(vhp::lanes::Tagged);
 }
 
 bool pool_supported(int nx, int ny) {

@@ -138,16 +138,6 @@ struct Shared {
   VHP_FN double* bin(int w) const { return lds + L.bins + w * kBin; }
 };
 
-// Columns from one y-major strip to the next.  Where the rows of the output alternate between starting on a 128-byte line and
-// half a line off (a row pitch that is an odd multiple of 64 bytes: nx = 8 mod 16 in fp64 -- the 1000-wide grid), strips of 128
-// columns side by side would split a line of every other row between two wavefronts, and a line that leaves in two pieces costs
-// the memory system several whole ones (y1k_mixed 3.7 TB/s, the same bytes in whole lines 5.0).  So
-// neighbouring strips overlap by one line's worth of columns there (16 in fp64, 32 in fp32): a strip still sweeps 128 columns,
-// but of a row whose lines start `o` columns into the strip it stores the columns o .. o + pitch - 1 -- whole lines, its
-// neighbour goes on where it ends -- (strip 0: from its first column; the last strip: to its last), and the columns it shares
-// with its neighbour are computed twice, bit for bit the same.  `cb` = bytes per cell.
-VHP_HD int y_pitch(int nx, int cb) { const int lc = 128 / cb; return (nx % lc) ? kYCols - lc : kYCols; }
-
 template <typename OutT>
 struct Args {
   Map m;
@@ -160,7 +150,6 @@ struct Args {
   int n_units;
   double* diag;       // scratch: diag(k) of the y-major unit of (source s, quadrant q) at (4 s + q) * diag_stride + k
   int diag_stride;
-  double* band;       // scratch (fp64 fields; else nullptr): the seam band of (source s, quadrant q), row j at ((4 s + q) * diag_stride + j) * 16
   Tagged* lines;      // scratch: the boundary lines; strip p of unit u at 64 * (line_base[u] + p * blocks(u)) entries
   const int* line_base;
   uint64_t epoch;     // the tag of this launch (never 0, never repeated on this scratch)
@@ -170,16 +159,13 @@ struct Args {
   int early_ctx;      // contexts >= this one open only once `late_after` units have been taken: towards the end of a launch a
   int late_after;     // workgroup holds more, shorter units at once (what is left then has nothing large to get in the way of)
   unsigned long long* unit_times;  // diagnostic builds: when unit u was installed / finished (wall clock), or nullptr
-  int overlap;        // 1: neighbouring y-major strips overlap where rows are off the line grid (y_pitch); 0: strips of 128 columns side by side
-  VHP_HD int yp() const { return overlap ? y_pitch(m.nx, (int)sizeof(OutT)) : kYCols; }  // columns from one y-major strip to the next
 };
 
 // Geometry of a unit without the direction templates: what the scheduler needs to tell whether a strip may start.
 struct UnitGeo {
-  int ni, nj, rows_total, cols_total, ya, n_strips, ph, nb, yp;
+  int ni, nj, rows_total, cols_total, ya, n_strips, ph, nb;
   bool x_major;
-  VHP_FN void init(int nx, int ny, int qo, int sx, int sy, int yp_) {
-    yp = yp_;
+  VHP_FN void init(int nx, int ny, int qo, int sx, int sy) {
     const int q = qo >> 1;
     const int dx = (q == 0 || q == 3) ? 1 : -1, dy = q < 2 ? 1 : -1;
     x_major = (qo & 1) == 0;
@@ -193,46 +179,15 @@ struct UnitGeo {
     nb = x_major ? (ni > 0 ? ((phx + ni - 1) >> 6) + 1 : 0) : (nj > 0 ? ((ph + nj - 1) >> 6) + 1 : 0);  // blocks of the march (Quad::Nbx / Nby)
     if (ni <= 0 || nj <= 0) n_strips = 0;
     else if (x_major) n_strips = (rows_total + kXRows - 1) / kXRows;
-    else n_strips = cols_total > 0 ? imax((cols_total + ya - (kYCols - yp) + yp - 1) / yp, 1) : 0;
+    else n_strips = cols_total > 0 ? (cols_total + ya + kYCols - 1) / kYCols : 0;
   }
   // first step of strip p
-  VHP_FN int first_step(int p) const { return x_major ? kXRows * p : imax(yp * p - ya, 0); }
+  VHP_FN int first_step(int p) const { return x_major ? kXRows * p : imax(kYCols * p - ya, 0); }
   // diagonal entries a y-major strip needs before it starts
-  // (an x-major strip needs the seam band of its own rows: BandTask)
-  VHP_FN int diag_need(int p, bool seam) const { return x_major ? (seam ? imin(kXRows * p + kXRows, rows_total) : 0) : imin(yp * p - ya + kYCols, rows_total); }
+  VHP_FN int diag_need(int p) const { return x_major ? 0 : imin(kYCols * p - ya + kYCols, rows_total); }
   // 64-entry blocks of boundary-line scratch: one line of nb blocks per strip that has a reader
   VHP_FN int line_blocks() const { return n_strips > 1 ? (n_strips - 1) * nb : 0; }
 };
-
-// ---------------------------------------------------------------------------------------------------------------
-// The seam of a quadrant (fp64 fields).  In row j the x-major octant owns the cells i >= j and the y-major octant the cells
-// i < j, so the 128-byte line of the output that holds the diagonal cell is written in part by a strip of each -- and a line that
-// reaches the memory in two pieces costs it several whole ones.  Instead the x-major strip stores that line
-// WHOLE: its own cells out of its tile, the <= 15 cells of the y-major side out of the quadrant's seam BAND, which the wavefront
-// that installs the x-major unit recomputes (BandTask: the y-major stencil needs only the row above, so the 15 cells next to the
-// diagonal of every row follow from the diagonal itself, 16 lanes wide, bit for bit what the y-major strips compute); and the
-// y-major strips store nothing of that line.  Rows whose seam line would reach across the source's column or out of the row
-// (the first <= 16 rows, the last few) keep the cell-wise split.
-//   phi = place of the diagonal cell in its line, A = the line's first x, cnt = cells of the y-major side in it
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kLineCells = 16;  // fp64 cells per 128-byte line
-template <int DX, int DY>
-VHP_FN bool seam_regular(const Quad<DX, DY>& g, int nx, int j, int& A, int& cnt) {
-  const int y = g.Y(j), xd = g.X(j);
-  const int phi = (y * nx + xd) & (kLineCells - 1);
-  A = xd - phi;
-  cnt = DX > 0 ? phi : kLineCells - 1 - phi;
-  return j < g.rows_total && j > cnt && (DX > 0 ? A + kLineCells <= nx : A >= 0);
-}
-template <int DX, int DY>
-VHP_FN vb seam_regular_v(const Quad<DX, DY>& g, int nx, const vi& j, vi& A, vi& cnt) {
-  const vi y = j * DY + g.sy, xd = j * DX + g.sx;
-  const vi phi = (y * nx + xd) & (kLineCells - 1);
-  A = xd - phi;
-  cnt = DX > 0 ? phi : vi(kLineCells - 1) - phi;
-  const vb inside = DX > 0 ? (A + kLineCells <= nx) : (A >= 0);
-  return (j < g.rows_total) && (j > cnt) && inside;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // The boundary line between a strip and its neighbours: what a strip reads from the strip below it and what it hands to
@@ -287,9 +242,6 @@ struct Link {
   }
   // the whole block nb (coordinate block blk = x >> 6) goes to my line in global memory, out of the ring
   VHP_FN void store_block(int nb, int blk) {
-#ifdef VHP_DIAG_NOLINES  // diagnostic builds only (with NOWAIT): no boundary line leaves for global memory
-    return;
-#endif
     wave_sync();
     g_store_tagged(line_out, lane + 64 * nb, lds_load(ring, lane + 64 * (blk & 3)), epoch);
   }
@@ -366,7 +318,6 @@ struct XStrip {
   int r_stride;   // 2: the row pitch is an odd multiple of 64 bytes, odd and even rows are half a line apart; else 1
   int p, j0, rows_here;
   bool has_consumer;
-  const double* band; // the quadrant's seam band (BandTask), or nullptr: the cell-wise split at the diagonal
   Link<DX> lk;        // the boundary lines: strip p-1's (read) and mine (written)
   double* bin;        // = lk.bin
   int pf_blk;         // the block (x >> 6) whose operands wait in ow_nx / rv_nx, or -1
@@ -403,36 +354,6 @@ struct XStrip {
     prev = vd(0.0);
     jd = to_f64(lane + j0);
     pf_blk = -1;
-    band = nullptr;
-    band_pending = false;
-  }
-
-  // The band cells this strip will store go into its tile when the strip starts -- a load inside a flush would wait for every
-  // store the wavefront has in flight (one counter for loads and stores, in order; measured: +0.15 ms on a 0.7 ms launch).  Lane =
-  // row: the row's band line (16 cells in the order of the output line that holds its diagonal cell) goes to the 16 column slots
-  // of its tile row.  Until the row's diagonal cell switches it on, the march leaves the row's slots alone (window8<true> / step1
-  // write the tile only for rows that are on), and after that it overwrites exactly the cells of its own side; when the seam line
-  // is complete, the tile holds all of it.  The pad slot of the row (column 16) takes the first x of the row's seam line for the
-  // flush (kNoSeam where the row keeps the cell-wise split).  The loads are issued before the strip's first block loads its
-  // operands and are written to the tile behind the wait those need anyway.
-  static constexpr double kNoSeam = -1.0e9;
-  vd bandc[kLineCells];
-  bool band_pending;
-  VHP_FN void prefill_issue() {
-    const vi jr = vmin(lane + j0, g.rows_total - 1);
-#pragma unroll
-    for (int k = 0; k < kLineCells; k += 2) g_load2_f64(band, jr * kLineCells + k, bandc[k], bandc[k + 1]);
-    band_pending = true;
-  }
-  VHP_FN void prefill_commit() {
-    const vi jr = vmin(lane + j0, g.rows_total - 1);
-    vi A, cnt;
-    const vb reg = seam_regular_v(g, m.nx, jr, A, cnt);
-#pragma unroll
-    for (int k = 0; k < kLineCells; ++k) lds_store(tile, tile_l + ((A + k) & (kLineCells - 1)), bandc[k]);
-    lds_store(tile, tile_l + kLineCells, select(reg, to_f64(A), vd(kNoSeam)));
-    wave_sync();
-    band_pending = false;
   }
 
   // Emits one line of the rows r = r_first, r_first + r_stride, ... of this strip from the tile, 8 rows per store instruction.
@@ -484,20 +405,10 @@ struct XStrip {
           continue;
 #endif
           const vi jr = r + j0;
-          const vb in0 = row_ok && (i0c <= i_now + i_extra), in1 = row_ok && (i1c <= i_now + i_extra);
-          if (band) {
-            // rows with a regular seam: the line is stored whole where it holds the diagonal cell (the y-major side's cells are
-            // in the tile since prefill_band) or lies beyond it, and not at all where it lies on the y-major side
-            const vd A = lds_load(tile, select(row_ok, r, vi(0)) * kTStride + kLineCells);  // the row's seam line (prefill_commit)
-            const vb reg = A > vd(-1.0e8);
-            const vb mine = DX > 0 ? (A <= vd((double)xa)) : (A >= vd((double)xa));
-            const vb ok0 = in0 && select(reg, mine, i0c >= jr);
-            const vb ok1 = in1 && select(reg, mine, i1c >= jr);
-            g_store2_if(ok0 && ok1, ok0, ok1, base, off, a, b);
-          } else {
-            const vb ok0 = in0 && (i0c >= jr), ok1 = in1 && (i1c >= jr);
-            g_store2_if(ok0 && ok1, ok0, ok1, base, off, a, b);
-          }
+          const vi jlo = jr;
+          const vb ok0 = row_ok && (i0c >= jlo) && (i0c <= i_now + i_extra);
+          const vb ok1 = row_ok && (i1c >= jlo) && (i1c <= i_now + i_extra);
+          g_store2_if(ok0 && ok1, ok0, ok1, base, off, a, b);
         }
         base += base_step;
       }
@@ -562,8 +473,7 @@ struct XStrip {
       v = select(isd, dcell, v);
     }
     prev = v;
-    if (band) lds_store_if(lane <= i - j0, tile, tile_l + (((x >> 3) & 1) * 8 + (x & 7)), v);  // (a row that is not on yet keeps its band cells)
-    else lds_store(tile, tile_l + (((x >> 3) & 1) * 8 + (x & 7)), v);
+    lds_store(tile, tile_l + (((x >> 3) & 1) * 8 + (x & 7)), v);
     if (has_consumer) lds_store_if(lane == 63, lk.ring, vi(x & (kRing - 1)), v);
   }
 
@@ -607,8 +517,7 @@ struct XStrip {
         v = select(isd, dcell, v);
       }
       prev = v;
-      if (DIAG && band) lds_store_if(lane <= i0 + k - j0, tile, tidx + col, v);  // (a row that is not on yet keeps its band cells)
-      else lds_store(tile, tidx + col, v);
+      lds_store(tile, tidx + col, v);
       lds_store(wbase, widx + col, v);
       di = di + 1.0;
     }
@@ -637,7 +546,6 @@ struct XStrip {
       pin(rv);
       lds_store(slab, lane, rv);
       wave_sync();
-      if (band_pending) prefill_commit();
       if (nb + 1 < g.Nbx) { pf_blk = blk + DX; load_block(pf_blk, ow_nx, rv_nx); } else { pf_blk = -1; }
       VHP_PP_ADDP(lk.pp, 4, tl);
     }
@@ -689,18 +597,11 @@ struct YStrip {
   vd prev0, prev1, id0, id1, dg0, dg1;
   vu64 ow0, ow1;
   vu32 xoff;  // byte offset of the lane's pair inside a row
-  // overlapping strips (y_pitch): the lanes that store a row are sl_lo + o/2 .. sl_hi + o/2, o = the columns from the strip's
-  // first to the row's first line start inside it (0 <= o < lc, even); bl = the lane whose second column is the left
-  // neighbour of the next strip's first
-  bool ovl;
-  int bl, lc, o_c0, o_c1, sl_lo, sl_hi;
-  vb mk[4];           // store_lanes(y) for y & 3 = 0 .. 3 (the row phases repeat every 2 or 4 rows: nx is a multiple of 8)
-  bool seam;          // the x-major strips store the line that holds the diagonal cell whole (BandTask): nothing of it leaves here
 
   // (the caller has initialised lk)
-  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const double* diag, int yp_) {
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const double* diag) {
     m = m_; out = out_;
-    g.init(m.nx, m.ny, sx, sy, yp_);
+    g.init(m.nx, m.ny, sx, sy);
     slab = sh.lds + sh.L.slabs + w * kBlock;
     bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * 8;
@@ -710,23 +611,6 @@ struct YStrip {
     jstart = g.ystart(q);
     has_consumer = q + 1 < g.Py;
     interior = i0 >= 0 && i0 + kYCols - 1 < g.ni;  // every column of the strip is a column of the grid
-    seam = false;
-    ovl = g.yp != kYCols;
-    bl = g.yp / 2 - 1;
-    lc = 128 / CB;
-    {
-      // the strip's lowest x and, from it, the row phase: row y's lines start o(y) = (o_c0 - y * o_c1) mod lc columns into the strip
-      const int x_low = DX > 0 ? g.sx + i0 : g.sx - (i0 + kYCols - 1);
-      o_c0 = (lc - (x_low & (lc - 1))) & (lc - 1);
-      o_c1 = m.nx & (lc - 1);
-      // places are counted from the strip's lowest x (marching down, lane 0 holds the HIGHEST x: store_lanes).  The strip next
-      // to the axis also stores what lies between the axis and its first whole line, the last strip what lies beyond its last.
-      const bool first = q == 0, last = !has_consumer;
-      sl_lo = (DX > 0 ? first : last) ? -64 : 0;
-      sl_hi = (DX > 0 ? last : first) ? 128 : g.yp / 2 - 1;
-#pragma unroll
-      for (int ph = 0; ph < 4; ++ph) mk[ph] = store_lanes_of(ph);
-    }
     ia = lane * 2 + i0;
     ib = ia + 1;
     prev0 = vd(0.0);
@@ -743,33 +627,13 @@ struct YStrip {
   }
 
   // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below the diagonal
-  // the lanes that store row y (overlapping strips only; see y_pitch)
-  VHP_FN vb store_lanes_of(int y) const {
-    const int o2 = ((o_c0 - y * o_c1) & (lc - 1)) >> 1;
-    const vi pos = DX > 0 ? lane : vi(63) - lane;  // the lane's place counted from the strip's lowest x
-    return (pos >= sl_lo + o2) && (pos <= sl_hi + o2);
-  }
-  VHP_FN vb store_lanes(int y) const {
-    const int ph = y & 3;
-    return ph == 0 ? mk[0] : ph == 1 ? mk[1] : ph == 2 ? mk[2] : mk[3];
-  }
   VHP_FN void store_pred(OutT* row, int j, vd v0, vd v1) {
 #ifdef VHP_DIAG_DROP_YPRED
     asm volatile("" :: "v"(v0), "v"(v1));
     return;
 #endif
-    int lim = j + 1;  // the columns below this one are stored: up to the diagonal cell, or up to the line that holds it
-    if (seam) {
-      int A, cnt;
-      if (seam_regular(g, m.nx, j, A, cnt)) lim = j - cnt;
-    }
-    vb ok0 = (ia >= 0) && (ia < g.ni) && (ia < lim);
-    vb ok1 = (ib >= 0) && (ib < g.ni) && (ib < lim);
-    if (ovl) {
-      const vb mine = store_lanes(g.Y(j));
-      ok0 = ok0 && mine;
-      ok1 = ok1 && mine;
-    }
+    vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
+    vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
     if (DX < 0) {
       // Column 0 is never swept (the march stops at x = 1) and reads as zero.  Whoever stores x = 1 stores
       // that zero with it: one 16-byte store instead of an 8-byte one here and another somewhere else, some other time.
@@ -780,11 +644,7 @@ struct YStrip {
     if (DX > 0) g_store2_if(ok0 && ok1, ok0, ok1, row, xoff, v0, v1);
     else g_store2_if(ok0 && ok1, ok1, ok0, row, xoff, v1, v0);
   }
-#ifdef VHP_DIAG_YALIGNED  // diagnostic builds only (WRONG results): every row of a y-major strip starts on a line (rows off a line are moved by half a line)
-  VHP_FN OutT* row_ptr(int y) const { return out + (size_t)y * (size_t)m.nx - (((size_t)y * (size_t)m.nx) & 15); }
-#else
   VHP_FN OutT* row_ptr(int y) const { return out + (size_t)y * (size_t)m.nx; }
-#endif
 
   VHP_FN void step1(int j) {
     const int y = g.Y(j);
@@ -803,11 +663,11 @@ struct YStrip {
     store_pred(row_ptr(y), j, v0, v1);
     prev0 = v0;
     prev1 = v1;
-    if (has_consumer) lds_store_if(lane == bl, lk.ring, vi(y & (kRing - 1)), v1);
+    if (has_consumer) lds_store_if(lane == 63, lk.ring, vi(y & (kRing - 1)), v1);
   }
 
   // eight steps covering one aligned window of y.  DIAG: seeding may happen (implies PRED); PRED: predicated stores
-  template <bool DIAG, bool PRED, bool OVL = false>
+  template <bool DIAG, bool PRED>
   VHP_FN void window8(int j0w) {
     const int y0 = g.Y(j0w);
     const int t0 = y0 & 63;
@@ -827,7 +687,7 @@ struct YStrip {
     const int sh = DY > 0 ? (t0 & 31) : (t0 & 31) - 7;
     const vu32 hs0 = half_shifted(ow0, t0, sh), hs1 = half_shifted(ow1, t0, sh);
     double* wbase = has_consumer ? lk.ring + (yb & (kRing - 1)) : dummy;
-    const vi widx = select(lane == bl, vi(0), vi((int)(dummy - wbase)));
+    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
     vd dj = vd((double)j0w);
     OutT* row = row_ptr(y0);
     const long rowstep = (long)DY * m.nx;
@@ -843,11 +703,6 @@ struct YStrip {
       }
 #ifndef VHP_DIAG_NOYSTORE  // diagnostic builds only: what the y-major stores cost
       if (PRED) store_pred(row, j0w + k, v0, v1);
-      else if (OVL) {
-        const vb mine = mk[bit & 3];  // (yb is a multiple of 8)
-        if (DX > 0) g_store2_mask(mine, row, xoff, v0, v1);
-        else g_store2_mask(mine, row, xoff, v1, v0);
-      }
       else if (DX > 0) g_store2(row, xoff, v0, v1);
       else g_store2(row, xoff, v1, v0);
 #else
@@ -857,11 +712,7 @@ struct YStrip {
       prev1 = v1;
       lds_store(wbase, widx + bit, v1);
       dj = dj + 1.0;
-#ifdef VHP_DIAG_YALIGNED
-      row = row_ptr(y0 + DY * (k + 1));
-#else
       row += rowstep;
-#endif
     }
   }
 
@@ -893,9 +744,8 @@ struct YStrip {
       const bool aligned = DY > 0 ? (y & 7) == 0 : (y & 7) == 7;
       if (aligned && j + 7 <= hi) {
         if (q > 0) lk.fetch(j, j + 7, nb);
-        if (j <= i0 + kYCols - 1 + (seam ? kLineCells : 0)) window8<true, true>(j);  // (the seam line may reach 15 columns back)
+        if (j <= i0 + kYCols - 1) window8<true, true>(j);
         else if (!interior) window8<false, true>(j);
-        else if (ovl) window8<false, false, true>(j);
         else window8<false, false>(j);
         j += 8;
       } else {
@@ -963,80 +813,7 @@ struct DiagTask {
       dprev = dcur;
       acc = select(lane == l, dcur, acc);
     }
-#ifndef VHP_DIAG_NOLINES
     g_store_f64_if(lane < (k1 - k0), diag, lane + k0, acc);
-#endif
-    k = k1;
-    return k1;
-  }
-};
-
-// The band of a quadrant, 64 rows per call, into its scratch: row j as one whole line of 16 doubles in the ORDER OF THE OUTPUT
-// LINE (the cell at x = A + c in place c), so that an x-major strip loads the pair it is about to store with one 16-byte load.
-//   lane m (0 .. 15) holds c(m, j) = V(j - m, j):  c(0, j) = diag(j) (DiagTask's two-term recurrence),
-//   c(m, j) = (a - r (a - b)) occ(j - m, j),  a = c(m - 1, j - 1),  b = c(m, j - 1),  r = (j - m) / j        (m >= 1; 0 where j < m)
-template <int DX, int DY>
-struct BandTask {
-  Map m;
-  Quad<DX, DY> g;
-  double* band;
-  int k;
-  vi lane;
-  vd cprev, sprev;
-
-  VHP_FN void init(const Map& m_, int sx, int sy, double* band_) {
-    m = m_;
-    g.init(m.nx, m.ny, sx, sy);
-    band = band_;
-    lane = lane_id();
-    k = 0;
-    cprev = vd(0.0);
-    sprev = vd(0.0);
-  }
-  VHP_FN bool done() const { return k >= g.rows_total; }
-  VHP_FN int run_chunk() {
-    const int k0 = k, k1 = imin(k0 + kBlock, g.rows_total);
-    // operands of row k0 + lane, fetched once per chunk
-    const vi kk = vmin(lane + k0, g.rows_total - 1);
-    const vi x = kk * DX + g.sx;
-    const vi ya = vmax(kk - 1, 0) * DY + g.sy, yb = kk * DY + g.sy;
-    const vu64 wa = g_load_u64(m.rows, ya * m.wpr + ((x >> 6) + 1));
-    const vu64 wb = g_load_u64(m.rows, yb * m.wpr + ((x >> 6) + 1));
-    const vd rk = g_load_f64(m.recip, kk);
-    const vi ma = bit_mask_lane(wa, x & 63), mb = bit_mask_lane(wb, x & 63);
-    // the 128 occupancy bits of row yb from the word that holds the band's lowest x (x - 15 marching up, x marching down; the pad
-    // word on either side of a row reads as blocked, and so does what lies left of the grid)
-    const vi w0 = (DX > 0 ? x - (kLineCells - 1) : x) >> 6;
-    const vu64 b0 = g_load_u64(m.rows, yb * m.wpr + (w0 + 1));
-    const vu64 b1 = g_load_u64(m.rows, yb * m.wpr + (w0 + 2));
-    for (int kq = k0; kq < k1; ++kq) {
-      const int l = kq - k0;
-      const double rkl = read_lane(rk, l);
-      vd dcur;
-      if (kq == 0) {
-        dcur = and_mask(vd(1.0), vi(read_lane_i(mb, l)));
-        sprev = vd(0.0);
-      } else {
-        const vd c = ratio(vd((double)(kq - 1)), (double)kq, rkl);
-        const vd sub = and_mask(stencil(cprev, sprev, c), vi(read_lane_i(ma, l)));  // (lane 0: a = diag(kq - 1), b = sub(kq - 1))
-        dcur = and_mask(sub, vi(read_lane_i(mb, l)));
-        sprev = sub;
-      }
-      // the band cells of this row
-      const uint64_t wA = read_lane_u64(b0, l), wB = read_lane_u64(b1, l);
-      const int wbase = read_lane_i(w0, l) * 64;
-      const int xk = g.X(kq);
-      const vi i = vi(kq) - lane;
-      const vi pos = (vi(xk) - lane * DX) - wbase;
-      const vb exists = (lane >= 1) && (lane < kLineCells) && (i >= 0);
-      const vi occ = bit_mask_lane(select(pos < 64, vu64(wA), vu64(wB)), pos & 63);
-      const vd a = shift_up(cprev, vd(0.0));
-      const vd bnd = and_mask(stencil(a, cprev, ratio(to_f64(vmax(i, 0)), (double)kq, rkl)), occ);
-      const vd cnew = select(lane == 0, dcur, select(exists, bnd, vd(0.0)));
-      const int phi = (g.Y(kq) * m.nx + xk) & (kLineCells - 1);
-      g_store_f64_if(lane < kLineCells, band + (size_t)kLineCells * kq, (vi(phi) - lane * DX) & (kLineCells - 1), cnew);
-      cprev = cnew;
-    }
     k = k1;
     return k1;
   }
@@ -1104,10 +881,10 @@ struct Worker {
       const int unit = lds_poll(cx + kUnit), sxsy = lds_poll(cx + kSxSy);
       const int qo = unit & 7, sx = sxsy & 0xffff, sy = sxsy >> 16;
       UnitGeo ug;
-      ug.init(a.m.nx, a.m.ny, qo, sx, sy, a.yp());
+      ug.init(a.m.nx, a.m.ny, qo, sx, sy);
 #ifndef VHP_DIAG_NOWAIT
       if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_step(p) + 8 + 1) continue;  // the strip below has swept my first window
-      if ((!ug.x_major || a.band) && lds_poll(cx + kDiagReady) < ug.diag_need(p, a.band != nullptr)) continue;
+      if (!ug.x_major && lds_poll(cx + kDiagReady) < ug.diag_need(p)) continue;
 #endif
       best_c = c; best_seq = rank; best_p = p; best_word = word; best_qo = qo; best_sx = sx; best_sy = sy;
     }
@@ -1164,7 +941,7 @@ struct Worker {
       return;
     }
     UnitGeo ug;
-    ug.init(a.m.nx, a.m.ny, qo, sx, sy, a.yp());
+    ug.init(a.m.nx, a.m.ny, qo, sx, sy);
     OutT* field = a.out + (size_t)s * a.field_stride;
     if (qo == 0) {
       // rows/columns no quadrant covers read as zero; the x-major unit of quadrant 1 always exists
@@ -1196,32 +973,6 @@ struct Worker {
         case 2: run_diag<-1, -1>(cx, sx, sy, dline); break;
         default: run_diag<+1, -1>(cx, sx, sy, dline); break;
       }
-    } else if (a.band) {
-      double* bline = band_of(s, qo);
-      switch (qo >> 1) {
-        case 0: run_band<+1, +1>(cx, sx, sy, bline); break;
-        case 1: run_band<-1, +1>(cx, sx, sy, bline); break;
-        case 2: run_band<-1, -1>(cx, sx, sy, bline); break;
-        default: run_band<+1, -1>(cx, sx, sy, bline); break;
-      }
-    }
-  }
-  VHP_FN double* band_of(int s, int qo) const { return a.band + (size_t)(4 * s + (qo >> 1)) * (size_t)a.diag_stride * kLineCells; }
-
-  template <int DX, int DY>
-  VHP_FN void run_band(int* cx, int sx, int sy, double* bline) {
-    BandTask<DX, DY> bt;
-    bt.init(a.m, sx, sy, bline);
-#ifdef VHP_DIAG_NOBANDTASK  // diagnostic builds only (WRONG results): what computing the band costs the launch
-    lds_publish(cx + kDiagReady, bt.g.rows_total);
-    return;
-#endif
-    while (!bt.done()) {
-      const int ready = bt.run_chunk();
-      stores_done();  // the rows are in memory (L2) before the count says so: the strips that load them run on this CU
-      lds_publish(cx + kDiagReady, ready);
-      sim_progress();
-      sim_point();
     }
   }
 
@@ -1265,7 +1016,6 @@ struct Worker {
     xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr,
                a.epoch, p > 0 ? lds_int_at(sh.owner(c) + (p - 1)) : -1, p > 0 ? tag_of(c, p - 1) : 0);
     xs.init(a.m, sx, sy, field, sh, w, p);
-    if (a.band) { xs.band = band_of(unit / kUnits, unit % kUnits); xs.prefill_issue(); }
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
     xs.lk.pp = prof;
 #endif
@@ -1289,12 +1039,11 @@ struct Worker {
   VHP_FN void run_y(int c, int unit, int q, int sx, int sy, OutT* field, const double* dline) {
     YStrip<DX, DY, OutT> ys;
     Quad<DX, DY> g;
-    g.init(a.m.nx, a.m.ny, sx, sy, a.yp());
+    g.init(a.m.nx, a.m.ny, sx, sy);
     int* mine = sh.prog(c) + q;
     ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr,
                a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
-    ys.init(a.m, sx, sy, field, sh, w, q, dline, a.yp());
-    ys.seam = a.band != nullptr;
+    ys.init(a.m, sx, sy, field, sh, w, q, dline);
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
     ys.lk.pp = prof;
 #endif

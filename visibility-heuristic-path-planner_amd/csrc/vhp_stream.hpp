@@ -133,17 +133,16 @@ struct Quad {
   int Px, Py;      // strips per octant
   int bx0, by0;    // block (>> 6) of the source
   int Nbx, Nby;    // blocks per march
-  int yp;          // columns from one y-major strip to the next: kYCols, or less where neighbouring strips overlap (vhp_pool.hpp)
 
-  VHP_FN void init(int nx, int ny, int sx_, int sy_, int yp_ = kYCols) {
-    sx = sx_; sy = sy_; yp = yp_;
+  VHP_FN void init(int nx, int ny, int sx_, int sy_) {
+    sx = sx_; sy = sy_;
     ni = DX > 0 ? nx - sx : sx;
     nj = DY > 0 ? ny - sy : sy;
     rows_total = imin(ni, nj);
     cols_total = imax(imin(ni, nj - 1), 0);
     ya = DX > 0 ? (sx & 15) : ((-(sx + 1)) & 15);
     Px = (rows_total + kXRows - 1) / kXRows;
-    Py = cols_total > 0 ? imax((cols_total + ya - (kYCols - yp) + yp - 1) / yp, 1) : 0;
+    Py = cols_total > 0 ? (cols_total + ya + kYCols - 1) / kYCols : 0;
     bx0 = sx >> 6; by0 = sy >> 6;
     Nbx = ni > 0 ? nbx(ni - 1) + 1 : 0;
     Nby = nj > 0 ? nby(nj - 1) + 1 : 0;
@@ -165,7 +164,7 @@ struct Quad {
     if (DY > 0) { lo = 64 * b - sy; hi = 64 * b + 63 - sy; } else { lo = sy - (64 * b + 63); hi = sy - 64 * b; }
     lo = imax(lo, 0); hi = imin(hi, nj - 1);
   }
-  VHP_FN int ycol0(int q) const { return yp * q - ya; }               // first column of y-major strip q (may be < 0)
+  VHP_FN int ycol0(int q) const { return kYCols * q - ya; }           // first column of y-major strip q (may be < 0)
   VHP_FN int ystart(int q) const { return imax(ycol0(q), 0); }        // its first step
 };
 

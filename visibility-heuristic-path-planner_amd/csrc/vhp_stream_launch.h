@@ -29,8 +29,6 @@ struct StreamArgs {
   hipEvent_t ev_begin, ev_end;
   int force_tile_slots;   // 0: automatic; 2 / 3: windows per staging tile (tuning, vhp_set_option "stream_tile_slots")
   int pool_contexts = 0;  // pool sweep: units a workgroup holds at once (0: automatic; vhp_set_option "pool_contexts")
-  int pool_no_overlap = 0; // pool sweep: 1 = y-major strips of 128 columns side by side (A/B runs; vhp_set_option "pool_overlap" 0)
-  int pool_no_seam = 0;   // pool sweep: 1 = the cell-wise split at the diagonal instead of the seam band (A/B runs; vhp_set_option "pool_seam" 0)
   int pool_heads = 0;     // pool sweep: contexts that pull from the head of the size-sorted queue (0: one)
   int pool_tail_pct = 0;  // pool sweep: share of the units (by count, smallest first) that the filler contexts may take from the small end (0: 50)
   int pool_early_ctx = 0, pool_late_pct = 0;  // pool sweep: contexts >= early_ctx open once late_pct % of the units are taken (0: all open)

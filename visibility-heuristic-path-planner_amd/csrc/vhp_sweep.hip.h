@@ -212,19 +212,24 @@ __device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
 // (Raw buffer stores with out-of-range offsets as predication were measured slower than
 // exec-masked global stores here: every store instruction costs the issuing wavefront
 // ~60-80 cycles whether or not its lanes are dropped.)
-template <typename OutT, bool MULTI = false>
+// NT: non-temporal stores (the nt bit) -- the batch sweeps, whose fields nobody reads back during the launch: a plain store
+// that covers part of a 128-byte line costs the memory side several whole lines' worth on most of the device's memory, an nt
+// store what it weighs (vhp_lanes.hpp VHP_FIELD_STORE).  The planner's sweeps, whose field the epilogue
+// reads right away, keep plain stores.
+template <typename OutT, bool MULTI = false, bool NT = false>
 struct StoreEmit {
   static constexpr int kCellBytes = sizeof(OutT);
   static constexpr bool kFastPath = true;  // use the unrolled windows
   static constexpr bool kMulti = MULTI;    // fronts may be longer than one round of W strips
   OutT* __restrict__ out;
   int nx;
-  struct alignas(2 * sizeof(OutT)) Two { OutT a, b; };
+  typedef OutT Two __attribute__((ext_vector_type(2)));
+  template <typename T> static __device__ __forceinline__ void put(T* p, T v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
   __device__ __forceinline__ StoreEmit(OutT* field, int nx_, int) : out(field), nx(nx_) {}
   // both cells valid; off = (y*nx + x) * kCellBytes, maintained incrementally by the caller
   __device__ __forceinline__ void pair_at(uint32_t off, int, int, double v0, double v1) {
     VHP_DIAG_FRONT_STORE_GUARD
-    *reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
+    put(reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off), Two{static_cast<OutT>(v0), static_cast<OutT>(v1)});
   }
   // `both`: store the pair; else `one`: store only the cell at off + sel*kCellBytes (value vs)
   __device__ __forceinline__ void pair_or_single_at(uint32_t off, int, int, double v0, double v1, bool both, bool one,
@@ -232,20 +237,20 @@ struct StoreEmit {
     asm volatile("" : "+v"(vs));  // keep the compiler from splitting the 16-byte store to share a half with the single
     VHP_DIAG_FRONT_STORE_GUARD
     if (both)
-      *reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off) = Two{static_cast<OutT>(v0), static_cast<OutT>(v1)};
+      put(reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off), Two{static_cast<OutT>(v0), static_cast<OutT>(v1)});
     else if (one)
-      *reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off + (uint32_t)(sel * kCellBytes)) = static_cast<OutT>(vs);
+      put(reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off + (uint32_t)(sel * kCellBytes)), static_cast<OutT>(vs));
   }
   // one cell at byte offset off
   __device__ __forceinline__ void single_at(uint32_t off, int, int, double v) {
     VHP_DIAG_FRONT_STORE_GUARD
-    *reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off) = static_cast<OutT>(v);
+    put(reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off), static_cast<OutT>(v));
   }
   __device__ __forceinline__ void pair(int x, int y, double v0, double v1, bool ok0, bool ok1) {
     VHP_DIAG_FRONT_STORE_GUARD
     OutT* p = out + (size_t)y * nx + x;
-    if (ok0) p[0] = static_cast<OutT>(v0);
-    if (ok1) p[1] = static_cast<OutT>(v1);
+    if (ok0) put(p, static_cast<OutT>(v0));
+    if (ok1) put(p + 1, static_cast<OutT>(v1));
   }
   __device__ __forceinline__ void zero(int x, int y) { out[(size_t)y * nx + x] = OutT(0); }
 };
@@ -1154,7 +1159,7 @@ __device__ __forceinline__ void sweep_slot(const DevMap& m, const int32_t* __res
     for (int t = 0; t <= sg.tmax_floor; ++t) __syncthreads();
     return;
   }
-  StoreEmit<OutT, MULTI> emit(out + (size_t)s * field_stride, m.nx, m.ny);
+  StoreEmit<OutT, MULTI, true> emit(out + (size_t)s * field_stride, m.nx, m.ny);
   sweep_quadrant<R>(m, emit, sx, sy, q, lds + (size_t)sub * sweep_lds_doubles(R, sg.W, MULTI), sg);
 }
 
