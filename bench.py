@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- visibility fields/s of the HIP front sweep on MI355X.
+"""bench.py -- visibility fields/s of the HIP batch sweep (vhp_sweep_batch_device) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
@@ -11,7 +11,11 @@ config 3, the configuration the metric "visibility fields/sec on 1000x1000 grid 
 per GPU, fp64 fields.  Sources are sharded over ranks (each rank sweeps its own 256;
 the sweep has no exchange step, so there is no data-path collective in the timed
 region: weak scaling).  `--workload c2` times the single-source README case instead,
-`--gather` adds the RCCL all-gather of the per-source fields after each step.
+`--gather` adds the RCCL all-gather of the per-source fields after each step.  At N > 1 the line also carries
+`value_with_collective`: the same job with the fp32 all-gather of the fields and with the max-union + arg-source
+(dist.union_fields) after every step, each timed over a few steps behind the main region (compute-only and
+compute + collective side by side).  `config.output_placement` says what kind of memory the timed buffer landed on
+(vhp_probe_stores) and what three more allocations of the process would have got -- reported, never selected.
 
 The defaults (100 steps after 10 warm-up launches, ~0.1 s of GPU time) are long enough to report the
 sustained rate: on this pool the first ~25 ms of work after idle run 15-25 % faster than steady state.
@@ -53,8 +57,8 @@ def parse():
                     help="diagnostic: allocate this many candidate outputs and time each with a few launches before the timed "
                          "region.  The timed region ALWAYS runs on the first allocation; the probe times (and their median / "
                          "best) are only reported, in config.output_placement")
-    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                    help="0 = the library's own choice, 1 = front sweep, 2 = streaming sweep, 3 = pool sweep (vhp_set_option \"kernel\")")
+    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 3, 4],
+                    help="0 = the library's own choice, 1 = front sweep, 3 = pool sweep, 4 = latency sweep (vhp_set_option \"kernel\")")
     ap.add_argument("--pool-contexts", type=int, default=0, help="pool sweep: units a workgroup holds at once (0 = automatic)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo only with --dry-run)")
     ap.add_argument("--dry-run", action="store_true",
@@ -226,14 +230,11 @@ def launch_workers(args):
     replacing itself, and the children need the devices untouched): it imports nothing but the standard library.  The
     children are `python -m torch.distributed.run` workers of this same file with the same arguments; rank 0's JSON line
     comes through on stdout; the exit code is the launcher's (non-zero if any rank failed)."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher picks a free rendezvous port itself (no bind-close-reuse race on a busy host)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node=%d" % args.gpus, os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -266,8 +267,24 @@ def bench_dry_run(args, rank, world):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    with_coll = None
+    if world > 1:  # the same two collectives as the real run, on stand-in fields of 8 x 8 cells
+        fields = torch.full((hi - lo, 8, 8), float(rank))
+        with_coll = {}
+        for name, fn in (("allgather_f32", lambda: vdist.gather_fields(fields.float(), world * n_src)),
+                         ("union_fields", lambda: vdist.union_fields(fields, lo, world * n_src))):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                work.sum()
+                fn()
+            barrier()
+            tc = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            with_coll[name] = {"value": round(world * n_src * 3 / float(tc.item()), 2), "unit": "fields/s", "steps": 3}
     if rank == 0:
         print(json.dumps({"metric": "visibility fields/sec on 1000x1000 grid", "value": round(world * n_src * args.steps / float(t.item()), 2),
+                          "value_with_collective": with_coll,
                           "unit": "fields/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4), "higher_is_better": True,
                           "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -404,6 +421,84 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    # ---- behind the timed region: the job with its collective (N > 1), then what memory the timed buffer was -----------------
+    with_coll = None
+    if world > 1 and not args.gather and args.workload in ("c3", "c5"):
+        # compute-only (`value`) and compute + collective side by side.  (a) the all-gather of per-source fields
+        # north_star names, in fp32 (the fp64 result of config 5 alone is 137 GB per GPU); (b) what the planner needs of a
+        # sharded batch: the max-union and the arg-source (dist.union_fields).  A few steps each, same barriers, max over ranks.
+        with_coll = {}
+        k_coll = max(2, min(args.steps, 10))
+        try:
+            out32 = torch.empty((n_src, ny, nx), dtype=torch.float32, device=dev)
+            all32 = torch.empty((world * n_src, ny, nx), dtype=torch.float32, device=dev)
+            first = rank * n_src
+
+            def step_gather():
+                ctx.sweep_batch_device(d_src.data_ptr(), n_src, out32.data_ptr(), dtype=vhp_amd.F32)
+                dist.all_gather_into_tensor(all32, out32)
+
+            def step_union():
+                ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_out.data_ptr(), dtype=vdt)
+                vdist.union_fields(d_out, first, world * n_src)
+
+            for name, fn in (("allgather_f32", step_gather), ("union_fields", step_union)):
+                fn()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(k_coll):
+                    fn()
+                barrier()
+                tc = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+                with_coll[name] = {"value": round(world * n_src * k_coll / float(tc.item()), 2), "unit": "fields/s", "steps": k_coll,
+                                   "ms_per_step": round(float(tc.item()) / k_coll * 1e3, 4)}
+            out32 = all32 = None
+            torch.cuda.empty_cache()
+        except Exception as e:  # (memory: config 5 gathered on every rank is 69 GB in fp32)
+            with_coll["error"] = repr(e)
+    placement = {"timed_on": "first allocation", "candidates": n_cand, "probe_kernel_ms": probe_ms,
+                 "probe_median_ms": (round(float(np.median(probe_ms)), 4) if probe_ms else None),
+                 "probe_best_ms": (min(probe_ms) if probe_ms else None)}
+    if rank == 0 and out_bytes >= (128 << 20) and not overlapped:
+        # What kind of memory did the timed buffer land on?  Two store patterns on it (vhp_probe_stores: whole lines / lines
+        # written in halves, plain stores), then three MORE allocations of this process with the same two patterns and a few
+        # launches of the sweep each: reported so that the line can be read against the state of its memory; nothing is
+        # selected, the timed region above ran on the first allocation.
+        def state_of(split):
+            return "fast" if split >= 4.6 else "slow" if split <= 4.1 else "mixed"
+
+        def launch_ms(buf, k=5):
+            for _ in range(2):
+                ctx.sweep_batch_device(d_src.data_ptr(), n_src, buf.data_ptr(), dtype=vdt)
+            torch.cuda.synchronize()
+            ctx.timing(True, prealloc=k + 2)
+            for _ in range(k):
+                ctx.sweep_batch_device(d_src.data_ptr(), n_src, buf.data_ptr(), dtype=vdt)
+            torch.cuda.synchronize()
+            v = float(np.median(ctx.timing_collect(k)))
+            ctx.timing(False)
+            return round(v, 4)
+        try:
+            whole, split = ctx.probe_stores(d_out.data_ptr(), out_bytes)
+            placement["timed_buffer"] = {"whole_lines_TBps": round(whole, 2), "split_lines_TBps": round(split, 2), "state": state_of(split),
+                                         "note": "vhp_probe_stores: 1 KB row pieces in many streams, plain stores; on this device an allocation "
+                                                 "answers split lines with 3.6-3.7 (slow) or 5.2-5.4 TB/s (fast), DESIGN.md section 7"}
+            others = []
+            n_more = max(0, min(3, int((40 << 30) // max(out_bytes, 1)) - 1))
+            keep = []
+            for _ in range(n_more):
+                b = torch.empty((n_src, ny, nx), dtype=tdt, device=dev)
+                keep.append(b)
+                ms = launch_ms(b)
+                w, sp = ctx.probe_stores(b.data_ptr(), out_bytes)
+                others.append({"kernel_ms": ms, "whole_lines_TBps": round(w, 2), "split_lines_TBps": round(sp, 2), "state": state_of(sp)})
+            placement["other_allocations_of_this_process"] = others
+            keep = None
+            torch.cuda.empty_cache()
+        except Exception as e:
+            placement["timed_buffer"] = {"error": repr(e)}
     kern_ms = float(kern.sum()) / args.steps  # sweep-kernel time per step (one launch, or the pieces of an overlapped step)
 
     if rank == 0:
@@ -413,7 +508,7 @@ def main():
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this
         # command): collected by tools/collect_profiles.sh into profiles/, not measured inside this run
         traffic, traffic_src = None, None
-        kname = {1: "vhp_sweep_fronts", 2: "vhp_stream_sweep", 3: "vhp_pool_sweep", 4: "vhp_lat_sweep"}.get(ctx.last_sweep_kernel(), "unknown")  # what the library launched
+        kname = {1: "vhp_sweep_fronts", 3: "vhp_pool_sweep", 4: "vhp_lat_sweep"}.get(ctx.last_sweep_kernel(), "unknown")  # what the library launched
         tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s_%s.json" % (args.workload, args.dtype, kname))
         if os.path.exists(tpath):
             try:
@@ -436,9 +531,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "grid": [nx, ny], "sources_per_gpu": n_src, "sharding": "sources/%d" % world,
                        "kernel_option": args.kernel,
-                       "output_placement": {"timed_on": "first allocation", "candidates": n_cand, "probe_kernel_ms": probe_ms,
-                                            "probe_median_ms": (round(float(np.median(probe_ms)), 4) if probe_ms else None),
-                                            "probe_best_ms": (min(probe_ms) if probe_ms else None)},
+                       "output_placement": placement,
                        "collective": ("rccl all_gather of fields (%s%s)" % (args.gather_mode if gathered is not None else "", ", %d chunks per shard" % args.chunks if overlapped else "")
                                       if gathered is not None else "none (independent sources)"),
                        "map": "rccl broadcast from rank 0" if world > 1 else "uploaded by the only rank"},
@@ -449,7 +542,9 @@ def main():
                          # the same rate counting only the field bytes written (the occupancy maps are read at 2 bits/cell)
                          "frac_field_bytes": round((alg_bytes - nx * ny * n_src) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if with_coll is not None:
+            out["value_with_collective"] = with_coll
+        if not args.no_cpu_baseline:  # (rank 0, at any N: the other ranks wait at the last barrier)
             try:
                 out["cpu_baseline"] = cpu_baseline(occ, src, args.cpu_seconds)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number

@@ -118,6 +118,9 @@ int vhp_planner_results_device(vhp_ctx* ctx, const uint32_t** labels, const doub
  *     rank order.  The outputs are a valid planner result (labels index pivots, every pivot was lit by an earlier one, the
  *     path reconstructs) but not the reference's pivots or path.
  * stats (may be NULL): [0] iterations whose pivot was cached, [1] iterations that swept, [2] fields swept.
+ * pivots_xy: at least 2*(max_iter+2+8) ints -- in mode 1 an iteration commits up to k pivots before the max_iter test, so
+ * *n_pivots can reach max_iter + 8.  Both modes are SLOWER than vhp_planner_solve since round 3 (their launches sweep k fields
+ * with the front sweep, 110-140 us, where the plain loop's single-source latency sweep takes 17): kept for the API, not for speed.
  * Results stay on the device as with vhp_planner_solve_device (vhp_planner_results_device); host outputs may be NULL. */
 int vhp_planner_solve_speculative(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold, uint64_t max_iter,
                                   int k, int mode, uint64_t* came_from, double* vis_global, double* vis_local, int32_t* pivots_xy,
@@ -180,14 +183,25 @@ int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n);
  * (0 / -1 = automatic, the default).  Keys: "rows_per_lane" (1, 2, 4), "strips" (1..8 wavefront
  * strips per octant), "multi_round" (1 = force the multi-round build), "slide" (0 / 1: y-major
  * column grid slid onto 128-byte lines), "pack" (1 = pack short quadrants), "kernel" (1 = front
- * sweep, 2 = streaming sweep, 3 = pool sweep, 4 = latency sweep), "stream_tile_slots" (2, 3, 4, 6, 8: staging-tile
- * depth of the streaming sweep), "pool_contexts" (1..11: units a workgroup of the pool sweep holds
- * at once).  The results never depend on these; only the schedule does. */
+ * sweep, 3 = pool sweep, 4 = latency sweep; 2 was the streaming sweep, retired in round 4 and refused),
+ * "pool_contexts" (1..16: units a workgroup of the pool sweep holds
+ * at once), "field_stride" (elements from one field of a device-pointer batch to the next; 0 = nx * ny, packed).  The
+ * results never depend on these; only the schedule (and, with field_stride, the placement of the fields) does. */
 int vhp_set_option(vhp_ctx* ctx, const char* key, long long value);
 /* Which kernel the last batch sweep of this context launched: 1 = front sweep (vhp_sweep_fronts),
- * 2 = streaming sweep (vhp_stream_sweep), 3 = pool sweep (vhp_pool_sweep), 4 = latency sweep
+ * 3 = pool sweep (vhp_pool_sweep), 4 = latency sweep
  * (vhp_lat_sweep), 0 = none yet.  For benchmarks and profiles. */
 int vhp_last_sweep_kernel(const vhp_ctx* ctx);
+
+/* A measurement aid, not part of the reference's surface (it has no device memory): the rate at which the memory behind a
+ * device buffer takes two store patterns of a sweep launch, in TB/s of bytes stored -- 1 KB row pieces in many concurrent
+ * streams, (a) every piece on the 128-byte line grid, (b) every other piece half a line off it, so that two lines per piece
+ * are written in halves by different wavefronts at different times, with PLAIN stores.  The same physical memory answers (a)
+ * with 4.9-5.0 or 5.9-6.1 and (b) with 3.6-3.7 or 5.2-5.4 depending on where the allocation landed;
+ * bench.py reports both for the buffer it timed so that a result can be read against the state of its memory.  Nothing in the
+ * library chooses anything by it.  d_buf: 128-byte aligned, at least 128 MB; its contents are overwritten with zeros
+ * (up to 16 GB of it are used).  Blocks until done. */
+int vhp_probe_stores(vhp_ctx* ctx, void* d_buf, unsigned long long bytes, float* whole_lines_TBps, float* split_lines_TBps);
 
 /* Library / build identification: "vhp-hip <version> gfx950". */
 const char* vhp_version(void);

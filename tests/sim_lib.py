@@ -1,8 +1,8 @@
-"""ctypes binding of tests/sim/libvhp_stream_sim.so -- TEST INFRASTRUCTURE ONLY.
+"""ctypes binding of tests/sim/libvhp_pool_sim.so -- TEST INFRASTRUCTURE ONLY.
 
-The simulator compiles the streaming sweep kernel's own source (csrc/vhp_stream.hpp) for the CPU with 64 explicit
-lanes per wavefront, so that its schedule and index arithmetic can be checked against the oracle without a GPU.
-Nothing in the product imports this.
+The simulator compiles the pool sweep's and the latency sweep's own source (csrc/vhp_pool.hpp, vhp_lat.hpp) for the CPU with
+64 explicit lanes per wavefront, so that their schedules and index arithmetic can be checked against the oracle without a
+GPU.  Nothing in the product imports this.
 """
 import ctypes as C
 import os
@@ -12,34 +12,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM_DIR = os.path.join(ROOT, "tests", "sim")
-_lib = None
-
-
-def load():
-    global _lib
-    if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", SIM_DIR, "libvhp_stream_sim.so"])
-        lib = C.CDLL(os.path.join(SIM_DIR, "libvhp_stream_sim.so"))
-        lib.vhp_sim_stream_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
-                                             C.c_int, C.c_void_p]
-        _lib = lib
-    return _lib
-
-
-def sweep(occ, sources, dtype=np.float64, W=4, order=0):
-    """Fields [n, ny, nx] of the simulated kernel (pre-filled with NaN: an unwritten cell stays NaN) and the stats dict."""
-    lib = load()
-    occ = np.ascontiguousarray(occ, np.uint8)
-    ny, nx = occ.shape
-    src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
-    out = np.full((len(src), ny, nx), np.nan, dtype)
-    stats = np.zeros(5, np.int64)
-    rc = lib.vhp_sim_stream_sweep(occ.ctypes.data, nx, ny, src.ctypes.data, len(src), 0 if dtype == np.float64 else 1,
-                                  out.ctypes.data, W, order, stats.ctypes.data)
-    assert rc == 0, rc
-    return out, dict(slots=int(stats[0]), max_slots=int(stats[1]), violations=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]))
-
-
 _pool = None
 
 

@@ -29,12 +29,18 @@ def test_gpus_2_spawns_two_ranks():
     assert line["config"]["sharding"] == "sources/2" and line["scaling"] == "weak"
     # whole-job aggregate: both ranks' sources over the slowest rank's time
     assert abs(line["value"] - 2 * 100 * 4 / (line["ms_per_step"] * 4e-3)) <= 0.02 * line["value"]
+    # at N > 1 the line carries the job with its collective next to the compute-only value, for both collectives
+    wc = line["value_with_collective"]
+    assert set(wc) == {"allgather_f32", "union_fields"}
+    for v in wc.values():
+        assert v["unit"] == "fields/s" and v["value"] > 0 and v["steps"] == 3
 
 
 def test_gpus_1_runs_in_process():
     r = _run("--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0")
     assert r.returncode == 0, r.stderr[-2000:]
-    assert _json_lines(r.stdout)[0]["n_gpus"] == 1
+    line = _json_lines(r.stdout)[0]
+    assert line["n_gpus"] == 1 and line["value_with_collective"] is None   # one rank: nothing to exchange
 
 
 def test_a_failing_rank_fails_the_command():

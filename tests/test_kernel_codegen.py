@@ -1,4 +1,4 @@
-"""Code-generation invariants of the two dataflow kernels (streaming sweep, pool sweep), checked on the gfx950 assembly.
+"""Code-generation invariants of the two dataflow kernels (pool sweep, latency sweep), checked on the gfx950 assembly.
 
 Their cross-wavefront protocols (progress words, ring headers, descriptors) are ordered by the LDS executing one
 wavefront's DS instructions in issue order, with compiler barriers only.  That holds as long as every LDS access IS a DS
@@ -34,7 +34,7 @@ def _kernels(asm, name):
     return out
 
 
-@pytest.mark.parametrize("src,kernel", [("vhp_stream.hip", "vhp_stream_sweep"), ("vhp_pool.hip", "vhp_pool_sweep"), ("vhp_lat.hip", "vhp_lat_sweep")])
+@pytest.mark.parametrize("src,kernel", [("vhp_pool.hip", "vhp_pool_sweep"), ("vhp_lat.hip", "vhp_lat_sweep")])
 def test_no_flat_and_no_scratch_instructions(tmp_path, src, kernel):
     asm = _asm(src, tmp_path)
     ks = _kernels(asm, kernel)

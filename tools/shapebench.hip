@@ -19,6 +19,10 @@
 constexpr int NX = 1000, NY = 1000, NF = 256;
 constexpr size_t PITCH = 8000, FIELD = (size_t)NX * NY * 8;
 __device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <int NT> __device__ __forceinline__ void put2(void* p, double2 v) { if (NT) __builtin_nontemporal_store(d2{v.x, v.y}, (d2*)p); else *(double2*)p = v; }
+template <int NT> __device__ __forceinline__ void put1(void* p, double v) { if (NT) __builtin_nontemporal_store(v, (double*)p); else *(double*)p = v; }
+template <int NT>
 __global__ void __launch_bounds__(256) shapes(char* out, int pattern, int n_tasks, unsigned* counter) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63;
@@ -35,8 +39,8 @@ __global__ void __launch_bounds__(256) shapes(char* out, int pattern, int n_task
       // 21: all rows aligned, but issued by lanes 4..59 of a rotated wavefront: lane m stores 16 bytes at 16 (m - 4)
       for (int row = 0; row < NY; ++row) {
         char* p = field + (size_t)row * PITCH + (pattern == 21 ? ((row & 1) ? 64 : 0) : 0) + (size_t)k * 1024;
-        if (pattern == 20) { if (!(row & 1) || (lane >= 4 && lane < 60)) *reinterpret_cast<double2*>(p + (size_t)lane * 16) = val; }
-        else { if (lane >= 4 && lane < 60) *reinterpret_cast<double2*>(p + (size_t)(lane - 4) * 16) = val; }
+        if (pattern == 20) { if (!(row & 1) || (lane >= 4 && lane < 60)) put2<NT>(p + (size_t)lane * 16, val); }
+        else { if (lane >= 4 && lane < 60) put2<NT>(p + (size_t)(lane - 4) * 16, val); }
       }
     } else if (pattern >= 14 && pattern <= 19) {
       // 14..17: y1k with 1 / 2 / 4 / 8 rows of every 16 off the lines by 64 B; 18: y1k_mixed without the half lines (odd rows store their
@@ -45,28 +49,28 @@ __global__ void __launch_bounds__(256) shapes(char* out, int pattern, int n_task
         const int m = pattern == 14 ? 1 : pattern == 15 ? 2 : pattern == 16 ? 4 : 8;
         const bool off_line = pattern >= 18 ? (row & 1) : (row & 15) < m;
         char* p = field + (size_t)row * PITCH + ((row & 1) ? 64 : 0) + (off_line ? 64 : 0) + (size_t)k * 1024 + (size_t)lane * 16;
-        if (pattern >= 18 && off_line) { if (lane < 56) *reinterpret_cast<double2*>(p + 64) = val; }
-        else *reinterpret_cast<double2*>(p) = val;
-        if (pattern == 19 && off_line && lane >= 56) *reinterpret_cast<double2*>(p + (lane >= 60 ? 64 : 64 - 1024)) = val;
+        if (pattern >= 18 && off_line) { if (lane < 56) put2<NT>(p + 64, val); }
+        else put2<NT>(p, val);
+        if (pattern == 19 && off_line && lane >= 56) put2<NT>(p + (lane >= 60 ? 64 : 64 - 1024), val);
       }
     } else if (pattern == 13) {
       for (int row = 0; row < NY; ++row) {
         const int sl = (row & 1) ? ((lane + 4) & 63) : lane;
         // the same bytes as y1k_mixed (the odd rows of a 1000-wide field start 64 B off a line), other lanes issuing them
         char* p = field + (size_t)row * PITCH + (size_t)k * 1024 + (size_t)sl * 16;
-        *reinterpret_cast<double2*>(p) = val;
+        put2<NT>(p, val);
       }
     } else if (pattern <= 2 || pattern == 10) {  // 7 bands of 1 KB per row (7168 of 8000 B)
       for (int row = 0; row < NY; ++row) {
         const int shift = pattern == 0 || pattern == 10 ? ((row & 1) ? 64 : 0) : pattern == 1 ? ((row & 1) ? 0 : 64) : 0;
         char* p = field + (size_t)row * PITCH + shift + (size_t)k * 1024 + (size_t)lane * 16;
-        if (pattern == 10) *reinterpret_cast<double*>(p) = val.x; else *reinterpret_cast<double2*>(p) = val;
+        if (pattern == 10) put1<NT>(p, val.x); else put2<NT>(p, val);
       }
     } else if (pattern == 12) {  // 3 bands of 2 KB
       for (int row = 0; row < NY; ++row) {
         char* p = field + (size_t)row * PITCH + ((row & 1) ? 64 : 0) + (size_t)k * 2048 + (size_t)lane * 16;
-        *reinterpret_cast<double2*>(p) = val;
-        *reinterpret_cast<double2*>(p + 1024) = val;
+        put2<NT>(p, val);
+        put2<NT>(p + 1024, val);
       }
     } else if (pattern >= 3 && pattern <= 6 || pattern == 11) {
       const int P = pattern == 3 || pattern == 11 ? 128 : pattern == 4 ? 64 : pattern == 5 ? 256 : 512;
@@ -79,27 +83,28 @@ __global__ void __launch_bounds__(256) shapes(char* out, int pattern, int n_task
           else r = (lane / lpr) + rpi * u;
           const int row = r0 + r;
           char* p = field + (size_t)row * PITCH + ((row & 1) ? 64 : 0) + (size_t)ix * P + (size_t)(lane % lpr) * 16;
-          if (row < NY) *reinterpret_cast<double2*>(p) = val;
+          if (row < NY) put2<NT>(p, val);
         }
     } else if (pattern == 7) {
       char* p = out + (size_t)t * 65536;
-      for (int i = 0; i < 64; ++i) *reinterpret_cast<double2*>(p + (size_t)i * 1024 + (size_t)lane * 16) = val;
+      for (int i = 0; i < 64; ++i) put2<NT>(p + (size_t)i * 1024 + (size_t)lane * 16, val);
     } else if (pattern == 8) {
       for (int i = 0; i < 64; ++i) {
         const uint32_t h = hash32(t * 64u + i) * 8u + (lane >> 3);
         const size_t line = (size_t)(hash32(h) % (uint32_t)((size_t)NF * FIELD / 128));
-        *reinterpret_cast<double2*>(out + line * 128 + (size_t)(lane & 7) * 16) = val;
+        put2<NT>(out + line * 128 + (size_t)(lane & 7) * 16, val);
       }
     } else if (pattern == 9) {
       for (int i = 0; i < 64; ++i) {
         const size_t piece = (size_t)(hash32(t * 64u + i) % (uint32_t)((size_t)NF * FIELD / 1024));
-        *reinterpret_cast<double2*>(out + piece * 1024 + (size_t)lane * 16) = val;
+        put2<NT>(out + piece * 1024 + (size_t)lane * 16, val);
       }
     }
   }
 }
 static unsigned* d_counter = nullptr;
-extern "C" int shape_run(void* buf, int pattern, int wpc, float* ms_out, double* bytes_out) {
+extern "C" int shape_run(void* buf, int pattern_in, int wpc, float* ms_out, double* bytes_out) {
+  const int nt = pattern_in >= 100; const int pattern = pattern_in % 100;
   if (!d_counter && hipMalloc(&d_counter, 4) != hipSuccess) return 1;
   int n_tasks; double bytes;
   if (pattern <= 2 || pattern >= 13) { n_tasks = NF * 7; bytes = (double)NF * NY * 7168; }
@@ -109,13 +114,15 @@ extern "C" int shape_run(void* buf, int pattern, int wpc, float* ms_out, double*
   else { n_tasks = (int)((size_t)NF * FIELD / 65536); bytes = (double)n_tasks * 65536; }
   const int wgs_per_cu = wpc / 4;
   const size_t lds = 160 * 1024 / wgs_per_cu - 512;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(shapes), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(shapes<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(shapes<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     hipMemsetAsync(d_counter, 0, 4, 0);
     hipEventRecord(a, 0);
-    hipLaunchKernelGGL(shapes, dim3(256 * wgs_per_cu), dim3(256), lds, 0, (char*)buf, pattern, n_tasks, d_counter);
+    if (nt) hipLaunchKernelGGL(shapes<1>, dim3(256 * wgs_per_cu), dim3(256), lds, 0, (char*)buf, pattern, n_tasks, d_counter);
+    else hipLaunchKernelGGL(shapes<0>, dim3(256 * wgs_per_cu), dim3(256), lds, 0, (char*)buf, pattern, n_tasks, d_counter);
     hipEventRecord(b, 0); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     if (rep > 0 && ms < best) best = ms;

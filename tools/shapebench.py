@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from importlib import import_module
-mod = import_module("visibility-heuristic-path-planner_amd")
+mod = import_module("visibility-heuristic-path-planner_amd"); mod.LIB_PATH = os.path.join(ROOT, "exp", "libvhp_BASE.so")
 synth = import_module("visibility-heuristic-path-planner_amd.synth")
 ncand = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 n, side = 256, 1000
@@ -30,8 +30,11 @@ print("C3 launch ms per candidate:", " ".join("%.3f" % t for t in t0), flush=Tru
 slow, fast = bufs[int(np.argmax(t0))], bufs[int(np.argmin(t0))]
 names = ["y1k", "y1k_half", "y1k_mixed", "x128", "x64", "x256", "x512", "fill", "rand128", "rand1k", "y1k_8B", "x128_rows2", "y2k", "y1k_rot", "y1k_off1of16", "y1k_off2of16", "y1k_off4of16", "y1k_off8of16", "y1k_nohalves", "y1k_halveslater", "y1k_mis_nohalves", "y1k_lanes4to59"]
 print("%-12s %4s | %9s %9s %6s" % ("pattern", "wpc", "slow TB/s", "fast TB/s", "ratio"))
-for pat, nm in enumerate(names):
-    if len(sys.argv) > 2 and pat < int(sys.argv[2]) and pat not in (0, 2): continue
+todo = [(pat, nm) for pat, nm in enumerate(names) if not (len(sys.argv) > 2 and pat < int(sys.argv[2]) and pat not in (0, 2))]
+if len(sys.argv) > 3:  # the same patterns with non-temporal stores
+    todo = [(pat, nm) for pat, nm in enumerate(names) if nm in sys.argv[3].split(",")]
+    todo = todo + [(100 + pat, nm + "+nt") for pat, nm in todo]
+for pat, nm in todo:
     for wpc in (8, 12, 16):
         ms, by = C.c_float(), C.c_double()
         r = []

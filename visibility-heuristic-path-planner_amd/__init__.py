@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
     "vhp_raycast_all", "vhp_timing", "vhp_timing_collect", "vhp_set_option", "vhp_sweep_batch_variant", "vhp_planner_solve_variant",
     "vhp_planner_solve_device", "vhp_planner_results_device", "vhp_last_sweep_kernel",
-    "vhp_last_elapsed_ms", "vhp_version", "vhp_sweep_batch_offset", "vhp_planner_solve_speculative",
+    "vhp_last_elapsed_ms", "vhp_version", "vhp_sweep_batch_offset", "vhp_planner_solve_speculative", "vhp_probe_stores",
 )
 
 
@@ -96,6 +96,7 @@ def load_library():
     lib.vhp_last_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.vhp_version.restype = C.c_char_p
     lib.vhp_last_sweep_kernel.argtypes = [vp]
+    lib.vhp_probe_stores.argtypes = [vp, vp, C.c_ulonglong, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     _lib = lib
     return lib
 
@@ -172,6 +173,12 @@ class Context:
         n = C.c_int(0)
         self._check(self.lib.vhp_timing_collect(self.h, _ptr(buf), cap, C.byref(n)))
         return buf[: n.value].copy()
+
+    def probe_stores(self, d_ptr, n_bytes):
+        """(whole-line TB/s, split-line TB/s) of the memory behind a device buffer (vhp_probe_stores; overwrites it)."""
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self.lib.vhp_probe_stores(self.h, C.c_void_p(d_ptr), int(n_bytes), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def last_elapsed_ms(self):
         ms = C.c_float(0)

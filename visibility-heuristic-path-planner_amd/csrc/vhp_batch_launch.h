@@ -1,5 +1,5 @@
-// vhp_stream_launch.h -- host-side interface of the streaming sweep (vhp_stream.hip) and of the pool sweep (vhp_pool.hip),
-// used by vhp_capi.hip.
+// vhp_batch_launch.h -- host-side interface of the persistent batch kernels: the pool sweep (vhp_pool.hip) and the latency
+// sweep (vhp_lat.hip), used by vhp_capi.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,7 +8,7 @@
 
 namespace vhp {
 
-struct StreamArgs {
+struct BatchArgs {
   const uint64_t* rows;   // packed maps and reciprocal table of the context (vhp_set_map)
   const uint64_t* cols;
   const double* recip;
@@ -19,7 +19,7 @@ struct StreamArgs {
   int dtype;              // VHP_F64 / VHP_F32
   long long field_stride; // elements
   int* d_err;             // device flag: a source outside the grid
-  int* d_queue;           // scratch of stream_queue_bytes(n_src): the pull queue, per-CU counters, the slots in launch order
+  int* d_queue;           // the launch's scratch (pool_scratch_bytes / lat_scratch_bytes)
   int n_cus;              // compute units of the device (the persistent grid is sized to what the chip holds at once)
   hipStream_t stream;
   // called with (kernel, bytes) before a launch that needs more than the default dynamic LDS: the per-device
@@ -27,8 +27,8 @@ struct StreamArgs {
   std::function<hipError_t(const void*, size_t)> raise_lds;
   // optional per-launch timing events, recorded around the sweep kernel only
   hipEvent_t ev_begin, ev_end;
-  int force_tile_slots;   // 0: automatic; 2 / 3: windows per staging tile (tuning, vhp_set_option "stream_tile_slots")
   int pool_contexts = 0;  // pool sweep: units a workgroup holds at once (0: automatic; vhp_set_option "pool_contexts")
+  int pool_burst_ctx = 0, pool_burst_pct = 0;  // pool sweep: contexts open only at the start of a launch, until this share of the units is taken
   int pool_heads = 0;     // pool sweep: contexts that pull from the head of the size-sorted queue (0: one)
   int pool_tail_pct = 0;  // pool sweep: share of the units (by count, smallest first) that the filler contexts may take from the small end (0: 50)
   int pool_early_ctx = 0, pool_late_pct = 0;  // pool sweep: contexts >= early_ctx open once late_pct % of the units are taken (0: all open)
@@ -39,25 +39,18 @@ struct StreamArgs {
   unsigned long long pool_epoch = 0;  // pool sweep: the tag of this launch's boundary-line entries: never 0, never reused on this scratch
 };
 
-// true if the streaming kernel can sweep this grid (pitch a multiple of 8 cells, LDS of a workgroup fits)
-bool stream_supported(int nx, int ny);
-// sweeping wavefronts per x-major unit of a launch on this grid, 0 if unsupported
-int stream_strips(int nx, int ny);
-hipError_t launch_stream(const StreamArgs& a);
-size_t stream_queue_bytes(int n_src);
-
-// The pool sweep (vhp_pool.hip): same arguments; d_queue is scratch of pool_scratch_bytes (pull counter, unit order, the
+// The pool sweep (vhp_pool.hip): d_queue is scratch of pool_scratch_bytes (pull counter, unit order, the
 // diagonal lines of the y-major units, the boundary lines of the strips) that is ZERO when it is first used and is
 // written by nothing else; pool_epoch differs from launch to launch.
 bool pool_supported(int nx, int ny);
-hipError_t launch_pool(const StreamArgs& a);
+hipError_t launch_pool(const BatchArgs& a);
 size_t pool_scratch_bytes(int n_src, int nx, int ny);
 
 // The latency sweep (vhp_lat.hip): one workgroup per octant, for launches of a few sources.  d_queue is scratch of
 // lat_scratch_bytes with the pool sweep's rules (zero when first used, written by nothing but these two kernels; the two
 // share the epoch counter, so either may follow the other on one allocation).
 bool lat_supported(int nx, int ny);
-hipError_t launch_lat(const StreamArgs& a);
+hipError_t launch_lat(const BatchArgs& a);
 size_t lat_scratch_bytes(int n_src, int nx, int ny);
 
 }  // namespace vhp

@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "vhp_stream_launch.h"
+#include "vhp_batch_launch.h"
 #include "vhp_sweep.hip.h"
 #include "vhp_planner.hip.h"
 #include "vhp_queue.hip.h"
@@ -48,8 +48,6 @@ struct vhp_ctx {
   size_t d_bnd_cap = 0;
   int* d_order = nullptr;   // launch order of the (source, quadrant) units (+ one int4 descriptor per workgroup)
   size_t d_order_cap = 0;
-  int* d_queue = nullptr;   // streaming sweep: unit queue, per-CU counters, launch order
-  size_t d_queue_cap = 0;
   int* d_pool = nullptr;    // pool sweep: pull counter, unit order, diagonal lines, tagged boundary lines (zeroed when allocated)
   size_t d_pool_cap = 0;
   unsigned long long pool_epoch = 0x5A17000000000000ull;  // tag of the last pool launch
@@ -66,15 +64,15 @@ struct vhp_ctx {
   const int* lat_src_index = nullptr;  // set around a latency-sweep launch of the planner's loop (vhp_planner_solve)
   const int* lat_skip = nullptr;
   bool lat_dark_unwritten = false;
-  int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 2 streaming sweep (vhp_stream), 3 pool sweep (vhp_pool)
-  int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 2 streaming sweep, 3 pool sweep
+  int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 3 pool sweep (vhp_pool), 4 latency sweep (vhp_lat); 2 was the streaming sweep (retired in round 4)
+  int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 3 pool sweep, 4 latency sweep
   long long opt_field_stride = 0;  // device-pointer batch sweeps: elements from one field to the next (0: nx * ny, packed)
+  int opt_pool_burst_ctx = 0, opt_pool_burst_pct = 0;  // pool sweep: contexts open only at the start of a launch
   int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
   int opt_pool_heads = 0;      // pool sweep: contexts that pull the largest units (0 auto)
   int opt_pool_tail_pct = 0;   // pool sweep: share of the units the filler contexts take from the small end (0 auto)
   int opt_pool_early_ctx = 0, opt_pool_late_pct = 0;  // pool sweep: late contexts (0 auto)
   int opt_pool_busy_cap = 0;   // pool sweep: no new unit while this many wavefronts of the workgroup are sweeping (0 auto)
-  int opt_stream_tile_slots = 0;  // streaming sweep: 0 auto, 2 or 3 tile slots of the x-major strips (vhp_stream.hpp)
 
   vhp::PlannerState pl;  // device-resident planner state
   vhp::SpecState spec;   // field cache of the speculative planner
@@ -181,18 +179,6 @@ void free_map(vhp_ctx* c) {
   c->nx = c->ny = 0;
 }
 
-// the pull queue / per-CU counters of a persistent launch (and the unit order of the streaming sweep)
-hipError_t ensure_queue_scratch(vhp_ctx* c, size_t bytes) {
-  if (c->d_queue_cap >= bytes) return hipSuccess;
-  if (c->d_queue) (void)hipFree(c->d_queue);
-  c->d_queue = nullptr;
-  c->d_queue_cap = 0;
-  hipError_t e = hipMalloc(&c->d_queue, bytes);
-  if (e != hipSuccess) return e;
-  c->d_queue_cap = bytes;
-  return hipSuccess;
-}
-
 template <int R, bool MULTI, typename OutT>
 hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, int W) {
   const bool pack = c->opt_pack != 0;
@@ -257,8 +243,9 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
   return el;
 }
 
-// Which kernel sweeps a batch: the streaming sweep (vhp_stream.hpp) is built for throughput -- many quadrants in
-// flight, whole-line stores, one barrier per 64 steps -- the front sweep (vhp_sweep.hip.h) for the latency of a few.
+// Which kernel sweeps a batch: the pool sweep (vhp_pool.hpp) is built for throughput -- a pool of wavefronts per CU pulling
+// strips of many units at once, whole-line non-temporal stores -- the front sweep (vhp_sweep.hip.h) takes what the two others
+// do not (33-191 sources, widths that are not a multiple of 8).
 // The latency sweep (vhp_lat.hpp): one workgroup per octant.  Measured on MI355X against the front sweep (tools/lat_vs_front.py,
 // kernel time in us, front / latency sweep): one source at 256^2 33 / 28, 512^2 70 / 55, 690^2 94 / 67, 1000^2 132 / 96, 1536^2
 // 291 / 176, 2048^2 380 / 244; 8 sources 65 / 47, 123 / 88, 176 / 130, 244 / 177, 607 / 362, 844 / 559; 32 sources 67 / 48, 138 / 92,
@@ -276,32 +263,16 @@ bool use_lat_kernel(const vhp_ctx* c, int n_src) {
 }
 
 bool use_pool_kernel(const vhp_ctx* c, int n_src) {
-  if (c->opt_kernel == 1 || c->opt_kernel == 2 || c->opt_kernel == 4) return false;
+  if (c->opt_kernel == 1 || c->opt_kernel == 4) return false;
   if (!vhp::pool_supported(c->nx, c->ny)) return false;
   if (c->opt_kernel == 3) return true;
-  // Measured on MI355X (tools/ab_libs.py: the three kernels on one buffer in one process; pool / streaming / front, ms):
+  // Measured on MI355X in round 3 (tools/ab_libs.py: three kernels on one buffer in one process; pool / streaming (since retired) / front, ms):
   // 256 sources at 1000^2 0.51-0.55 / 0.61 / 0.56 on one box and 0.67-0.70 / 0.73 / 0.74 on another; 512: 0.96 / - / 1.03;
   // 128: 0.44-0.46 / - / 0.45; 128 sources at 2048^2 1.25 / 1.42 / -; at 4096^2 3.88 / 4.29 / -.  The pool sweep from 192
   // sources up to side 1024, and wherever the streaming sweep used to be picked above it.
   const int maxdim = std::max(c->nx, c->ny);
   if (maxdim <= 1024) return n_src >= 192;
   return n_src >= (maxdim >= 3072 ? 64 : 96);
-}
-
-bool use_stream_kernel(const vhp_ctx* c, int n_src) {
-  if (c->opt_kernel == 1 || c->opt_kernel == 3 || c->opt_kernel == 4) return false;
-  if (!vhp::stream_supported(c->nx, c->ny)) return false;
-  if (c->opt_kernel == 2) return true;
-  // Measured on MI355X (tools/ab_libs.py on one buffer, tools/ab_bench.sh in fresh processes; DESIGN.md "which kernel").
-  // The streaming sweep needs a batch that keeps every CU pulling units for much longer than its largest unit takes.
-  // front / streaming, ms: 128 sources at 1536^2 0.97 / 0.86, at 2048^2 1.60 / 1.41, at 2304^2 1.76 / 1.55, at 3072^2
-  // 3.23 / 2.45, at 4096^2 6.36 / 4.29; 96 sources at 2048^2 1.24 / 1.19, at 4096^2 4.42 / 3.98; 64 sources at 2304^2
-  // 1.23 / 1.25, at 3072^2 2.27 / 2.19, at 4096^2 3.90 / 3.65; 48 sources at 4096^2 3.39 / 3.60.  At 1000^2 the answer
-  // depends on where the output buffer lies (DESIGN.md "output placement"): 256 sources take 0.73-0.75 ms in it against
-  // 0.76 ms on a buffer in the slow state, 0.64 against 0.56-0.62 ms on one in the fast state -- the front sweep has the
-  // better expectation there.
-  const int maxdim = std::max(c->nx, c->ny);
-  return maxdim > 1024 && n_src >= (maxdim >= 3072 ? 64 : 96);
 }
 
 // the pool sweep's scratch: its own allocation (nothing else may write the tagged lines), zero when new
@@ -319,21 +290,20 @@ hipError_t ensure_pool_scratch(vhp_ctx* c, size_t bytes) {
 }
 
 template <typename OutT>
-hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, bool pool = false, bool lat = false) {
+hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out, bool lat) {
   {
-    hipError_t eo = lat ? ensure_pool_scratch(c, vhp::lat_scratch_bytes(n_src, c->nx, c->ny))
-                  : pool ? ensure_pool_scratch(c, vhp::pool_scratch_bytes(n_src, c->nx, c->ny)) : ensure_queue_scratch(c, vhp::stream_queue_bytes(n_src));
+    hipError_t eo = ensure_pool_scratch(c, lat ? vhp::lat_scratch_bytes(n_src, c->nx, c->ny) : vhp::pool_scratch_bytes(n_src, c->nx, c->ny));
     if (eo != hipSuccess) return eo;
   }
-  vhp::StreamArgs a;
+  vhp::BatchArgs a;
   a.rows = c->d_rows; a.cols = c->d_cols; a.recip = c->d_recip;
   a.wpr = c->wpr; a.wpc = c->wpc; a.nx = c->nx; a.ny = c->ny;
   a.d_src = d_src; a.n_src = n_src; a.d_out = d_out;
   a.dtype = sizeof(OutT) == 8 ? VHP_F64 : VHP_F32;
   a.field_stride = c->opt_field_stride > 0 ? c->opt_field_stride : (long long)c->nx * c->ny;
   a.d_err = c->d_err;
-  a.d_queue = (pool || lat) ? c->d_pool : c->d_queue;
-  a.pool_epoch = (pool || lat) ? ++c->pool_epoch : 0;
+  a.d_queue = c->d_pool;
+  a.pool_epoch = ++c->pool_epoch;
   a.d_src_index = lat ? c->lat_src_index : nullptr;
   a.d_skip = lat ? c->lat_skip : nullptr;
   a.lat_dead_cells_are_zero = lat && c->lat_dark_unwritten;
@@ -341,8 +311,9 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
   a.stream = c->stream;
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
   a.ev_begin = a.ev_end = nullptr;
-  a.force_tile_slots = c->opt_stream_tile_slots;
   a.pool_contexts = c->opt_pool_contexts;
+  a.pool_burst_ctx = c->opt_pool_burst_ctx;
+  a.pool_burst_pct = c->opt_pool_burst_pct;
   a.pool_busy_cap = c->opt_pool_busy_cap;
   a.pool_early_ctx = c->opt_pool_early_ctx;
   a.pool_late_pct = c->opt_pool_late_pct;
@@ -358,7 +329,7 @@ hipError_t launch_stream_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT
       if (hipEventCreate(&a.ev_end) != hipSuccess) { (void)hipEventDestroy(a.ev_begin); return hipErrorOutOfMemory; }
     }
   }
-  const hipError_t e = lat ? vhp::launch_lat(a) : pool ? vhp::launch_pool(a) : vhp::launch_stream(a);
+  const hipError_t e = lat ? vhp::launch_lat(a) : vhp::launch_pool(a);
   if (c->timing) {
     // (a launch that failed before its events were recorded must not leave a pair that can never be waited for)
     if (e == hipSuccess) c->timed_launches.push_back({a.ev_begin, a.ev_end});
@@ -371,15 +342,11 @@ template <typename OutT>
 hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out) {
   if (use_lat_kernel(c, n_src)) {
     c->last_kernel = 4;
-    return launch_stream_sweep<OutT>(c, d_src, n_src, d_out, false, true);
+    return launch_batch_sweep<OutT>(c, d_src, n_src, d_out, true);
   }
   if (use_pool_kernel(c, n_src)) {
     c->last_kernel = 3;
-    return launch_stream_sweep<OutT>(c, d_src, n_src, d_out, true);
-  }
-  if (use_stream_kernel(c, n_src)) {
-    c->last_kernel = 2;
-    return launch_stream_sweep<OutT>(c, d_src, n_src, d_out);
+    return launch_batch_sweep<OutT>(c, d_src, n_src, d_out, false);
   }
   c->last_kernel = 1;
   int R, W;
@@ -390,8 +357,9 @@ hipError_t launch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_out
     // instantiations needed 72-276 bytes of scratch per lane at 128 registers (round-2 verdict), and a scratch reload in
     // the flush path serialises the stores with their own completion; they are gone.  (Sides above 1024 take the streaming
     // sweep from 64-96 sources up as before; smaller fp32 batches there run one row per lane in rounds of 512 rows.)
-    (void)R;
-    const int Wf = c->opt_strips ? W : 8;
+    // (pick_shape's strip count where it already chose one row per lane -- small and odd-width grids keep their small
+    // workgroups --, else as many strips as the rows need, up to 8; "rows_per_lane" other than 1 is ignored for fp32 fields)
+    const int Wf = (c->opt_strips || R == 1) ? W : std::min(W * R, 8);
     const bool multi_f = Wf * 64 < std::max(c->nx, c->ny) || c->opt_multi;
     return multi_f ? launch_sweep_t<1, true, OutT>(c, d_src, n_src, d_out, Wf) : launch_sweep_t<1, false, OutT>(c, d_src, n_src, d_out, Wf);
   } else {
@@ -478,7 +446,6 @@ int vhp_destroy(vhp_ctx* ctx) {
   if (ctx->d_out) hipFree(ctx->d_out);
   if (ctx->d_bnd) hipFree(ctx->d_bnd);
   if (ctx->d_order) hipFree(ctx->d_order);
-  if (ctx->d_queue) hipFree(ctx->d_queue);
   if (ctx->d_pool) hipFree(ctx->d_pool);
   for (auto& pr : ctx->timed_launches) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -792,15 +759,16 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "multi_round") { ctx->opt_multi = v != 0; }
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
-  else if (k == "stream_tile_slots") { if (v != 0 && v != 2 && v != 3 && v != 4 && v != 6 && v != 8) return fail(ctx, VHP_ERR_ARG, "stream_tile_slots: 0, 2, 3, 4, 6 or 8"); ctx->opt_stream_tile_slots = v; }
-  else if (k == "kernel") { if (v < 0 || v > 4) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 2 stream, 3 pool, 4 latency"); ctx->opt_kernel = v; }
+  else if (k == "kernel") { if (v < 0 || v > 4 || v == 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 3 pool, 4 latency (2, the streaming sweep, was retired)"); ctx->opt_kernel = v; }
   else if (k == "field_stride") { if (value < 0) return fail(ctx, VHP_ERR_ARG, "field_stride: 0 (packed) or elements per field"); ctx->opt_field_stride = value; }
+  else if (k == "pool_burst_ctx") { if (v < 0 || v > 12) return fail(ctx, VHP_ERR_ARG, "pool_burst_ctx: 0 .. 12"); ctx->opt_pool_burst_ctx = v; }
+  else if (k == "pool_burst_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_burst_pct: 0 (automatic) .. 100"); ctx->opt_pool_burst_pct = v; }
   else if (k == "pool_heads") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_heads: 0 (automatic) .. 16"); ctx->opt_pool_heads = v; }
   else if (k == "pool_tail_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_tail_pct: 0 (automatic) .. 100"); ctx->opt_pool_tail_pct = v; }
   else if (k == "pool_early_ctx") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_early_ctx: 0 (automatic) .. 16"); ctx->opt_pool_early_ctx = v; }
   else if (k == "pool_late_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_late_pct: 0 (automatic) .. 100"); ctx->opt_pool_late_pct = v; }
   else if (k == "pool_busy_cap") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_busy_cap: 0 (automatic) .. 16"); ctx->opt_pool_busy_cap = v; }
-  else if (k == "pool_contexts") { if (v < 0 || v > 11) return fail(ctx, VHP_ERR_ARG, "pool_contexts: 0 (automatic) .. 11"); ctx->opt_pool_contexts = v; }
+  else if (k == "pool_contexts") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_contexts: 0 (automatic) .. 16"); ctx->opt_pool_contexts = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;
 }
@@ -826,6 +794,63 @@ int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n) {
   ctx->timed_launches.clear();
   *n = std::min(k, cap);
   if (bad) return fail(ctx, VHP_ERR_HIP, "vhp_timing_collect: " + std::to_string(bad) + " timed launch(es) could not be read");
+  return VHP_OK;
+}
+
+// ---- vhp_probe_stores: what the memory behind a buffer does with whole and with split lines (a measurement aid) -----------
+namespace {
+// Persistent wavefronts pull tasks; a task = 1000 rows of 8000 B (the C3 field's pitch: every other row starts half a 128-byte
+// line off the grid) x a band of 1 KB; a store instruction = one row of the band, plain stores.  split = 0: every piece moved
+// onto the line grid (whole lines only); split = 1: the pieces where they fall (two half lines per odd row).
+__global__ void __launch_bounds__(256) vhp_store_probe_kernel(char* out, int n_tasks, int split, unsigned* counter) {
+  extern __shared__ double probe_lds[];
+  const int lane = threadIdx.x & 63;
+  const double2 val = make_double2(0.0, 0.0);
+  for (;;) {
+    unsigned t = 0;
+    if (lane == 0) t = atomicAdd(counter, 1u);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= (unsigned)n_tasks) break;
+    const unsigned blk = t / 7u, band = t - blk * 7u;
+    char* base = out + (size_t)blk * 8000000u + (size_t)band * 1024u + (size_t)lane * 16u;
+    for (int row = 0; row < 1000; ++row) *reinterpret_cast<double2*>(base + (size_t)row * 8000u + ((!split && (row & 1)) ? 64 : 0)) = val;
+  }
+}
+}  // namespace
+
+int vhp_probe_stores(vhp_ctx* ctx, void* d_buf, unsigned long long bytes, float* whole_lines_TBps, float* split_lines_TBps) {
+  if (!ctx || !d_buf || !whole_lines_TBps || !split_lines_TBps) return VHP_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(d_buf) & 127u) != 0) return fail(ctx, VHP_ERR_ARG, "vhp_probe_stores: the buffer must start on a 128-byte line");
+  const unsigned long long blocks = bytes / 8000000ull;
+  if (blocks < 16) return fail(ctx, VHP_ERR_ARG, "vhp_probe_stores: needs at least 128 MB to say anything about the memory");
+  VHP_ON_DEVICE(ctx);
+  const int n_tasks = (int)std::min<unsigned long long>(blocks, 2048) * 7;
+  unsigned* d_counter = nullptr;
+  VHP_HIP(hipMalloc(&d_counter, 8));
+  hipEvent_t e0, e1;
+  VHP_HIP(hipEventCreate(&e0));
+  VHP_HIP(hipEventCreate(&e1));
+  float res[2] = {0.f, 0.f};
+  for (int split = 0; split < 2; ++split) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+      VHP_HIP(hipMemsetAsync(d_counter, 0, 4, ctx->stream));
+      VHP_HIP(hipEventRecord(e0, ctx->stream));
+      // three workgroups of four wavefronts per CU (52 KB of LDS each keeps a fourth out): what a launch of the pool sweep holds
+      hipLaunchKernelGGL(vhp_store_probe_kernel, dim3((unsigned)ctx->n_cus * 3), dim3(256), 52 * 1024, ctx->stream, static_cast<char*>(d_buf), n_tasks, split, d_counter);
+      VHP_HIP(hipEventRecord(e1, ctx->stream));
+      VHP_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      VHP_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (rep > 0 && ms < best) best = ms;
+    }
+    res[split] = (float)((double)n_tasks * 1000.0 * 1024.0 / ((double)best * 1e-3) / 1e12);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d_counter);
+  *whole_lines_TBps = res[0];
+  *split_lines_TBps = res[1];
   return VHP_OK;
 }
 
@@ -863,7 +888,7 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
         ctx->lat_src_index = nb;
         ctx->lat_skip = done;
         ctx->lat_dark_unwritten = dark_unwritten;
-        const hipError_t e = launch_stream_sweep<double>(ctx, pivots, 1, out, false, true);
+        const hipError_t e = launch_batch_sweep<double>(ctx, pivots, 1, out, true);
         ctx->lat_src_index = ctx->lat_skip = nullptr;
         ctx->lat_dark_unwritten = false;
         return e;

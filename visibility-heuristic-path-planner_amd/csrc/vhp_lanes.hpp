@@ -490,7 +490,11 @@ VHP_LANE_FN int ffs_u32(uint32_t v) { return v ? __builtin_ctz(v) : -1; }
 struct alignas(16) Tagged { double v; uint64_t tag; };
 VHP_LANE_FN void g_store_tagged(Tagged* base, vi idx, vd v, uint64_t tag) { base[idx] = Tagged{v, tag}; }
 VHP_LANE_FN bool g_load_tagged(const Tagged* base, vi idx, uint64_t tag, vd& v) {
+  // tag FIRST, then the value: the writer stores both words with one 16-byte store, so a value loaded after a matching tag is
+  // the one that came with it.  The hardware issues and returns a wavefront's loads in program order; the compiler barrier keeps
+  // the program order that way (two relaxed atomic loads of different addresses may otherwise be swapped).
   const uint64_t t = __hip_atomic_load(&base[idx].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::: "memory");
   v = __hip_atomic_load(&base[idx].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return t == tag;
 }

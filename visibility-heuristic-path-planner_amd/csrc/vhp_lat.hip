@@ -2,7 +2,7 @@
 // Plain field stores here (not the batch kernels' non-temporal ones, vhp_lanes.hpp): a launch of this kernel writes a few fields
 // that its caller reads right away -- the planner's epilogue, the host copy of a small batch -- out of the caches.
 #define VHP_FIELD_STORE_PLAIN 1
-#include "vhp_stream_launch.h"
+#include "vhp_batch_launch.h"
 
 #include <hip/hip_runtime.h>
 
@@ -53,7 +53,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 size_t lat_lds_bytes(int nx, int ny) { return (size_t)pool::make_layout(pool::kLatWaves, 1, nx, ny).total * 8; }
 
 template <typename OutT>
-hipError_t launch_lat_t(const StreamArgs& a) {
+hipError_t launch_lat_t(const BatchArgs& a) {
   using namespace pool;
   auto k = vhp_lat_sweep<OutT>;
   const size_t lds = lat_lds_bytes(a.nx, a.ny);
@@ -106,7 +106,7 @@ extern "C" int vhp_debug_read_lat_strip_times(unsigned long long* dst, int n_wor
 }
 #endif
 
-hipError_t launch_lat(const StreamArgs& a) {
+hipError_t launch_lat(const BatchArgs& a) {
   if (!lat_supported(a.nx, a.ny)) return hipErrorInvalidValue;
   return a.dtype == VHP_F64 ? launch_lat_t<double>(a) : launch_lat_t<float>(a);
 }

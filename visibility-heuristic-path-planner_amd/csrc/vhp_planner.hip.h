@@ -375,11 +375,12 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
     VHP_PL_HIP(hipMalloc(&s.pivots, pcap * sizeof(int32_t)));
     s.pivot_cap = pcap;
   }
-  if (!s.vis_local2) VHP_PL_HIP(hipMalloc(&s.vis_local2, cells * 8));  // (the speculative solve, which shares this state, has one local field)
+  // (the second local field only where the latency sweep runs the loop; the speculative solve, which shares this state, has one)
+  if (s.lat_sweep && !s.vis_local2) VHP_PL_HIP(hipMalloc(&s.vis_local2, cells * 8));
   // reset(): visibility_global_ = 0, visibility_ = 0, cameFrom_ = 1e15   (solver.cpp:42-47)
   VHP_PL_HIP(hipMemsetAsync(s.vis_global, 0, cells * 8, stream));
   VHP_PL_HIP(hipMemsetAsync(s.vis_local, 0, cells * 8, stream));
-  VHP_PL_HIP(hipMemsetAsync(s.vis_local2, 0, cells * 8, stream));
+  if (s.vis_local2) VHP_PL_HIP(hipMemsetAsync(s.vis_local2, 0, cells * 8, stream));
   VHP_PL_HIP(hipMemsetAsync(s.label, 0xff, cells * 4, stream));
   VHP_PL_HIP(hipMemsetAsync(s.pivots, 0, pcap * sizeof(int32_t), stream));
   VHP_PL_HIP(hipMemsetAsync(s.ticket, 0, sizeof(unsigned int), stream));
@@ -521,22 +522,21 @@ __global__ void vhp_spec_lookup(PlannerDev d, SpecDev sp) {
   c->head = (base + sp.K) % kSpecSlots;
   c->cand[0] = px;  // (it is: the pick wrote both)
   c->cand[1] = py;
-  int n = 0;
+  int n = 0, committed = 1;
   for (int j = 0; j < sp.K; ++j) {
     const int x = c->cand[2 * j], y = c->cand[2 * j + 1];
     c->slot_key[2 * (base + j)] = x;
     c->slot_key[2 * (base + j) + 1] = y;
     if (x >= 0) ++n;
-    if (sp.mode == 1 && j > 0 && x >= 0 && (unsigned long long)(nb + j) <= d.max_iter + 1) {
+    // (the candidates are packed -- the pick fills them front to back -- so the committed ones are cand[0 .. committed))
+    if (sp.mode == 1 && j > 0 && x >= 0 && committed == j && (unsigned long long)(nb + j) <= d.max_iter + 1) {
       // committed in rank order: lightSources_[nb + j]
       d.pivots[2 * (nb + j)] = x;
       d.pivots[2 * (nb + j) + 1] = y;
+      committed = j + 1;
     }
   }
-  if (sp.mode == 1) {
-    // the candidates are packed (the pick fills them front to back), so the committed ones are cand[0 .. n)
-    c->n_commit = n;
-  }
+  if (sp.mode == 1) c->n_commit = committed;  // only what has a pivot slot: a candidate past max_iter + 1 is swept but not committed
   c->cur_slot = base;
   c->sweep = 1;
   c->misses += 1;

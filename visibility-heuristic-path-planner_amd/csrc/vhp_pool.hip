@@ -1,5 +1,5 @@
 // vhp_pool.hip -- gfx950 build of the pool sweep (vhp_pool.hpp), its unit-order pre-kernel and its launcher.
-#include "vhp_stream_launch.h"
+#include "vhp_batch_launch.h"
 
 #include <hip/hip_runtime.h>
 
@@ -165,7 +165,7 @@ PoolShape pool_shape(int nx, int ny, int force_ctx) {
 }
 
 template <typename OutT>
-hipError_t launch_pool_t(const StreamArgs& a) {
+hipError_t launch_pool_t(const BatchArgs& a) {
   using namespace pool;
   auto k = vhp_pool_sweep<OutT>;
   const PoolShape sh = pool_shape(a.nx, a.ny, a.pool_contexts);
@@ -198,6 +198,9 @@ hipError_t launch_pool_t(const StreamArgs& a) {
   g.tail_limit = (int)((long long)g.n_units * (a.pool_tail_pct > 0 ? a.pool_tail_pct : 15) / 100);  // (100 / 50 / 25 / 15 %: 0.56 / 0.55 / 0.53 / - and - / - / - / 0.67 ms on two boxes)
   g.early_ctx = a.pool_early_ctx > 0 ? a.pool_early_ctx : sh.n_ctx;
   g.late_after = (int)((long long)g.n_units * (a.pool_late_pct > 0 ? a.pool_late_pct : 50) / 100);
+  g.burst_ctx = a.pool_burst_ctx;
+  g.burst_until = (int)((long long)g.n_units * (a.pool_burst_pct > 0 ? a.pool_burst_pct : 40) / 100);
+  if (g.burst_ctx > 0 && a.pool_early_ctx <= 0) g.early_ctx = sh.n_ctx - g.burst_ctx > 0 ? sh.n_ctx - g.burst_ctx : 1;
   g.unit_times = nullptr;
 #ifdef VHP_DIAG_POOLPROF
   if (a.n_src <= 1024) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_unit_times)) == hipSuccess) g.unit_times = static_cast<unsigned long long*>(p); }
@@ -236,7 +239,7 @@ extern "C" int vhp_debug_read_hist(unsigned long long* dst, int n_words) {
 }
 #endif
 
-hipError_t launch_pool(const StreamArgs& a) {
+hipError_t launch_pool(const BatchArgs& a) {
   if (!pool_supported(a.nx, a.ny)) return hipErrorInvalidValue;
   return a.dtype == VHP_F64 ? launch_pool_t<double>(a) : launch_pool_t<float>(a);
 }
