@@ -146,9 +146,6 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   a.tail_limit = (int)((long long)n_units * (10 + (seed * 37) % 91) / 100);
   a.early_ctx = (seed & 1) ? C : 1 + (int)(seed % (unsigned)C);   // sometimes the contexts past the first few open late
   a.late_after = n_units / 2;  // one to three contexts pull from the head of the queue
-  a.burst_ctx = (seed % 5 == 3 && C > 2) ? 1 : 0;   // sometimes a context that is open only at the start of the launch
-  a.burst_until = n_units / 3;
-  if (a.burst_ctx && a.early_ctx + a.burst_ctx > C) a.early_ctx = C - a.burst_ctx;
   a.busy_cap = (policy & 64) ? 2 : W;   // policy & 64: a tight cap on the wavefronts that may sweep while units are installed
 
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
@@ -344,7 +341,7 @@ extern "C" {
 // The latency sweep: n_src * 8 workgroups of W wavefronts, one per unit.  Arguments and stats as vhp_sim_pool_sweep.
 int vhp_sim_lat_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W, int policy, unsigned seed,
                       long long* stats) {
-  if (!occ || !src || !out || nx <= 0 || ny <= 0 || (nx & 1) != 0 || W < 2 || W > 16 || W * kXRows * kTStride < (nx < ny ? nx : ny)) return 1;
+  if (!occ || !src || !out || nx <= 0 || ny <= 0 || W < 2 || W > 16 || W * kXRows * kTStride < (nx < ny ? nx : ny)) return 1;
   if (dtype == 0) return run_lat<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), W, policy, seed, stats);
   return run_lat<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), W, policy, seed, stats);
 }

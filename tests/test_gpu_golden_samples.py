@@ -59,7 +59,7 @@ def test_hip_offset1_sweep_equals_reference_png(ctx, gold, oracle):
 def test_hip_head_sweep_on_reference_map(ctx, gold, oracle):
     # HEAD semantics (offset = 0): the tuned kernels == the oracle == the offset kernel at 0, and NOT the published image
     want = oracle.sweep_full(gold["occ"], *gold["source"])
-    for kernel in (0, 1, 2):
+    for kernel in (0, 1, 3):
         ctx.set_option("kernel", kernel)
         got = ctx.sweep_batch([gold["source"]])[0]
         assert got.tobytes() == want.tobytes(), "kernel option %d" % kernel
@@ -72,7 +72,7 @@ def test_hip_head_sweep_on_reference_map(ctx, gold, oracle):
     src[0] = (1, 998)
     if not gold["occ"][998, 1]:
         src[0] = gold["source"]
-    for kernel in (1, 2):
+    for kernel in (1, 3):
         ctx.set_option("kernel", kernel)
         got = ctx.sweep_batch(src)
         for k, (sx, sy) in enumerate(src):

@@ -64,6 +64,7 @@ def test_config1_rnd1_mask_planner(vhp, oracle):
     occ = maps.c1_rnd1_mask()
     for thr in (0.5, 0.2):
         c, got, want = _solve_both(vhp, oracle, occ, (5, 5), (95, 95), thr, 120)
+        assert c.last_sweep_kernel() == 4  # the latency sweep runs the loop on this odd width too (round 4)
         _assert_same_solution(got, want, "C1 rnd_1 mask thr %g" % thr)
         if got["status"] == vhp.VHP_OK:
             d, path = c.reconstruct_path(got["came_from"], got["pivots"], (95, 95))

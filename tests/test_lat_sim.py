@@ -39,7 +39,8 @@ def _sources(occ, n, seed):
 
 
 SIZES = [(8, 8), (8, 1), (16, 3), (8, 200), (264, 9), (104, 77), (96, 96), (200, 163), (328, 300), (640, 603), (72, 1100), (1104, 72),
-         (2, 5), (10, 9), (106, 77), (130, 131), (690, 402)]  # (any even width: the planner's maze is 690 wide)
+         (2, 5), (10, 9), (106, 77), (130, 131), (690, 402),  # (the planner's maze is 690 wide)
+         (1, 1), (3, 7), (9, 9), (101, 101), (105, 78), (263, 300), (689, 402), (71, 1100), (971, 65)]  # odd widths: rows off the 16-byte grid (C1 is 101 x 101)
 SHAPES = [  # W wavefronts per workgroup, policy, dtype
     (12, POOL_ROUND_ROBIN | POOL_POINTS_ALWAYS, np.float64),
     (12, POOL_RANDOM | POOL_POINTS_RANDOM, np.float32),
@@ -83,7 +84,7 @@ def _walled(nx, ny, seed, density):
     return occ
 
 
-@pytest.mark.parametrize("nx,ny,density", [(200, 163, 0.5), (328, 300, 0.2), (640, 603, 0.08), (1104, 72, 0.3), (72, 1100, 0.3), (130, 131, 0.95)])
+@pytest.mark.parametrize("nx,ny,density", [(200, 163, 0.5), (328, 300, 0.2), (640, 603, 0.08), (1104, 72, 0.3), (72, 1100, 0.3), (130, 131, 0.95), (201, 163, 0.5), (329, 301, 0.2), (131, 130, 0.95)])
 def test_lat_sim_strips_that_die(oracle, nx, ny, density):
     """Maps where every strip's values turn +0.0 long before its march ends (a strip that is dead, below a dead strip, stops sweeping
     and stores zeros): the fields must still equal the oracle's bit for bit, whatever the order the wavefronts run in."""

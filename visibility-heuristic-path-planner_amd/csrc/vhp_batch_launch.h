@@ -28,7 +28,6 @@ struct BatchArgs {
   // optional per-launch timing events, recorded around the sweep kernel only
   hipEvent_t ev_begin, ev_end;
   int pool_contexts = 0;  // pool sweep: units a workgroup holds at once (0: automatic; vhp_set_option "pool_contexts")
-  int pool_burst_ctx = 0, pool_burst_pct = 0;  // pool sweep: contexts open only at the start of a launch, until this share of the units is taken
   int pool_heads = 0;     // pool sweep: contexts that pull from the head of the size-sorted queue (0: one)
   int pool_tail_pct = 0;  // pool sweep: share of the units (by count, smallest first) that the filler contexts may take from the small end (0: 50)
   int pool_early_ctx = 0, pool_late_pct = 0;  // pool sweep: contexts >= early_ctx open once late_pct % of the units are taken (0: all open)

@@ -20,6 +20,7 @@
 
 #ifdef VHP_SIM
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #define VHP_LANE_FN inline
 #else
@@ -172,6 +173,9 @@ template <typename OutT> inline void g_store2_if(const vb& p2, const vb& p_lo, c
   store_stats().n16 += 1;
   store_stats().end_instruction();
 }
+// is the pair at byte offset off aligned to its own size (2 cells)?  On a grid of odd width every other row is not.
+template <typename OutT> inline vb pair_aligned(const OutT* base, const vu32& off) {
+  vb r; for (int l = 0; l < kLanes; ++l) r.v[l] = ((reinterpret_cast<uintptr_t>(base) + off.v[l]) & (2 * sizeof(OutT) - 1)) == 0; return r; }
 // the pair, from the lanes of p only (nothing of a pair is ever split)
 template <typename OutT> inline void g_store2_mask(const vb& p, OutT* base, const vu32& off, const vd& a, const vd& b) {
   g_store2_if(p, vb(false), vb(false), base, off, a, b);
@@ -361,6 +365,9 @@ template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p
   if (p2) VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
   else if (p_lo || p_hi)
     VHP_FIELD_STORE(reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off + (p_lo ? 0u : (uint32_t)sizeof(OutT))), static_cast<OutT>(single));
+}
+template <typename OutT> VHP_LANE_FN bool pair_aligned(const OutT* base, vu32 off) {
+  return ((reinterpret_cast<uintptr_t>(base) + off) & (2 * sizeof(OutT) - 1)) == 0;
 }
 template <typename OutT> VHP_LANE_FN void g_store2_mask(bool p, OutT* base, vu32 off, vd a, vd b) {
   VHP_DIAG_STORE_GUARD(a, b, off)

@@ -92,7 +92,7 @@ size_t lat_scratch_bytes(int n_src, int nx, int ny) {
 }
 
 bool lat_supported(int nx, int ny) {
-  if (nx <= 0 || ny <= 0 || (nx & 1) != 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return false;
+  if (nx <= 0 || ny <= 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return false;
   // (a y-major workgroup keeps its quadrant's diagonal where an x-major one has its tiles)
   return lat_lds_bytes(nx, ny) <= kLdsLimit && (size_t)pool::kLatWaves * pool::kXRows * pool::kTStride >= (size_t)(nx < ny ? nx : ny);
 }

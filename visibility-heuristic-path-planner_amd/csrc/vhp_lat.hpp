@@ -23,7 +23,8 @@
 // The boundary protocol is the pool sweep's (vhp_pool.hpp Link: LDS ring of the writing wavefront first, tagged lines in
 // global memory as the durable copy), so a strip waits only for the strip below it and a wavefront sweeps its strips in
 // rising order: whatever the number of strips and wavefronts, the lowest unfinished strip can always run.
-// Grids: any height, an even width (the x-major cells leave in pairs of 16 bytes).
+// Grids: any height and width (on an odd width every other row of a field starts 8 bytes off the 16-byte grid: the x-major cells
+// of those rows leave one by one instead of in pairs -- store_group --, everything else stores single cells anyway).
 //
 // Written against vhp_lanes.hpp: compiled for gfx950 (vhp_lat.hip) and for the CPU simulator (tests/sim), bit-exact against
 // the oracle in both (tests/test_lat_sim.py, tests/test_gpu_lat.py).
@@ -152,6 +153,15 @@ VHP_FN void lat_zero_rect(OutT* out, int nx, int x0, int x1, int y0, int y1) {
   if (x0 > x1 || y0 > y1) return;
   constexpr int CB = sizeof(OutT);
   const vi lane = lane_id();
+  if ((nx & 1) != 0 || (reinterpret_cast<uintptr_t>(out) & (2 * CB - 1)) != 0) {
+    // an odd pitch (or a field that starts off the pair grid): no pair is aligned in every row -- single cells, 64 columns of a row
+    // per instruction
+    for (int y = y0; y <= y1; ++y) {
+      for (int xc = x0; xc <= x1; xc += kLanes) g_store_scalar_if((lane + xc) <= x1, out, lane + (y * nx + xc), OutT(0));
+      if (((y - y0) & 63) == 63) sim_point();
+    }
+    return;
+  }
   const int xe = x0 + (x0 & 1);            // the first even column: (y * nx + x) is even there, whatever the row
   const int np = (x1 + 1 - xe) >> 1;       // whole pairs
   const vi pi = lane & 31, ro = lane >> 5;
@@ -197,6 +207,7 @@ struct LatX {
   bool skip_fill;          // a dead strip stores nothing (LatArgs::dead_cells_are_zero)
   vi lane, tile_l, fl_t;
   vu32 fl_off;
+  bool odd_pitch;     // pairs of cells are not 16-byte aligned in every row (an odd width, or a field that starts off the grid)
   vd prev, jd;
   vu64 ow, ow_nx;
   vd rv_nx;
@@ -220,6 +231,7 @@ struct LatX {
       const vi rs = DY > 0 ? rslot : 7 - rslot;
       fl_t = rslot * kTStride + pc * 2;
       fl_off = to_u32((rs * m.nx + pc * 2) * CB);
+      odd_pitch = (m.nx & 1) != 0 || (reinterpret_cast<uintptr_t>(out) & (2 * CB - 1)) != 0;
     }
     p = p_;
     j0 = kXRows * p;
@@ -291,6 +303,15 @@ struct LatX {
 
   // The 16 cells of every row of the window at xw (lowest step ia) leave: fa[u], fb[u] = the lane's pair of cells of the rows of
   // group u (8 rows).  A cell (i', j) exists for j <= i' <= lim.
+  // One group of 8 rows of a window: the lane's pair (cells ok0, ok1).  On an odd pitch the pairs of every other row lie 8 bytes
+  // off the 16-byte grid: those rows' cells leave one by one.
+  VHP_FN void store_group(OutT* base, const vb& ok0, const vb& ok1, const vd& a, const vd& b) {
+    if (!odd_pitch) { g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, a, b); return; }
+    const vb al = pair_aligned(base, fl_off);
+    g_store2_if(al && ok0 && ok1, al && ok0, al && ok1, base, fl_off, a, b);
+    g_store2_if(vb(false), (!al) && ok0, vb(false), base, fl_off, a, b);
+    g_store2_if(vb(false), vb(false), (!al) && ok1, base, fl_off, a, b);
+  }
   template <bool DIAG>
   VHP_FN void store_window(int ia, int xw, int lim, const vd (&fa)[8], const vd (&fb)[8]) {
 #ifndef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
@@ -299,7 +320,7 @@ struct LatX {
       // by cell.  A cell (i', j) exists for j <= i' <= lim; the window's steps are ia .. ia + 15.
       OutT* base = out + (long)(DY > 0 ? g.Y(j0) : g.Y(j0 + 7)) * (long)m.nx + xw;
       const long base_step = (long)(8 * DY) * m.nx;
-      if (!DIAG && rows_here == kXRows && ia + kLW - 1 <= i_last) {  // past the diagonal, inside the march, all 64 rows: every group whole
+      if (!DIAG && !odd_pitch && rows_here == kXRows && ia + kLW - 1 <= i_last) {  // past the diagonal, inside the march, all 64 rows: every group whole
 #pragma unroll
         for (int u = 0; u < 8; ++u) { g_store2(base, fl_off, fa[u], fb[u]); base += base_step; }
       } else {
@@ -310,7 +331,7 @@ struct LatX {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (u < u_full) {
-          g_store2(base, fl_off, fa[u], fb[u]);
+          if (odd_pitch) store_group(base, vb(true), vb(true), fa[u], fb[u]); else g_store2(base, fl_off, fa[u], fb[u]);
         } else if (u < u_end) {
           const vi cc = (lane & 7) * 2;
           const vi s0 = DX > 0 ? cc + ia : (-cc) + (kLW - 1 + ia), s1 = s0 + DX;  // step indices of the pair's two cells
@@ -319,7 +340,7 @@ struct LatX {
           const vi jr = r + j0;
           const vb ok0 = row_ok && (s0 >= jr) && (s0 <= lim);
           const vb ok1 = row_ok && (s1 >= jr) && (s1 <= lim);
-          g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, fa[u], fb[u]);
+          store_group(base, ok0, ok1, fa[u], fb[u]);
         }
         base += base_step;
       }

@@ -195,12 +195,9 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   g.busy_cap = a.pool_busy_cap > 0 ? a.pool_busy_cap : kWaves;
   // two contexts take the largest units left, the others the smallest (0.75 against 0.78 ms with one head at 1000^2)
   g.n_head = a.pool_heads > 0 ? a.pool_heads : (sh.n_ctx >= 3 ? 2 : 1);  // (all three from the head: 0.51 / 0.70 ms on two boxes, this: 0.53 / 0.67)
-  g.tail_limit = (int)((long long)g.n_units * (a.pool_tail_pct > 0 ? a.pool_tail_pct : 15) / 100);  // (100 / 50 / 25 / 15 %: 0.56 / 0.55 / 0.53 / - and - / - / - / 0.67 ms on two boxes)
+  g.tail_limit = (int)((long long)g.n_units * (a.pool_tail_pct > 0 ? a.pool_tail_pct : 15) / 100);  // (100 / 50 / 25 / 15 %: 0.56 / 0.55 / 0.53 / - and - / - / - / 0.67 ms on two boxes; round 4, with non-temporal stores: 5 / 15 / 30 / 60 %: 0.580 / 0.608 / 0.608 / 0.616 ms on a slow buffer, level on a fast one -- within the noise of 1-2 %)
   g.early_ctx = a.pool_early_ctx > 0 ? a.pool_early_ctx : sh.n_ctx;
   g.late_after = (int)((long long)g.n_units * (a.pool_late_pct > 0 ? a.pool_late_pct : 50) / 100);
-  g.burst_ctx = a.pool_burst_ctx;
-  g.burst_until = (int)((long long)g.n_units * (a.pool_burst_pct > 0 ? a.pool_burst_pct : 40) / 100);
-  if (g.burst_ctx > 0 && a.pool_early_ctx <= 0) g.early_ctx = sh.n_ctx - g.burst_ctx > 0 ? sh.n_ctx - g.burst_ctx : 1;
   g.unit_times = nullptr;
 #ifdef VHP_DIAG_POOLPROF
   if (a.n_src <= 1024) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_unit_times)) == hipSuccess) g.unit_times = static_cast<unsigned long long*>(p); }

@@ -103,7 +103,7 @@ constexpr int kHdr = 8;
 constexpr int kBin = 72;   // doubles of a boundary-in slab (66 used)
 constexpr int kRing = 256; // entries of a wavefront's boundary ring, indexed by the marching coordinate & 255
 constexpr int kRingSafe = 232;  // a reader trusts ring entries only while the writer is at most this many steps past them
-enum { kQEmpty = 0, kSeq = 2, kBusy = 3, kLateOpen = 4, kBurstClosed = 5 };
+enum { kQEmpty = 0, kSeq = 2, kBusy = 3, kLateOpen = 4 };
 enum { kState = 0, kWord = 1, kUnit = 2, kNStrips = 3, kLeft = 4, kSxSy = 5, kDiagReady = 6 };
 struct Layout {
   int W, C, S;
@@ -158,8 +158,6 @@ struct Args {
   int tail_limit;     // ... while fewer than this many units have been taken from the small end; then the largest left, too
   int early_ctx;      // contexts >= this one open only once `late_after` units have been taken: towards the end of a launch a
   int late_after;     // workgroup holds more, shorter units at once (what is left then has nothing large to get in the way of)
-  int burst_ctx;      // the first `burst_ctx` contexts from early_ctx on are open at the START of a launch instead, until `burst_until`
-  int burst_until;    // units have been taken: every unit opens on its slow diagonal phase, and more of them fill the wavefronts sooner
   unsigned long long* unit_times;  // diagnostic builds: when unit u was installed / finished (wall clock), or nullptr
 };
 
@@ -867,11 +865,10 @@ struct Worker {
     int free_c = -1;
     bool unclaimed = false, installing = false;
     const bool late_open = a.early_ctx >= sh.L.C || lds_poll(sc + kLateOpen) != 0;  // (raised by this workgroup's own pulls: install)
-    const bool burst_open = a.burst_ctx > 0 && lds_poll(sc + kBurstClosed) == 0;
     for (int c = 0; c < sh.L.C; ++c) {
       int* cx = sh.ctx(c);
       const int st = lds_poll(cx + kState);
-      if (st == 0) { if (c < a.early_ctx || (c < a.early_ctx + a.burst_ctx ? burst_open : late_open)) free_c = c; continue; }
+      if (st == 0) { if (c < a.early_ctx || late_open) free_c = c; continue; }
       if (st == 1) { installing = true; continue; }
       const int word = lds_poll(cx + kWord);
       if (word < 0) continue;  // being recycled
@@ -929,7 +926,6 @@ struct Worker {
     const unsigned taken_head = (unsigned)old, taken_tail = (unsigned)(old >> 32);
     const int idx = from_tail ? a.n_units - 1 - (int)taken_tail : (int)taken_head;
     if ((int)(taken_head + taken_tail) >= a.late_after) lds_publish(sc + kLateOpen, 1);
-    if ((int)(taken_head + taken_tail) >= a.burst_until) lds_publish(sc + kBurstClosed, 1);
     sim_progress();
     if (taken_head + taken_tail >= (unsigned)a.n_units) {
       lds_publish(sc + kQEmpty, 1);
