@@ -29,7 +29,7 @@ python3 $R/tools/traffic_from_pmc.py $O/${tag}_pmc_fetch_size_driver_cmd.csv $O/
 profile_workload c5 --gpus 1 --workload c5 --steps 10 --warmup 3 --no-cpu-baseline
 python3 $R/tools/traffic_from_pmc.py $O/${tag}_pmc_fetch_size_c5.csv $O/${tag}_pmc_write_size_c5.csv c5 f64 $O > $O/traffic_c5.log 2>&1
 DRV="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
-for k in 1 2 3; do python3 $R/bench.py $DRV --kernel $k > $O/${tag}_bench_c3_kernel$k.json 2>/dev/null; done
+for k in 1 3; do python3 $R/bench.py $DRV --kernel $k > $O/${tag}_bench_c3_kernel$k.json 2>/dev/null; done
 python3 $R/bench.py --steps 300 --no-cpu-baseline > $O/${tag}_bench_c3_300steps.json 2>/dev/null
 python3 $R/bench.py --dtype f32 --steps 100 --no-cpu-baseline > $O/${tag}_bench_c3_f32.json 2>/dev/null
 python3 $R/bench.py --workload c2 --steps 300 --no-cpu-baseline > $O/${tag}_bench_c2.json 2>/dev/null
@@ -42,4 +42,14 @@ for w in c2 c4; do
   rm -rf $O/kt_$w
 done
 python3 $R/tools/lat_vs_front.py 256 512 690 1000 1536 2048 > $O/${tag}_lat_vs_front.txt 2>/dev/null
+# odd widths (the latency sweep takes them since round 4): BASELINE config 1 is 101 wide, benchmarkSeries sweeps 971, 1001 ...
+python3 $R/tools/lat_vs_front.py 101 255 689 971 1001 2049 > $O/${tag}_lat_vs_front_odd_widths.txt 2>/dev/null
+python3 $R/tools/c1_planner_ab.py > $O/${tag}_planner_odd_widths.txt 2>/dev/null
+# what the memory behind an output buffer does with whole and with split lines, plain and non-temporal stores; the map of a
+# process's allocations; the timeline of the C3 launch on a slow and on a fast buffer
+python3 $R/tools/shapebench.py 32 0 y1k,y1k_mixed,x128,x64,x128_rows2,y1k_8B,fill > $O/${tag}_shapebench_nt.txt 2>/dev/null
+python3 $R/tools/policybench.py 32 > $O/${tag}_policybench.txt 2>/dev/null
+python3 $R/tools/alloc_map.py 100 3 > $O/${tag}_alloc_map.txt 2>/dev/null
+python3 $R/tools/launch_timeline.py exp/libvhp_TL.so ${tag} 256 24 > $O/${tag}_launch_timeline.txt 2>/dev/null && cp $R/gpurun_out/timeline_${tag}.csv $O/${tag}_launch_timeline.csv
+python3 $R/tools/ab_slowfast.py 40 256 - exp/libvhp_PLAIN.so exp/libvhp_NWNM.so exp/libvhp_NOSTORE.so > $O/${tag}_slow_fast_ab.txt 2>/dev/null
 ls -la $O

@@ -11,7 +11,7 @@ n, side = 256, 1000
 occ = synth.random_rect_map(side, side, 50, 20, 100, 20, 100, seed=1)
 src = synth.free_sources(occ, n, seed=7)
 d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
-mod.LIB_PATH = os.path.join(ROOT, "exp", "libvhp_BASE.so")
+mod.LIB_PATH = os.path.join(ROOT, "exp", "libvhp_PLAIN.so")  # (the candidates are told apart by the launch with PLAIN stores: 0.51 / 0.72 ms)
 c = mod.Context(0); c.set_stream(torch.cuda.current_stream().cuda_stream); c.set_map(occ); c.set_option("kernel", 3)
 hip = C.CDLL("libamdhip64.so")
 hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from importlib import import_module
-mod = import_module("visibility-heuristic-path-planner_amd"); mod.LIB_PATH = os.path.join(ROOT, "exp", "libvhp_BASE.so")
+mod = import_module("visibility-heuristic-path-planner_amd"); mod.LIB_PATH = os.path.join(ROOT, "exp", "libvhp_PLAIN.so")  # (the candidates are told apart by the launch with PLAIN stores: 0.51 / 0.72 ms)
 synth = import_module("visibility-heuristic-path-planner_amd.synth")
 ncand = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 n, side = 256, 1000
