@@ -91,11 +91,11 @@ void quadrant_nest(const Grid& g, double* vis, int sx, int sy, int dirx, int dir
       } else if (j == 0) {
         v = vis[g.at(xm, y)];
       } else if (i > j) {
-        const double c = offset == 0.0 ? (double)j / (double)i : (double)(j + offset) / (i + offset);
+        const double c = ((double)j + offset) / ((double)i + offset);  // (offset = 0.0 at HEAD: j + 0.0 is exact, so this IS j / i)
         const double a = vis[g.at(xm, y)];
         v = a - c * (a - vis[g.at(xm, ym)]);
       } else if (j > i) {
-        const double c = offset == 0.0 ? (double)i / (double)j : (double)(i + offset) / (j + offset);
+        const double c = ((double)i + offset) / ((double)j + offset);
         const double a = vis[g.at(x, ym)];
         v = a - c * (a - vis[g.at(xm, ym)]);
       }
