@@ -146,6 +146,7 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   a.tail_limit = (int)((long long)n_units * (10 + (seed * 37) % 91) / 100);
   a.early_ctx = (seed & 1) ? C : 1 + (int)(seed % (unsigned)C);   // sometimes the contexts past the first few open late
   a.late_after = n_units / 2;  // one to three contexts pull from the head of the queue
+  a.claim_ahead = (int)((seed * 7) % 5) * 8;   // 0, 8 .. 32 steps: a strip claimed before the strip below has reached its first window
   a.busy_cap = (policy & 64) ? 2 : W;   // policy & 64: a tight cap on the wavefronts that may sweep while units are installed
 
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));

@@ -105,3 +105,21 @@ def test_pool_kernel_all_256_fields_of_the_bench_launch(vhp, oracle, dtype):
     with pytest.raises(vhp.VhpError) as e:
         c.sync()
     assert e.value.code == vhp.VHP_ERR_SOURCE_OOB
+
+
+def test_probe_stores_measures_and_validates(vhp):
+    # vhp_probe_stores (the measurement aid bench.py reports the state of its timed buffer with): plausible rates, the whole-line
+    # pattern not slower than the split-line one, the buffer overwritten with zeros where it was used, bad arguments refused
+    import torch
+    occ, _ = maps.config_c3(1)
+    c = _ctx(vhp, occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    buf = torch.full((32, 1000, 1000), 7.0, dtype=torch.float64, device="cuda")
+    whole, split = c.probe_stores(buf.data_ptr(), buf.numel() * 8)
+    torch.cuda.synchronize()
+    assert 1.0 < split <= whole * 1.05 and whole < 8.0, (whole, split)
+    assert float(buf[0, 0, 0]) == 0.0 and float(buf[31, 999, 500]) == 0.0
+    with pytest.raises(vhp.VhpError):
+        c.probe_stores(buf.data_ptr(), 1 << 20)          # too small to say anything
+    with pytest.raises(vhp.VhpError):
+        c.probe_stores(buf.data_ptr() + 8, buf.numel() * 8 - 8)   # not on a 128-byte line

@@ -28,6 +28,7 @@ struct BatchArgs {
   // optional per-launch timing events, recorded around the sweep kernel only
   hipEvent_t ev_begin, ev_end;
   int pool_contexts = 0;  // pool sweep: units a workgroup holds at once (0: automatic; vhp_set_option "pool_contexts")
+  int pool_claim_ahead = -1;  // pool sweep: steps by which a strip is claimed ahead of the strip below's progress (-1: automatic)
   int pool_heads = 0;     // pool sweep: contexts that pull from the head of the size-sorted queue (0: one)
   int pool_tail_pct = 0;  // pool sweep: share of the units (by count, smallest first) that the filler contexts may take from the small end (0: 50)
   int pool_early_ctx = 0, pool_late_pct = 0;  // pool sweep: contexts >= early_ctx open once late_pct % of the units are taken (0: all open)

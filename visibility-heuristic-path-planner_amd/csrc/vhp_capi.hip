@@ -67,6 +67,7 @@ struct vhp_ctx {
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 3 pool sweep (vhp_pool), 4 latency sweep (vhp_lat); 2 was the streaming sweep (retired in round 4)
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 3 pool sweep, 4 latency sweep
   long long opt_field_stride = 0;  // device-pointer batch sweeps: elements from one field to the next (0: nx * ny, packed)
+  int opt_pool_claim_ahead = -1;  // pool sweep: claim a strip this many steps ahead (-1 auto)
   int opt_pool_contexts = 0;   // pool sweep: units a workgroup holds at once (0 auto)
   int opt_pool_heads = 0;      // pool sweep: contexts that pull the largest units (0 auto)
   int opt_pool_tail_pct = 0;   // pool sweep: share of the units the filler contexts take from the small end (0 auto)
@@ -311,6 +312,7 @@ hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT*
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
   a.ev_begin = a.ev_end = nullptr;
   a.pool_contexts = c->opt_pool_contexts;
+  a.pool_claim_ahead = c->opt_pool_claim_ahead;
   a.pool_busy_cap = c->opt_pool_busy_cap;
   a.pool_early_ctx = c->opt_pool_early_ctx;
   a.pool_late_pct = c->opt_pool_late_pct;
@@ -758,6 +760,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "pack") { ctx->opt_pack = v != 0; }
   else if (k == "kernel") { if (v < 0 || v > 4 || v == 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 3 pool, 4 latency (2, the streaming sweep, was retired)"); ctx->opt_kernel = v; }
   else if (k == "field_stride") { if (value < 0) return fail(ctx, VHP_ERR_ARG, "field_stride: 0 (packed) or elements per field"); ctx->opt_field_stride = value; }
+  else if (k == "pool_claim_ahead") { if (v < -1 || v > 64) return fail(ctx, VHP_ERR_ARG, "pool_claim_ahead: -1 (automatic) .. 64"); ctx->opt_pool_claim_ahead = v; }
   else if (k == "pool_heads") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_heads: 0 (automatic) .. 16"); ctx->opt_pool_heads = v; }
   else if (k == "pool_tail_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_tail_pct: 0 (automatic) .. 100"); ctx->opt_pool_tail_pct = v; }
   else if (k == "pool_early_ctx") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_early_ctx: 0 (automatic) .. 16"); ctx->opt_pool_early_ctx = v; }

@@ -198,6 +198,10 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   g.tail_limit = (int)((long long)g.n_units * (a.pool_tail_pct > 0 ? a.pool_tail_pct : 15) / 100);  // (100 / 50 / 25 / 15 %: 0.56 / 0.55 / 0.53 / - and - / - / - / 0.67 ms on two boxes; round 4, with non-temporal stores: 5 / 15 / 30 / 60 %: 0.580 / 0.608 / 0.608 / 0.616 ms on a slow buffer, level on a fast one -- within the noise of 1-2 %)
   g.early_ctx = a.pool_early_ctx > 0 ? a.pool_early_ctx : sh.n_ctx;
   g.late_after = (int)((long long)g.n_units * (a.pool_late_pct > 0 ? a.pool_late_pct : 50) / 100);
+  // measured (tools/ab_slowfast.py, ab_libs.py; 0 / 16 / 32 / 48 / 64 steps): C3 on a fast buffer 0.485 / 0.468 / 0.463 / 0.461 / 0.460 ms, on a
+  // slow one 0.583 / 0.582 / 0.597 / 0.589 / 0.591 (bound by the memory there); C5 3.567 / 3.483 / 3.476 / 3.474 / 3.482; 128 sources at
+  // 2048^2 1.316 / - / 1.277 / - / 1.238; 512 at 512^2 0.445 / - / 0.419 / - / 0.416
+  g.claim_ahead = a.pool_claim_ahead >= 0 ? a.pool_claim_ahead : 48;
   g.unit_times = nullptr;
 #ifdef VHP_DIAG_POOLPROF
   if (a.n_src <= 1024) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_unit_times)) == hipSuccess) g.unit_times = static_cast<unsigned long long*>(p); }

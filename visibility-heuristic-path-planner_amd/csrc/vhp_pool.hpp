@@ -158,6 +158,7 @@ struct Args {
   int tail_limit;     // ... while fewer than this many units have been taken from the small end; then the largest left, too
   int early_ctx;      // contexts >= this one open only once `late_after` units have been taken: towards the end of a launch a
   int late_after;     // workgroup holds more, shorter units at once (what is left then has nothing large to get in the way of)
+  int claim_ahead;    // a strip may be claimed this many steps before the strip below has swept its first window (find_work)
   unsigned long long* unit_times;  // diagnostic builds: when unit u was installed / finished (wall clock), or nullptr
 };
 
@@ -883,7 +884,10 @@ struct Worker {
       UnitGeo ug;
       ug.init(a.m.nx, a.m.ny, qo, sx, sy);
 #ifndef VHP_DIAG_NOWAIT
-      if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_step(p) + 8 + 1) continue;  // the strip below has swept my first window
+      // the strip below has (all but) swept my first window.  claim_ahead > 0: claimed that many steps EARLIER -- the claim, the
+      // strip's set-up and the loads of its first block (a round trip to memory) then run beside the strip below instead of
+      // behind it; the new strip waits for its first boundary values inside fetch(), for a strip claimed before it as ever
+      if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_step(p) + 8 + 1 - a.claim_ahead) continue;
       if (!ug.x_major && lds_poll(cx + kDiagReady) < ug.diag_need(p)) continue;
 #endif
       best_c = c; best_seq = rank; best_p = p; best_word = word; best_qo = qo; best_sx = sx; best_sy = sy;
