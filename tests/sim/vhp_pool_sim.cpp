@@ -229,16 +229,16 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
 }
 
 // ---- the latency sweep (csrc/vhp_lat.hpp): one workgroup of W wavefronts per unit, strips bound to wavefronts ---------------
-template <typename OutT>
+template <typename OutT, bool ODD>
 struct LatCo {
-  LatWorker<OutT> wk;
+  LatWorker<OutT, ODD> wk;
   int unit;
 };
-template <typename OutT>
-void lat_entry(void* p) { auto* c = static_cast<LatCo<OutT>*>(p); c->wk.run(c->unit); }
+template <typename OutT, bool ODD>
+void lat_entry(void* p) { auto* c = static_cast<LatCo<OutT, ODD>*>(p); c->wk.run(c->unit); }
 
-template <typename OutT>
-int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int policy, uint32_t seed, long long* stats) {
+template <typename OutT, bool ODD>
+int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int policy, uint32_t seed, long long* stats) {
   HostMap h;
   build_map(occ, nx, ny, h);
   const Layout L = make_layout(W, 1, nx, ny);
@@ -261,17 +261,17 @@ int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, O
   a.dead_cells_are_zero = false;
   a.strip_times = nullptr;
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
-  std::vector<LatCo<OutT>> workers((size_t)G * W);
+  std::vector<LatCo<OutT, ODD>> workers((size_t)G * W);
   std::vector<Coro> coros((size_t)G * W);
   for (int gI = 0; gI < G; ++gI) {
-    LatWorker<OutT>::clear(lds[gI].data(), L, 0, 1);
+    LatWorker<OutT, ODD>::clear(lds[gI].data(), L, 0, 1);
     for (int w = 0; w < W; ++w) {
-      LatCo<OutT>& wk = workers[(size_t)gI * W + w];
+      LatCo<OutT, ODD>& wk = workers[(size_t)gI * W + w];
       wk.wk.init(a, lds[gI].data(), L, w);
       wk.unit = gI;
       Coro& c = coros[(size_t)gI * W + w];
       c.stack.reset(new char[kStack]);
-      c.entry = lat_entry<OutT>;
+      c.entry = lat_entry<OutT, ODD>;
       c.arg = &wk;
       getcontext(&c.ctx);
       c.ctx.uc_stack.ss_sp = c.stack.get();
@@ -336,6 +336,13 @@ int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, O
 }
 
 }  // namespace
+
+// (the ODD build of the kernel where the launch needs it, as launch_lat_t picks it: vhp_lat.hip)
+template <typename OutT>
+int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int policy, uint32_t seed, long long* stats) {
+  return lat_needs_odd<OutT>(nx, (long long)nx * ny, out) ? run_lat_t<OutT, true>(occ, nx, ny, src, n_src, out, W, policy, seed, stats)
+                                                          : run_lat_t<OutT, false>(occ, nx, ny, src, n_src, out, W, policy, seed, stats);
+}
 
 extern "C" {
 

@@ -317,49 +317,18 @@ VHP_LANE_FN void g_load2_f64(const double* base, vi idx, vd& a, vd& b) { const d
 // of a row piece that is half a line off the line grid, the cells next to a diagonal or an axis) several whole lines' worth on
 // two thirds of the device's memory; with nt a partially written line costs what it weighs (tools/policybench.hip: the same
 // bytes, every other row half a line off: 3.65 -> 4.81 TB/s on a slow buffer, 5.27 -> 5.96 on a fast one).
-#if defined(VHP_DIAG_PLAINSTORE) || defined(VHP_FIELD_STORE_PLAIN)  // the latency sweep (vhp_lat.hip); diagnostic builds: what a launch took until round 4
+#ifdef VHP_FIELD_STORE_PLAIN  // the latency sweep (vhp_lat.hip); -DVHP_DIAG_PLAINSTORE builds (vhp_diag.h): what a launch took until round 4
 #define VHP_FIELD_STORE(ptr, val) (*(ptr) = (val))
 #else
 #define VHP_FIELD_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #endif
 template <typename OutT> using Pair = OutT __attribute__((ext_vector_type(2)));
-#ifdef VHP_DIAG_WHOLELINES
-// diagnostic builds only (WRONG results): a 16-byte store leaves only as part of a whole 128-byte line that this instruction writes
-// (fp64: 8 consecutive lanes, all storing, the first on a line) -- the bound on what a launch without partially written lines takes
-VHP_LANE_FN bool diag_whole_line(bool active, const void* addr) {
-  // lanes are laid along the addresses, 16 bytes apart, upward or downward: the lane with the line's first 16 bytes is k lanes away
-  const unsigned long long m = __builtin_amdgcn_ballot_w64(active);
-  const int lane = (int)(threadIdx.x & 63u);
-  const unsigned long long a = (unsigned long long)addr;
-  const int k = (int)((a >> 4) & 7u);
-  bool whole = false;
-  for (int dir = -1; dir <= 1; dir += 2) {
-    const int l0 = lane + dir * k;                 // holds the first piece if the addresses rise (dir = -1) / fall (dir = +1) with the lane
-    const int lo = dir < 0 ? l0 : l0 - 7;
-    const bool in = lo >= 0 && lo + 7 <= 63;
-    const int src = in ? l0 : lane;
-    const unsigned lo32 = (unsigned)__shfl((int)(unsigned)a, src), hi32 = (unsigned)__shfl((int)(unsigned)(a >> 32), src);
-    const unsigned long long a0 = ((unsigned long long)hi32 << 32) | lo32;
-    const bool ok = in && ((m >> (lo & 63)) & 0xffull) == 0xffull && a0 == a - 16ull * (unsigned long long)k;
-    whole = whole || ok;
-  }
-  return active && whole;
-}
-#endif
 template <typename OutT> VHP_LANE_FN void g_store2(OutT* base, vu32 off, vd a, vd b) {
   VHP_DIAG_STORE_GUARD(a, b, off)
-#ifdef VHP_DIAG_WHOLELINES
-  if (!diag_whole_line(true, reinterpret_cast<char*>(base) + off)) return;
-#endif
   VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
 }
 template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p_hi, OutT* base, vu32 off, vd a, vd b) {
   VHP_DIAG_STORE_GUARD(a, b, off)
-  VHP_DIAG_PARTIAL_GUARD(a, b, off)
-#ifdef VHP_DIAG_WHOLELINES
-  if (diag_whole_line(p2, reinterpret_cast<char*>(base) + off)) VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
-  return;
-#endif
   vd single = p_lo ? a : b;
   asm volatile("" : "+v"(single));  // keep the compiler from splitting the 16-byte store to share a half with the single
   if (p2) VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
@@ -522,18 +491,14 @@ VHP_LANE_FN void lds_acquire() {
 // bit-identical to the division by oracle/markstein_check.c.  num is a lane vector, den and rden are uniform.
 template <typename D, typename R>
 VHP_LANE_FN vd ratio(vd num, D den, R rden) {
-#ifdef VHP_DIAG_NOMATH  // diagnostic builds only: the memory traffic of the sweep without its arithmetic (wrong results)
-  return num;
-#endif
+  VHP_DIAG_NOMATH_RETURN(num)
   const vd q = num * vd(rden);
   const vd r = vfma(-vd(den), q, num);
   return vfma(r, vd(rden), q);
 }
 // the reference's update (solver.cpp:592-594 / 598-600): a - c*(a - b), no contraction
 VHP_LANE_FN vd stencil(vd a, vd b, vd c) {
-#ifdef VHP_DIAG_NOMATH
-  return a;
-#endif
+  VHP_DIAG_NOMATH_RETURN(a)
   const vd t = a - b;
   const vd u = c * t;
   return a - u;

@@ -24,16 +24,16 @@ __device__ unsigned long long g_latprof[256 * 16 * 20];
 __device__ unsigned long long g_lat_strip_times[64 * 48 * 4];
 #endif
 
-template <typename OutT>
+template <typename OutT, bool ODD>
 __global__ void __launch_bounds__(64 * kLatWaves, 1) vhp_lat_sweep(LatArgs<OutT> a) {
   extern __shared__ double lds[];
   const Layout L = make_layout(kLatWaves, 1, a.m.nx, a.m.ny);
 #ifdef VHP_DIAG_POOLPROF
   const unsigned long long t_begin = wall_clock64();
 #endif
-  LatWorker<OutT>::clear(lds, L, (int)threadIdx.x, 64 * kLatWaves);
+  LatWorker<OutT, ODD>::clear(lds, L, (int)threadIdx.x, 64 * kLatWaves);
   __syncthreads();
-  LatWorker<OutT> wk;
+  LatWorker<OutT, ODD> wk;
   wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
   wk.run((int)blockIdx.x);
 #ifdef VHP_DIAG_POOLPROF
@@ -55,7 +55,8 @@ size_t lat_lds_bytes(int nx, int ny) { return (size_t)pool::make_layout(pool::kL
 template <typename OutT>
 hipError_t launch_lat_t(const BatchArgs& a) {
   using namespace pool;
-  auto k = vhp_lat_sweep<OutT>;
+  const bool odd = lat_needs_odd<OutT>(a.nx, a.field_stride, static_cast<const OutT*>(a.d_out));
+  auto k = odd ? vhp_lat_sweep<OutT, true> : vhp_lat_sweep<OutT, false>;
   const size_t lds = lat_lds_bytes(a.nx, a.ny);
   if (lds > kLdsLimit || a.pool_epoch == 0) return hipErrorInvalidValue;
   if (a.raise_lds) {

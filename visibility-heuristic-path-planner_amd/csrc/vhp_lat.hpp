@@ -186,7 +186,9 @@ VHP_FN void lat_zero_rect(OutT* out, int nx, int x0, int x1, int y0, int y1) {
 // ---------------------------------------------------------------------------------------------------------------
 // x-major strip p of a unit: rows j = 64 p + lane; steps i = 64 p .. ni - 1; cells (i, j), j <= i.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DX, int DY, typename OutT>
+// ODD: pairs of cells are not 16-byte aligned in every row (an odd width, or fields that start off the pair grid): a build of its
+// own, so that the even-width kernel carries none of it (the kernel sits at its register limit: one more live mask spills).
+template <int DX, int DY, typename OutT, bool ODD = false>
 struct LatX {
   static constexpr int CB = sizeof(OutT);
   Map m;
@@ -207,7 +209,7 @@ struct LatX {
   bool skip_fill;          // a dead strip stores nothing (LatArgs::dead_cells_are_zero)
   vi lane, tile_l, fl_t;
   vu32 fl_off;
-  bool odd_pitch;     // pairs of cells are not 16-byte aligned in every row (an odd width, or a field that starts off the grid)
+  static constexpr bool odd_pitch = ODD;
   vd prev, jd;
   vu64 ow, ow_nx;
   vd rv_nx;
@@ -231,7 +233,6 @@ struct LatX {
       const vi rs = DY > 0 ? rslot : 7 - rslot;
       fl_t = rslot * kTStride + pc * 2;
       fl_off = to_u32((rs * m.nx + pc * 2) * CB);
-      odd_pitch = (m.nx & 1) != 0 || (reinterpret_cast<uintptr_t>(out) & (2 * CB - 1)) != 0;
     }
     p = p_;
     j0 = kXRows * p;
@@ -292,11 +293,7 @@ struct LatX {
 #pragma unroll
     for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (xw & (2 * kBlock - 1)) + (DX > 0 ? k : kLW - 1 - k));
     if (below) {
-#ifndef VHP_DIAG_NOWAIT
-      nx.request(lk, dead_below, bin, xw, DX > 0 ? xw : xw + kLW - 1, nb);
-#else
-      nx.ring = false;
-#endif
+      if (VHP_DIAG_WAITS) nx.request(lk, dead_below, bin, xw, DX > 0 ? xw : xw + kLW - 1, nb); else nx.ring = false;
     }
     nx_ia = ia;
   }
@@ -307,14 +304,13 @@ struct LatX {
   // off the 16-byte grid: those rows' cells leave one by one.
   VHP_FN void store_group(OutT* base, const vb& ok0, const vb& ok1, const vd& a, const vd& b) {
     if (!odd_pitch) { g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, a, b); return; }
-    const vb al = pair_aligned(base, fl_off);
-    g_store2_if(al && ok0 && ok1, al && ok0, al && ok1, base, fl_off, a, b);
-    g_store2_if(vb(false), (!al) && ok0, vb(false), base, fl_off, a, b);
-    g_store2_if(vb(false), vb(false), (!al) && ok1, base, fl_off, a, b);
+    // (every row's cells one by one: telling the rows whose pairs ARE aligned apart costs a live lane mask, and this kernel sits
+    // at its register limit -- with the mask the fp64 build spilled 10 registers)
+    g_store2_if(vb(false), ok0, vb(false), base, fl_off, a, b);
+    g_store2_if(vb(false), vb(false), ok1, base, fl_off, a, b);
   }
   template <bool DIAG>
   VHP_FN void store_window(int ia, int xw, int lim, const vd (&fa)[8], const vd (&fb)[8]) {
-#ifndef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
     {
       // Groups of 8 rows (u): whole (every cell a computed cell of a row of this strip: 16-byte stores), none (skipped), or cell
       // by cell.  A cell (i', j) exists for j <= i' <= lim; the window's steps are ia .. ia + 15.
@@ -346,7 +342,6 @@ struct LatX {
       }
       }
     }
-#endif
   }
 
   // One window: steps ia + k, k = 0 .. 15, at x = xw + (k marching up, 15 - k marching down).  DIAG: the strip's diagonal may fall
@@ -648,11 +643,7 @@ struct LatY {
 #pragma unroll
     for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (yw & (2 * kBlock - 1)) + (DY > 0 ? k : kLW - 1 - k));
     if (below) {
-#ifndef VHP_DIAG_NOWAIT
-      nx.request(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, nb);
-#else
-      nx.ring = false;
-#endif
+      if (VHP_DIAG_WAITS) nx.request(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, nb); else nx.ring = false;
     }
     nx_ja = ja;
   }
@@ -697,14 +688,12 @@ struct LatY {
 #ifdef VHP_DIAG_NODIAGSTORE
         if (!DIAG)
 #endif
-#ifndef VHP_DIAG_NOYSTORE  // diagnostic builds only: what the y-major stores cost
         if (PRED) {
           const int j = ja + k;
           g_store1_if(first_j <= (j <= j_last ? j : -1), row, xoff, v);
         } else {
           g_store1_if(vb(true), row, xoff, v);
         }
-#endif
         prev = v;
         lds_store(wbase, widx + c, v);
         dj = dj + 1.0;
@@ -902,7 +891,13 @@ struct LatDiag {
   }
 };
 
+// the launch needs the ODD build of the kernel: some pair of cells that an x-major strip stores is not aligned to its size
 template <typename OutT>
+VHP_HD bool lat_needs_odd(int nx, long long field_stride, const OutT* out) {
+  return (nx & 1) != 0 || (field_stride & 1) != 0 || (reinterpret_cast<uintptr_t>(out) & (2 * sizeof(OutT) - 1)) != 0;
+}
+
+template <typename OutT, bool ODD = false>
 struct LatWorker {
   LatArgs<OutT> a;
   Shared sh;
@@ -938,7 +933,7 @@ struct LatWorker {
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* prog = sh.prog(0);
     for (int p = w; p < g.Px; p += W) {
-      LatX<DX, DY, OutT> xs;
+      LatX<DX, DY, OutT, ODD> xs;
       xs.lk.init(sh, w, sx, kXRows * p, tag_of(p), prog + p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr,
                  a.epoch, p > 0 ? (p - 1) % W : -1, p > 0 ? tag_of(p - 1) : 0);
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
@@ -948,13 +943,9 @@ struct LatWorker {
       xs.skip_fill = a.dead_cells_are_zero;
       xs.prefetch_ops(g.X(xs.i_first) >> 6);
       VHP_LAT_STAMP(unit, p, 0);
-#ifndef VHP_DIAG_NOWAIT
-      if (p > 0) wait_for(prog + (p - 1), imin(kXRows * p + 2, g.ni));  // the strip below has got to my rows
-#endif
+      if (VHP_DIAG_WAITS && p > 0) wait_for(prog + (p - 1), imin(kXRows * p + 2, g.ni));  // the strip below has got to my rows
       VHP_LAT_STAMP(unit, p, 1);
-      VHP_PP_T0(tsb);
       xs.run();
-      VHP_PP_ADD(2, tsb);
       VHP_LAT_STAMP(unit, p, 3);
       lds_publish(prog + p, 0x3fff);  // finished (a march can end before the first window of the strip above does)
       sim_progress();
@@ -997,9 +988,7 @@ struct LatWorker {
       ys.init(a.m, sx, sy, field, sh, w, q, n_strips, diag_lds);
       ys.skip_fill = a.dead_cells_are_zero;
       ys.prefetch_ops(g.Y(ys.j_first) >> 6);
-#ifndef VHP_DIAG_NOWAIT
-      if (q > 0) wait_for(prog + (q - 1), imin(kBlock * q + 1, g.nj));
-#endif
+      if (VHP_DIAG_WAITS && q > 0) wait_for(prog + (q - 1), imin(kBlock * q + 1, g.nj));
       VHP_LAT_STAMP(unit, q, 1);
       ys.run();
       VHP_LAT_STAMP(unit, q, 3);

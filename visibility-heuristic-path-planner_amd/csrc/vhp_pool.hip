@@ -15,36 +15,16 @@ namespace pool {
 #endif
 constexpr int kWaves = VHP_POOL_WAVES;
 
-#ifdef VHP_DIAG_POOLPROF  // diagnostic builds only (tools/pool_timeline.py)
-__device__ unsigned long long g_poolprof[512 * 16 * 12];
-__device__ unsigned long long g_unit_times[2 * 8 * 1024];
-#endif
 
 template <typename OutT>
 __global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, int n_ctx) {
   extern __shared__ double lds[];
   const Layout L = make_layout(kWaves, n_ctx, a.m.nx, a.m.ny);
-#ifdef VHP_DIAG_POOLPROF
-  const unsigned long long t_begin = wall_clock64(), c_begin = __builtin_readcyclecounter();
-#endif
   Worker<OutT>::clear(lds, L, (int)threadIdx.x, 64 * kWaves);
   __syncthreads();
   Worker<OutT> wk;
   wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
   wk.run();
-#ifdef VHP_DIAG_POOLPROF
-  if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) {
-    unsigned long long* o = g_poolprof + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 12;
-    for (int k = 0; k < 8; ++k) o[k] = wk.prof[k];
-    o[8] = t_begin;
-    o[9] = wall_clock64();
-    o[10] = __builtin_readcyclecounter() - c_begin;
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    o[11] = ((unsigned long long)xcc << 32) | hwid;
-  }
-#endif
 }
 
 // Launch order: one workgroup counting-sorts the 8 n_src units by the length of their march (then by cell count), longest first,
@@ -78,10 +58,7 @@ __global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict
   __shared__ int start[kBuckets];
   __shared__ int wave_tot[16];
   const int n_units = n_src * kUnits;
-#ifdef VHP_DIAG_TIMELINE
-  for (int k = threadIdx.x; k < 256 * 2 * kPpBins; k += blockDim.x) g_pp_hist[k] = 0;
-  if (threadIdx.x == 0) g_pp_t0 = wall_clock64();
-#endif
+  VHP_DIAG_TL_RESET
   {
     // boundary lines: thread t lays out the units [t * per, (t + 1) * per)
     auto blocks_of = [&](int u) {
@@ -202,10 +179,6 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   // slow one 0.583 / 0.582 / 0.597 / 0.589 / 0.591 (bound by the memory there); C5 3.567 / 3.483 / 3.476 / 3.474 / 3.482; 128 sources at
   // 2048^2 1.316 / - / 1.277 / - / 1.238; 512 at 512^2 0.445 / - / 0.419 / - / 0.416
   g.claim_ahead = a.pool_claim_ahead >= 0 ? a.pool_claim_ahead : 48;
-  g.unit_times = nullptr;
-#ifdef VHP_DIAG_POOLPROF
-  if (a.n_src <= 1024) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_unit_times)) == hipSuccess) g.unit_times = static_cast<unsigned long long*>(p); }
-#endif
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs
   hipLaunchKernelGGL(vhp_pool_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, order, line_base,
                      line_blocks_per_source(a.nx, a.ny) * a.n_src, reinterpret_cast<unsigned long long*>(a.d_queue), a.d_err);
@@ -225,14 +198,6 @@ bool pool_supported(int nx, int ny) {
   return pool_shape(nx, ny, 0).lds <= kLdsLimit;
 }
 
-#ifdef VHP_DIAG_POOLPROF
-extern "C" int vhp_debug_read_poolprof(unsigned long long* dst, int n_words) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_poolprof), (size_t)n_words * 8);
-}
-extern "C" int vhp_debug_read_unit_times(unsigned long long* dst, int n_words) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_unit_times), (size_t)n_words * 8);
-}
-#endif
 
 #ifdef VHP_DIAG_TIMELINE
 extern "C" int vhp_debug_read_hist(unsigned long long* dst, int n_words) {

@@ -58,35 +58,7 @@ constexpr int kXRows = geom::kXRows;
 constexpr int kYCols = geom::kYCols;
 constexpr int kTStride = 17;  // doubles per tile row: two windows of 8 columns + 1 (spreads the column writes over the banks)
 constexpr int kUnits = 8;     // units per source: 4 quadrants x {x-major, y-major}
-
-#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)  // diagnostic builds only (tools/pool_timeline.py): where a wavefront's cycles go
-#define VHP_PP_T0(var) const unsigned long long var = __builtin_readcyclecounter()
-#define VHP_PP_ADD(slot, var) prof[slot] += __builtin_readcyclecounter() - var
-#define VHP_PP_ADDP(pp, slot, var) (pp)[slot] += __builtin_readcyclecounter() - var
-#define VHP_PP_COUNT(slot) prof[slot] += 1
-#else
-#define VHP_PP_T0(var)
-#define VHP_PP_ADD(slot, var)
-#define VHP_PP_ADDP(pp, slot, var)
-#define VHP_PP_COUNT(slot)
-#endif
-#if defined(VHP_DIAG_TIMELINE) && !defined(VHP_SIM)
-// the launch's timeline: cells swept (= bytes stored, one window late) and strips running, per 10 us of wall clock since the
-// order pre-kernel (g_pp_t0); one atomic per 64-step block of a strip, into the histogram of the wavefront's own workgroup
-// (one histogram for the chip was 3000 wavefronts adding to one address: +30 % launch time)
-constexpr int kPpBins = 256;
-static __device__ unsigned long long g_pp_hist[256 * 2 * kPpBins];
-static __device__ unsigned long long g_pp_t0;
-static __device__ __forceinline__ unsigned long long* pp_slot(int which) {
-  const unsigned long long b_ = (wall_clock64() - g_pp_t0) / 1000;
-  return g_pp_hist + ((size_t)(blockIdx.x & 255) * 2 + which) * kPpBins + (b_ < kPpBins - 1 ? b_ : kPpBins - 1);
-}
-#define VHP_PP_BYTES(n) do { if ((threadIdx.x & 63) == 0) atomicAdd(pp_slot(0), (unsigned long long)(n)); } while (0)
-#define VHP_PP_STRIPS(d) do { if ((threadIdx.x & 63) == 0) atomicAdd(pp_slot(1), (unsigned long long)(long long)(d)); } while (0)
-#else
-#define VHP_PP_BYTES(n)
-#define VHP_PP_STRIPS(d)
-#endif
+VHP_DIAG_TL_DECLARE
 
 // ---- LDS of a workgroup -------------------------------------------------------------------------------------------
 // doubles per wavefront: the staging tile, the reciprocal slab, the boundary line of the strip below for the current
@@ -159,7 +131,6 @@ struct Args {
   int early_ctx;      // contexts >= this one open only once `late_after` units have been taken: towards the end of a launch a
   int late_after;     // workgroup holds more, shorter units at once (what is left then has nothing large to get in the way of)
   int claim_ahead;    // a strip may be claimed this many steps before the strip below has swept its first window (find_work)
-  unsigned long long* unit_times;  // diagnostic builds: when unit u was installed / finished (wall clock), or nullptr
 };
 
 // Geometry of a unit without the direction templates: what the scheduler needs to tell whether a strip may start.
@@ -214,7 +185,6 @@ struct Link {
   uint64_t epoch;
   int c0;
   vi lane;
-  unsigned long long* pp;  // diagnostic builds: the wavefront's cycle accounts (Worker::prof), else unused
 
   VHP_FN int coord(int i) const { return c0 + D * i; }
   VHP_FN int block_of(int i) const { const int b = coord(i) >> 6; return D > 0 ? b - (c0 >> 6) : (c0 >> 6) - b; }
@@ -269,15 +239,7 @@ struct Link {
   // block from global memory.
   VHP_FN void fetch(int ia, int ib, int nb) {
     if (bin_block == nb) return;
-    VHP_PP_T0(tq);
-    fetch_(ia, ib, nb);
-    VHP_PP_ADDP(pp, 1, tq);
-  }
-  VHP_FN void fetch_(int ia, int ib, int nb) {
-#ifdef VHP_DIAG_NOWAIT  // diagnostic builds only (WRONG results): no strip waits for another -- the launch's store trace at full speed
-    (void)ia; (void)ib; (void)nb;
-    return;
-#endif
+    VHP_DIAG_NOWAIT_RETURN  // (vhp_diag.h: diagnostic builds in which no strip waits for another)
     for (;;) {
       const int h = lds_poll(rd_hdr);
       if ((h >> 14) != rd_tag) break;                 // the writer has finished that strip: its line is (being) stored
@@ -361,9 +323,6 @@ struct XStrip {
   // (PRED: only the cells with step index j <= i' <= i_now.)
   template <bool PRED>
   VHP_FN void flush(int xa, int r_first, int i_now, int i_extra = 0) {
-#ifdef VHP_DIAG_NOXSTORE  // diagnostic builds only: what the x-major stores cost
-    return;
-#endif
     wave_sync();
     const int win = (xa >> 3) + 24;  // (xa may be -8 at the end of a march)
     const int sA = win & 1, sB = sA ^ 1;
@@ -397,14 +356,8 @@ struct XStrip {
         const vd a = lds_load(tile, tix);
         const vd b = lds_load(tile, tix + 1);
         if (!PRED) {
-#ifndef VHP_DIAG_DROP_XRAGGED
           g_store2_if(row_ok, vb(false), vb(false), base, off, a, b);
-#endif
         } else {
-#ifdef VHP_DIAG_DROP_XPRED
-          base += base_step;
-          continue;
-#endif
           const vi jr = r + j0;
           const vi jlo = jr;
           const vb ok0 = row_ok && (i0c >= jlo) && (i0c <= i_now + i_extra);
@@ -540,7 +493,6 @@ struct XStrip {
     if (lo > hi) return;
     const int blk = g.X(lo) >> 6;
     {
-      VHP_PP_T0(tl);
       vd rv;
       if (pf_blk == blk) { ow = ow_nx; rv = rv_nx; } else { load_block(blk, ow, rv); }
       pin(ow);
@@ -548,7 +500,6 @@ struct XStrip {
       lds_store(slab, lane, rv);
       wave_sync();
       if (nb + 1 < g.Nbx) { pf_blk = blk + DX; load_block(pf_blk, ow_nx, rv_nx); } else { pf_blk = -1; }
-      VHP_PP_ADDP(lk.pp, 4, tl);
     }
     int i = lo;
     while (i <= hi) {
@@ -571,9 +522,7 @@ struct XStrip {
       if (boundary && i_last != g.ni - 1) flush_completed(xl, i_last);  // (the last step of the march is end_of_march's)
     }
     if (has_consumer) lk.store_block(nb, blk);
-#if defined(VHP_DIAG_TIMELINE) && !defined(VHP_SIM)
-    { long cells = 0; for (int ii = lo; ii <= hi; ++ii) cells += imin(rows_here, ii - j0 + 1); VHP_PP_BYTES(cells * CB); }
-#endif
+    VHP_DIAG_TL_XBLOCK(lo, hi, rows_here, j0, CB)
   }
 };
 
@@ -629,10 +578,6 @@ struct YStrip {
 
   // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below the diagonal
   VHP_FN void store_pred(OutT* row, int j, vd v0, vd v1) {
-#ifdef VHP_DIAG_DROP_YPRED
-    asm volatile("" :: "v"(v0), "v"(v1));
-    return;
-#endif
     vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
     vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
     if (DX < 0) {
@@ -702,13 +647,9 @@ struct YStrip {
         v0 = select(ia == j0w + k, dg0, v0);
         v1 = select(ib == j0w + k, dg1, v1);
       }
-#ifndef VHP_DIAG_NOYSTORE  // diagnostic builds only: what the y-major stores cost
       if (PRED) store_pred(row, j0w + k, v0, v1);
       else if (DX > 0) g_store2(row, xoff, v0, v1);
       else g_store2(row, xoff, v1, v0);
-#else
-      asm volatile("" :: "v"(v0), "v"(v1));
-#endif
       prev0 = v0;
       prev1 = v1;
       lds_store(wbase, widx + bit, v1);
@@ -731,13 +672,11 @@ struct YStrip {
       const vi jt = (lane + (blk * 64 - g.sy)) * DY;
       const vb ok = (jt >= 0) && (jt < g.nj);
       vd rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
-      VHP_PP_T0(tl);
       pin(ow0);
       pin(ow1);
       pin(rv);
       lds_store(slab, lane, rv);
       wave_sync();
-      VHP_PP_ADDP(lk.pp, 4, tl);
     }
     int j = lo;
     while (j <= hi) {
@@ -757,9 +696,7 @@ struct YStrip {
       if (has_consumer) lk.publish(j);
     }
     if (has_consumer) lk.store_block(nb, blk);
-#if defined(VHP_DIAG_TIMELINE) && !defined(VHP_SIM)
-    { long cells = 0; for (int jj = lo; jj <= hi; ++jj) cells += imax(imin(imin(i0 + kYCols - 1, g.ni - 1), jj) - imax(i0, 0) + 1, 0); VHP_PP_BYTES(cells * CB); }
-#endif
+    VHP_DIAG_TL_YBLOCK(lo, hi, i0, kYCols, g.ni, CB)
   }
 };
 
@@ -832,11 +769,6 @@ struct Worker {
   Shared sh;
   int w;
   vi lane;
-#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
-  // cycles: [0] looking for work / idle, [1] waiting for the strip below, [2] sweeping (stores included), [3] installing units
-  // (diagonal chains included), [4] boundary line out; counts: [5] strips, [6] blocks, [7] units installed
-  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ([1]: inside the sweep, waiting for / copying the boundary values; [4]: block-start loads)
-#endif
 
   VHP_FN void init(const Args<OutT>& a_, double* lds, const Layout& L, int w_) {
     a = a_;
@@ -883,13 +815,11 @@ struct Worker {
       const int qo = unit & 7, sx = sxsy & 0xffff, sy = sxsy >> 16;
       UnitGeo ug;
       ug.init(a.m.nx, a.m.ny, qo, sx, sy);
-#ifndef VHP_DIAG_NOWAIT
       // the strip below has (all but) swept my first window.  claim_ahead > 0: claimed that many steps EARLIER -- the claim, the
       // strip's set-up and the loads of its first block (a round trip to memory) then run beside the strip below instead of
       // behind it; the new strip waits for its first boundary values inside fetch(), for a strip claimed before it as ever
-      if (p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_step(p) + 8 + 1 - a.claim_ahead) continue;
-      if (!ug.x_major && lds_poll(cx + kDiagReady) < ug.diag_need(p)) continue;
-#endif
+      if (VHP_DIAG_WAITS && p > 0 && lds_poll(sh.prog(c) + (p - 1)) < ug.first_step(p) + 8 + 1 - a.claim_ahead) continue;
+      if (VHP_DIAG_WAITS && !ug.x_major && lds_poll(cx + kDiagReady) < ug.diag_need(p)) continue;
       best_c = c; best_seq = rank; best_p = p; best_word = word; best_qo = qo; best_sx = sx; best_sy = sy;
     }
     if (best_c >= 0) {
@@ -907,10 +837,7 @@ struct Worker {
     if (free_c >= 0 && !q_empty && lds_poll(sc + kBusy) < a.busy_cap) {
       sim_point();
       if (lds_cas(sh.ctx(free_c) + kState, 0, 1) == 0) {
-        VHP_PP_T0(ti);
         install(free_c);
-        VHP_PP_ADD(3, ti);
-        VHP_PP_COUNT(7);
       }
       return kRetry;
     }
@@ -957,9 +884,6 @@ struct Worker {
       lds_publish(cx + kState, 0);
       return;
     }
-#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
-    if ((threadIdx.x & 63) == 0 && a.unit_times) a.unit_times[2 * unit] = wall_clock64();
-#endif
     lds_set_int(cx + kUnit, unit);
     lds_set_int(cx + kNStrips, ug.n_strips);
     lds_set_int(cx + kLeft, ug.n_strips);
@@ -997,9 +921,6 @@ struct Worker {
   VHP_FN void strip_done(int c) {
     int* cx = sh.ctx(c);
     if (lds_add(cx + kLeft, -1) == 1) {
-#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
-      if ((threadIdx.x & 63) == 0 && a.unit_times) a.unit_times[2 * lds_int_at(cx + kUnit) + 1] = wall_clock64();
-#endif
       lds_publish(cx + kWord, -1);
       lds_publish(cx + kState, 0);
     }
@@ -1020,22 +941,15 @@ struct Worker {
     xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr,
                a.epoch, p > 0 ? lds_int_at(sh.owner(c) + (p - 1)) : -1, p > 0 ? tag_of(c, p - 1) : 0);
     xs.init(a.m, sx, sy, field, sh, w, p);
-#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
-    xs.lk.pp = prof;
-#endif
-    VHP_PP_COUNT(5);
-    VHP_PP_STRIPS(1);
+    VHP_DIAG_TL_STRIPS(1)
     for (int n = p; n < xs.g.Nbx; ++n) {
-      VHP_PP_T0(ts);
       xs.sweep_block(n);
       if (n == xs.g.Nbx - 1) xs.end_of_march();
-      VHP_PP_ADD(2, ts);
-      VHP_PP_COUNT(6);
       sim_progress();
       sim_point();
     }
     lds_publish(mine, 0x3fff);  // finished: whatever the strip above needs to start is there (a march can end before its first window does)
-    VHP_PP_STRIPS(-1);
+    VHP_DIAG_TL_STRIPS(-1)
     strip_done(c);
   }
 
@@ -1048,21 +962,14 @@ struct Worker {
     ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr,
                a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
     ys.init(a.m, sx, sy, field, sh, w, q, dline);
-#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
-    ys.lk.pp = prof;
-#endif
-    VHP_PP_COUNT(5);
-    VHP_PP_STRIPS(1);
+    VHP_DIAG_TL_STRIPS(1)
     for (int n = ys.g.nby(ys.jstart); n < ys.g.Nby; ++n) {
-      VHP_PP_T0(ts);
       ys.sweep_block(n);
-      VHP_PP_ADD(2, ts);
-      VHP_PP_COUNT(6);
       sim_progress();
       sim_point();
     }
     lds_publish(mine, 0x3fff);
-    VHP_PP_STRIPS(-1);
+    VHP_DIAG_TL_STRIPS(-1)
     strip_done(c);
   }
 
@@ -1086,12 +993,10 @@ struct Worker {
   VHP_FN void run() {
     for (;;) {
       int c = 0, p = 0, qo = 0, sx = 0, sy = 0;
-      VHP_PP_T0(tf);
       const int r = find_work(c, p, qo, sx, sy);
       if (r == kExit) break;
-      if (r == kIdle) { backoff(); VHP_PP_ADD(0, tf); continue; }
+      if (r == kIdle) { backoff(); continue; }
       if (r == kRetry) continue;
-      VHP_PP_ADD(0, tf);
       lds_add(sh.sched() + kBusy, 1);
       run_strip(c, p, qo, sx, sy);
       lds_add(sh.sched() + kBusy, -1);
