@@ -270,9 +270,14 @@ bool use_pool_kernel(const vhp_ctx* c, int n_src) {
   // 256 sources at 1000^2 0.51-0.55 / 0.61 / 0.56 on one box and 0.67-0.70 / 0.73 / 0.74 on another; 512: 0.96 / - / 1.03;
   // 128: 0.44-0.46 / - / 0.45; 128 sources at 2048^2 1.25 / 1.42 / -; at 4096^2 3.88 / 4.29 / -.  The pool sweep from 192
   // sources up to side 1024, and wherever the streaming sweep used to be picked above it.
+  // Round 4, with non-temporal stores and strips claimed ahead (tools/ab_libs.py, one buffer; front / pool, ms): 1000^2: 48 sources
+  // 0.293 / 0.289, 64: 0.298 / 0.295, 96: 0.353 / 0.321, 128: 0.424 / 0.399, 192: 0.593 / 0.511; 512^2: 96: 0.137 / 0.165, 192: 0.199 /
+  // 0.191, 384: 0.341 / 0.328; 2048^2: 32: 0.82 / 0.64, 48: 0.92 / 0.66, 64: 1.15 / 0.77, 96: 1.57 / 1.03; 4096^2: 24: 2.67 / 1.95, 48:
+  // 3.43 / 2.18, 64: 4.42 / 2.42.  (Up to 32 sources the latency sweep has taken the launch before this is asked.)
   const int maxdim = std::max(c->nx, c->ny);
-  if (maxdim <= 1024) return n_src >= 192;
-  return n_src >= (maxdim >= 3072 ? 64 : 96);
+  if (maxdim <= 768) return n_src >= 192;
+  if (maxdim <= 1024) return n_src >= 96;
+  return n_src >= 24;
 }
 
 // the pool sweep's scratch: its own allocation (nothing else may write the tagged lines), zero when new
