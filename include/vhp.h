@@ -203,6 +203,28 @@ int vhp_last_sweep_kernel(const vhp_ctx* ctx);
  * (up to 16 GB of it are used).  Blocks until done. */
 int vhp_probe_stores(vhp_ctx* ctx, void* d_buf, unsigned long long bytes, float* whole_lines_TBps, float* split_lines_TBps);
 
+/* ---- several devices of one node (the reference is one thread on one CPU and has nothing to replace here) ----
+ * The sources of a batch are independent, so a batch shards over devices with no exchange step: device d of n sweeps the
+ * block vhp_multi_shard_bounds(n_src, n, d) of the sources into its own buffer.  vhp_multi_create makes one context per listed
+ * device (an ordinal may be listed twice: two contexts on one device), each with a stream of its own; vhp_multi_set_map gives
+ * every device the map; vhp_multi_sweep_batch uploads the shards' sources, launches every device's sweep before it waits for
+ * any, and returns the first device-side status that is not VHP_OK (d_out_per_device[d]: device memory ON device d for its
+ * shard's fields, packed; NULL allowed where the shard is empty); vhp_multi_allgather_fields then lands all n_src fields in
+ * source order in d_all_per_device[d] on every device by direct peer copies -- xGMI is point to point, every pair of devices
+ * has a link of its own, so the N (N - 1) copies of an all-gather all run at once.  The planner does not shard (pivot k + 1
+ * needs the union after pivot k): use vhp_multi_context(m, d) for replicas.  (torch.distributed / RCCL form of the same:
+ * dist.py.)  Not thread-safe; every call restores the caller's current device. */
+typedef struct vhp_multi vhp_multi;
+int vhp_multi_create(const int* device_ordinals, int n_devices, vhp_multi** out);
+int vhp_multi_destroy(vhp_multi* m);
+const char* vhp_multi_last_error(const vhp_multi* m);
+int vhp_multi_devices(const vhp_multi* m);
+vhp_ctx* vhp_multi_context(vhp_multi* m, int d);
+void vhp_multi_shard_bounds(int n_src, int n_devices, int d, int* lo, int* hi);
+int vhp_multi_set_map(vhp_multi* m, const uint8_t* occ_rowmajor, int nx, int ny);
+int vhp_multi_sweep_batch(vhp_multi* m, const int32_t* src_xy, int n_src, int variant, int dtype, void* const* d_out_per_device);
+int vhp_multi_allgather_fields(vhp_multi* m, int n_src, int dtype, void* const* d_shard_per_device, void* const* d_all_per_device);
+
 /* Library / build identification: "vhp-hip <version> gfx950". */
 const char* vhp_version(void);
 

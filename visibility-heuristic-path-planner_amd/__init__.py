@@ -41,6 +41,8 @@ ABI_SYMBOLS = (
     "vhp_raycast_all", "vhp_timing", "vhp_timing_collect", "vhp_set_option", "vhp_sweep_batch_variant", "vhp_planner_solve_variant",
     "vhp_planner_solve_device", "vhp_planner_results_device", "vhp_last_sweep_kernel",
     "vhp_last_elapsed_ms", "vhp_version", "vhp_sweep_batch_offset", "vhp_planner_solve_speculative", "vhp_probe_stores",
+    "vhp_multi_create", "vhp_multi_destroy", "vhp_multi_last_error", "vhp_multi_devices", "vhp_multi_context", "vhp_multi_shard_bounds",
+    "vhp_multi_set_map", "vhp_multi_sweep_batch", "vhp_multi_allgather_fields",
 )
 
 
@@ -97,6 +99,18 @@ def load_library():
     lib.vhp_version.restype = C.c_char_p
     lib.vhp_last_sweep_kernel.argtypes = [vp]
     lib.vhp_probe_stores.argtypes = [vp, vp, C.c_ulonglong, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.vhp_multi_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    lib.vhp_multi_destroy.argtypes = [vp]
+    lib.vhp_multi_last_error.argtypes = [vp]
+    lib.vhp_multi_last_error.restype = C.c_char_p
+    lib.vhp_multi_devices.argtypes = [vp]
+    lib.vhp_multi_context.argtypes = [vp, i32]
+    lib.vhp_multi_context.restype = vp
+    lib.vhp_multi_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.vhp_multi_shard_bounds.restype = None
+    lib.vhp_multi_set_map.argtypes = [vp, vp, i32, i32]
+    lib.vhp_multi_sweep_batch.argtypes = [vp, vp, i32, i32, i32, C.POINTER(vp)]
+    lib.vhp_multi_allgather_fields.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(vp)]
     _lib = lib
     return lib
 
