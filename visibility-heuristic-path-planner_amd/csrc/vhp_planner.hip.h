@@ -152,18 +152,32 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
   best.rank = ~0ull;
   best.x = best.y = -1;
   const size_t cells = (size_t)nx * ny;
-  // Four cells of a thread at a time, their loads issued together: the kernel is a chain of memory latencies, not of bytes.
+  // The pivots a label can name (lightSources_[0 .. nb]) into LDS, beside the first batch of loads: a lit cell's parent then
+  // costs no round trip to memory of its own (beyond kPivLds entries: from global memory as before).
+  constexpr int kPivLds = 1024;
+  __shared__ int piv_lds[2 * kPivLds];
+  const int n_piv = nb + 1 < kPivLds ? nb + 1 : kPivLds;
+  for (int t = threadIdx.x; t < 2 * n_piv; t += blockDim.x) piv_lds[t] = d.pivots[t];
+  // Four cells of a thread at a time, their loads issued together -- the label's too, whether or not the cell turns out lit: the
+  // kernel is a chain of memory latencies, not of bytes.
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t k0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k0 < cells; k0 += 4 * stride) {
-    double vv[4], oo[4];
+  double vv[4], oo[4];
+  uint32_t ll[4];
+  auto load_batch = [&](size_t k0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t k = k0 + u * stride;
       const bool in = k < cells;
       vv[u] = in ? d.vis_local[k] : 0.0;
       oo[u] = in ? d.vis_global[k] : 0.0;
+      ll[u] = in ? d.label[k] : 0u;
       if (d.vis_other && in && d.vis_other[k] != 0.0) d.vis_other[k] = 0.0;
     }
+  };
+  size_t k0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  load_batch(k0);   // (issued before the barrier that the staged pivots need: one round trip to memory for both)
+  __syncthreads();
+  for (;;) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t k = k0 + u * stride;
@@ -175,14 +189,15 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
       const double v = vv[u];
       const double old = oo[u];
       const double g = fmax(v, old);  // :417-418
-      if (g != old) d.vis_global[k] = g;  // (most cells of most iterations are dark: nothing to write, no label to read)
+      if (g != old) d.vis_global[k] = g;  // (most cells of most iterations are dark: nothing to write)
       if (g >= d.threshold) {  // :424-430 (v >= threshold implies g >= threshold)
-        uint32_t lab = d.label[k];
+        uint32_t lab = ll[u];
         if (v >= d.threshold && lab == kUnlabelled32) {  // :419-423
           lab = (uint32_t)nb;
           d.label[k] = lab;
         }
-        const int px = d.pivots[2 * lab], py = d.pivots[2 * lab + 1];
+        const int px = lab < (uint32_t)kPivLds ? piv_lds[2 * lab] : d.pivots[2 * lab];
+        const int py = lab < (uint32_t)kPivLds ? piv_lds[2 * lab + 1] : d.pivots[2 * lab + 1];
         const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, px, py));
         PlannerKey c;
         c.h = (unsigned long long)__double_as_longlong(h);
@@ -192,6 +207,9 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
         if (key_less(c, best)) best = c;
       }
     }
+    k0 += 4 * stride;
+    if (k0 >= cells) break;
+    load_batch(k0);
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
