@@ -174,7 +174,7 @@ class Context:
         self._check(self.lib.vhp_set_option(self.h, key.encode(), int(value)))
 
     def last_sweep_kernel(self):
-        """1 = front sweep, 2 = streaming sweep: what the last batch sweep launched."""
+        """1 = front sweep, 3 = pool sweep, 4 = latency sweep: what the last batch sweep (or planner solve) launched."""
         return int(self.lib.vhp_last_sweep_kernel(self.h))
 
     def timing(self, enable=True, prealloc=0):

@@ -1,6 +1,6 @@
 // vhp_lanes.hpp -- the wavefront as a value type.
 //
-// The streaming sweep kernel (vhp_stream.hpp) is written once against the few operations below and compiled twice:
+// The pool sweep and the latency sweep (vhp_pool.hpp, vhp_lat.hpp) are written once against the few operations below and compiled twice:
 //
 //   * by hipcc for gfx950 (the product): a "lane vector" is the plain per-thread scalar of the SIMT model, every
 //     operation is the instruction it names (DPP wave shifts, v_readlane, v_bfe_i32, ds_read/ds_write, global

@@ -1,13 +1,12 @@
 // vhp_pool.hpp -- the pool sweep: computeVisibility() (reference src/visibilityBasedSolver.cpp:570-696) for large
 // batches of sources, organised as a pool of wavefronts per CU that pull STRIPS.
 //
-// Same mathematics and the same per-step code as the streaming sweep (vhp_stream.hpp: a quadrant is an x-major octant
-// whose fronts are columns and a y-major octant whose fronts are rows; a unit is one octant; a strip is 64 rows / 128
-// columns of it; a block is 64 steps of a strip), a different machine around it.  What the streaming sweep left on the
-// table: a workgroup sweeps ONE unit with a fixed team, wavefront w owns strips w, w+W, ... one
-// after the other (wavefront 0 of a full-size octant: 2424 dependent steps), half of an x-major team only flushes, a
-// y-major team keeps 2 of 7 wavefronts busy, and so a launch without stores still takes 0.46 ms for 0.1 ms of
-// arithmetic.  Here
+// A quadrant is an x-major octant whose fronts are columns and a y-major octant whose fronts are rows (vhp_geom.hpp); a unit
+// is one octant; a strip is 64 rows / 128 columns of it; a block is 64 steps of a strip.  The per-step code is that of round
+// 2's streaming sweep (retired: DESIGN.md section 4b), the machine around it is not.  There a workgroup swept ONE unit with a
+// fixed team, wavefront w owned strips w, w+W, ... one after the other (wavefront 0 of a full-size octant: 2424 dependent
+// steps), half of an x-major team only flushed, a y-major team kept 2 of 7 wavefronts busy, and so a launch without stores
+// still took 0.46 ms for 0.1 ms of arithmetic.  Here
 //
 //   * ONE workgroup of W wavefronts per CU, persistent, holds up to C units at once (contexts in LDS);
 //   * every wavefront is a worker: it claims the next strip of a context whose predecessor strip has got far enough
@@ -36,7 +35,7 @@
 //     complete leave as whole lines, 8 rows per store instruction, issued by the wavefront that computed them (a
 //     wavefront stalled in a store is covered by the other wavefronts of its SIMD: that is what a pool is for);
 //   * the stale diagonal of a y-major unit is produced by the wavefront that installed the unit -- the serial
-//     two-term recurrence of stream::DiagWave -- into a scratch line in global memory, 64 entries at a time; a strip
+//     two-term recurrence of DiagTask -- into a scratch line in global memory, 64 entries at a time; a strip
 //     loads the seeds of its own columns into registers when it starts.
 //
 // Written against vhp_lanes.hpp: compiled for gfx950 (vhp_pool.hip) and, unchanged, for the CPU simulator of tests/sim,
@@ -267,7 +266,7 @@ struct Link {
 
 // ---------------------------------------------------------------------------------------------------------------
 // x-major strip p of a unit: rows j = 64p + lane; steps i = 64p .. ni-1; cells (i, j), j <= i.  The step code is the
-// streaming sweep's (stream::XWave::window8 / step1); the tile has two windows and the wavefront flushes it itself.
+// streaming sweep's, round 2; the tile has two windows and the wavefront flushes it itself.
 // ---------------------------------------------------------------------------------------------------------------
 template <int DX, int DY, typename OutT>
 struct XStrip {
@@ -528,7 +527,7 @@ struct XStrip {
 
 // ---------------------------------------------------------------------------------------------------------------
 // y-major strip q of a unit: columns i = 128q - ya + 2*lane + {0,1}; steps j = max(i0,0) .. nj-1; cells (i, j), i <= j
-// (the diagonal cell is the seed diag(j), stored again with its neighbour).  stream::YWave's step code; the seeds of the
+// (the diagonal cell is the seed diag(j), stored again with its neighbour).  the streaming sweep's step code (round 2); the seeds of the
 // lane's two columns wait in registers.
 // ---------------------------------------------------------------------------------------------------------------
 template <int DX, int DY, typename OutT>
@@ -701,7 +700,7 @@ struct YStrip {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// The diagonal of a quadrant for its y-major unit (stream::DiagWave's recurrence), into the unit's scratch line in global
+// The diagonal of a quadrant for its y-major unit (the two-term recurrence below), into the unit's scratch line in global
 // memory, 64 entries per call.  diag(0) = occ(source); for k >= 1:
 //   sub(k)  = V(k, k-1) = (a - c*(a - b)) * occ(k, k-1),  a = diag(k-1), b = sub(k-1), c = (k-1)/k
 //   diag(k) = sub(k) * occ(k, k)                                            (the stale diagonal)
