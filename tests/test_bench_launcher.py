@@ -48,3 +48,22 @@ def test_a_failing_rank_fails_the_command():
     r = _run("--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
     assert not _json_lines(r.stdout)
+
+
+def test_bench_workloads_are_the_tested_launches():
+    # bench.py's timed region checks no results; what makes its numbers results of a CORRECT launch is that rank 0's launch of
+    # the default workload is, input for input, the launch tests/test_gpu_sweep.py checks against the oracle (maps.config_c3 /
+    # config_c5): same map, same sources, same order
+    import importlib.util
+    import numpy as np
+    import maps
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name, ref in (("c3", maps.config_c3(256)), ("c5", maps.config_c5(128))):
+        occ, src, _ = bench.make_workload(name, 0, 0)
+        assert occ.shape == ref[0].shape and np.array_equal(occ, ref[0])
+        assert np.array_equal(np.asarray(src), np.asarray(ref[1]))
+    # other ranks sweep other sources of the same map
+    occ1, src1, _ = bench.make_workload("c3", 1, 0)
+    assert np.array_equal(occ1, maps.config_c3(1)[0]) and not np.array_equal(np.asarray(src1), np.asarray(maps.config_c3(256)[1]))
