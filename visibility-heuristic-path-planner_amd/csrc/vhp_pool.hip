@@ -132,7 +132,11 @@ struct PoolShape { int n_ctx; size_t lds; };
 // large (a 4096^2 octant is 67 MB, 64 strips) keep every wavefront busy by themselves and only lose to a neighbour.
 PoolShape pool_shape(int nx, int ny, int force_ctx) {
   PoolShape s;
-  s.n_ctx = force_ctx > 0 ? force_ctx : ((nx > ny ? nx : ny) > 2048 ? 1 : 3);
+  // Round 4 (non-temporal stores, strips claimed ahead; 128 sources, 1 / 2 / 3 contexts, ms): 1280^2 0.617 / 0.538 / 0.561; 1536^2 0.771 /
+  // 0.741 / 0.772; 1792^2 0.933 / 0.956 / 1.005; 2048^2 1.106 / 1.189 / 1.233; 3072^2 (64 sources) 1.463 / 1.569 / 1.659; 4096^2 3.46 / 4.18 /
+  // 4.35; 1024^2 (256 sources) - / 0.624 / 0.608: three up to 1024, two up to 1664, one above.
+  const int maxdim = nx > ny ? nx : ny;
+  s.n_ctx = force_ctx > 0 ? force_ctx : (maxdim > 1664 ? 1 : maxdim > 1024 ? 2 : 3);
   if (s.n_ctx > 16) s.n_ctx = 16;
   for (;; --s.n_ctx) {
     s.lds = (size_t)pool::make_layout(pool::kWaves, s.n_ctx, nx, ny).total * 8;
