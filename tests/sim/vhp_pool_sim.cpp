@@ -89,13 +89,13 @@ void trampoline() {
   swapcontext(&g_cur->ctx, &g_sched);
 }
 
-template <typename OutT>
-void worker_entry(void* p) { static_cast<Worker<OutT>*>(p)->run(); }
+template <typename OutT, bool ANYW>
+void worker_entry(void* p) { static_cast<Worker<OutT, ANYW>*>(p)->run(); }
 
 // policy & 7: 0 round robin, 1 backward, 2 random wavefront, 3 greedy (the same wavefront again while it gets things done),
 // 4 random with bursts;  policy & 8: sim points always switch;  policy & 16: sim points switch at random
-template <typename OutT>
-int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int C, int G, int policy,
+template <typename OutT, bool ANYW>
+int run_batch_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int C, int G, int policy,
               uint32_t seed, long long* stats) {
   HostMap h;
   build_map(occ, nx, ny, h);
@@ -150,16 +150,16 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   a.busy_cap = (policy & 64) ? 2 : W;   // policy & 64: a tight cap on the wavefronts that may sweep while units are installed
 
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
-  std::vector<Worker<OutT>> workers((size_t)G * W);
+  std::vector<Worker<OutT, ANYW>> workers((size_t)G * W);
   std::vector<Coro> coros((size_t)G * W);
   for (int gI = 0; gI < G; ++gI) {
-    Worker<OutT>::clear(lds[gI].data(), L, 0, 1);
+    Worker<OutT, ANYW>::clear(lds[gI].data(), L, 0, 1);
     for (int w = 0; w < W; ++w) {
-      Worker<OutT>& wk = workers[(size_t)gI * W + w];
+      Worker<OutT, ANYW>& wk = workers[(size_t)gI * W + w];
       wk.init(a, lds[gI].data(), L, w);
       Coro& c = coros[(size_t)gI * W + w];
       c.stack.reset(new char[kStack]);
-      c.entry = worker_entry<OutT>;
+      c.entry = worker_entry<OutT, ANYW>;
       c.arg = &wk;
       getcontext(&c.ctx);
       c.ctx.uc_stack.ss_sp = c.stack.get();
@@ -225,7 +225,15 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
     stats[11] = vhp::lanes::store_stats().lines_whole;
     stats[12] = vhp::lanes::store_stats().lines_part;
   }
+  if (vhp::lanes::store_stats().misaligned) return 3;  // a pair stored off the grid of its own size
   return 0;
+}
+
+// (the ANYW build of the kernel where the launch needs it, as launch_pool_t picks it: vhp_pool.hip)
+template <typename OutT>
+int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int C, int G, int policy, uint32_t seed, long long* stats) {
+  return pool_needs_anyw<OutT>(nx, (long long)nx * ny, out) ? run_batch_t<OutT, true>(occ, nx, ny, src, n_src, out, W, C, G, policy, seed, stats)
+                                                            : run_batch_t<OutT, false>(occ, nx, ny, src, n_src, out, W, C, G, policy, seed, stats);
 }
 
 // ---- the latency sweep (csrc/vhp_lat.hpp): one workgroup of W wavefronts per unit, strips bound to wavefronts ---------------
@@ -332,6 +340,7 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
     stats[6] = vhp::lanes::sim_counts().c[4];  // strips that died (stopped sweeping: all zeros from there on)
     for (int k = 0; k < 4; ++k) stats[7 + k] = vhp::lanes::sim_counts().c[k];
   }
+  if (vhp::lanes::store_stats().misaligned) return 3;  // a pair stored off the grid of its own size
   return 0;
 }
 
@@ -359,7 +368,7 @@ int vhp_sim_lat_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, in
 // coroutine switches, progress events, deadlock (0/1), 16-byte / 8-byte store instructions, the error flag, units pulled.
 int vhp_sim_pool_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W, int C, int G,
                        int policy, unsigned seed, long long* stats) {
-  if (!occ || !src || !out || nx <= 0 || ny <= 0 || (nx & 7) != 0 || W < 1 || W > 16 || C < 1 || C > 16 || G < 1) return 1;
+  if (!occ || !src || !out || nx <= 0 || ny <= 0 || W < 1 || W > 16 || C < 1 || C > 16 || G < 1) return 1;
   if (dtype == 0) return run_batch<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), W, C, G, policy, seed, stats);
   return run_batch<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), W, C, G, policy, seed, stats);
 }

@@ -18,8 +18,9 @@ _pool = None
 def load_pool():
     global _pool
     if _pool is None:
-        subprocess.check_call(["make", "-s", "-C", SIM_DIR, "libvhp_pool_sim.so"])
-        lib = C.CDLL(os.path.join(SIM_DIR, "libvhp_pool_sim.so"))
+        name = os.environ.get("VHP_SIM_LIB", "libvhp_pool_sim.so")   # (libvhp_pool_sim_asan.so: the AddressSanitizer build)
+        subprocess.check_call(["make", "-s", "-C", SIM_DIR, name])
+        lib = C.CDLL(os.path.join(SIM_DIR, name))
         lib.vhp_sim_pool_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_uint, C.c_void_p]
         lib.vhp_sim_lat_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint,

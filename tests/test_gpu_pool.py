@@ -42,7 +42,10 @@ def _sources(occ, n, seed):
 
 
 @pytest.mark.parametrize("nx,ny", [(8, 8), (8, 1), (16, 3), (8, 200), (264, 9), (104, 77), (96, 96), (200, 163), (328, 300),
-                                   (640, 603), (72, 1100), (1104, 72), (1000, 1000), (1024, 700), (1016, 520)])
+                                   (640, 603), (72, 1100), (1104, 72), (1000, 1000), (1024, 700), (1016, 520),
+                                   # widths that are not a multiple of 8 (the ANYW build), even and odd
+                                   (1, 1), (1, 70), (3, 2), (7, 9), (12, 9), (10, 140), (101, 101), (202, 163), (333, 77), (37, 300),
+                                   (690, 402), (1101, 70), (1002, 700), (1001, 971)])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_pool_kernel_bit_exact(vhp, oracle, nx, ny, dtype):
     nb = max(3, min(40, nx * ny // 400))
@@ -65,7 +68,7 @@ def test_pool_kernel_context_counts(vhp, oracle, contexts):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%d contexts, source (%d,%d)" % (contexts, sx, sy))
 
 
-@pytest.mark.parametrize("nx,ny", [(2048, 1500), (1536, 2600), (4096, 4096), (3000, 2504), (8192, 24), (24, 8192)])
+@pytest.mark.parametrize("nx,ny", [(2048, 1500), (1536, 2600), (4096, 4096), (3000, 2504), (8192, 24), (24, 8192), (2049, 1500), (3002, 2501), (8191, 24)])
 def test_pool_kernel_large_grids(vhp, oracle, nx, ny):
     occ = maps.random_rect_map(nx, ny, 40, min(10, ny // 6 - 1, nx // 6 - 1) if min(nx, ny) < 64 else 10, max(nx // 6, 2), 1 if min(nx, ny) < 64 else 10, max(ny // 6, 2), nx + 3)
     src = _sources(occ, 2, ny)[:6]
@@ -123,3 +126,55 @@ def test_probe_stores_measures_and_validates(vhp):
         c.probe_stores(buf.data_ptr(), 1 << 20)          # too small to say anything
     with pytest.raises(vhp.VhpError):
         c.probe_stores(buf.data_ptr() + 8, buf.numel() * 8 - 8)   # not on a 128-byte line
+
+
+@pytest.mark.parametrize("kernel", [1, 3, 4])
+@pytest.mark.parametrize("nx,ny,pad", [(200, 163, 3), (200, 163, 8), (101, 77, 1), (1002, 300, 5)])
+def test_field_stride_pads_between_fields(vhp, oracle, kernel, nx, ny, pad):
+    # "field_stride": the fields of a device batch `pad` elements apart (an odd pad puts every other field off the 16-byte grid: the
+    # kernels' builds for unaligned pairs); every field bit-exact, the padding untouched
+    import torch
+    occ = maps.random_rect_map(nx, ny, 20, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx + 11 * ny)
+    src = _sources(occ, 3, nx)[:6]
+    c = vhp.Context(0)
+    c.set_map(occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_option("kernel", kernel)
+    stride = nx * ny + pad
+    c.set_option("field_stride", stride)
+    for tdt, dt in ((torch.float64, vhp.F64), (torch.float32, vhp.F32)):
+        buf = torch.full((len(src) * stride,), -7.0, dtype=tdt, device="cuda")
+        d_src = torch.from_numpy(src).cuda()
+        c.sweep_batch_device(d_src.data_ptr(), len(src), buf.data_ptr(), dtype=dt)
+        c.sync()
+        assert c.last_sweep_kernel() == kernel
+        got = buf.cpu().numpy().reshape(len(src), stride)
+        assert (got[:, nx * ny:] == -7.0).all(), "padding written"
+        for k, (sx, sy) in enumerate(src):
+            want = oracle.sweep_full(occ, int(sx), int(sy)).astype(got.dtype)
+            _assert_same(got[k, :nx * ny].reshape(ny, nx), want, "%dx%d stride +%d kernel %d, source (%d,%d)" % (nx, ny, pad, kernel, sx, sy))
+
+
+@pytest.mark.parametrize("nx,ny,n", [(1002, 700, 64), (1001, 971, 48), (690, 402, 96), (500, 500, 192)])
+def test_pool_is_the_default_for_batches_on_other_widths(vhp, oracle, nx, ny, n):
+    # the library's own choice (vhp_capi.hip use_pool_kernel) on widths that are not a multiple of 8: the pool sweep's ANYW build from
+    # these batch sizes up; every 8th field against the oracle, all of them written
+    import torch
+    occ = maps.random_rect_map(nx, ny, 40, 3, nx // 8, 3, ny // 8, nx + 5 * ny)
+    src = maps.free_sources(occ, n, 11)
+    c = vhp.Context(0)
+    c.set_map(occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
+    d_out = torch.full((n, ny, nx), float("nan"), dtype=torch.float64, device="cuda")
+    c.sweep_batch_device(d_src.data_ptr(), n, d_out.data_ptr())
+    c.sync()
+    assert c.last_sweep_kernel() == 3
+    assert not bool(torch.isnan(d_out).any())
+    for k in range(0, n, 8):
+        _assert_same(d_out[k].cpu().numpy(), oracle.sweep_full(occ, int(src[k][0]), int(src[k][1])), "%dx%d default kernel, source %d" % (nx, ny, k))
+    c.set_option("kernel", 1)   # ... and the front sweep leaves the same bytes
+    d_ref = torch.empty_like(d_out)
+    c.sweep_batch_device(d_src.data_ptr(), n, d_ref.data_ptr())
+    c.sync()
+    assert c.last_sweep_kernel() == 1 and torch.equal(d_ref, d_out)

@@ -38,7 +38,7 @@ def _kernels(asm, name):
 def test_no_flat_and_no_scratch_instructions(tmp_path, src, kernel):
     asm = _asm(src, tmp_path)
     ks = _kernels(asm, kernel)
-    want = 4 if kernel == "vhp_lat_sweep" else 2   # fp64 and fp32; the latency sweep also in its odd-pitch build
+    want = 4   # fp64 and fp32, each also in its build for the other widths (pool sweep: not a multiple of 8; latency sweep: odd)
     assert len(ks) == want, "%d instantiations of %s expected, found %r" % (want, kernel, list(ks))
     for name, body in ks.items():
         flat = re.findall(r"^\s+flat_\w+", body, re.M)

@@ -40,7 +40,9 @@ def _sources(occ, n, seed):
     return src
 
 
-SIZES = [(8, 8), (8, 1), (16, 3), (8, 200), (264, 9), (104, 77), (96, 96), (200, 163), (328, 300), (640, 603), (72, 1100), (1104, 72)]
+SIZES = [(8, 8), (8, 1), (16, 3), (8, 200), (264, 9), (104, 77), (96, 96), (200, 163), (328, 300), (640, 603), (72, 1100), (1104, 72),
+         # widths that are not a multiple of 8 (the kernel's ANYW build: 8-column windows leave as they are swept), even and odd
+         (1, 1), (1, 70), (3, 2), (7, 9), (12, 9), (10, 140), (101, 101), (202, 163), (333, 77), (37, 300), (690, 402), (1101, 70)]
 SHAPES = [  # W wavefronts, C contexts, G workgroups, policy, dtype
     (12, 4, 1, POOL_ROUND_ROBIN | POOL_POINTS_ALWAYS, np.float64),
     (12, 4, 2, POOL_RANDOM | POOL_POINTS_RANDOM, np.float64),
@@ -62,7 +64,7 @@ def test_pool_sim_small_and_ragged_grids(oracle, nx, ny):
                W=W, C=C, G=G, policy=policy, seed=nx + ny)
 
 
-@pytest.mark.parametrize("nx,ny", [(1000, 1000), (1024, 700), (1016, 520), (2048, 1500), (2176, 2200)])
+@pytest.mark.parametrize("nx,ny", [(1000, 1000), (1024, 700), (1016, 520), (2048, 1500), (2176, 2200), (1002, 700), (1001, 971), (2049, 1100)])
 def test_pool_sim_large_grids(oracle, nx, ny):
     # full-size octants: up to 34 strips of one unit, marches of up to 35 blocks
     occ = maps.random_rect_map(nx, ny, 40, 5, nx // 8, 5, ny // 8, nx * 3 + ny)
@@ -109,3 +111,43 @@ def test_pool_sim_open_grid_walls_and_a_rejected_source(oracle):
     got, st = sim_lib.pool_sweep(occ, bad, W=4, C=2)
     assert st["err"] == 1 and st["deadlock"] == 0
     assert got[0].tobytes() == oracle.sweep_full(occ, 60, 67).tobytes() and np.isnan(got[1]).all()
+
+
+_ASAN_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import maps, sim_lib
+for nx, ny in [(7, 9), (12, 9), (104, 77), (101, 101), (202, 163), (333, 77), (264, 200)]:
+    occ = maps.random_rect_map(nx, ny, max(3, min(40, nx * ny // 400)), 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 7 + ny)
+    src = np.array([(0, 0), (nx - 1, ny - 1), (nx - 1, 0), (0, ny - 1), (nx // 2, ny // 2), (1, max(ny - 2, 0))], np.int32)
+    for dtype in (np.float64, np.float32):
+        # the fields exactly as large as they are: a store one cell outside is a store outside the allocation
+        got, st = sim_lib.pool_sweep(occ, src, dtype, W=6, C=3, G=2, policy=sim_lib.POOL_RANDOM | sim_lib.POOL_POINTS_RANDOM, seed=nx)
+        assert st["deadlock"] == 0 and not np.isnan(got).any()
+        got, st = sim_lib.lat_sweep(occ, src, dtype, W=8, policy=2, seed=ny)
+        assert st["deadlock"] == 0 and not np.isnan(got).any()
+print("asan-clean")
+"""
+
+
+def test_sims_under_address_sanitizer(tmp_path):
+    # The kernels' own source under AddressSanitizer, in a child process (the sanitizer's runtime has to be loaded first): every
+    # global and LDS access of both persistent kernels inside its allocation, on widths of every residue.  GPU sanitizers are not
+    # available on the test pool; this is the CPU build's.
+    import os
+    import shutil
+    import subprocess
+    import sys
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    asan = subprocess.check_output([gxx, "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan")
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = tmp_path / "asan_child.py"
+    script.write_text(_ASAN_CHILD % dict(tests=here, root=os.path.dirname(here)))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", VHP_SIM_LIB="libvhp_pool_sim_asan.so")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "asan-clean" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

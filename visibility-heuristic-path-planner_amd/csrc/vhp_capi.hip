@@ -275,6 +275,21 @@ bool use_pool_kernel(const vhp_ctx* c, int n_src) {
   // 0.191, 384: 0.341 / 0.328; 2048^2: 32: 0.82 / 0.64, 48: 0.92 / 0.66, 64: 1.15 / 0.77, 96: 1.57 / 1.03; 4096^2: 24: 2.67 / 1.95, 48:
   // 3.43 / 2.18, 64: 4.42 / 2.42.  (Up to 32 sources the latency sweep has taken the launch before this is asked.)
   const int maxdim = std::max(c->nx, c->ny);
+  if ((c->nx & 7) != 0) {
+    // Widths that are not a multiple of 8 (the pool sweep's ANYW build: half lines from its x-major strips; the front sweep stores
+    // 8-byte cells there).  Front / pool, us: 1002x1000: 48 sources 373 / 336, 96: 621 / 384, 192: 1107 / 670; 1001x971: 48: 367 / 361,
+    // 96: 639 / 394; 690x402: 48: 152 / 172, 96: 236 / 187, 192: 395 / 204; 500^2: 96: 166 / 196, 192: 280 / 209, 512: 663 / 462;
+    // 250^2: 192: 94 / 123, 512: 220 / 259; 101^2: 512: 50 / 191.
+    if (maxdim < 400) return false;
+    if (maxdim <= 600) return n_src >= 192;
+    if (maxdim <= 768) return n_src >= 96;
+    if (maxdim <= 1100) return n_src >= 48;
+    return n_src >= 24;
+  }
+  // (later in round 4, tools/kernel_ab.py, front / pool, us: 256^2: 192 sources 72 / 113, 384: 91 / 191; 384^2: 192: 124 / 148, 384: 175 / 249;
+  // 512^2: 192: 157 / 184, 384: 284 / 315 -- the other way round by 4 % on another box --; 640^2: 96: 186 / 211, 192: 296 / 247, 384: 477 / 403;
+  // 768^2: 96: 227 / 237, 192: 397 / 329, 384: 747 / 534: the front sweep below a side of 576)
+  if (maxdim < 576) return false;
   if (maxdim <= 768) return n_src >= 192;
   if (maxdim <= 1024) return n_src >= 96;
   return n_src >= 24;

@@ -6,6 +6,8 @@
 //
 //   VHP_DIAG_NOSTORE    all the work, none of the field stores                        (every batch kernel)
 //   VHP_DIAG_PLAINSTORE the field stores of the batch kernels without the nt bit (what a launch took until round 4)
+//   VHP_DIAG_NOXSTORE   ... none of the x-major strips' (pool sweep, the build for widths that are not a multiple of 8: flush_half)
+//   VHP_DIAG_NOYSTORE   ... none of the y-major strips' (pool sweep, both builds)
 //   VHP_DIAG_NOMATH     the stencil and the ratio return an operand: the traffic without the arithmetic
 //   VHP_DIAG_NOWAIT     no strip waits for the strip below or for its seeds: the launch's stores at full speed (pool sweep)
 //   VHP_DIAG_TIMELINE   bytes swept and strips running per 10 us of a launch, per workgroup (pool sweep; tools/launch_timeline.py)
@@ -16,8 +18,7 @@
 //                       another wavefront could buy (C2: 98.8 -> 79 us)                                     (latency sweep)
 //
 // Experiments that are over were deleted together with their switches.  Round 3: FLATPOLL, MASKPUB, HEAVYSYNC, NOLOAD, YDRAIN,
-// NOREFILL, SLOTTIME, SMALLSTORE, NOSTORE_X/_Y of the front sweep, PRIO, the back-off lengths as -D values.  Round 4: NOXSTORE /
-// NOYSTORE, NOPARTIAL, DROP_XPRED / _YPRED / _XRAGGED, WHOLELINES, NOLINES, YALIGNED, NOBANDLOAD / NOBANDTASK (the seam band
+// NOREFILL, SLOTTIME, SMALLSTORE, NOSTORE_X/_Y of the front sweep, PRIO, the back-off lengths as -D values.  Round 4: NOPARTIAL, DROP_XPRED / _YPRED / _XRAGGED, WHOLELINES, NOLINES, YALIGNED, NOBANDLOAD / NOBANDTASK (the seam band
 // itself: `git show a1f0eca`), WGTIME (it went with the streaming sweep), the pool sweep's cycle accounts (POOLPROF there: one
 // s_memtime per probe slowed the launch by a third; the timeline took their place).  What they measured is in DESIGN.md
 // sections 4, 4b, 4c and 7.  The kernels' sources contain the macros below and no #if of these switches (the latency sweep's
@@ -31,6 +32,18 @@
 #else
 #define VHP_DIAG_STORE_GUARD(a, b, off)
 #define VHP_DIAG_FRONT_STORE_GUARD
+#endif
+
+// one kind of strip of the pool sweep stores nothing (wrong results): what the other kind's stores cost by themselves
+#ifdef VHP_DIAG_NOXSTORE
+#define VHP_DIAG_NOXSTORE_RETURN return;
+#else
+#define VHP_DIAG_NOXSTORE_RETURN
+#endif
+#ifdef VHP_DIAG_NOYSTORE
+#define VHP_DIAG_NOYSTORE_RETURN return;
+#else
+#define VHP_DIAG_NOYSTORE_RETURN
 #endif
 
 // the field stores of the batch kernels without the nt bit
@@ -81,5 +94,9 @@
 
 // back-off of a wavefront that waits (s_sleep units of 64 cycles): measured in round 2, 12 for a hand-off that is not
 // ready, 4 for a dependency that usually is (lesson 3)
+#ifndef VHP_BACKOFF_SLEEP
 #define VHP_BACKOFF_SLEEP 12
+#endif
+#ifndef VHP_READY_SLEEP
 #define VHP_READY_SLEEP 4
+#endif

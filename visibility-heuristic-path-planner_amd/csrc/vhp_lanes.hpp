@@ -124,7 +124,7 @@ inline void g_load2_f64(const double* base, const vi& idx, vd& a, vd& b) { for (
 // ... and, for stores into the registered output [base, base + bytes), how many 128-byte lines an instruction wrote whole and
 // how many only in part (a line that leaves in pieces costs the memory several whole ones: DESIGN.md section 7).
 struct StoreStats {
-  long long n16 = 0, n8 = 0, n4 = 0, lines_whole = 0, lines_part = 0;
+  long long n16 = 0, n8 = 0, n4 = 0, lines_whole = 0, lines_part = 0, misaligned = 0;  // misaligned: pairs off their own size's grid (must stay 0)
   const char* base = nullptr;
   size_t bytes = 0;
   // one store instruction: byte ranges [p, p + n) of its active lanes
@@ -158,6 +158,7 @@ template <typename OutT> inline void g_store2(OutT* base, const vu32& off, const
     OutT* p = reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]);
     p[0] = (OutT)a.v[l]; p[1] = (OutT)b.v[l];
     store_stats().add(p, 2 * (int)sizeof(OutT));
+    store_stats().misaligned += (reinterpret_cast<uintptr_t>(p) & (2 * sizeof(OutT) - 1)) != 0;
   }
   store_stats().n16 += 1;
   store_stats().end_instruction();
@@ -166,13 +167,16 @@ template <typename OutT> inline void g_store2_if(const vb& p2, const vb& p_lo, c
   // p2: both cells; else p_lo: only the first; else p_hi: only the second
   for (int l = 0; l < kLanes; ++l) {
     OutT* p = reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off.v[l]);
-    if (p2.v[l]) { p[0] = (OutT)a.v[l]; p[1] = (OutT)b.v[l]; store_stats().add(p, 2 * (int)sizeof(OutT)); }
+    if (p2.v[l]) { p[0] = (OutT)a.v[l]; p[1] = (OutT)b.v[l]; store_stats().add(p, 2 * (int)sizeof(OutT)); store_stats().misaligned += (reinterpret_cast<uintptr_t>(p) & (2 * sizeof(OutT) - 1)) != 0; }
     else if (p_lo.v[l]) { p[0] = (OutT)a.v[l]; store_stats().add(p, (int)sizeof(OutT)); }
     else if (p_hi.v[l]) { p[1] = (OutT)b.v[l]; store_stats().add(p + 1, (int)sizeof(OutT)); }
   }
   store_stats().n16 += 1;
   store_stats().end_instruction();
 }
+// (the device build's stores without the nt bit: the same thing here)
+template <typename OutT> inline void g_store2_plain(OutT* base, const vu32& off, const vd& a, const vd& b) { g_store2(base, off, a, b); }
+template <typename OutT> inline void g_store2_if_plain(const vb& p2, const vb& p_lo, const vb& p_hi, OutT* base, const vu32& off, const vd& a, const vd& b) { g_store2_if(p2, p_lo, p_hi, base, off, a, b); }
 // is the pair at byte offset off aligned to its own size (2 cells)?  On a grid of odd width every other row is not.
 template <typename OutT> inline vb pair_aligned(const OutT* base, const vu32& off) {
   vb r; for (int l = 0; l < kLanes; ++l) r.v[l] = ((reinterpret_cast<uintptr_t>(base) + off.v[l]) & (2 * sizeof(OutT) - 1)) == 0; return r; }
@@ -334,6 +338,19 @@ template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p
   if (p2) VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
   else if (p_lo || p_hi)
     VHP_FIELD_STORE(reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off + (p_lo ? 0u : (uint32_t)sizeof(OutT))), static_cast<OutT>(single));
+}
+// Without the nt bit, whatever the translation unit's VHP_FIELD_STORE is: for 64-byte pieces, which a wavefront's L2 merges into
+// lines when they are plain stores (3.75 TB/s against 3.07 with nt on the slow kind of memory).
+template <typename OutT> VHP_LANE_FN void g_store2_plain(OutT* base, vu32 off, vd a, vd b) {
+  VHP_DIAG_STORE_GUARD(a, b, off)
+  *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
+}
+template <typename OutT> VHP_LANE_FN void g_store2_if_plain(bool p2, bool p_lo, bool p_hi, OutT* base, vu32 off, vd a, vd b) {
+  VHP_DIAG_STORE_GUARD(a, b, off)
+  vd single = p_lo ? a : b;
+  asm volatile("" : "+v"(single));
+  if (p2) *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};
+  else if (p_lo || p_hi) *reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off + (p_lo ? 0u : (uint32_t)sizeof(OutT))) = static_cast<OutT>(single);
 }
 template <typename OutT> VHP_LANE_FN bool pair_aligned(const OutT* base, vu32 off) {
   return ((reinterpret_cast<uintptr_t>(base) + off) & (2 * sizeof(OutT) - 1)) == 0;

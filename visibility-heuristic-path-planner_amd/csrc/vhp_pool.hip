@@ -16,13 +16,13 @@ namespace pool {
 constexpr int kWaves = VHP_POOL_WAVES;
 
 
-template <typename OutT>
+template <typename OutT, bool ANYW>
 __global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, int n_ctx) {
   extern __shared__ double lds[];
   const Layout L = make_layout(kWaves, n_ctx, a.m.nx, a.m.ny);
-  Worker<OutT>::clear(lds, L, (int)threadIdx.x, 64 * kWaves);
+  Worker<OutT, ANYW>::clear(lds, L, (int)threadIdx.x, 64 * kWaves);
   __syncthreads();
-  Worker<OutT> wk;
+  Worker<OutT, ANYW> wk;
   wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
   wk.run();
 }
@@ -148,7 +148,8 @@ PoolShape pool_shape(int nx, int ny, int force_ctx) {
 template <typename OutT>
 hipError_t launch_pool_t(const BatchArgs& a) {
   using namespace pool;
-  auto k = vhp_pool_sweep<OutT>;
+  const bool anyw = pool_needs_anyw<OutT>(a.nx, a.field_stride > 0 ? a.field_stride : (long long)a.nx * a.ny, static_cast<const OutT*>(a.d_out));
+  auto k = anyw ? vhp_pool_sweep<OutT, true> : vhp_pool_sweep<OutT, false>;
   const PoolShape sh = pool_shape(a.nx, a.ny, a.pool_contexts);
   if (sh.lds > kLdsLimit || a.pool_epoch == 0) return hipErrorInvalidValue;
   if (a.raise_lds) {
@@ -198,7 +199,7 @@ size_t pool_scratch_bytes(int n_src, int nx, int ny) {
 }
 
 bool pool_supported(int nx, int ny) {
-  if (nx <= 0 || ny <= 0 || (nx & 7) != 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return false;
+  if (nx <= 0 || ny <= 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return false;
   return pool_shape(nx, ny, 0).lds <= kLdsLimit;
 }
 

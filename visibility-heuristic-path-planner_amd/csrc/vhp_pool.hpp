@@ -268,7 +268,8 @@ struct Link {
 // x-major strip p of a unit: rows j = 64p + lane; steps i = 64p .. ni-1; cells (i, j), j <= i.  The step code is the
 // streaming sweep's, round 2; the tile has two windows and the wavefront flushes it itself.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DX, int DY, typename OutT>
+// ANYW: the build for widths that are not a multiple of 8 (flush_half below); the build for the others contains none of it
+template <int DX, int DY, typename OutT, bool ANYW>
 struct XStrip {
   static constexpr int CB = sizeof(OutT);
   Map m;
@@ -277,7 +278,9 @@ struct XStrip {
   double* tile;
   double* slab;   // reciprocals of the current block's 64 steps, indexed by x & 63
   double* dummy;  // where the lanes that are not the boundary lane "write" theirs
-  int r_stride;   // 2: the row pitch is an odd multiple of 64 bytes, odd and even rows are half a line apart; else 1
+  int r_stride;   // 2: the row pitch is an odd multiple of 64 bytes, odd and even rows are half a line apart; 1: every row starts on a line
+  int nxm, cell0; // ANYW: nx mod 16 and the index of the field's first cell in memory mod 16
+  vi phi;         // ANYW: the phase of the lane's row: (index of its first cell in memory) mod 16
   int p, j0, rows_here;
   bool has_consumer;
   Link<DX> lk;        // the boundary lines: strip p-1's (read) and mine (written)
@@ -298,6 +301,8 @@ struct XStrip {
     bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * 8;
     r_stride = ((m.nx >> 3) & 1) ? 2 : 1;
+    nxm = m.nx & 15;
+    cell0 = (int)((reinterpret_cast<uintptr_t>(out) / CB) & 15);
     lane = lane_id();
     tile_l = lane * kTStride;
     {
@@ -316,7 +321,11 @@ struct XStrip {
     prev = vd(0.0);
     jd = to_f64(lane + j0);
     pf_blk = -1;
+    phi = ANYW ? (((lane + j0) * DY + g.sy) * nxm + cell0) & 15 : vi(0);
   }
+
+  // the tile slot of column x of the lane's row
+  VHP_FN vi slot_of(int x) const { return ANYW ? tile_l + ((phi + x) & 15) : tile_l + (x & 15); }
 
   // Emits one line of the rows r = r_first, r_first + r_stride, ... of this strip from the tile, 8 rows per store instruction.
   // (PRED: only the cells with step index j <= i' <= i_now.)
@@ -369,12 +378,54 @@ struct XStrip {
     wave_sync();
   }
 
+  // ANYW build (a width that is not a multiple of 8: a row starts anywhere in a line, and each row somewhere else).  The tile ring
+  // of a row is shifted by the row's phase -- column x sits in slot (x + phi) & 15, phi = the row's first cell's index in memory
+  // mod 16 -- so that a slot IS the cell's place in its 128-byte line (64-byte line of fp32 cells).  Every window of 8 steps then
+  // completes exactly one half line of every row (8 cells, aligned, up to 7 columns behind the window), and that is what leaves:
+  // 16 rows x 64 aligned bytes per store instruction.  Pairs of cells are aligned whatever the width's parity.  Plain stores: the
+  // two halves of a line leave a window apart and merge in the wavefront's L2.
+  // xref: a column of the half that leaves, of every row (the window's first-marched... its lowest marching up, highest marching down).
+  template <bool PRED>
+  VHP_FN void flush_half(int xref, int i_now, int i_extra = 0) {
+    VHP_DIAG_NOXSTORE_RETURN
+    wave_sync();
+    const vi rslot = lane >> 2, pc2 = (lane & 3) * 2;
+    OutT* base = out - 16;  // (offsets from 16 cells before the field: a half line may begin before row 0's first cell)
+    for (int u = 0; 16 * u < rows_here; ++u) {
+      const vi r = rslot + 16 * u;
+      const vb row_ok = r < rows_here;
+      const vi y = (r + j0) * DY + g.sy;
+      const vi t = (y * nxm + (cell0 + xref)) & 15;   // slot of column xref in row r
+      const vi xc = (xref + pc2) - (t & 7);           // x of the pair's first cell
+      const vi tix = select(row_ok, r * kTStride + (t & 8) + pc2, vi(0));
+      const vd a = lds_load(tile, tix);
+      const vd b = lds_load(tile, tix + 1);
+      const vu32 off = to_u32((y * m.nx + xc + 16) * CB);
+      if (!PRED) {
+        g_store2_plain(base, off, a, b);
+      } else {
+        const vi jr = r + j0;
+        const vi i0c = (xc - g.sx) * DX, i1c = (xc + 1 - g.sx) * DX;
+        const vb ok0 = row_ok && (i0c >= jr) && (i0c <= i_now + i_extra);
+        const vb ok1 = row_ok && (i1c >= jr) && (i1c <= i_now + i_extra);
+        g_store2_if_plain(ok0 && ok1, ok0, ok1, base, off, a, b);
+      }
+    }
+    wave_sync();
+  }
+
   // After the step at x_b, which ends an 8-cell window of x: the rows whose 128-byte line this completes leave.
   // (y*nx + x) % 16 == 0 marks a line start; with nx = 8*m that is x % 16 == 8 * ((y*m) & 1).
   VHP_FN void flush_completed(int x_b, int i_now) {
     const int edge = DX > 0 ? x_b + 1 : x_b;
     const int hbit = (edge >> 3) & 1;
     const int xa = DX > 0 ? x_b - 15 : x_b;
+    if (ANYW) {
+      const int xref = DX > 0 ? x_b - 7 : x_b + 7;  // the window's first-marched column
+      // (steady: the first-marched cell of every row's half line is past the row's diagonal, and every row of the strip exists)
+      if (i_now - 14 >= j0 + kXRows - 1 && rows_here == kXRows) flush_half<false>(xref, i_now); else flush_half<true>(xref, i_now);
+      return;
+    }
     const bool steady = i_now - 15 >= j0 + kXRows - 1;  // the line's first-marched cell is past every row's diagonal
     int r_first = 0;
     if (r_stride == 1) {
@@ -394,10 +445,15 @@ struct XStrip {
     const int extra = DX < 0 ? 1 : 0;
     if (DX < 0) {
       wave_sync();
-      lds_store(tile, tile_l, vd(0.0));  // x = 0: slot 0, column 0 of every row's ring
+      lds_store(tile, slot_of(0), vd(0.0));  // x = 0: slot 0, column 0 of every row's ring
       wave_sync();
     }
-    if (r_stride == 1) {
+    if (ANYW) {
+      // every row: what is left of the half line the march's last window would have completed, and the beginning of the next one
+      const int xw = xe & ~7;
+      flush_half<true>(DX > 0 ? xw : xw + 7, i_now, extra);
+      flush_half<true>(DX > 0 ? xw + 8 : xw - 1, i_now, extra);
+    } else if (r_stride == 1) {
       flush<true>(xe & ~15, 0, i_now, extra);
     } else {
       for (int ph = 0; ph < 2; ++ph) {  // rows whose lines start at x % 16 == 8*ph
@@ -426,7 +482,7 @@ struct XStrip {
       v = select(isd, dcell, v);
     }
     prev = v;
-    lds_store(tile, tile_l + (((x >> 3) & 1) * 8 + (x & 7)), v);
+    lds_store(tile, slot_of(x), v);
     if (has_consumer) lds_store_if(lane == 63, lk.ring, vi(x & (kRing - 1)), v);
   }
 
@@ -452,6 +508,7 @@ struct XStrip {
     }
     const vu32 hs = half_shifted(ow, t0, DX > 0 ? (t0 & 31) : (t0 & 31) - 7);  // step k's bit at position (x & 7)
     const vi tidx = tile_l + ((xw >> 3) & 1) * 8;
+    const vi pw = phi + (xw & 15);  // (ANYW: the slot of the window's lowest column, before the wrap)
     // every lane writes "its boundary value" each step -- lane 63 into the block's out slab, the others into a dummy
     // slot: one ds_write instead of an exec-masked region per step
     double* wbase = has_consumer ? lk.ring + (xw & (kRing - 1)) : dummy;
@@ -470,7 +527,7 @@ struct XStrip {
         v = select(isd, dcell, v);
       }
       prev = v;
-      lds_store(tile, tidx + col, v);
+      if (ANYW) lds_store(tile, tile_l + ((pw + col) & 15), v); else lds_store(tile, tidx + col, v);
       lds_store(wbase, widx + col, v);
       di = di + 1.0;
     }
@@ -530,7 +587,7 @@ struct XStrip {
 // (the diagonal cell is the seed diag(j), stored again with its neighbour).  the streaming sweep's step code (round 2); the seeds of the
 // lane's two columns wait in registers.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DX, int DY, typename OutT>
+template <int DX, int DY, typename OutT, bool ANYW>
 struct YStrip {
   static constexpr int CB = sizeof(OutT);
   Map m;
@@ -539,7 +596,7 @@ struct YStrip {
   double* slab;   // reciprocals of the current block's 64 steps, indexed by y & 63
   double* dummy;
   int q, i0, jstart;
-  bool has_consumer, interior;
+  bool has_consumer, interior, odd_pitch;
   Link<DY> lk;        // the boundary lines, along y
   double* bin;        // = lk.bin
   vi lane, ia, ib;
@@ -550,6 +607,7 @@ struct YStrip {
   // (the caller has initialised lk)
   VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const double* diag) {
     m = m_; out = out_;
+    odd_pitch = ANYW && ((m.nx & 1) != 0 || (reinterpret_cast<uintptr_t>(out) & (2 * CB - 1)) != 0);
     g.init(m.nx, m.ny, sx, sy);
     slab = sh.lds + sh.L.slabs + w * kBlock;
     bin = lk.bin;
@@ -575,20 +633,41 @@ struct YStrip {
     xoff = to_u32(xlo * CB);
   }
 
-  // stores the lane's two cells of row y (step j): predicated on the cells being columns of the grid at or below the diagonal
-  VHP_FN void store_pred(OutT* row, int j, vd v0, vd v1) {
-    vb ok0 = (ia >= 0) && (ia < g.ni) && (ia <= j);
-    vb ok1 = (ib >= 0) && (ib < g.ni) && (ib <= j);
-    if (DX < 0) {
-      // Column 0 is never swept (the march stops at x = 1) and reads as zero.  Whoever stores x = 1 stores
-      // that zero with it: one 16-byte store instead of an 8-byte one here and another somewhere else, some other time.
-      const vb col0 = (ib == g.ni) && ok0;
-      v1 = select(col0, vd(0.0), v1);
-      ok1 = ok1 || col0;
-    }
-    if (DX > 0) g_store2_if(ok0 && ok1, ok0, ok1, row, xoff, v0, v1);
-    else g_store2_if(ok0 && ok1, ok1, ok0, row, xoff, v1, v0);
+  // is column c a column of the grid at or below the diagonal at step j?
+  VHP_FN vb col_ok(const vi& c, int j) const { return (c >= 0) && (c < g.ni) && (c <= j); }
+  // ... the lower-x cell of the pair of columns (ca, ca + 1)?  Marching down that is column ca + 1 -- or x = 0, which is never swept
+  // (the march stops at x = 1) and reads as zero: whoever stores x = 1 stores that zero with it.
+  VHP_FN vb lo_ok(const vi& ca, int j) const {
+    if (DX > 0) return col_ok(ca, j);
+    return col_ok(ca + 1, j) || ((ca + 1 == g.ni) && col_ok(ca, j));
   }
+
+  // stores the lane's two cells of row y (step j).  PRED: only the cells that are columns of the grid at or below the diagonal
+  template <bool PRED>
+  VHP_FN void store_row(OutT* row, int j, vd v0, vd v1) {
+    VHP_DIAG_NOYSTORE_RETURN
+    if (DX < 0 && PRED) v1 = select((ib == g.ni), vd(0.0), v1);  // x = 0
+    const vd lo = DX > 0 ? v0 : v1, hi = DX > 0 ? v1 : v0;        // in memory order
+    vb oklo = vb(true), okhi = vb(true);
+    if (PRED) { oklo = lo_ok(ia, j); okhi = col_ok(DX > 0 ? ib : ia, j); }
+    if (ANYW && odd_pitch && !row_aligned(row)) {
+      // An odd width: in every other row the pairs of the lanes are off the 16-byte grid, and the pairs that are on it are a
+      // lane's higher cell with the next lane's lower one.  That is what leaves; the strip's first cell in memory goes alone.
+      const vd nb = DX > 0 ? shift_down(lo, vd(0.0)) : shift_up(lo, vd(0.0));
+      const vi nlane = DX > 0 ? lane + 1 : lane - 1;
+      vb oknb = (nlane >= 0) && (nlane < 64);
+      if (PRED) oknb = oknb && lo_ok(DX > 0 ? ia + 2 : ia - 2, j);
+      // (offsets from two cells before the row: marching down, the lane past x = 1 stores the x = 0 of its neighbour, and its own
+      // xoff is "negative" -- the 32-bit sum wraps back)
+      g_store2_if(okhi && oknb, okhi, oknb, row - 2, xoff + (uint32_t)(3 * CB), hi, nb);
+      g_store1_if((lane == (DX > 0 ? 0 : 63)) && oklo, row, xoff, lo);
+      return;
+    }
+    if (PRED) g_store2_if(oklo && okhi, oklo, okhi, row, xoff, lo, hi);
+    else g_store2(row, xoff, lo, hi);
+  }
+  // (a strip's pairs start on an even x: a row is aligned or not as a whole)
+  VHP_FN bool row_aligned(const OutT* row) const { return (reinterpret_cast<uintptr_t>(row) & (2 * CB - 1)) == 0; }
   VHP_FN OutT* row_ptr(int y) const { return out + (size_t)y * (size_t)m.nx; }
 
   VHP_FN void step1(int j) {
@@ -605,7 +684,7 @@ struct YStrip {
       v0 = select(ia == j, dg0, v0);
       v1 = select(ib == j, dg1, v1);
     }
-    store_pred(row_ptr(y), j, v0, v1);
+    store_row<true>(row_ptr(y), j, v0, v1);
     prev0 = v0;
     prev1 = v1;
     if (has_consumer) lds_store_if(lane == 63, lk.ring, vi(y & (kRing - 1)), v1);
@@ -646,9 +725,7 @@ struct YStrip {
         v0 = select(ia == j0w + k, dg0, v0);
         v1 = select(ib == j0w + k, dg1, v1);
       }
-      if (PRED) store_pred(row, j0w + k, v0, v1);
-      else if (DX > 0) g_store2(row, xoff, v0, v1);
-      else g_store2(row, xoff, v1, v0);
+      store_row<PRED>(row, j0w + k, v0, v1);
       prev0 = v0;
       prev1 = v1;
       lds_store(wbase, widx + bit, v1);
@@ -762,7 +839,14 @@ struct DiagTask {
 enum { kFound = 0, kRetry = 1, kIdle = 2, kExit = 3 };
 
 
+// the launch needs the ANYW build of the kernel: rows that do not start on a 64-byte half line (a width that is not a multiple of 8),
+// or fields whose pairs of cells are not aligned to their size
 template <typename OutT>
+VHP_HD bool pool_needs_anyw(int nx, long long field_stride, const OutT* out) {
+  return (nx & 7) != 0 || (field_stride & 1) != 0 || (reinterpret_cast<uintptr_t>(out) & (2 * sizeof(OutT) - 1)) != 0;
+}
+
+template <typename OutT, bool ANYW = false>
 struct Worker {
   Args<OutT> a;
   Shared sh;
@@ -933,7 +1017,7 @@ struct Worker {
 
   template <int DX, int DY>
   VHP_FN void run_x(int c, int unit, int p, int sx, int sy, OutT* field) {
-    XStrip<DX, DY, OutT> xs;
+    XStrip<DX, DY, OutT, ANYW> xs;
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* mine = sh.prog(c) + p;
@@ -954,7 +1038,7 @@ struct Worker {
 
   template <int DX, int DY>
   VHP_FN void run_y(int c, int unit, int q, int sx, int sy, OutT* field, const double* dline) {
-    YStrip<DX, DY, OutT> ys;
+    YStrip<DX, DY, OutT, ANYW> ys;
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* mine = sh.prog(c) + q;
