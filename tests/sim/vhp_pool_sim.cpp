@@ -99,7 +99,7 @@ int run_batch_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_sr
               uint32_t seed, long long* stats) {
   HostMap h;
   build_map(occ, nx, ny, h);
-  const Layout L = make_layout(W, C, nx, ny);
+  const Layout L = make_layout(W, C, nx, ny, ANYW ? kTStrideAny : kTStride);
   const int n_units = n_src * kUnits;
   // launch order: by cell count, largest first, as vhp_pool_order does (policy & 32: shuffled instead -- the result must not depend on it)
   std::vector<int> order(n_units), line_base(n_units, 0);

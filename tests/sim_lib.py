@@ -34,17 +34,22 @@ POOL_ROUND_ROBIN, POOL_BACKWARD, POOL_RANDOM, POOL_GREEDY, POOL_BURSTS = 0, 1, 2
 POOL_POINTS_ALWAYS, POOL_POINTS_RANDOM, POOL_SHUFFLED_QUEUE, POOL_TIGHT_BUSY_CAP = 8, 16, 32, 64
 
 
-def pool_sweep(occ, sources, dtype=np.float64, W=12, C=4, G=1, policy=0, seed=1):
-    """Fields [n, ny, nx] of the simulated pool kernel (csrc/vhp_pool.hpp; pre-filled with NaN) and the stats dict."""
+def pool_sweep(occ, sources, dtype=np.float64, W=12, C=4, G=1, policy=0, seed=1, out_offset=0):
+    """Fields [n, ny, nx] of the simulated pool kernel (csrc/vhp_pool.hpp; pre-filled with NaN) and the stats dict.
+    out_offset: the fields start that many cells into a 128-byte aligned buffer (off the line grid, or off the 16-byte grid)."""
     lib = load_pool()
     occ = np.ascontiguousarray(occ, np.uint8)
     ny, nx = occ.shape
     src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
-    out = np.full((len(src), ny, nx), np.nan, dtype)
+    item = np.dtype(dtype).itemsize
+    raw = np.full(len(src) * ny * nx + out_offset + 128 // item + 32, np.nan, dtype)
+    lead = (-raw.ctypes.data % 128) // item + out_offset
+    out = raw[lead: lead + len(src) * ny * nx].reshape(len(src), ny, nx)
     stats = np.zeros(13, np.int64)
     rc = lib.vhp_sim_pool_sweep(occ.ctypes.data, nx, ny, src.ctypes.data, len(src), 0 if dtype == np.float64 else 1, out.ctypes.data,
                                 W, C, G, policy, seed, stats.ctypes.data)
     assert rc == 0, rc
+    assert np.isnan(raw[:lead]).all() and np.isnan(raw[lead + out.size:]).all(), "a store outside the fields"
     return out, dict(switches=int(stats[0]), progress=int(stats[1]), deadlock=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]),
                      err=int(stats[5]), pulled=int(stats[6]), from_ring=int(stats[7]), from_global=int(stats[8]), too_far=int(stats[9]),
                      overwritten=int(stats[10]), lines_whole=int(stats[11]), lines_part=int(stats[12]))

@@ -129,7 +129,7 @@ def test_probe_stores_measures_and_validates(vhp):
 
 
 @pytest.mark.parametrize("kernel", [1, 3, 4])
-@pytest.mark.parametrize("nx,ny,pad", [(200, 163, 3), (200, 163, 8), (101, 77, 1), (1002, 300, 5)])
+@pytest.mark.parametrize("nx,ny,pad", [(200, 163, 3), (200, 163, 8), (101, 77, 1), (1002, 300, 5), (208, 90, 1), (1008, 120, 6)])
 def test_field_stride_pads_between_fields(vhp, oracle, kernel, nx, ny, pad):
     # "field_stride": the fields of a device batch `pad` elements apart (an odd pad puts every other field off the 16-byte grid: the
     # kernels' builds for unaligned pairs); every field bit-exact, the padding untouched

@@ -64,6 +64,21 @@ def test_pool_sim_small_and_ragged_grids(oracle, nx, ny):
                W=W, C=C, G=G, policy=policy, seed=nx + ny)
 
 
+@pytest.mark.parametrize("nx,ny", [(208, 77), (104, 90), (200, 163), (101, 50), (64, 64)])
+@pytest.mark.parametrize("offset", [1, 2, 5, 8, 15])
+def test_pool_sim_fields_off_the_line_grid(oracle, nx, ny, offset):
+    # the fields begin `offset` cells into a line: the ANYW build of the kernel also on widths that are a multiple of 8 or 16 (every
+    # row at the same place in its line: one set of rows, or two), pairs off the 16-byte grid for odd offsets; nothing outside the fields
+    occ = maps.random_rect_map(nx, ny, 12, 1, max(nx // 8, 2), 1, max(ny // 8, 2), nx * 3 + ny + offset)
+    src = _sources(occ, 3, nx + offset)
+    for dtype in (np.float64, np.float32):
+        got, st = sim_lib.pool_sweep(occ, src, dtype, W=9, C=3, G=2, policy=POOL_RANDOM | POOL_POINTS_RANDOM, seed=offset, out_offset=offset)
+        assert st["deadlock"] == 0 and st["err"] == 0
+        for k, (sx, sy) in enumerate(src):
+            want = oracle.sweep_full(occ, int(sx), int(sy)).astype(dtype)
+            assert got[k].tobytes() == want.tobytes(), "%dx%d offset %d %s source (%d,%d)" % (nx, ny, offset, dtype.__name__, sx, sy)
+
+
 @pytest.mark.parametrize("nx,ny", [(1000, 1000), (1024, 700), (1016, 520), (2048, 1500), (2176, 2200), (1002, 700), (1001, 971), (2049, 1100)])
 def test_pool_sim_large_grids(oracle, nx, ny):
     # full-size octants: up to 34 strips of one unit, marches of up to 35 blocks

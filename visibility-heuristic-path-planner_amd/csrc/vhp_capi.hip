@@ -276,11 +276,13 @@ bool use_pool_kernel(const vhp_ctx* c, int n_src) {
   // 3.43 / 2.18, 64: 4.42 / 2.42.  (Up to 32 sources the latency sweep has taken the launch before this is asked.)
   const int maxdim = std::max(c->nx, c->ny);
   if ((c->nx & 7) != 0) {
-    // Widths that are not a multiple of 8 (the pool sweep's ANYW build: half lines from its x-major strips; the front sweep stores
+    // Widths that are not a multiple of 8 (the pool sweep's ANYW build; the front sweep stores
     // 8-byte cells there).  Front / pool, us: 1002x1000: 48 sources 373 / 336, 96: 621 / 384, 192: 1107 / 670; 1001x971: 48: 367 / 361,
     // 96: 639 / 394; 690x402: 48: 152 / 172, 96: 236 / 187, 192: 395 / 204; 500^2: 96: 166 / 196, 192: 280 / 209, 512: 663 / 462;
     // 250^2: 192: 94 / 123, 512: 220 / 259; 101^2: 512: 50 / 191.
-    if (maxdim < 400) return false;
+    // (with the whole-line build: 1002x1000: 32: 309 / 329, 48: 365 / 320, 96: 621 / 394, 192: 1116 / 604; 690x402: 48: 152 / 189, 96: 240 / 195;
+    // 500^2: 96: 167 / 185, 192: 285 / 208; 398^2: 96: 132 / 150, 192: 213 / 174)
+    if (maxdim < 384) return false;
     if (maxdim <= 600) return n_src >= 192;
     if (maxdim <= 768) return n_src >= 96;
     if (maxdim <= 1100) return n_src >= 48;

@@ -6,7 +6,7 @@
 //
 //   VHP_DIAG_NOSTORE    all the work, none of the field stores                        (every batch kernel)
 //   VHP_DIAG_PLAINSTORE the field stores of the batch kernels without the nt bit (what a launch took until round 4)
-//   VHP_DIAG_NOXSTORE   ... none of the x-major strips' (pool sweep, the build for widths that are not a multiple of 8: flush_half)
+//   VHP_DIAG_NOXSTORE   ... none of the x-major strips' (pool sweep, both builds)
 //   VHP_DIAG_NOYSTORE   ... none of the y-major strips' (pool sweep, both builds)
 //   VHP_DIAG_NOMATH     the stencil and the ratio return an operand: the traffic without the arithmetic
 //   VHP_DIAG_NOWAIT     no strip waits for the strip below or for its seeds: the launch's stores at full speed (pool sweep)

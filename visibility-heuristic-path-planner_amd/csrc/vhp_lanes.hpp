@@ -372,6 +372,7 @@ VHP_LANE_FN void wave_sync() {
 // the first real use (where the s_waitcnt vmcnt would also drain every store issued in between).
 VHP_LANE_FN void pin(double& v) { asm volatile("" : "+v"(v)); }
 VHP_LANE_FN void pin(uint64_t& v) { asm volatile("" : "+v"(v)); }
+VHP_LANE_FN void pin(int& v) { asm volatile("" : "+v"(v)); }  // (... and nothing derived from it is computed ahead of this point and kept)
 VHP_LANE_FN int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 typedef __attribute__((address_space(3))) int lds_int;
 // Release of LDS data to the other wavefronts of the workgroup: the progress word is an LDS write issued after the data's

@@ -14,13 +14,19 @@ namespace pool {
 #define VHP_POOL_WAVES 12
 #endif
 constexpr int kWaves = VHP_POOL_WAVES;
+// the build for widths that are not a multiple of 8: its tiles are three windows (12.8 KB a wavefront), nine wavefronts fit the LDS
+#ifndef VHP_POOL_WAVES_ANYW
+#define VHP_POOL_WAVES_ANYW 9
+#endif
+constexpr int kWavesAny = VHP_POOL_WAVES_ANYW;
 
 
 template <typename OutT, bool ANYW>
 __global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, int n_ctx) {
   extern __shared__ double lds[];
-  const Layout L = make_layout(kWaves, n_ctx, a.m.nx, a.m.ny);
-  Worker<OutT, ANYW>::clear(lds, L, (int)threadIdx.x, 64 * kWaves);
+  constexpr int W = ANYW ? kWavesAny : kWaves;
+  const Layout L = make_layout(W, n_ctx, a.m.nx, a.m.ny, ANYW ? kTStrideAny : kTStride);
+  Worker<OutT, ANYW>::clear(lds, L, (int)threadIdx.x, 64 * W);
   __syncthreads();
   Worker<OutT, ANYW> wk;
   wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
@@ -130,7 +136,7 @@ struct PoolShape { int n_ctx; size_t lds; };
 // Measured (tools/ab_libs.py on one buffer, final launch order): 256 sources at 1000^2, 2 / 3 / 4 / 5 contexts 0.69 / 0.67-0.70 /
 // 0.74 / 0.77 ms; 128 sources at 2048^2, 1 / 2 / 3 contexts 1.25 / 1.38 / 1.41 ms; at 4096^2 1 / 2: 3.88 / 4.80 ms -- units that
 // large (a 4096^2 octant is 67 MB, 64 strips) keep every wavefront busy by themselves and only lose to a neighbour.
-PoolShape pool_shape(int nx, int ny, int force_ctx) {
+PoolShape pool_shape(int nx, int ny, int force_ctx, bool anyw) {
   PoolShape s;
   // Round 4 (non-temporal stores, strips claimed ahead; 128 sources, 1 / 2 / 3 contexts, ms): 1280^2 0.617 / 0.538 / 0.561; 1536^2 0.771 /
   // 0.741 / 0.772; 1792^2 0.933 / 0.956 / 1.005; 2048^2 1.106 / 1.189 / 1.233; 3072^2 (64 sources) 1.463 / 1.569 / 1.659; 4096^2 3.46 / 4.18 /
@@ -139,7 +145,7 @@ PoolShape pool_shape(int nx, int ny, int force_ctx) {
   s.n_ctx = force_ctx > 0 ? force_ctx : (maxdim > 1664 ? 1 : maxdim > 1024 ? 2 : 3);
   if (s.n_ctx > 16) s.n_ctx = 16;
   for (;; --s.n_ctx) {
-    s.lds = (size_t)pool::make_layout(pool::kWaves, s.n_ctx, nx, ny).total * 8;
+    s.lds = (size_t)(anyw ? pool::make_layout(pool::kWavesAny, s.n_ctx, nx, ny, pool::kTStrideAny) : pool::make_layout(pool::kWaves, s.n_ctx, nx, ny)).total * 8;
     if (s.lds <= kLdsLimit || s.n_ctx == 1) break;
   }
   return s;
@@ -150,7 +156,8 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   using namespace pool;
   const bool anyw = pool_needs_anyw<OutT>(a.nx, a.field_stride > 0 ? a.field_stride : (long long)a.nx * a.ny, static_cast<const OutT*>(a.d_out));
   auto k = anyw ? vhp_pool_sweep<OutT, true> : vhp_pool_sweep<OutT, false>;
-  const PoolShape sh = pool_shape(a.nx, a.ny, a.pool_contexts);
+  const PoolShape sh = pool_shape(a.nx, a.ny, a.pool_contexts, anyw);
+  const int waves = anyw ? kWavesAny : kWaves;
   if (sh.lds > kLdsLimit || a.pool_epoch == 0) return hipErrorInvalidValue;
   if (a.raise_lds) {
     hipError_t e = a.raise_lds(reinterpret_cast<const void*>(k), sh.lds);
@@ -174,7 +181,7 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   g.diag_stride = diag_stride_of(a.nx, a.ny);
   g.lines = reinterpret_cast<vhp::lanes::Tagged*>(scratch + head_bytes(a.n_src) + diag_bytes(a.n_src, a.nx, a.ny));
   g.epoch = a.pool_epoch;
-  g.busy_cap = a.pool_busy_cap > 0 ? a.pool_busy_cap : kWaves;
+  g.busy_cap = a.pool_busy_cap > 0 ? a.pool_busy_cap : waves;
   // two contexts take the largest units left, the others the smallest (0.75 against 0.78 ms with one head at 1000^2)
   g.n_head = a.pool_heads > 0 ? a.pool_heads : (sh.n_ctx >= 3 ? 2 : 1);  // (all three from the head: 0.51 / 0.70 ms on two boxes, this: 0.53 / 0.67)
   g.tail_limit = (int)((long long)g.n_units * (a.pool_tail_pct > 0 ? a.pool_tail_pct : 15) / 100);  // (100 / 50 / 25 / 15 %: 0.56 / 0.55 / 0.53 / - and - / - / - / 0.67 ms on two boxes; round 4, with non-temporal stores: 5 / 15 / 30 / 60 %: 0.580 / 0.608 / 0.608 / 0.616 ms on a slow buffer, level on a fast one -- within the noise of 1-2 %)
@@ -187,7 +194,7 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs
   hipLaunchKernelGGL(vhp_pool_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, order, line_base,
                      line_blocks_per_source(a.nx, a.ny) * a.n_src, reinterpret_cast<unsigned long long*>(a.d_queue), a.d_err);
-  hipLaunchKernelGGL(k, dim3((unsigned)a.n_cus), dim3(64 * kWaves), sh.lds, a.stream, g, sh.n_ctx);
+  hipLaunchKernelGGL(k, dim3((unsigned)a.n_cus), dim3(64 * waves), sh.lds, a.stream, g, sh.n_ctx);
   const hipError_t e = hipGetLastError();
   if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
   return e;
@@ -200,7 +207,7 @@ size_t pool_scratch_bytes(int n_src, int nx, int ny) {
 
 bool pool_supported(int nx, int ny) {
   if (nx <= 0 || ny <= 0 || nx > VHP_MAX_SIDE || ny > VHP_MAX_SIDE) return false;
-  return pool_shape(nx, ny, 0).lds <= kLdsLimit;
+  return pool_shape(nx, ny, 0, false).lds <= kLdsLimit && pool_shape(nx, ny, 0, true).lds <= kLdsLimit;
 }
 
 

@@ -56,6 +56,7 @@ constexpr int kBlock = geom::kBlock;
 constexpr int kXRows = geom::kXRows;
 constexpr int kYCols = geom::kYCols;
 constexpr int kTStride = 17;  // doubles per tile row: two windows of 8 columns + 1 (spreads the column writes over the banks)
+constexpr int kTStrideAny = 25;  // ... of the build for widths that are not a multiple of 8: three windows + 1 (XStrip::flush_rows)
 constexpr int kUnits = 8;     // units per source: 4 quadrants x {x-major, y-major}
 VHP_DIAG_TL_DECLARE
 
@@ -80,12 +81,12 @@ struct Layout {
   int W, C, S;
   int tiles, slabs, bins, rings, dummies, sched, ctx_stride, total;
 };
-VHP_HD Layout make_layout(int W, int C, int nx, int ny) {
+VHP_HD Layout make_layout(int W, int C, int nx, int ny, int tstride = kTStride) {
   Layout L;
   L.W = W; L.C = C;
   L.S = ((imax(nx, ny) + 63) / 64 + 2 + 3) & ~3;  // most strips a unit can have (+ slack)
   int o = 0;
-  L.tiles = o; o += W * kXRows * kTStride;
+  L.tiles = o; o += W * kXRows * tstride;
   L.slabs = o; o += W * 2 * kBlock;  // (64 per wavefront here; the latency sweep, vhp_lat.hpp, keeps two blocks per wavefront)
   L.bins = o; o += W * kBin;
   L.rings = o; o += W * kRing;
@@ -268,7 +269,7 @@ struct Link {
 // x-major strip p of a unit: rows j = 64p + lane; steps i = 64p .. ni-1; cells (i, j), j <= i.  The step code is the
 // streaming sweep's, round 2; the tile has two windows and the wavefront flushes it itself.
 // ---------------------------------------------------------------------------------------------------------------
-// ANYW: the build for widths that are not a multiple of 8 (flush_half below); the build for the others contains none of it
+// ANYW: the build for widths that are not a multiple of 8 (flush_rows below); the build for the others contains none of it
 template <int DX, int DY, typename OutT, bool ANYW>
 struct XStrip {
   static constexpr int CB = sizeof(OutT);
@@ -279,8 +280,12 @@ struct XStrip {
   double* slab;   // reciprocals of the current block's 64 steps, indexed by x & 63
   double* dummy;  // where the lanes that are not the boundary lane "write" theirs
   int r_stride;   // 2: the row pitch is an odd multiple of 64 bytes, odd and even rows are half a line apart; 1: every row starts on a line
-  int nxm, cell0; // ANYW: nx mod 16 and the index of the field's first cell in memory mod 16
-  vi phi;         // ANYW: the phase of the lane's row: (index of its first cell in memory) mod 16
+  static constexpr int kTS = ANYW ? kTStrideAny : kTStride;
+  // ANYW: nx mod 16; the index of the field's first cell in memory mod 16; rows r and r + n_phase start at the same place in a line
+  int nxm, cell0, n_phase;
+  vi rr_a[4], rr_b[4];  // ANYW: the rows whose lines a window with (x & 8) == 0 completes / the other rows: row slot (lane >> 3) of store instruction q
+  bool both_sets;       // ANYW: every row starts at the same place (a field off the line grid on a width that is a multiple of 16): ...
+  bool both_on_even;    // ... both sets leave after the same windows, those with (x & 8) == 0 or the others
   int p, j0, rows_here;
   bool has_consumer;
   Link<DX> lk;        // the boundary lines: strip p-1's (read) and mine (written)
@@ -296,15 +301,16 @@ struct XStrip {
   VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int p_) {
     m = m_; out = out_;
     g.init(m.nx, m.ny, sx, sy);
-    tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
+    tile = sh.lds + sh.L.tiles + w * kXRows * kTS;
     slab = sh.lds + sh.L.slabs + w * kBlock;
     bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * 8;
     r_stride = ((m.nx >> 3) & 1) ? 2 : 1;
     nxm = m.nx & 15;
     cell0 = (int)((reinterpret_cast<uintptr_t>(out) / CB) & 15);
+    n_phase = (nxm & 1) ? 16 : (nxm & 2) ? 8 : (nxm & 4) ? 4 : (nxm & 8) ? 2 : 1;
     lane = lane_id();
-    tile_l = lane * kTStride;
+    tile_l = lane * kTS;
     {
       // flush geometry: lane -> (row slot = lane >> 3, piece = lane & 7 = cells xa + 2*piece, +1); the row slots of a
       // store instruction are counted upward in y, so that byte offsets from its lowest row are never negative
@@ -321,16 +327,48 @@ struct XStrip {
     prev = vd(0.0);
     jd = to_f64(lane + j0);
     pf_blk = -1;
-    phi = ANYW ? (((lane + j0) * DY + g.sy) * nxm + cell0) & 15 : vi(0);
+    if (ANYW) init_sets();
   }
 
-  // the tile slot of column x of the lane's row
-  VHP_FN vi slot_of(int x) const { return ANYW ? tile_l + ((phi + x) & 15) : tile_l + (x & 15); }
+  // the place of row r's first cell in its line
+  VHP_FN int row_phase(int r) const { return (cell0 + (g.sy + DY * (j0 + r)) * nxm) & 15; }
+  // A window [xw, xw + 8) completes the line of a row iff ((psi + xw) & 15) >= 8, psi = the row's phase marching up (the line's last
+  // cell is marched last), the phase - 1 marching down (its first cell is).  The windows alternate, so the rows fall into two sets.
+  static VHP_FN int psi_of(int phase) { return DX > 0 ? phase : (phase - 1) & 15; }
+  VHP_FN void init_sets() {
+    const vi rslot = lane >> 3;
+    both_sets = n_phase == 1;
+    both_on_even = psi_of(row_phase(0)) >= 8;
+    if (both_sets) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { rr_a[q] = rslot + 8 * q; rr_b[q] = rslot + (32 + 8 * q); }
+      return;
+    }
+    // the residues mod n_phase of the rows of either set, a nibble each
+    int pack_a = 0, pack_b = 0, n_a = 0, n_b = 0;
+    for (int c = 0; c < n_phase; ++c) {
+      if (psi_of(row_phase(c)) >= 8) pack_a |= c << (4 * n_a++); else pack_b |= c << (4 * n_b++);
+    }
+    const int half = n_phase >> 1, lg = half == 8 ? 3 : half == 4 ? 2 : half == 2 ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const vi n = rslot + 8 * q;  // the n-th row of its set: residue n % half, period n / half
+      const vi sh = (n & (half - 1)) * 4;
+      const vi hi = (n >> lg) * n_phase;
+      rr_a[q] = ((vi(pack_a) >> sh) & 15) + hi;
+      rr_b[q] = ((vi(pack_b) >> sh) & 15) + hi;
+    }
+  }
+
+  // the tile slot of column x (x >= -48): a ring of two windows, of three in the ANYW build
+  static VHP_FN int ring_slot(int x) { return ANYW ? (x + 48) % 24 : (x & 15); }
+  VHP_FN vi slot_of(int x) const { return tile_l + ring_slot(x); }
 
   // Emits one line of the rows r = r_first, r_first + r_stride, ... of this strip from the tile, 8 rows per store instruction.
   // (PRED: only the cells with step index j <= i' <= i_now.)
   template <bool PRED>
   VHP_FN void flush(int xa, int r_first, int i_now, int i_extra = 0) {
+    VHP_DIAG_NOXSTORE_RETURN
     wave_sync();
     const int win = (xa >> 3) + 24;  // (xa may be -8 at the end of a march)
     const int sA = win & 1, sB = sA ^ 1;
@@ -378,40 +416,65 @@ struct XStrip {
     wave_sync();
   }
 
-  // ANYW build (a width that is not a multiple of 8: a row starts anywhere in a line, and each row somewhere else).  The tile ring
-  // of a row is shifted by the row's phase -- column x sits in slot (x + phi) & 15, phi = the row's first cell's index in memory
-  // mod 16 -- so that a slot IS the cell's place in its 128-byte line (64-byte line of fp32 cells).  Every window of 8 steps then
-  // completes exactly one half line of every row (8 cells, aligned, up to 7 columns behind the window), and that is what leaves:
-  // 16 rows x 64 aligned bytes per store instruction.  Pairs of cells are aligned whatever the width's parity.  Plain stores: the
-  // two halves of a line leave a window apart and merge in the wavefront's L2.
-  // xref: a column of the half that leaves, of every row (the window's first-marched... its lowest marching up, highest marching down).
-  template <bool PRED>
-  VHP_FN void flush_half(int xref, int i_now, int i_extra = 0) {
+  // ANYW build (a width that is not a multiple of 8, a field off the line grid): the 128-byte lines of a row (64-byte lines of fp32
+  // cells: 16 cells either way) start anywhere, and each row's somewhere else.  The tile is a ring of THREE windows: a line that a
+  // window completes is up to 7 columns behind the window's end and 16 long.  After every window the rows whose line it completed
+  // -- every other window the same half of the rows: init_sets() -- store that line whole, 8 rows x 128 bytes per store instruction
+  // like the other build, each row slot of an instruction with its own x.  A line is aligned in memory, so its pairs of cells are,
+  // whatever the width's parity.
+  // MODE 0: the line the window [xw, xw + 8) completed.  At the end of a march (xw = the window of its last step xe): MODE 1 the line
+  // the march ended in; 2 the line before that, if the march's last window completed it (nobody has flushed it); 3 marching down, the
+  // line of x = 0 if it is not the line of xe.
+  template <bool PRED, int MODE>
+  VHP_FN void flush_rows(const vi (&rr)[4], int xw, int xe, int i_now, int i_extra = 0) {
     VHP_DIAG_NOXSTORE_RETURN
-    wave_sync();
-    const vi rslot = lane >> 2, pc2 = (lane & 3) * 2;
-    OutT* base = out - 16;  // (offsets from 16 cells before the field: a half line may begin before row 0's first cell)
-    for (int u = 0; 16 * u < rows_here; ++u) {
-      const vi r = rslot + 16 * u;
-      const vb row_ok = r < rows_here;
+    const vi pc2 = (lane & 7) * 2;
+    const int sw = ring_slot(xw);
+    OutT* base = out - 32;  // (offsets from 32 cells before the field: a line may begin before row 0's first cell)
+    // (the arithmetic of a row slot is redone at every flush from the row's index alone: kept across the march for the 8 row slots
+    // of a lane it would cost 40 registers; pin() keeps the compiler from doing just that)
+    vd a[4], b[4];
+    vu32 off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      vi r = rr[q];
+      pin(r);
+      vb row_ok = r < rows_here;
       const vi y = (r + j0) * DY + g.sy;
-      const vi t = (y * nxm + (cell0 + xref)) & 15;   // slot of column xref in row r
-      const vi xc = (xref + pc2) - (t & 7);           // x of the pair's first cell
-      const vi tix = select(row_ok, r * kTStride + (t & 8) + pc2, vi(0));
-      const vd a = lds_load(tile, tix);
-      const vd b = lds_load(tile, tix + 1);
-      const vu32 off = to_u32((y * m.nx + xc + 16) * CB);
-      if (!PRED) {
-        g_store2_plain(base, off, a, b);
+      const vi ph = (y * nxm + cell0) & 15;
+      vi xa;  // x of the line's first cell
+      if (MODE == 0) {
+        xa = DX > 0 ? ((ph + (xw + 8)) & ~15) - ph - 16 : ((ph + (xw + 7)) & ~15) - ph;
       } else {
+        const vi cur = vi(xe) - ((ph + xe) & 15);
+        if (MODE == 1) xa = cur;
+        if (MODE == 2) { xa = cur - 16 * DX; row_ok = row_ok && (DX > 0 ? cur - 1 >= xw : cur + 16 <= xw + 7); }
+        if (MODE == 3) { xa = cur - 16; row_ok = row_ok && (cur > xe - 1); }
+      }
+      vi s0 = (xa - xw) + sw;  // the ring slot of xa: -32 <= xa - xw < 24
+      if (MODE != 0) { s0 = select(s0 < 0, s0 + 24, s0); s0 = select(s0 >= 24, s0 - 24, s0); }
+      if (MODE != 0 || DX > 0) s0 = select(s0 < 0, s0 + 24, s0);
+      vi sl0 = s0 + pc2;
+      sl0 = select(sl0 >= 24, sl0 - 24, sl0);
+      vi sl1 = sl0 + 1;
+      sl1 = select(sl1 >= 24, sl1 - 24, sl1);
+      const vi tix = select(row_ok, r * kTS, vi(0));
+      a[q] = lds_load(tile, tix + sl0);
+      b[q] = lds_load(tile, tix + sl1);
+      const vi xc = xa + pc2;
+      off[q] = to_u32((y * m.nx + xc + 32) * CB);
+      if (PRED) {  // (one row slot at a time: the start of a strip and the end of a march)
         const vi jr = r + j0;
         const vi i0c = (xc - g.sx) * DX, i1c = (xc + 1 - g.sx) * DX;
         const vb ok0 = row_ok && (i0c >= jr) && (i0c <= i_now + i_extra);
         const vb ok1 = row_ok && (i1c >= jr) && (i1c <= i_now + i_extra);
-        g_store2_if_plain(ok0 && ok1, ok0, ok1, base, off, a, b);
+        g_store2_if(ok0 && ok1, ok0, ok1, base, off[q], a[q], b[q]);
       }
     }
-    wave_sync();
+    if (!PRED) {  // (every row exists, every cell counts: four loads in flight, then four stores)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g_store2(base, off[q], a[q], b[q]);
+    }
   }
 
   // After the step at x_b, which ends an 8-cell window of x: the rows whose 128-byte line this completes leave.
@@ -421,9 +484,15 @@ struct XStrip {
     const int hbit = (edge >> 3) & 1;
     const int xa = DX > 0 ? x_b - 15 : x_b;
     if (ANYW) {
-      const int xref = DX > 0 ? x_b - 7 : x_b + 7;  // the window's first-marched column
-      // (steady: the first-marched cell of every row's half line is past the row's diagonal, and every row of the strip exists)
-      if (i_now - 14 >= j0 + kXRows - 1 && rows_here == kXRows) flush_half<false>(xref, i_now); else flush_half<true>(xref, i_now);
+      const int xw = x_b & ~7;  // the window [xw, xw + 8)
+      const bool even = (xw & 8) == 0;
+      if (both_sets && even != both_on_even) return;
+      // (steady: the first-marched cell of a line that ends in the window is past every row's diagonal, and every row exists)
+      const bool st = i_now - 22 >= j0 + kXRows - 1 && rows_here == kXRows;
+      wave_sync();
+      if (both_sets || even) { if (st) flush_rows<false, 0>(rr_a, xw, 0, i_now); else flush_rows<true, 0>(rr_a, xw, 0, i_now); }
+      if (both_sets || !even) { if (st) flush_rows<false, 0>(rr_b, xw, 0, i_now); else flush_rows<true, 0>(rr_b, xw, 0, i_now); }
+      wave_sync();
       return;
     }
     const bool steady = i_now - 15 >= j0 + kXRows - 1;  // the line's first-marched cell is past every row's diagonal
@@ -449,10 +518,17 @@ struct XStrip {
       wave_sync();
     }
     if (ANYW) {
-      // every row: what is left of the half line the march's last window would have completed, and the beginning of the next one
       const int xw = xe & ~7;
-      flush_half<true>(DX > 0 ? xw : xw + 7, i_now, extra);
-      flush_half<true>(DX > 0 ? xw + 8 : xw - 1, i_now, extra);
+      wave_sync();
+      flush_rows<true, 1>(rr_a, xw, xe, i_now, extra);
+      flush_rows<true, 1>(rr_b, xw, xe, i_now, extra);
+      flush_rows<true, 2>(rr_a, xw, xe, i_now, extra);
+      flush_rows<true, 2>(rr_b, xw, xe, i_now, extra);
+      if (DX < 0) {
+        flush_rows<true, 3>(rr_a, xw, xe, i_now, extra);
+        flush_rows<true, 3>(rr_b, xw, xe, i_now, extra);
+      }
+      wave_sync();
     } else if (r_stride == 1) {
       flush<true>(xe & ~15, 0, i_now, extra);
     } else {
@@ -507,8 +583,7 @@ struct XStrip {
       for (int k = 1; k < 9; ++k) rb[k] = lds_bcast(bin, xb + (DX > 0 ? k - 1 : 8 - k));
     }
     const vu32 hs = half_shifted(ow, t0, DX > 0 ? (t0 & 31) : (t0 & 31) - 7);  // step k's bit at position (x & 7)
-    const vi tidx = tile_l + ((xw >> 3) & 1) * 8;
-    const vi pw = phi + (xw & 15);  // (ANYW: the slot of the window's lowest column, before the wrap)
+    const vi tidx = tile_l + ring_slot(xw);  // (a window never straddles the ring's wrap)
     // every lane writes "its boundary value" each step -- lane 63 into the block's out slab, the others into a dummy
     // slot: one ds_write instead of an exec-masked region per step
     double* wbase = has_consumer ? lk.ring + (xw & (kRing - 1)) : dummy;
@@ -527,7 +602,7 @@ struct XStrip {
         v = select(isd, dcell, v);
       }
       prev = v;
-      if (ANYW) lds_store(tile, tile_l + ((pw + col) & 15), v); else lds_store(tile, tidx + col, v);
+      lds_store(tile, tidx + col, v);
       lds_store(wbase, widx + col, v);
       di = di + 1.0;
     }
