@@ -45,6 +45,13 @@ python3 $R/tools/lat_vs_front.py 256 512 690 1000 1536 2048 > $O/${tag}_lat_vs_f
 # odd widths (the latency sweep takes them since round 4): BASELINE config 1 is 101 wide, benchmarkSeries sweeps 971, 1001 ...
 python3 $R/tools/lat_vs_front.py 101 255 689 971 1001 2049 > $O/${tag}_lat_vs_front_odd_widths.txt 2>/dev/null
 python3 $R/tools/c1_planner_ab.py > $O/${tag}_planner_odd_widths.txt 2>/dev/null
+# widths that are not a multiple of 8 (the pool sweep's ANYW build since round 4): against the front sweep by batch size, and what
+# its two kinds of strips cost by themselves, next to a width of 1000 on the same box
+python3 $R/tools/kernel_ab.py 1,3 32,48,96,192,256 1002x1000 1001x971 690x402 500x500 398x398 250x250 > $O/${tag}_front_vs_pool_other_widths.txt 2>/dev/null
+python3 $R/tools/kernel_ab.py 1,3 96,192,384 256x256 384x384 512x512 640x640 768x768 1000x1000 > $O/${tag}_front_vs_pool_multiples_of_8.txt 2>/dev/null
+for s in 1000 1002 1004 1001; do python3 $R/tools/ab_libs.py $s 256 -@kernel=3 -@kernel=1 exp/libvhp_NOSTORE.so@kernel=3 exp/libvhp_NOX.so@kernel=3 exp/libvhp_NOY.so@kernel=3 exp/libvhp_NWNM.so@kernel=3 exp/libvhp_NWNMX.so@kernel=3 exp/libvhp_NWNMY.so@kernel=3 2>/dev/null | grep "^side"; done > $O/${tag}_ab_other_widths_store_cost_by_strip_kind.txt
+AB_DTYPE=f32 python3 $R/tools/ab_libs.py 1002 256 -@kernel=3 -@kernel=1 2>/dev/null | grep "^side" > $O/${tag}_ab_other_widths_f32.txt
+AB_DTYPE=f32 python3 $R/tools/ab_libs.py 1000 256 -@kernel=3 -@kernel=1 2>/dev/null | grep "^side" >> $O/${tag}_ab_other_widths_f32.txt
 # what the memory behind an output buffer does with whole and with split lines, plain and non-temporal stores; the map of a
 # process's allocations; the timeline of the C3 launch on a slow and on a fast buffer
 python3 $R/tools/shapebench.py 32 0 y1k,y1k_mixed,x128,x64,x128_rows2,y1k_8B,fill > $O/${tag}_shapebench_nt.txt 2>/dev/null
