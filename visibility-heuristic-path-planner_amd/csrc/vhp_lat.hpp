@@ -416,15 +416,17 @@ struct LatX {
 #endif
     if (DIAG) VHP_WP_ADDP(lk.pp, 10, tw2);
     VHP_WP_T0(tw3);
+    // The boundary values first, the window's own stores after: the strip above -- the one that is growing, the chain of the launch --
+    // is let past its gate a window's worth of store instructions earlier (C2 100.4 -> 98.0 us, 8 sources at 1000^2 178.5 -> 172.0).
+    if (has_consumer) {
+      lds_store(lk.ring, (lane & (kLW - 1)) + (xw & (kRing - 1)), bv);  // (every lane: the four lanes of an entry write the same value)
+      lk.publish(ia + k_hi + 1);
+    }
 #ifdef VHP_DIAG_NODIAGSTORE  // diagnostic builds only (WRONG results): what the stores of a strip that is growing cost its chain
     if (!DIAG)
 #endif
     store_window<DIAG>(ia, xw, lim, fa, fb);
     if (DIAG) VHP_WP_ADDP(lk.pp, 11, tw3);
-    if (has_consumer) {
-      lds_store(lk.ring, (lane & (kLW - 1)) + (xw & (kRing - 1)), bv);  // (every lane: the four lanes of an entry write the same value)
-      lk.publish(ia + k_hi + 1);
-    }
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
     if (DIAG) { VHP_WP_ADDP(lk.pp, 14, tw0); lk.pp[13] += 1; } else { VHP_WP_ADDP(lk.pp, 15, tw0); lk.pp[12] += 1; }
 #endif
