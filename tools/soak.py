@@ -1,0 +1,57 @@
+"""Soak: random grids (every residue of the width), batch sizes, dtypes and field strides; the pool sweep and the latency sweep against
+the front sweep on the same inputs, byte for byte, launch after launch.  Diagnostic only (the parity tests proper are tests/test_gpu_*).
+usage: soak.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from importlib import import_module
+mod = import_module("visibility-heuristic-path-planner_amd")
+synth = import_module("visibility-heuristic-path-planner_amd.synth")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+n_cases = n_launch = 0
+while time.time() < t_end:
+    nx = int(rng.integers(1, 1400)) if rng.random() < 0.8 else int(rng.integers(1400, 3000))
+    ny = int(rng.integers(1, 1400)) if rng.random() < 0.8 else int(rng.integers(1400, 3000))
+    n = int(rng.choice([1, 2, 7, 32, 33, 64, 100, 256]))
+    while n * nx * ny * 8 > 6e9:
+        n = max(n // 2, 1)
+    f32 = bool(rng.random() < 0.3)
+    pad = int(rng.choice([0, 0, 1, 3, 8, 16]))
+    nb = max(2, min(60, nx * ny // 300))
+    occ = synth.random_rect_map(nx, ny, nb, 1, max(nx // 6, 2), 1, max(ny // 6, 2), seed=int(rng.integers(1 << 30)))
+    src = np.stack([rng.integers(0, nx, n), rng.integers(0, ny, n)], 1).astype(np.int32)
+    c = mod.Context(0)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_map(occ)
+    stride = nx * ny + pad
+    c.set_option("field_stride", stride if pad else 0)
+    d_src = torch.from_numpy(src).cuda()
+    tdt = torch.float32 if f32 else torch.float64
+    ref = None
+    for k in (1, 3, 4):
+        if k == 4 and n > 64:
+            continue
+        c.set_option("kernel", k)
+        for rep in range(2 if k == 1 else 3):
+            buf = torch.full((n * stride,), -3.0, dtype=tdt, device="cuda")
+            try:
+                c.sweep_batch_device(d_src.data_ptr(), n, buf.data_ptr(), dtype=mod.F32 if f32 else mod.F64)
+                c.sync()
+            except mod.VhpError as e:
+                if k == 1:
+                    raise
+                print("kernel %d refused %dx%d n=%d: %s" % (k, nx, ny, n, e)); break
+            n_launch += 1
+            if c.last_sweep_kernel() != k:
+                break
+            if ref is None:
+                ref = buf
+            elif not torch.equal(ref, buf):
+                bad = (ref != buf).nonzero()
+                print("MISMATCH kernel %d rep %d: %dx%d n=%d %s pad=%d: %d cells, first at flat %d" % (k, rep, nx, ny, n, "f32" if f32 else "f64", pad, len(bad), int(bad[0])))
+                sys.exit(1)
+    n_cases += 1
+print("soak: %d cases, %d launches, all equal" % (n_cases, n_launch))
