@@ -40,9 +40,17 @@ __global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, i
 // when they are installed).  If the lines do not fit `capacity_blocks` (the launcher sizes the scratch by an upper
 // bound, so they do) nothing is swept and the error flag says so.
 constexpr int kBuckets = 1024;
-__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* wave_tot, int* total) {
+constexpr int kOrderLdsUnits = 8192;  // batches of up to 1024 sources keep the per-unit scratch of the ordering in LDS
+
+// exclusive prefix sums over arr[0..n), in place, by the 1024 threads of the workgroup (a contiguous chunk each); returns the total
+template <typename Arr>
+__device__ __forceinline__ int block_exclusive_scan_1024(Arr arr, int n, int* wave_tot) {
+  const int per = (n + 1023) / 1024;
+  const int lo = (int)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  int mine = 0;
+  for (int k = lo; k < hi; ++k) mine += arr[k];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int inc = v;
+  int inc = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int t = __shfl_up(inc, off, 64);
@@ -53,68 +61,71 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* wave_tot, i
   int before = 0, all = 0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) { before += k < wv ? wave_tot[k] : 0; all += wave_tot[k]; }
+  int at = before + inc - mine;
+  for (int k = lo; k < hi; ++k) { const int v = arr[k]; arr[k] = at; at += v; }
   __syncthreads();
-  if (total) *total = all;
-  return before + inc - v;
+  return all;
 }
+
+// (PerUnit: int* in LDS, or line_base itself in global memory for batches whose units do not fit there)
+template <typename PerUnit>
+__device__ __forceinline__ void order_units(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order,
+                                            int* __restrict__ line_base, long long capacity_blocks, unsigned long long* __restrict__ queue,
+                                            int* __restrict__ err_flag, int* hist, int* wave_tot, PerUnit blocks) {
+  const int n_units = n_src * kUnits;
+  const double inv_area = 1.0 / ((double)nx * (double)ny), inv_side = 1.0 / (double)(nx > ny ? nx : ny);
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  // one pass over the units: the blocks of a unit's boundary lines and its bucket (0 = first), kept for the two scatters below
+  for (int u = threadIdx.x; u < n_units; u += 1024) {
+    const int s = u / kUnits, qo = u - s * kUnits;
+    const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
+    int nb = 0, bucket = kBuckets - 1;
+    if (!(sx < 0 || sy < 0 || sx >= nx || sy >= ny)) {
+      UnitGeo g;
+      g.init(nx, ny, qo, sx, sy);
+      nb = g.line_blocks();
+      double cells = 0.0;
+      if (g.n_strips > 0) {
+        if (g.x_major) { const double r = g.rows_total; cells = r * g.ni - r * (r - 1) * 0.5; }
+        else { const double c = g.cols_total; cells = c * (g.nj - 1) - c * (c - 1) * 0.5; }
+      }
+      // Launch order = how early a unit has to start, not how large it is: a unit is as long as its march (a thin octant along
+      // an axis is one strip, i.e. one wavefront, for 15 blocks: sorted by cells it started last and the launch ended on it),
+      // so the key is mostly the march length; among equally long ones the larger first.
+      const double march = (double)(g.x_major ? g.ni : g.nj) * inv_side;
+      double f = 0.8 * march + 0.2 * (cells * inv_area * 1.6 > 1.0 ? 1.0 : cells * inv_area * 1.6);
+      if (f > 1.0) f = 1.0;
+      bucket = (kBuckets - 1) - (int)(f * (kBuckets - 1));
+    }
+    blocks[u] = nb | (bucket << 20);  // (nb < 2^20: a unit has at most 129 strips of 130 blocks)
+    atomicAdd(&hist[bucket], 1);
+  }
+  __syncthreads();
+  (void)block_exclusive_scan_1024(hist, kBuckets, wave_tot);
+  for (int u = threadIdx.x; u < n_units; u += 1024) order[atomicAdd(&hist[blocks[u] >> 20], 1)] = u;
+  __syncthreads();
+  for (int u = threadIdx.x; u < n_units; u += 1024) blocks[u] &= (1 << 20) - 1;
+  __syncthreads();
+  const int total = block_exclusive_scan_1024(blocks, n_units, wave_tot);
+  if ((const int*)blocks != (const int*)line_base)
+    for (int u = threadIdx.x; u < n_units; u += 1024) line_base[u] = blocks[u];
+  if (threadIdx.x == 0) {
+    const bool fits = (long long)total <= capacity_blocks;
+    *queue = fits ? 0ull : (unsigned long long)n_units;
+    if (!fits) atomicOr(err_flag, 4);
+  }
+}
+
 __global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order,
                                                        int* __restrict__ line_base, long long capacity_blocks,
                                                        unsigned long long* __restrict__ queue, int* __restrict__ err_flag) {
   __shared__ int hist[kBuckets];
-  __shared__ int start[kBuckets];
   __shared__ int wave_tot[16];
-  const int n_units = n_src * kUnits;
+  __shared__ int blocks[kOrderLdsUnits];
   VHP_DIAG_TL_RESET
-  {
-    // boundary lines: thread t lays out the units [t * per, (t + 1) * per)
-    auto blocks_of = [&](int u) {
-      const int s = u / kUnits, qo = u - s * kUnits;
-      const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
-      if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return 0;
-      UnitGeo g;
-      g.init(nx, ny, qo, sx, sy);
-      return g.line_blocks();
-    };
-    const int per = (n_units + 1023) / 1024;
-    const int u0 = (int)threadIdx.x * per, u1 = u0 + per < n_units ? u0 + per : n_units;
-    int mine = 0;
-    for (int u = u0; u < u1; ++u) mine += blocks_of(u);
-    int total = 0;
-    int at = block_exclusive_scan_1024(mine, wave_tot, &total);
-    for (int u = u0; u < u1; ++u) { line_base[u] = at; at += blocks_of(u); }
-    if (threadIdx.x == 0) {
-      const bool fits = (long long)total <= capacity_blocks;
-      *queue = fits ? 0ull : (unsigned long long)n_units;
-      if (!fits) atomicOr(err_flag, 4);
-    }
-  }
-  const double inv_area = 1.0 / ((double)nx * (double)ny);
-  auto bucket_of = [&](int u) {  // bucket 0 = largest
-    const int s = u / kUnits, qo = u - s * kUnits;
-    const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
-    if (sx < 0 || sy < 0 || sx >= nx || sy >= ny) return kBuckets - 1;
-    UnitGeo g;
-    g.init(nx, ny, qo, sx, sy);
-    double cells = 0.0;
-    if (g.n_strips > 0) {
-      if (g.x_major) { const double r = g.rows_total; cells = r * g.ni - r * (r - 1) * 0.5; }
-      else { const double c = g.cols_total; cells = c * (g.nj - 1) - c * (c - 1) * 0.5; }
-    }
-    // Launch order = how early a unit has to start, not how large it is: a unit is as long as its march (a thin octant along
-    // an axis is one strip, i.e. one wavefront, for 15 blocks: sorted by cells it started last and the launch ended on it),
-    // so the key is mostly the march length; among equally long ones the larger first.
-    const double march = (double)(g.x_major ? g.ni : g.nj) / (double)(nx > ny ? nx : ny);
-    double f = 0.8 * march + 0.2 * (cells * inv_area * 1.6 > 1.0 ? 1.0 : cells * inv_area * 1.6);
-    if (f > 1.0) f = 1.0;
-    return (kBuckets - 1) - (int)(f * (kBuckets - 1));
-  };
-  hist[threadIdx.x] = 0;
-  __syncthreads();
-  for (int u = threadIdx.x; u < n_units; u += blockDim.x) atomicAdd(&hist[bucket_of(u)], 1);
-  __syncthreads();
-  start[threadIdx.x] = block_exclusive_scan_1024(hist[threadIdx.x], wave_tot, nullptr);
-  __syncthreads();
-  for (int u = threadIdx.x; u < n_units; u += blockDim.x) order[atomicAdd(&start[bucket_of(u)], 1)] = u;
+  if (n_src * kUnits <= kOrderLdsUnits) order_units(src_xy, n_src, nx, ny, order, line_base, capacity_blocks, queue, err_flag, hist, wave_tot, blocks);
+  else order_units(src_xy, n_src, nx, ny, order, line_base, capacity_blocks, queue, err_flag, hist, wave_tot, line_base);
 }
 
 }  // namespace pool
