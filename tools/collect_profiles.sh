@@ -8,6 +8,11 @@
 #      program directly after `--`)                        -> <tag>_pmc_*_<w>.csv and traffic_<w>_f64_<kernel>.json
 #   4. the other workloads (fp32, C2, C4 planner, each batch kernel forced on C3) as plain bench lines; C2 and C4 also under
 #      rocprofv3 --kernel-trace --stats; the latency sweep against the front sweep by grid side and source count
+# The diagnostic libraries it uses are built HERE first (exp/ is not in the history; the GPU box gets them with the snapshot):
+#   for b in "PLAIN -DVHP_DIAG_PLAINSTORE" "NOSTORE -DVHP_DIAG_NOSTORE" "NOX -DVHP_DIAG_NOXSTORE" "NOY -DVHP_DIAG_NOYSTORE" "TL -DVHP_DIAG_TIMELINE" \
+#            "NWNM -DVHP_DIAG_NOWAIT -DVHP_DIAG_NOMATH" "NWNMX -DVHP_DIAG_NOWAIT -DVHP_DIAG_NOMATH -DVHP_DIAG_NOYSTORE" \
+#            "NWNMY -DVHP_DIAG_NOWAIT -DVHP_DIAG_NOMATH -DVHP_DIAG_NOXSTORE"; do set -- $b; n=$1; shift; bash tools/build_exp.sh $n "$*"; done
+#   (and tools/shapebench.hip / policybench.hip as their headers say)
 tag=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles_$tag
