@@ -81,7 +81,9 @@ int vhp_set_map_device(vhp_ctx* ctx, const uint8_t* d_occ_rowmajor, int nx, int 
  * reference on a freshly reset() solver. */
 int vhp_sweep_batch(vhp_ctx* ctx, const int32_t* src_xy, int n_src, int variant, int dtype, void* out_host);
 /* Device-resident form: d_src_xy and d_out are device pointers; asynchronous on the
- * context stream.  Sources are validated on the device; query with vhp_sync(). */
+ * context stream.  Sources are validated on the device; query with vhp_sync().  d_out may start at any element of the caller's
+ * buffer (aligned to the element type, else VHP_ERR_ARG); fields that start on a 128-byte line, on a width that is a multiple of 8,
+ * are stored fastest. */
 int vhp_sweep_batch_device(vhp_ctx* ctx, const int32_t* d_src_xy, int n_src, int variant, int dtype, void* d_out);
 /* Waits for the stream and returns the status of device-side validation
  * (VHP_ERR_SOURCE_OOB if any source of an earlier *_device call was out of range). */

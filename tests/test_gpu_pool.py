@@ -178,3 +178,32 @@ def test_pool_is_the_default_for_batches_on_other_widths(vhp, oracle, nx, ny, n)
     c.sweep_batch_device(d_src.data_ptr(), n, d_ref.data_ptr())
     c.sync()
     assert c.last_sweep_kernel() == 1 and torch.equal(d_ref, d_out)
+
+
+@pytest.mark.parametrize("kernel", [1, 3, 4])
+def test_output_anywhere_on_the_element_grid(vhp, oracle, kernel):
+    # the fields of a device batch may start at any element of the caller's buffer (one element in: off the 16-byte grid, off
+    # the lines), but not inside an element
+    import torch
+    nx, ny = 208, 131
+    occ = maps.random_rect_map(nx, ny, 20, 1, nx // 8, 1, ny // 8, 99)
+    src = _sources(occ, 3, 5)[:6]
+    c = vhp.Context(0)
+    c.set_map(occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_option("kernel", kernel)
+    d_src = torch.from_numpy(src).cuda()
+    for tdt, dt, item in ((torch.float64, vhp.F64, 8), (torch.float32, vhp.F32, 4)):
+        for lead in (1, 3, 16):
+            buf = torch.full((len(src) * nx * ny + 64,), -7.0, dtype=tdt, device="cuda")
+            c.sweep_batch_device(d_src.data_ptr(), len(src), buf.data_ptr() + lead * item, dtype=dt)
+            c.sync()
+            assert c.last_sweep_kernel() == kernel
+            got = buf.cpu().numpy()
+            assert (got[:lead] == -7.0).all() and (got[lead + len(src) * nx * ny:] == -7.0).all(), "a store outside the fields"
+            got = got[lead: lead + len(src) * nx * ny].reshape(len(src), ny, nx)
+            for k, (sx, sy) in enumerate(src):
+                _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)).astype(got.dtype), "lead %d kernel %d source (%d,%d)" % (lead, kernel, sx, sy))
+        with pytest.raises(vhp.VhpError) as e:
+            c.sweep_batch_device(d_src.data_ptr(), len(src), buf.data_ptr() + item // 2, dtype=dt)
+        assert e.value.code == vhp.VHP_ERR_ARG

@@ -506,6 +506,8 @@ int vhp_sweep_batch_device(vhp_ctx* ctx, const int32_t* d_src_xy, int n_src, int
   if (!ctx->d_rows) return fail(ctx, VHP_ERR_NO_MAP, "vhp_sweep_batch_device: no map set");
   if (dtype != VHP_F64 && dtype != VHP_F32) return fail(ctx, VHP_ERR_ARG, "bad dtype");
   if (variant != VHP_SWEEP_FULL && variant != VHP_SWEEP_QUEUE) return fail(ctx, VHP_ERR_ARG, "bad variant");
+  // (any alignment of whole elements is swept -- the kernels' builds for fields off the 16-byte grid --, a pointer inside an element is not)
+  if (reinterpret_cast<uintptr_t>(d_out) % (dtype == VHP_F64 ? 8 : 4) != 0) return fail(ctx, VHP_ERR_ARG, "vhp_sweep_batch_device: d_out is not aligned to its element type");
   if (n_src == 0) return VHP_OK;
   VHP_ON_DEVICE(ctx);
   VHP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
