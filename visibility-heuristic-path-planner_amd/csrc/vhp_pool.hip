@@ -9,7 +9,8 @@
 namespace vhp {
 namespace pool {
 
-// One persistent workgroup per CU; every wavefront is a Worker.  kWaves wavefronts: three per SIMD, 168 vector registers each.
+// One persistent workgroup per CU; every wavefront is a Worker.  kWaves wavefronts: three per SIMD, 168 vector registers each
+// (the builds use 121 and 114).
 #ifndef VHP_POOL_WAVES
 #define VHP_POOL_WAVES 12
 #endif

@@ -34,6 +34,8 @@
 //   * an x-major strip flushes its own staging tile: after every 8-step window the rows whose 128-byte line is
 //     complete leave as whole lines, 8 rows per store instruction, issued by the wavefront that computed them (a
 //     wavefront stalled in a store is covered by the other wavefronts of its SIMD: that is what a pool is for);
+//     two builds: widths that are a multiple of 8 (a row's lines start at one of two places: a tile of two windows), and every
+//     other width, padded or unaligned field (ANYW: the lines of a row start anywhere, a tile of three windows; XStrip::flush_rows);
 //   * the stale diagonal of a y-major unit is produced by the wavefront that installed the unit -- the serial
 //     two-term recurrence of DiagTask -- into a scratch line in global memory, 64 entries at a time; a strip
 //     loads the seeds of its own columns into registers when it starts.
