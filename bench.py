@@ -503,6 +503,25 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             placement["timed_buffer"] = {"error": repr(e)}
+        # The same launch on a result buffer PLACED by the library (vhp_alloc_output: the best of up to 32 probed allocations): what
+        # a caller gets who allocates his fields through the C ABI instead of hipMalloc.  Reported beside the line's own figures,
+        # which stay those of the first allocation; HIP-event time of the kernel over as many launches as the timed region had.
+        try:
+            n_try = max(1, min(32, int((120 << 30) // max(out_bytes, 1))))
+            ptr, w, sp, tried = ctx.alloc_output(out_bytes, n_try)
+
+            class _Placed:  # (what launch_ms needs of a tensor)
+                def data_ptr(self):
+                    return ptr
+            ms = launch_ms(_Placed(), k=max(args.steps, 5))
+            ctx.free_output(ptr)
+            placement["library_placed_buffer"] = {
+                "policy": "vhp_alloc_output: up to %d allocations probed, the fastest kept" % n_try, "allocations_tried": tried,
+                "whole_lines_TBps": round(w, 2), "split_lines_TBps": round(sp, 2), "state": state_of(sp), "kernel_ms": ms,
+                "fields_per_s_by_kernel_time": round(n_src / (ms * 1e-3), 1),
+                "roofline_frac_by_kernel_time": round(BYTES_PER_CELL[args.dtype] * nx * ny * n_src / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        except Exception as e:
+            placement["library_placed_buffer"] = {"error": repr(e)}
     kern_ms = float(kern.sum()) / args.steps  # sweep-kernel time per step (one launch, or the pieces of an overlapped step)
 
     if rank == 0:

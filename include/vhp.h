@@ -200,10 +200,22 @@ int vhp_last_sweep_kernel(const vhp_ctx* ctx);
  * streams, (a) every piece on the 128-byte line grid, (b) every other piece half a line off it, so that two lines per piece
  * are written in halves by different wavefronts at different times, with PLAIN stores.  The same physical memory answers (a)
  * with 4.9-5.0 or 5.9-6.1 and (b) with 3.6-3.7 or 5.2-5.4 depending on where the allocation landed;
- * bench.py reports both for the buffer it timed so that a result can be read against the state of its memory.  Nothing in the
- * library chooses anything by it.  d_buf: 128-byte aligned, at least 128 MB; its contents are overwritten with zeros
+ * bench.py reports both for the buffer it timed so that a result can be read against the state of its memory; vhp_alloc_output
+ * (below) places a result buffer by it.  d_buf: 128-byte aligned, at least 128 MB; its contents are overwritten with zeros
  * (up to 16 GB of it are used).  Blocks until done. */
 int vhp_probe_stores(vhp_ctx* ctx, void* d_buf, unsigned long long bytes, float* whole_lines_TBps, float* split_lines_TBps);
+
+/* Device memory for results, placed by the library (the reference has no device memory; a maintainer's binding allocates its
+ * result fields with this instead of hipMalloc).  The memory behind an allocation is of a faster or a slower kind, and no allocation
+ * API chooses (a launch of 256 fields at 1000^2 takes 0.46-0.49 ms on the one, 0.585-0.60 on the other): up to
+ * max_candidates allocations of `bytes` are made (at most 64, within 3/4 of the free memory), each is probed (vhp_probe_stores; from
+ * 128 MB up), the one that takes a sweep's stores fastest is kept, the others are freed; the search ends early on a buffer of the
+ * fast kind.  d_buf: 256-byte aligned, contents undefined.  whole_lines_TBps / split_lines_TBps (may be NULL): the probe's rates
+ * of the buffer kept (0 below 128 MB); n_tried (may be NULL): allocations made.  Blocks; a one-off cost of 5-10 ms per candidate.
+ * Buffers still allocated when the context is destroyed are freed with it. */
+int vhp_alloc_output(vhp_ctx* ctx, unsigned long long bytes, int max_candidates, void** d_buf, float* whole_lines_TBps,
+                     float* split_lines_TBps, int* n_tried);
+int vhp_free_output(vhp_ctx* ctx, void* d_buf);
 
 /* ---- several devices of one node (the reference is one thread on one CPU and has nothing to replace here) ----
  * The sources of a batch are independent, so a batch shards over devices with no exchange step: device d of n sweeps the

@@ -207,3 +207,36 @@ def test_output_anywhere_on_the_element_grid(vhp, oracle, kernel):
         with pytest.raises(vhp.VhpError) as e:
             c.sweep_batch_device(d_src.data_ptr(), len(src), buf.data_ptr() + item // 2, dtype=dt)
         assert e.value.code == vhp.VHP_ERR_ARG
+
+
+def test_alloc_output_places_a_result_buffer(vhp, oracle):
+    # vhp_alloc_output: a result buffer placed by the library (the best of up to N probed allocations); sweeping into it leaves the
+    # bytes the same launch leaves anywhere else; freeing is checked
+    import torch
+    occ, src = maps.config_c3(40)
+    c = _ctx(vhp, occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    n_bytes = 40 * 1000 * 1000 * 8
+    ptr, whole, split, tried = c.alloc_output(n_bytes, 6)
+    assert ptr and ptr % 256 == 0 and 1 <= tried <= 6
+    assert 0.3 < whole < 8.0 and 0.3 < split < 8.0, (whole, split)
+    d_src = torch.from_numpy(src).cuda()
+    ref = torch.empty((40, 1000, 1000), dtype=torch.float64, device="cuda")
+    c.sweep_batch_device(d_src.data_ptr(), 40, ref.data_ptr())
+    c.sweep_batch_device(d_src.data_ptr(), 40, ptr)
+    c.sync()
+    import ctypes
+    got = torch.empty_like(ref)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(got.data_ptr(), ptr, n_bytes, 3) == 0   # device to device
+    assert torch.equal(got, ref)
+    _assert_same(got[7].cpu().numpy(), oracle.sweep_full(occ, int(src[7][0]), int(src[7][1])), "placed buffer, source 7")
+    small, w0, s0, t0 = c.alloc_output(1 << 20, 8)   # below 128 MB nothing can be probed: one allocation, no rates
+    assert small and t0 == 1 and w0 == 0.0 and s0 == 0.0
+    c.free_output(small)
+    c.free_output(ptr)
+    with pytest.raises(vhp.VhpError):
+        c.free_output(ptr)
+    with pytest.raises(vhp.VhpError):
+        c.alloc_output(0, 4)

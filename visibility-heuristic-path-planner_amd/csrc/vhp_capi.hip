@@ -31,6 +31,7 @@ struct vhp_ctx {
   std::string err;
 
   int n_cus = 256;
+  std::vector<void*> placed;   // buffers handed out by vhp_alloc_output
   int nx = 0, ny = 0;
   uint8_t* d_occ = nullptr;    // uint8 map (kept for the planner's validation and packing)
   uint64_t* d_rows = nullptr;  // packed along x
@@ -471,6 +472,7 @@ int vhp_destroy(vhp_ctx* ctx) {
   for (auto& pr : ctx->timed_launches) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (ctx->d_err) hipFree(ctx->d_err);
+  for (void* p : ctx->placed) (void)hipFree(p);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -873,6 +875,54 @@ int vhp_probe_stores(vhp_ctx* ctx, void* d_buf, unsigned long long bytes, float*
   (void)hipFree(d_counter);
   *whole_lines_TBps = res[0];
   *split_lines_TBps = res[1];
+  return VHP_OK;
+}
+
+int vhp_alloc_output(vhp_ctx* ctx, unsigned long long bytes, int max_candidates, void** d_buf, float* whole_lines_TBps, float* split_lines_TBps,
+                     int* n_tried) {
+  if (!ctx || !d_buf || bytes == 0 || max_candidates < 1) return fail(ctx, VHP_ERR_ARG, "vhp_alloc_output: bad argument");
+  VHP_ON_DEVICE(ctx);
+  *d_buf = nullptr;
+  size_t free_b = 0, total_b = 0;
+  VHP_HIP(hipMemGetInfo(&free_b, &total_b));
+  // (every candidate stays allocated until the choice is made -- a freed one would be handed out again --, within 3/4 of what is free)
+  const int cap = (int)std::min<unsigned long long>((unsigned long long)std::min(max_candidates, 64), std::max<unsigned long long>(1, (unsigned long long)free_b * 3 / 4 / bytes));
+  const bool probed = bytes >= 16ull * 8000000ull;   // (vhp_probe_stores says nothing about less than 128 MB)
+  std::vector<void*> cand;
+  int best = -1, tried = 0;
+  float best_w = 0.f, best_s = 0.f;
+  for (int k = 0; k < cap; ++k) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    cand.push_back(p);
+    ++tried;
+    float w = 0.f, sp = 0.f;
+    if (probed) {
+      const int rc = vhp_probe_stores(ctx, p, bytes, &w, &sp);
+      if (rc != VHP_OK) { for (void* q : cand) (void)hipFree(q); return rc; }
+    }
+    // what a sweep's non-temporal whole-line stores run at decides; the split-line rate breaks ties
+    if (best < 0 || w > best_w + 0.05f || (w > best_w - 0.05f && sp > best_s)) { best = k; best_w = w; best_s = sp; }
+    if (!probed || (w >= 5.6f && sp >= 4.9f)) break;   // the fast kind: nothing better to find
+  }
+  if (best < 0) return fail(ctx, VHP_ERR_HIP, "vhp_alloc_output: out of device memory");
+  for (int k = 0; k < (int)cand.size(); ++k) if (k != best) (void)hipFree(cand[k]);
+  ctx->placed.push_back(cand[best]);
+  *d_buf = cand[best];
+  if (whole_lines_TBps) *whole_lines_TBps = best_w;
+  if (split_lines_TBps) *split_lines_TBps = best_s;
+  if (n_tried) *n_tried = tried;
+  return VHP_OK;
+}
+
+int vhp_free_output(vhp_ctx* ctx, void* d_buf) {
+  if (!ctx || !d_buf) return VHP_ERR_ARG;
+  auto it = std::find(ctx->placed.begin(), ctx->placed.end(), d_buf);
+  if (it == ctx->placed.end()) return fail(ctx, VHP_ERR_ARG, "vhp_free_output: not a buffer of vhp_alloc_output of this context");
+  VHP_ON_DEVICE(ctx);
+  VHP_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->placed.erase(it);
+  VHP_HIP(hipFree(d_buf));
   return VHP_OK;
 }
 
