@@ -503,11 +503,11 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             placement["timed_buffer"] = {"error": repr(e)}
-        # The same launch on a result buffer PLACED by the library (vhp_alloc_output: the best of up to 32 probed allocations): what
+        # The same launch on a result buffer PLACED by the library (vhp_alloc_output: the best of up to 64 probed allocations): what
         # a caller gets who allocates his fields through the C ABI instead of hipMalloc.  Reported beside the line's own figures,
         # which stay those of the first allocation; HIP-event time of the kernel over as many launches as the timed region had.
         try:
-            n_try = max(1, min(32, int((120 << 30) // max(out_bytes, 1))))
+            n_try = max(1, min(64, int((160 << 30) // max(out_bytes, 1))))
             ptr, w, sp, tried = ctx.alloc_output(out_bytes, n_try)
 
             class _Placed:  # (what launch_ms needs of a tensor)

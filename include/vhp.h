@@ -209,7 +209,7 @@ int vhp_probe_stores(vhp_ctx* ctx, void* d_buf, unsigned long long bytes, float*
  * result fields with this instead of hipMalloc).  The memory behind an allocation is of a faster or a slower kind, and no allocation
  * API chooses (a launch of 256 fields at 1000^2 takes 0.46-0.49 ms on the one, 0.585-0.60 on the other): up to
  * max_candidates allocations of `bytes` are made (at most 64, within 3/4 of the free memory), each is probed (vhp_probe_stores; from
- * 128 MB up), the one that takes a sweep's stores fastest is kept, the others are freed; the search ends early on a buffer of the
+ * 128 MB up), the one whose two rates add up highest is kept, the others are freed; the search ends early on a buffer of the
  * fast kind.  d_buf: 256-byte aligned, contents undefined.  whole_lines_TBps / split_lines_TBps (may be NULL): the probe's rates
  * of the buffer kept (0 below 128 MB); n_tried (may be NULL): allocations made.  Blocks; a one-off cost of 5-10 ms per candidate.
  * Buffers still allocated when the context is destroyed are freed with it. */

@@ -901,9 +901,10 @@ int vhp_alloc_output(vhp_ctx* ctx, unsigned long long bytes, int max_candidates,
       const int rc = vhp_probe_stores(ctx, p, bytes, &w, &sp);
       if (rc != VHP_OK) { for (void* q : cand) (void)hipFree(q); return rc; }
     }
-    // what a sweep's non-temporal whole-line stores run at decides; the split-line rate breaks ties
-    if (best < 0 || w > best_w + 0.05f || (w > best_w - 0.05f && sp > best_s)) { best = k; best_w = w; best_s = sp; }
-    if (!probed || (w >= 5.6f && sp >= 4.9f)) break;   // the fast kind: nothing better to find
+    // (the two rates move together -- 4.9 / 3.6 on the slow kind, 6.0 / 5.3 on the fast, anything between on a buffer that straddles
+    // both --: their sum ranks the candidates)
+    if (best < 0 || w + sp > best_w + best_s) { best = k; best_w = w; best_s = sp; }
+    if (!probed || (w >= 5.5f && sp >= 4.7f)) break;   // the fast kind (5.6-6.1 / 4.7-5.4 by box): nothing better to find
   }
   if (best < 0) return fail(ctx, VHP_ERR_HIP, "vhp_alloc_output: out of device memory");
   for (int k = 0; k < (int)cand.size(); ++k) if (k != best) (void)hipFree(cand[k]);
