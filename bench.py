@@ -14,8 +14,9 @@ region: weak scaling).  `--workload c2` times the single-source README case inst
 `--gather` adds the RCCL all-gather of the per-source fields after each step.  At N > 1 the line also carries
 `value_with_collective`: the same job with the fp32 all-gather of the fields and with the max-union + arg-source
 (dist.union_fields) after every step, each timed over a few steps behind the main region (compute-only and
-compute + collective side by side).  `config.output_placement` says what kind of memory the timed buffer landed on
-(vhp_probe_stores) and what three more allocations of the process would have got -- reported, never selected.
+compute + collective side by side).  The timed launches write into a result buffer placed by the library's own allocator (vhp_alloc_output; --output-buffer first: into
+the first allocation of the process); `config.output_placement` says what kind of memory that buffer, the other of the two and three
+more allocations of the process are on (vhp_probe_stores), with the launch timed on each.
 
 The defaults (100 steps after 10 warm-up launches, ~0.1 s of GPU time) are long enough to report the
 sustained rate: on this pool the first ~25 ms of work after idle run 15-25 % faster than steady state.
@@ -55,8 +56,12 @@ def parse():
     ap.add_argument("--chunks", type=int, default=4, help="pieces per shard for --gather-mode overlapped")
     ap.add_argument("--placements", type=int, default=1,
                     help="diagnostic: allocate this many candidate outputs and time each with a few launches before the timed "
-                         "region.  The timed region ALWAYS runs on the first allocation; the probe times (and their median / "
-                         "best) are only reported, in config.output_placement")
+                         "region (a round-1 diagnostic; the probe times are only reported, in config.output_placement)")
+    ap.add_argument("--output-buffer", default="placed", choices=["placed", "first"],
+                    help="where the timed launches write: 'placed' = a result buffer from the library's own allocator (vhp_alloc_output: "
+                         "up to 64 allocations probed before the timed region, the fastest kept -- what a caller of the C ABI gets who "
+                         "allocates his fields through it); 'first' = the first allocation of the process, whatever memory it landed "
+                         "on.  Either way config.output_placement reports both buffers: their kind of memory and the launch on each")
     ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 3, 4],
                     help="0 = the library's own choice, 1 = front sweep, 3 = pool sweep, 4 = latency sweep (vhp_set_option \"kernel\")")
     ap.add_argument("--pool-contexts", type=int, default=0, help="pool sweep: units a workgroup holds at once (0 = automatic)")
@@ -381,11 +386,32 @@ def main():
             torch.cuda.synchronize()
             probe_ms.append(round(float(np.median(ctx.timing_collect(5))), 4))
             ctx.timing(False)
-    d_out = cands[0]
+    d_first = cands[0]   # the first allocation of the process
     cands = None
     torch.cuda.empty_cache()
     gathered = None
     overlapped = args.gather and args.gather_mode == "overlapped" and world >= 1 and n_src % args.chunks == 0 and dist.is_initialized()
+    # The timed launches write into a result buffer placed by the library (vhp_alloc_output, include/vhp.h: the memory behind an
+    # allocation is of a faster or a slower kind and no allocation API chooses, so the library tries up to 64 allocations, probes
+    # each and keeps the fastest: DESIGN.md section 7) -- set up here, before the timed region, like the map and the sources.
+    # --output-buffer first: into the first allocation instead.  The other of the two is timed behind the region and reported.
+    placed = None
+    d_out = d_first
+    if args.output_buffer == "placed" and not args.gather and out_bytes >= (128 << 20):
+        try:
+            n_try = max(1, min(64, int((160 << 30) // max(out_bytes, 1))))
+            p_ptr, p_w, p_sp, p_tried = ctx.alloc_output(out_bytes, n_try)
+
+            class _Placed:  # (what the launches need of a tensor)
+                def data_ptr(self):
+                    return p_ptr
+            d_out = _Placed()
+            placed = {"policy": "vhp_alloc_output: up to %d allocations probed, the fastest kept" % n_try, "allocations_tried": p_tried,
+                      "whole_lines_TBps": round(p_w, 2), "split_lines_TBps": round(p_sp, 2)}
+        except Exception as e:  # (out of memory on a shared device: the first allocation then)
+            placed = None
+            d_out = d_first
+            sys.stderr.write("vhp_alloc_output failed (%r): timing the first allocation\n" % (e,))
     if args.gather and (world > 1 or overlapped):
         gathered = torch.empty((world * n_src, ny, nx), dtype=tdt, device=dev)
 
@@ -444,8 +470,8 @@ def main():
                 dist.all_gather_into_tensor(all32, out32)
 
             def step_union():
-                ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_out.data_ptr(), dtype=vdt)
-                vdist.union_fields(d_out, first, world * n_src)
+                ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_first.data_ptr(), dtype=vdt)
+                vdist.union_fields(d_first, first, world * n_src)
 
             for name, fn in (("allgather_f32", step_gather), ("union_fields", step_union)):
                 fn()
@@ -462,14 +488,15 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:  # (memory: config 5 gathered on every rank is 69 GB in fp32)
             with_coll["error"] = repr(e)
-    placement = {"timed_on": "first allocation", "candidates": n_cand, "probe_kernel_ms": probe_ms,
+    placement = {"timed_on": ("library-placed buffer (vhp_alloc_output, set up before the timed region)" if placed else "first allocation"),
+                 "candidates": n_cand, "probe_kernel_ms": probe_ms,
                  "probe_median_ms": (round(float(np.median(probe_ms)), 4) if probe_ms else None),
                  "probe_best_ms": (min(probe_ms) if probe_ms else None)}
     if rank == 0 and out_bytes >= (128 << 20) and not overlapped:
-        # What kind of memory did the timed buffer land on?  Two store patterns on it (vhp_probe_stores: whole lines / lines
-        # written in halves, plain stores), then three MORE allocations of this process with the same two patterns and a few
-        # launches of the sweep each: reported so that the line can be read against the state of its memory; nothing is
-        # selected, the timed region above ran on the first allocation.
+        # What kind of memory did the timed buffer land on, and what would the other choice have been?  Two store patterns
+        # (vhp_probe_stores: whole lines / lines written in halves, plain stores) and a few launches of the sweep on: the timed
+        # buffer, the buffer that was NOT timed (the first allocation of the process, or a library-placed one), and three more
+        # allocations of this process.
         def state_of(split):
             return "fast" if split >= 4.6 else "slow" if split <= 4.1 else "mixed"
 
@@ -484,11 +511,34 @@ def main():
             v = float(np.median(ctx.timing_collect(k)))
             ctx.timing(False)
             return round(v, 4)
+
+        def figures(ms):
+            return {"kernel_ms": ms, "fields_per_s_by_kernel_time": round(n_src / (ms * 1e-3), 1),
+                    "roofline_frac_by_kernel_time": round(BYTES_PER_CELL[args.dtype] * nx * ny * n_src / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        note = ("vhp_probe_stores: 1 KB row pieces in many streams, plain stores; on this device an allocation answers whole lines with "
+                "4.7-5.0 (slow) or 5.6-6.1 TB/s (fast), split lines with 3.5-3.7 or 4.7-5.4, DESIGN.md section 7")
         try:
-            whole, split = ctx.probe_stores(d_out.data_ptr(), out_bytes)
-            placement["timed_buffer"] = {"whole_lines_TBps": round(whole, 2), "split_lines_TBps": round(split, 2), "state": state_of(split),
-                                         "note": "vhp_probe_stores: 1 KB row pieces in many streams, plain stores; on this device an allocation "
-                                                 "answers split lines with 3.6-3.7 (slow) or 5.2-5.4 TB/s (fast), DESIGN.md section 7"}
+            if placed:
+                placement["timed_buffer"] = dict(placed, state=state_of(placed["split_lines_TBps"]), note=note)
+                ms = launch_ms(d_first, k=max(args.steps, 5))
+                w, sp = ctx.probe_stores(d_first.data_ptr(), out_bytes)
+                placement["first_allocation_of_this_process"] = dict(figures(ms), whole_lines_TBps=round(w, 2), split_lines_TBps=round(sp, 2),
+                                                                      state=state_of(sp), note="not timed in the main region: --output-buffer first does")
+            else:
+                whole, split = ctx.probe_stores(d_out.data_ptr(), out_bytes)
+                placement["timed_buffer"] = {"whole_lines_TBps": round(whole, 2), "split_lines_TBps": round(split, 2), "state": state_of(split), "note": note}
+                if not args.gather:
+                    n_try = max(1, min(64, int((160 << 30) // max(out_bytes, 1))))
+                    ptr, w, sp, tried = ctx.alloc_output(out_bytes, n_try)
+
+                    class _P:
+                        def data_ptr(self):
+                            return ptr
+                    ms = launch_ms(_P(), k=max(args.steps, 5))
+                    ctx.free_output(ptr)
+                    placement["library_placed_buffer"] = dict(figures(ms), policy="vhp_alloc_output: up to %d allocations probed, the fastest kept" % n_try,
+                                                              allocations_tried=tried, whole_lines_TBps=round(w, 2), split_lines_TBps=round(sp, 2),
+                                                              state=state_of(sp), note="not timed in the main region: the default --output-buffer placed does")
             others = []
             n_more = max(0, min(3, int((40 << 30) // max(out_bytes, 1)) - 1))
             keep = []
@@ -502,26 +552,7 @@ def main():
             keep = None
             torch.cuda.empty_cache()
         except Exception as e:
-            placement["timed_buffer"] = {"error": repr(e)}
-        # The same launch on a result buffer PLACED by the library (vhp_alloc_output: the best of up to 64 probed allocations): what
-        # a caller gets who allocates his fields through the C ABI instead of hipMalloc.  Reported beside the line's own figures,
-        # which stay those of the first allocation; HIP-event time of the kernel over as many launches as the timed region had.
-        try:
-            n_try = max(1, min(64, int((160 << 30) // max(out_bytes, 1))))
-            ptr, w, sp, tried = ctx.alloc_output(out_bytes, n_try)
-
-            class _Placed:  # (what launch_ms needs of a tensor)
-                def data_ptr(self):
-                    return ptr
-            ms = launch_ms(_Placed(), k=max(args.steps, 5))
-            ctx.free_output(ptr)
-            placement["library_placed_buffer"] = {
-                "policy": "vhp_alloc_output: up to %d allocations probed, the fastest kept" % n_try, "allocations_tried": tried,
-                "whole_lines_TBps": round(w, 2), "split_lines_TBps": round(sp, 2), "state": state_of(sp), "kernel_ms": ms,
-                "fields_per_s_by_kernel_time": round(n_src / (ms * 1e-3), 1),
-                "roofline_frac_by_kernel_time": round(BYTES_PER_CELL[args.dtype] * nx * ny * n_src / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        except Exception as e:
-            placement["library_placed_buffer"] = {"error": repr(e)}
+            placement["error"] = repr(e)
     kern_ms = float(kern.sum()) / args.steps  # sweep-kernel time per step (one launch, or the pieces of an overlapped step)
 
     if rank == 0:
