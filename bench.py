@@ -14,12 +14,19 @@ region: weak scaling).  `--workload c2` times the single-source README case inst
 `--gather` adds the RCCL all-gather of the per-source fields after each step.  At N > 1 the line also carries
 `value_with_collective`: the same job with the fp32 all-gather of the fields and with the max-union + arg-source
 (dist.union_fields) after every step, each timed over a few steps behind the main region (compute-only and
-compute + collective side by side).  The timed launches write into a result buffer placed by the library's own allocator (vhp_alloc_output; --output-buffer first: into
-the first allocation of the process); `config.output_placement` says what kind of memory that buffer, the other of the two and three
-more allocations of the process are on (vhp_probe_stores), with the launch timed on each.
+compute + collective side by side).
 
-The defaults (100 steps after 10 warm-up launches, ~0.1 s of GPU time) are long enough to report the
-sustained rate: on this pool the first ~25 ms of work after idle run 15-25 % faster than steady state.
+Two numbers, both at the top level of the line, because the memory behind an allocation is of a faster or a slower kind (DESIGN.md
+section 7) and the same launch takes 15-20 % longer on the one than on the other:
+  * `value` / `roofline.frac` -- the timed region writes into the FIRST allocation of the process, whatever memory it landed on
+    (what every round's driver record has measured; also `value_first_allocation`, `roofline.frac_first_allocation`);
+  * `value_placed_buffer` / `roofline.frac_placed_buffer` -- the same K steps, same barriers, behind the main region, into a result
+    buffer placed by the library's own allocator (vhp_alloc_output: a bounded number of allocations probed, the best kept; what
+    the search cost is in `config.output_placement.search_ms` / `.search_bytes_peak`).
+`--output-buffer placed` swaps the roles (the main region on the placed buffer).  `config.output_placement` also says what kind of
+memory both buffers and three more allocations of the process are on (vhp_probe_stores), with the launch timed on each.
+
+The defaults (100 steps after 10 warm-up launches, ~0.1 s of GPU time) report the sustained rate.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
@@ -57,11 +64,12 @@ def parse():
     ap.add_argument("--placements", type=int, default=1,
                     help="diagnostic: allocate this many candidate outputs and time each with a few launches before the timed "
                          "region (a round-1 diagnostic; the probe times are only reported, in config.output_placement)")
-    ap.add_argument("--output-buffer", default="placed", choices=["placed", "first"],
-                    help="where the timed launches write: 'placed' = a result buffer from the library's own allocator (vhp_alloc_output: "
-                         "up to 64 allocations probed before the timed region, the fastest kept -- what a caller of the C ABI gets who "
-                         "allocates his fields through it); 'first' = the first allocation of the process, whatever memory it landed "
-                         "on.  Either way config.output_placement reports both buffers: their kind of memory and the launch on each")
+    ap.add_argument("--output-buffer", default="first", choices=["placed", "first"],
+                    help="where the launches of the MAIN timed region (`value`) write: 'first' = the first allocation of the process, "
+                         "whatever memory it landed on; 'placed' = a result buffer from the library's own allocator (vhp_alloc_output: "
+                         "up to 16 allocations / 32 GB probed before the timed region, the best kept -- what a caller of the C ABI gets "
+                         "who allocates his fields through it).  Either way the OTHER buffer is timed over the same number of steps "
+                         "behind the main region and both are reported at the top level (value_first_allocation, value_placed_buffer)")
     ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 3, 4],
                     help="0 = the library's own choice, 1 = front sweep, 3 = pool sweep, 4 = latency sweep (vhp_set_option \"kernel\")")
     ap.add_argument("--pool-contexts", type=int, default=0, help="pool sweep: units a workgroup holds at once (0 = automatic)")
@@ -367,9 +375,8 @@ def main():
     d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).to(dev)
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     vdt = vhp_amd.F64 if args.dtype == "f64" else vhp_amd.F32
-    # The timed region runs on the FIRST allocation of the process, whatever its placement.  (Round 1 saw the same
-    # launch run 0.55 or 0.75 ms depending on the output allocation; --placements N > 1 times N candidates first and
-    # reports them, for diagnosis only.)
+    # The first allocation of the process is made here, before anything else asks for device memory.  (--placements N > 1: a round-1
+    # diagnostic that times N candidate allocations first and reports them.)
     out_bytes = n_src * ny * nx * (8 if args.dtype == "f64" else 4)
     n_cand = max(1, min(args.placements, int((24 << 30) // max(out_bytes, 1))))
     cands, probe_ms = [], []
@@ -391,27 +398,31 @@ def main():
     torch.cuda.empty_cache()
     gathered = None
     overlapped = args.gather and args.gather_mode == "overlapped" and world >= 1 and n_src % args.chunks == 0 and dist.is_initialized()
-    # The timed launches write into a result buffer placed by the library (vhp_alloc_output, include/vhp.h: the memory behind an
-    # allocation is of a faster or a slower kind and no allocation API chooses, so the library tries up to 64 allocations, probes
-    # each and keeps the fastest: DESIGN.md section 7) -- set up here, before the timed region, like the map and the sources.
-    # --output-buffer first: into the first allocation instead.  The other of the two is timed behind the region and reported.
+    # A second result buffer, placed by the library (vhp_alloc_output, include/vhp.h: the memory behind an allocation is of a faster or a
+    # slower kind and no allocation API chooses, so the library tries a bounded number of allocations, probes each and keeps the best:
+    # DESIGN.md section 7) -- set up here, before any timed region, like the map and the sources.  --output-buffer first (the default):
+    # the main region writes into the first allocation and the placed buffer is timed behind it; placed: the other way round.
     placed = None
-    d_out = d_first
-    if args.output_buffer == "placed" and not args.gather and out_bytes >= (128 << 20):
+    d_placed = None
+    if not args.gather and out_bytes >= (128 << 20):   # (every rank: the region behind the main one has the same barriers)
         try:
-            n_try = max(1, min(64, int((160 << 30) // max(out_bytes, 1))))
+            n_try = max(1, min(16, int((32 << 30) // max(out_bytes, 1))))
             p_ptr, p_w, p_sp, p_tried = ctx.alloc_output(out_bytes, n_try)
+            s_ms, s_peak = ctx.alloc_output_cost()
 
             class _Placed:  # (what the launches need of a tensor)
                 def data_ptr(self):
                     return p_ptr
-            d_out = _Placed()
-            placed = {"policy": "vhp_alloc_output: up to %d allocations probed, the fastest kept" % n_try, "allocations_tried": p_tried,
+            d_placed = _Placed()
+            placed = {"policy": "vhp_alloc_output: up to %d allocations (32 GB) probed, the best kept" % n_try, "allocations_tried": p_tried,
+                      "search_ms": round(s_ms, 1), "search_bytes_peak": int(s_peak),
                       "whole_lines_TBps": round(p_w, 2), "split_lines_TBps": round(p_sp, 2)}
-        except Exception as e:  # (out of memory on a shared device: the first allocation then)
+        except Exception as e:  # (out of memory on a shared device: the first allocation only, then)
             placed = None
-            d_out = d_first
-            sys.stderr.write("vhp_alloc_output failed (%r): timing the first allocation\n" % (e,))
+            d_placed = None
+            sys.stderr.write("vhp_alloc_output failed (%r): the first allocation only\n" % (e,))
+    d_out = d_placed if (args.output_buffer == "placed" and d_placed is not None) else d_first
+    d_other = None if d_placed is None else (d_first if d_out is d_placed else d_placed)
     if args.gather and (world > 1 or overlapped):
         gathered = torch.empty((world * n_src, ny, nx), dtype=tdt, device=dev)
 
@@ -419,11 +430,11 @@ def main():
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.sweep_batch_device(d_src[a:b].data_ptr(), b - a, dst.data_ptr(), dtype=vdt)
 
-    def step():
+    def step(dst=None):
         if overlapped:
             vdist.sweep_gather_overlapped(launch_piece, range(world * n_src), gathered, args.chunks)
             return
-        ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_out.data_ptr(), dtype=vdt)
+        ctx.sweep_batch_device(d_src.data_ptr(), n_src, (dst if dst is not None else d_out).data_ptr(), dtype=vdt)
         if gathered is not None:
             dist.all_gather_into_tensor(gathered, d_out)
 
@@ -432,25 +443,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
     launches_per_step = args.chunks if overlapped else 1
-    ctx.timing(True, prealloc=args.steps * launches_per_step + 2)  # HIP events around every sweep kernel, on the stream it is launched on;
-    #                                              the event pairs exist before the timed region starts
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.sync()  # surfaces device-side validation errors
-    kern = ctx.timing_collect(args.steps * launches_per_step)
-    ctx.timing(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    def timed_region(dst=None):
+        """W warm-up steps, barrier, K timed steps, barrier: (seconds -- max over ranks --, this rank's kernel ms per step)."""
+        for _ in range(args.warmup):
+            step(dst)
+        barrier()
+        ctx.timing(True, prealloc=args.steps * launches_per_step + 2)  # HIP events around every sweep kernel, on the stream it is launched on;
+        #                                              the event pairs exist before the timed region starts
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(dst)
+        barrier()
+        el = time.perf_counter() - t0
+        ctx.sync()  # surfaces device-side validation errors
+        k = ctx.timing_collect(args.steps * launches_per_step)
+        ctx.timing(False)
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), float(k.sum()) / args.steps
+
+    elapsed, kern_ms = timed_region()
+    # the same K steps into the OTHER result buffer (the library-placed one, or with --output-buffer placed the first allocation)
+    other = None
+    if d_other is not None:
+        other = timed_region(d_other)
 
     # ---- behind the timed region: the job with its collective (N > 1), then what memory the timed buffer was -----------------
     with_coll = None
@@ -488,15 +507,18 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:  # (memory: config 5 gathered on every rank is 69 GB in fp32)
             with_coll["error"] = repr(e)
-    placement = {"timed_on": ("library-placed buffer (vhp_alloc_output, set up before the timed region)" if placed else "first allocation"),
+    on_placed = d_placed is not None and d_out is d_placed
+    placement = {"timed_on": ("library-placed buffer (vhp_alloc_output, set up before the timed region)" if on_placed else "first allocation of the process"),
                  "candidates": n_cand, "probe_kernel_ms": probe_ms,
                  "probe_median_ms": (round(float(np.median(probe_ms)), 4) if probe_ms else None),
                  "probe_best_ms": (min(probe_ms) if probe_ms else None)}
+    if placed:
+        placement["search_ms"] = placed["search_ms"]
+        placement["search_bytes_peak"] = placed["search_bytes_peak"]
     if rank == 0 and out_bytes >= (128 << 20) and not overlapped:
-        # What kind of memory did the timed buffer land on, and what would the other choice have been?  Two store patterns
-        # (vhp_probe_stores: whole lines / lines written in halves, plain stores) and a few launches of the sweep on: the timed
-        # buffer, the buffer that was NOT timed (the first allocation of the process, or a library-placed one), and three more
-        # allocations of this process.
+        # What kind of memory are the two buffers on?  Two store patterns (vhp_probe_stores: whole lines / lines written in halves,
+        # plain stores) on the first allocation (the placed buffer was probed by the search), and the same plus a few launches of the
+        # sweep on three more allocations of this process.
         def state_of(split):
             return "fast" if split >= 4.6 else "slow" if split <= 4.1 else "mixed"
 
@@ -512,33 +534,13 @@ def main():
             ctx.timing(False)
             return round(v, 4)
 
-        def figures(ms):
-            return {"kernel_ms": ms, "fields_per_s_by_kernel_time": round(n_src / (ms * 1e-3), 1),
-                    "roofline_frac_by_kernel_time": round(BYTES_PER_CELL[args.dtype] * nx * ny * n_src / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         note = ("vhp_probe_stores: 1 KB row pieces in many streams, plain stores; on this device an allocation answers whole lines with "
                 "4.7-5.0 (slow) or 5.6-6.1 TB/s (fast), split lines with 3.5-3.7 or 4.7-5.4, DESIGN.md section 7")
         try:
+            w, sp = ctx.probe_stores(d_first.data_ptr(), out_bytes)
+            placement["first_allocation_of_this_process"] = {"whole_lines_TBps": round(w, 2), "split_lines_TBps": round(sp, 2), "state": state_of(sp), "note": note}
             if placed:
-                placement["timed_buffer"] = dict(placed, state=state_of(placed["split_lines_TBps"]), note=note)
-                ms = launch_ms(d_first, k=max(args.steps, 5))
-                w, sp = ctx.probe_stores(d_first.data_ptr(), out_bytes)
-                placement["first_allocation_of_this_process"] = dict(figures(ms), whole_lines_TBps=round(w, 2), split_lines_TBps=round(sp, 2),
-                                                                      state=state_of(sp), note="not timed in the main region: --output-buffer first does")
-            else:
-                whole, split = ctx.probe_stores(d_out.data_ptr(), out_bytes)
-                placement["timed_buffer"] = {"whole_lines_TBps": round(whole, 2), "split_lines_TBps": round(split, 2), "state": state_of(split), "note": note}
-                if not args.gather:
-                    n_try = max(1, min(64, int((160 << 30) // max(out_bytes, 1))))
-                    ptr, w, sp, tried = ctx.alloc_output(out_bytes, n_try)
-
-                    class _P:
-                        def data_ptr(self):
-                            return ptr
-                    ms = launch_ms(_P(), k=max(args.steps, 5))
-                    ctx.free_output(ptr)
-                    placement["library_placed_buffer"] = dict(figures(ms), policy="vhp_alloc_output: up to %d allocations probed, the fastest kept" % n_try,
-                                                              allocations_tried=tried, whole_lines_TBps=round(w, 2), split_lines_TBps=round(sp, 2),
-                                                              state=state_of(sp), note="not timed in the main region: the default --output-buffer placed does")
+                placement["library_placed_buffer"] = dict(placed, state=state_of(placed["split_lines_TBps"]))
             others = []
             n_more = max(0, min(3, int((40 << 30) // max(out_bytes, 1)) - 1))
             keep = []
@@ -553,12 +555,14 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             placement["error"] = repr(e)
-    kern_ms = float(kern.sum()) / args.steps  # sweep-kernel time per step (one launch, or the pieces of an overlapped step)
 
     if rank == 0:
         fields = world * n_src * args.steps
         alg_bytes = BYTES_PER_CELL[args.dtype] * nx * ny * n_src  # per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        # the main region and the region on the other buffer, by name: (seconds, kernel ms) of each
+        first_reg = (elapsed, kern_ms) if not on_placed else other
+        placed_reg = (elapsed, kern_ms) if on_placed else other
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this
         # command): collected by tools/collect_profiles.sh into profiles/, not measured inside this run
         traffic, traffic_src = None, None
@@ -573,6 +577,8 @@ def main():
         out = {
             "metric": "visibility fields/sec on %dx%d grid" % (nx, ny),
             "value": round(fields / elapsed, 2),
+            "value_first_allocation": (round(fields / first_reg[0], 2) if first_reg else None),
+            "value_placed_buffer": (round(fields / placed_reg[0], 2) if placed_reg else None),
             "unit": "fields/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -592,6 +598,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": round(kern_ms, 4),
+                         "frac_first_allocation": (round(alg_bytes / (first_reg[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if first_reg else None),
+                         "kernel_ms_first_allocation": (round(first_reg[1], 4) if first_reg else None),
+                         "frac_placed_buffer": (round(alg_bytes / (placed_reg[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if placed_reg else None),
+                         "kernel_ms_placed_buffer": (round(placed_reg[1], 4) if placed_reg else None),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          # the same rate counting only the field bytes written (the occupancy maps are read at 2 bits/cell)
                          "frac_field_bytes": round((alg_bytes - nx * ny * n_src) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -187,7 +187,11 @@ int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n);
  * column grid slid onto 128-byte lines), "pack" (1 = pack short quadrants), "kernel" (1 = front
  * sweep, 3 = pool sweep, 4 = latency sweep; 2 was the streaming sweep, retired in round 4 and refused),
  * "pool_contexts" (1..16: units a workgroup of the pool sweep holds
- * at once), "field_stride" (elements from one field of a device-pointer batch to the next; 0 = nx * ny, packed).  The
+ * at once), "pool_static_round" (0: every unit of a pool-sweep launch is pulled from its queue; 1, the default: the first unit of
+ * every context is handed out by workgroup index), "field_stride" (elements from one field of a DEVICE-pointer batch to the next;
+ * 0 = nx * ny, packed; a value below nx * ny makes vhp_sweep_batch_device fail with VHP_ERR_ARG; the host-buffer entry points
+ * ignore it -- their results are packed --, the queue variant refuses it, and vhp_set_map resets it to 0),
+ * "alloc_budget_pct" (vhp_alloc_output below).  The
  * results never depend on these; only the schedule (and, with field_stride, the placement of the fields) does. */
 int vhp_set_option(vhp_ctx* ctx, const char* key, long long value);
 /* Which kernel the last batch sweep of this context launched: 1 = front sweep (vhp_sweep_fronts),
@@ -207,14 +211,21 @@ int vhp_probe_stores(vhp_ctx* ctx, void* d_buf, unsigned long long bytes, float*
 
 /* Device memory for results, placed by the library (the reference has no device memory; a maintainer's binding allocates its
  * result fields with this instead of hipMalloc).  The memory behind an allocation is of a faster or a slower kind, and no allocation
- * API chooses (a launch of 256 fields at 1000^2 takes 0.46-0.49 ms on the one, 0.585-0.60 on the other): up to
- * max_candidates allocations of `bytes` are made (at most 64, within 3/4 of the free memory), each is probed (vhp_probe_stores; from
- * 128 MB up), the one whose two rates add up highest is kept, the others are freed; the search ends early on a buffer of the
- * fast kind.  d_buf: 256-byte aligned, contents undefined.  whole_lines_TBps / split_lines_TBps (may be NULL): the probe's rates
- * of the buffer kept (0 below 128 MB); n_tried (may be NULL): allocations made.  Blocks; a one-off cost of 5-10 ms per candidate.
+ * API chooses (a launch of 256 fields at 1000^2 takes 15-20 % longer on the one than on the other): up to
+ * max_candidates allocations of `bytes` are made, each is probed (vhp_probe_stores; from 128 MB up), the one whose two rates add up
+ * highest is kept, the others are freed.  BEST EFFORT: where the fast kind is rare the keeper is merely the best of what was tried.
+ * The search is a guest on the device: the candidates -- all held until the choice is made, a freed one would be handed out
+ * again -- stay within 25 % of the device memory that is free when the search starts (vhp_set_option "alloc_budget_pct", 1..90)
+ * and within 64; it ends on the first buffer of the fast kind and after 8 candidates in a row that are no better than the best so
+ * far.  While it runs, other users of the device see that much less free memory.  d_buf: 256-byte aligned, contents undefined.
+ * whole_lines_TBps / split_lines_TBps (may be NULL): the probe's rates of the buffer kept (0 below 128 MB); n_tried (may be NULL):
+ * allocations made.  Blocks; a one-off cost of 5-10 ms per candidate (vhp_alloc_output_cost tells what the last search took).
  * Buffers still allocated when the context is destroyed are freed with it. */
 int vhp_alloc_output(vhp_ctx* ctx, unsigned long long bytes, int max_candidates, void** d_buf, float* whole_lines_TBps,
                      float* split_lines_TBps, int* n_tried);
+/* What the last vhp_alloc_output of this context cost: wall-clock milliseconds of the search, and the device memory its
+ * candidates held at the peak (bytes).  Either pointer may be NULL. */
+int vhp_alloc_output_cost(const vhp_ctx* ctx, double* search_ms, unsigned long long* peak_bytes);
 int vhp_free_output(vhp_ctx* ctx, void* d_buf);
 
 /* ---- several devices of one node (the reference is one thread on one CPU and has nothing to replace here) ----
@@ -223,11 +234,19 @@ int vhp_free_output(vhp_ctx* ctx, void* d_buf);
  * device (an ordinal may be listed twice: two contexts on one device), each with a stream of its own; vhp_multi_set_map gives
  * every device the map; vhp_multi_sweep_batch uploads the shards' sources, launches every device's sweep before it waits for
  * any, and returns the first device-side status that is not VHP_OK (d_out_per_device[d]: device memory ON device d for its
- * shard's fields, packed; NULL allowed where the shard is empty); vhp_multi_allgather_fields then lands all n_src fields in
- * source order in d_all_per_device[d] on every device by direct peer copies -- xGMI is point to point, every pair of devices
- * has a link of its own, so the N (N - 1) copies of an all-gather all run at once.  The planner does not shard (pivot k + 1
- * needs the union after pivot k): use vhp_multi_context(m, d) for replicas.  (torch.distributed / RCCL form of the same:
- * dist.py.)  Not thread-safe; every call restores the caller's current device. */
+ * shard's fields, packed; NULL allowed where the shard is empty; on an error of device d the sweeps already enqueued on the
+ * devices before it are waited for before the call returns); vhp_multi_allgather_fields then lands all n_src fields in source
+ * order in d_all_per_device[d] on every device.  By default by direct peer copies: xGMI is point to point, every pair of devices
+ * has a link of its own, and every (destination, source) pair has a STREAM of its own ("lane" k of device `to` carries the copy
+ * from device (to + k) mod N), so the N - 1 inbound copies of a device are in flight together, one per link, and in round k no
+ * two destinations pull from one source.  vhp_multi_allgather_plan returns that enqueue plan as data -- (to, from, lane, first
+ * and one-past-last source of the piece) per copy, in enqueue order, up to `cap` entries; its return value is the number of
+ * copies; host arithmetic only.  vhp_multi_use_rccl(m, 1) switches to RCCL instead (ncclAllGather on a single-process
+ * communicator over the listed devices, one group call; librccl is loaded at run time; distinct devices only -- VHP_ERR_ARG when
+ * an ordinal is listed twice --; a batch that does not divide by the number of devices still takes the peer copies).  The planner
+ * does not shard (pivot k + 1 needs the union after pivot k): use vhp_multi_context(m, d) for replicas.  (torch.distributed /
+ * RCCL form of the same: dist.py.)  Not thread-safe; every call restores the caller's current device.  Never run across devices
+ * so far (no multi-GPU node was available): correct by construction, tested with one ordinal listed several times. */
 typedef struct vhp_multi vhp_multi;
 int vhp_multi_create(const int* device_ordinals, int n_devices, vhp_multi** out);
 int vhp_multi_destroy(vhp_multi* m);
@@ -238,6 +257,8 @@ void vhp_multi_shard_bounds(int n_src, int n_devices, int d, int* lo, int* hi);
 int vhp_multi_set_map(vhp_multi* m, const uint8_t* occ_rowmajor, int nx, int ny);
 int vhp_multi_sweep_batch(vhp_multi* m, const int32_t* src_xy, int n_src, int variant, int dtype, void* const* d_out_per_device);
 int vhp_multi_allgather_fields(vhp_multi* m, int n_src, int dtype, void* const* d_shard_per_device, void* const* d_all_per_device);
+int vhp_multi_allgather_plan(int n_src, int n_devices, int* to, int* from, int* lane, int* lo, int* hi, int cap);
+int vhp_multi_use_rccl(vhp_multi* m, int enable);
 
 /* Library / build identification: "vhp-hip <version> gfx950". */
 const char* vhp_version(void);

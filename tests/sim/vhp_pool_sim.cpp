@@ -119,17 +119,23 @@ int run_batch_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_sr
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] > weight[b]; });
   g_rng = seed * 2654435761u + 12345u;
   if (policy & 32) for (int k = n_units - 1; k > 0; --k) std::swap(order[k], order[lcg() % (k + 1)]);
+  // the launch's records, as vhp_pool_order writes them: {unit, sx | sy << 16 (-1: outside the grid), line base, 0} in launch order
+  std::vector<int> recs((size_t)4 * n_units + 4);
+  for (int k = 0; k < n_units; ++k) {
+    const int u = order[k], s = u / kUnits, sx = src[2 * s], sy = src[2 * s + 1];
+    const bool inside = !(sx < 0 || sy < 0 || sx >= nx || sy >= ny);
+    recs[4 * k] = u; recs[4 * k + 1] = inside ? (sx | (sy << 16)) : -1; recs[4 * k + 2] = line_base[u]; recs[4 * k + 3] = 0;
+  }
   unsigned long long queue = 0;
   int err = 0;
   const int dstride = ((nx < ny ? nx : ny) + 64 + 15) & ~15;
   std::vector<double> diag((size_t)n_src * 4 * dstride, std::numeric_limits<double>::quiet_NaN());
   Args<OutT> a;
   a.m = h.m;
-  a.src_xy = src;
   a.out = out;
   a.field_stride = (long long)nx * ny;
   a.err_flag = &err;
-  a.order = order.data();
+  a.recs = recs.data();
   a.queue = &queue;
   a.n_units = n_units;
   a.diag = diag.data();
@@ -140,14 +146,17 @@ int run_batch_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_sr
   std::vector<vhp::lanes::Tagged> lines((size_t)line_blocks * 64 + 64);
   for (size_t k = 0; k < lines.size(); ++k) { lines[k].v = std::numeric_limits<double>::quiet_NaN(); lines[k].tag = (k % 5 == 0) ? 0 : epoch - 1 - (k % 3); }
   a.lines = lines.data();
-  a.line_base = line_base.data();
   a.epoch = epoch;
-  a.n_head = 1 + (int)(seed % 3);
+  a.n_head = std::min(1 + (int)(seed % 3), C);
   a.tail_limit = (int)((long long)n_units * (10 + (seed * 37) % 91) / 100);
   a.early_ctx = (seed & 1) ? C : 1 + (int)(seed % (unsigned)C);   // sometimes the contexts past the first few open late
   a.late_after = n_units / 2;  // one to three contexts pull from the head of the queue
   a.claim_ahead = (int)((seed * 7) % 5) * 8;   // 0, 8 .. 32 steps: a strip claimed before the strip below has reached its first window
   a.busy_cap = (policy & 64) ? 2 : W;   // policy & 64: a tight cap on the wavefronts that may sweep while units are installed
+  // the first unit of every context by workgroup index wherever the launcher would do so (vhp_pool.hip launch_pool_t), in two runs of three
+  a.n_groups = G;
+  a.static_round = (seed % 3) != 2 && a.early_ctx >= C && n_units >= C * G;
+  if (a.static_round) queue = (unsigned long long)(a.n_head * G) | ((unsigned long long)((C - a.n_head) * G) << 32);
 
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
   std::vector<Worker<OutT, ANYW>> workers((size_t)G * W);
@@ -156,7 +165,7 @@ int run_batch_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_sr
     Worker<OutT, ANYW>::clear(lds[gI].data(), L, 0, 1);
     for (int w = 0; w < W; ++w) {
       Worker<OutT, ANYW>& wk = workers[(size_t)gI * W + w];
-      wk.init(a, lds[gI].data(), L, w);
+      wk.init(a, lds[gI].data(), L, w, gI);
       Coro& c = coros[(size_t)gI * W + w];
       c.stack.reset(new char[kStack]);
       c.entry = worker_entry<OutT, ANYW>;
@@ -224,6 +233,7 @@ int run_batch_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_sr
     for (int k = 0; k < 4; ++k) stats[7 + k] = vhp::lanes::sim_counts().c[k];  // hand-offs: from the ring, from global memory, "too far ahead", "overwritten while copying"
     stats[11] = vhp::lanes::store_stats().lines_whole;
     stats[12] = vhp::lanes::store_stats().lines_part;
+    stats[13] = a.static_round ? 1 : 0;  // the contexts' first units were handed out by workgroup index
   }
   if (vhp::lanes::store_stats().misaligned) return 3;  // a pair stored off the grid of its own size
   return 0;

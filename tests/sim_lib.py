@@ -45,14 +45,14 @@ def pool_sweep(occ, sources, dtype=np.float64, W=12, C=4, G=1, policy=0, seed=1,
     raw = np.full(len(src) * ny * nx + out_offset + 128 // item + 32, np.nan, dtype)
     lead = (-raw.ctypes.data % 128) // item + out_offset
     out = raw[lead: lead + len(src) * ny * nx].reshape(len(src), ny, nx)
-    stats = np.zeros(13, np.int64)
+    stats = np.zeros(14, np.int64)
     rc = lib.vhp_sim_pool_sweep(occ.ctypes.data, nx, ny, src.ctypes.data, len(src), 0 if dtype == np.float64 else 1, out.ctypes.data,
                                 W, C, G, policy, seed, stats.ctypes.data)
     assert rc == 0, rc
     assert np.isnan(raw[:lead]).all() and np.isnan(raw[lead + out.size:]).all(), "a store outside the fields"
     return out, dict(switches=int(stats[0]), progress=int(stats[1]), deadlock=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]),
                      err=int(stats[5]), pulled=int(stats[6]), from_ring=int(stats[7]), from_global=int(stats[8]), too_far=int(stats[9]),
-                     overwritten=int(stats[10]), lines_whole=int(stats[11]), lines_part=int(stats[12]))
+                     overwritten=int(stats[10]), lines_whole=int(stats[11]), lines_part=int(stats[12]), static_round=int(stats[13]))
 
 
 def lat_sweep(occ, sources, dtype=np.float64, W=12, policy=0, seed=1):

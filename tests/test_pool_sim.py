@@ -128,6 +128,23 @@ def test_pool_sim_open_grid_walls_and_a_rejected_source(oracle):
     assert got[0].tobytes() == oracle.sweep_full(occ, 60, 67).tobytes() and np.isnan(got[1]).all()
 
 
+def test_pool_sim_first_units_by_workgroup_index(oracle):
+    # Args::static_round: the first unit of every context by workgroup index, the queue behind them -- every unit still swept exactly
+    # once, whether the launch has just enough units for the contexts (8 sources = 64 units, 4 workgroups x 4 contexts x ... ) or many
+    # more, whatever the number of head contexts (seed % 3 + 1), and also when the queue is empty before a context took its first
+    occ = maps.random_rect_map(200, 163, 12, 4, 30, 4, 30, 5)
+    occ[:2, :2] = 1
+    seen = set()
+    for n_src, W, C, G, seed in [(2, 4, 4, 4, 1), (8, 6, 3, 2, 3), (24, 4, 2, 5, 7), (8, 12, 4, 16, 9), (9, 3, 3, 3, 1), (6, 2, 4, 12, 3), (1, 4, 4, 4, 1)]:
+        src = _sources(occ, n_src, seed)[:n_src] if n_src > 1 else np.array([(1, 1)], np.int32)
+        for policy in (POOL_ROUND_ROBIN | POOL_POINTS_ALWAYS, POOL_RANDOM | POOL_POINTS_RANDOM, POOL_BACKWARD, POOL_GREEDY | POOL_TIGHT_BUSY_CAP):
+            st = _check(oracle, occ, src, "static round n=%d W=%d C=%d G=%d seed=%d policy=%d" % (n_src, W, C, G, seed, policy),
+                        W=W, C=C, G=G, policy=policy, seed=seed)
+            assert st["static_round"] == (1 if 8 * len(src) >= C * G else 0)
+            seen.add(st["static_round"])
+    assert seen == {0, 1}
+
+
 _ASAN_CHILD = r"""
 import sys
 import numpy as np

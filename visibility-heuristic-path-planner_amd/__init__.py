@@ -40,9 +40,9 @@ ABI_SYMBOLS = (
     "vhp_sweep_batch", "vhp_sweep_batch_device", "vhp_sync", "vhp_planner_solve", "vhp_reconstruct_path",
     "vhp_raycast_all", "vhp_timing", "vhp_timing_collect", "vhp_set_option", "vhp_sweep_batch_variant", "vhp_planner_solve_variant",
     "vhp_planner_solve_device", "vhp_planner_results_device", "vhp_last_sweep_kernel",
-    "vhp_last_elapsed_ms", "vhp_version", "vhp_sweep_batch_offset", "vhp_planner_solve_speculative", "vhp_probe_stores", "vhp_alloc_output", "vhp_free_output",
+    "vhp_last_elapsed_ms", "vhp_version", "vhp_sweep_batch_offset", "vhp_planner_solve_speculative", "vhp_probe_stores", "vhp_alloc_output", "vhp_alloc_output_cost", "vhp_free_output",
     "vhp_multi_create", "vhp_multi_destroy", "vhp_multi_last_error", "vhp_multi_devices", "vhp_multi_context", "vhp_multi_shard_bounds",
-    "vhp_multi_set_map", "vhp_multi_sweep_batch", "vhp_multi_allgather_fields",
+    "vhp_multi_set_map", "vhp_multi_sweep_batch", "vhp_multi_allgather_fields", "vhp_multi_allgather_plan", "vhp_multi_use_rccl",
 )
 
 
@@ -101,6 +101,7 @@ def load_library():
     lib.vhp_probe_stores.argtypes = [vp, vp, C.c_ulonglong, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.vhp_alloc_output.argtypes = [vp, C.c_ulonglong, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.vhp_free_output.argtypes = [vp, vp]
+    lib.vhp_alloc_output_cost.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]
     lib.vhp_multi_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
     lib.vhp_multi_destroy.argtypes = [vp]
     lib.vhp_multi_last_error.argtypes = [vp]
@@ -113,6 +114,8 @@ def load_library():
     lib.vhp_multi_set_map.argtypes = [vp, vp, i32, i32]
     lib.vhp_multi_sweep_batch.argtypes = [vp, vp, i32, i32, i32, C.POINTER(vp)]
     lib.vhp_multi_allgather_fields.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(vp)]
+    lib.vhp_multi_allgather_plan.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32]
+    lib.vhp_multi_use_rccl.argtypes = [vp, i32]
     _lib = lib
     return lib
 
@@ -201,6 +204,12 @@ class Context:
         p, a, b, n = C.c_void_p(), C.c_float(0), C.c_float(0), C.c_int(0)
         self._check(self.lib.vhp_alloc_output(self.h, int(n_bytes), int(max_candidates), C.byref(p), C.byref(a), C.byref(b), C.byref(n)))
         return p.value, a.value, b.value, n.value
+
+    def alloc_output_cost(self):
+        """(wall-clock ms, peak bytes held) of the last alloc_output of this context (vhp_alloc_output_cost)."""
+        ms, peak = C.c_double(0), C.c_ulonglong(0)
+        self._check(self.lib.vhp_alloc_output_cost(self.h, C.byref(ms), C.byref(peak)))
+        return ms.value, peak.value
 
     def free_output(self, d_ptr):
         self._check(self.lib.vhp_free_output(self.h, C.c_void_p(d_ptr)))

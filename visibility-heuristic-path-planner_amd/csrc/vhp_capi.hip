@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +33,10 @@ struct vhp_ctx {
 
   int n_cus = 256;
   std::vector<void*> placed;   // buffers handed out by vhp_alloc_output
+  unsigned* d_probe_counter = nullptr;  // task counter of vhp_probe_stores
+  double last_alloc_ms = 0.0;  // what the last vhp_alloc_output cost: wall time of the search ...
+  unsigned long long last_alloc_peak_bytes = 0;  // ... and the device memory it held at its peak (vhp_alloc_output_cost)
+  int opt_alloc_budget_pct = 25;  // vhp_alloc_output: share of the free device memory its candidates may hold at once
   int nx = 0, ny = 0;
   uint8_t* d_occ = nullptr;    // uint8 map (kept for the planner's validation and packing)
   uint64_t* d_rows = nullptr;  // packed along x
@@ -74,6 +79,7 @@ struct vhp_ctx {
   int opt_pool_tail_pct = 0;   // pool sweep: share of the units the filler contexts take from the small end (0 auto)
   int opt_pool_early_ctx = 0, opt_pool_late_pct = 0;  // pool sweep: late contexts (0 auto)
   int opt_pool_busy_cap = 0;   // pool sweep: no new unit while this many wavefronts of the workgroup are sweeping (0 auto)
+  int opt_pool_static_round = 1;  // pool sweep: every context's first unit by workgroup index (0: every unit pulled from the queue)
 
   vhp::PlannerState pl;  // device-resident planner state
   vhp::SpecState spec;   // field cache of the speculative planner
@@ -341,6 +347,7 @@ hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT*
   a.pool_late_pct = c->opt_pool_late_pct;
   a.pool_tail_pct = c->opt_pool_tail_pct;
   a.pool_heads = c->opt_pool_heads;
+  a.pool_static_round = c->opt_pool_static_round;
   if (c->timing) {
     if (!c->event_pool.empty()) {
       a.ev_begin = c->event_pool.back().first;
@@ -473,6 +480,7 @@ int vhp_destroy(vhp_ctx* ctx) {
   for (auto& pr : ctx->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (ctx->d_err) hipFree(ctx->d_err);
   for (void* p : ctx->placed) (void)hipFree(p);
+  if (ctx->d_probe_counter) (void)hipFree(ctx->d_probe_counter);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -494,6 +502,7 @@ static int set_map_common(vhp_ctx* ctx, const uint8_t* src, int nx, int ny, bool
   VHP_ON_DEVICE(ctx);
   VHP_HIP(hipStreamSynchronize(ctx->stream));
   free_map(ctx);
+  ctx->opt_field_stride = 0;  // (a stride belongs to a grid: one left over from a smaller grid would make the fields overlap)
   const size_t n = (size_t)nx * ny;
   VHP_HIP(hipMalloc(&ctx->d_occ, n));
   VHP_HIP(hipMemcpyAsync(ctx->d_occ, src, n, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
@@ -510,6 +519,10 @@ int vhp_sweep_batch_device(vhp_ctx* ctx, const int32_t* d_src_xy, int n_src, int
   if (variant != VHP_SWEEP_FULL && variant != VHP_SWEEP_QUEUE) return fail(ctx, VHP_ERR_ARG, "bad variant");
   // (any alignment of whole elements is swept -- the kernels' builds for fields off the 16-byte grid --, a pointer inside an element is not)
   if (reinterpret_cast<uintptr_t>(d_out) % (dtype == VHP_F64 ? 8 : 4) != 0) return fail(ctx, VHP_ERR_ARG, "vhp_sweep_batch_device: d_out is not aligned to its element type");
+  if (ctx->opt_field_stride > 0 && ctx->opt_field_stride < (long long)ctx->nx * ctx->ny)
+    return fail(ctx, VHP_ERR_ARG, "vhp_sweep_batch_device: field_stride is smaller than a field (nx * ny elements): the fields would overlap");
+  if (variant == VHP_SWEEP_QUEUE && ctx->opt_field_stride > 0 && ctx->opt_field_stride != (long long)ctx->nx * ctx->ny)
+    return fail(ctx, VHP_ERR_ARG, "vhp_sweep_batch_device: the queue variant writes packed fields (field_stride must be 0)");
   if (n_src == 0) return VHP_OK;
   VHP_ON_DEVICE(ctx);
   VHP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -549,6 +562,9 @@ int vhp_sweep_batch(vhp_ctx* ctx, const int32_t* src_xy, int n_src, int variant,
       return fail(ctx, VHP_ERR_SOURCE_OOB, "a sweep source lies outside the grid");
   if (n_src == 0) return VHP_OK;
   VHP_ON_DEVICE(ctx);
+  // (the library's own scratch holds packed fields and is copied out packed: "field_stride" is a property of a caller's device buffer)
+  struct PackedHere { long long& v; long long keep; ~PackedHere() { v = keep; } } packed{ctx->opt_field_stride, ctx->opt_field_stride};
+  ctx->opt_field_stride = 0;
   const size_t esz = dtype == VHP_F64 ? 8 : 4;
   const size_t cells = (size_t)ctx->nx * ctx->ny;
   // bound device scratch: process the batch in slices of at most ~1 GiB of output
@@ -793,6 +809,8 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "pool_late_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_late_pct: 0 (automatic) .. 100"); ctx->opt_pool_late_pct = v; }
   else if (k == "pool_busy_cap") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_busy_cap: 0 (automatic) .. 16"); ctx->opt_pool_busy_cap = v; }
   else if (k == "pool_contexts") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_contexts: 0 (automatic) .. 16"); ctx->opt_pool_contexts = v; }
+  else if (k == "pool_static_round") { ctx->opt_pool_static_round = v != 0; }
+  else if (k == "alloc_budget_pct") { if (v < 1 || v > 90) return fail(ctx, VHP_ERR_ARG, "alloc_budget_pct: 1 .. 90 (per cent of the free device memory)"); ctx->opt_alloc_budget_pct = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;
 }
@@ -849,30 +867,27 @@ int vhp_probe_stores(vhp_ctx* ctx, void* d_buf, unsigned long long bytes, float*
   if (blocks < 16) return fail(ctx, VHP_ERR_ARG, "vhp_probe_stores: needs at least 128 MB to say anything about the memory");
   VHP_ON_DEVICE(ctx);
   const int n_tasks = (int)std::min<unsigned long long>(blocks, 2048) * 7;
-  unsigned* d_counter = nullptr;
-  VHP_HIP(hipMalloc(&d_counter, 8));
-  hipEvent_t e0, e1;
-  VHP_HIP(hipEventCreate(&e0));
-  VHP_HIP(hipEventCreate(&e1));
+  // (the task counter lives with the context: vhp_alloc_output probes up to 64 buffers, and a hipFree per probe synchronises the device;
+  // the timing pair is the context's own ev0 / ev1 -- nothing here can leak on an early return)
+  if (!ctx->d_probe_counter) VHP_HIP(hipMalloc(&ctx->d_probe_counter, 8));
   float res[2] = {0.f, 0.f};
   for (int split = 0; split < 2; ++split) {
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
-      VHP_HIP(hipMemsetAsync(d_counter, 0, 4, ctx->stream));
-      VHP_HIP(hipEventRecord(e0, ctx->stream));
+      VHP_HIP(hipMemsetAsync(ctx->d_probe_counter, 0, 4, ctx->stream));
+      VHP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
       // three workgroups of four wavefronts per CU (52 KB of LDS each keeps a fourth out): what a launch of the pool sweep holds
-      hipLaunchKernelGGL(vhp_store_probe_kernel, dim3((unsigned)ctx->n_cus * 3), dim3(256), 52 * 1024, ctx->stream, static_cast<char*>(d_buf), n_tasks, split, d_counter);
-      VHP_HIP(hipEventRecord(e1, ctx->stream));
-      VHP_HIP(hipEventSynchronize(e1));
+      hipLaunchKernelGGL(vhp_store_probe_kernel, dim3((unsigned)ctx->n_cus * 3), dim3(256), 52 * 1024, ctx->stream, static_cast<char*>(d_buf), n_tasks, split, ctx->d_probe_counter);
+      VHP_HIP(hipGetLastError());
+      VHP_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+      VHP_HIP(hipEventSynchronize(ctx->ev1));
       float ms = 0.f;
-      VHP_HIP(hipEventElapsedTime(&ms, e0, e1));
+      VHP_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
       if (rep > 0 && ms < best) best = ms;
     }
     res[split] = (float)((double)n_tasks * 1000.0 * 1024.0 / ((double)best * 1e-3) / 1e12);
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(d_counter);
+  ctx->timed = false;  // (ev0 / ev1 no longer bracket a sweep)
   *whole_lines_TBps = res[0];
   *split_lines_TBps = res[1];
   return VHP_OK;
@@ -883,36 +898,55 @@ int vhp_alloc_output(vhp_ctx* ctx, unsigned long long bytes, int max_candidates,
   if (!ctx || !d_buf || bytes == 0 || max_candidates < 1) return fail(ctx, VHP_ERR_ARG, "vhp_alloc_output: bad argument");
   VHP_ON_DEVICE(ctx);
   *d_buf = nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
   size_t free_b = 0, total_b = 0;
   VHP_HIP(hipMemGetInfo(&free_b, &total_b));
-  // (every candidate stays allocated until the choice is made -- a freed one would be handed out again --, within 3/4 of what is free)
-  const int cap = (int)std::min<unsigned long long>((unsigned long long)std::min(max_candidates, 64), std::max<unsigned long long>(1, (unsigned long long)free_b * 3 / 4 / bytes));
+  // Every candidate stays allocated until the choice is made -- a freed one would be handed out again.  The search is a guest on
+  // the device: what it holds at once stays within "alloc_budget_pct" (default 25) per cent of the memory that is free when it
+  // starts, it ends on the first buffer of the fast kind, and it gives up after 8 candidates in a row that are no better than the
+  // best so far (where the fast kind is rare a longer search mostly finds more of the same).
+  const unsigned long long budget = (unsigned long long)free_b / 100ull * (unsigned long long)ctx->opt_alloc_budget_pct;
+  const int cap = (int)std::min<unsigned long long>((unsigned long long)std::min(max_candidates, 64), std::max<unsigned long long>(1, budget / bytes));
   const bool probed = bytes >= 16ull * 8000000ull;   // (vhp_probe_stores says nothing about less than 128 MB)
-  std::vector<void*> cand;
-  int best = -1, tried = 0;
+  struct Held {  // (whatever way this function is left, only the keeper survives)
+    std::vector<void*> v;
+    void* keep = nullptr;
+    ~Held() { for (void* q : v) if (q != keep) (void)hipFree(q); }
+  } cand;
+  int best = -1, tried = 0, since_best = 0;
   float best_w = 0.f, best_s = 0.f;
   for (int k = 0; k < cap; ++k) {
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-    cand.push_back(p);
+    cand.v.push_back(p);
     ++tried;
     float w = 0.f, sp = 0.f;
     if (probed) {
       const int rc = vhp_probe_stores(ctx, p, bytes, &w, &sp);
-      if (rc != VHP_OK) { for (void* q : cand) (void)hipFree(q); return rc; }
+      if (rc != VHP_OK) return rc;
     }
     // (the two rates move together -- 4.9 / 3.6 on the slow kind, 6.0 / 5.3 on the fast, anything between on a buffer that straddles
-    // both --: their sum ranks the candidates)
-    if (best < 0 || w + sp > best_w + best_s) { best = k; best_w = w; best_s = sp; }
-    if (!probed || (w >= 5.5f && sp >= 4.7f)) break;   // the fast kind (5.6-6.1 / 4.7-5.4 by box): nothing better to find
+    // both --: their sum ranks the candidates; an improvement is more than the probe's own scatter of ~0.05 TB/s)
+    if (best < 0 || w + sp > best_w + best_s + 0.05f) { best = k; best_w = w; best_s = sp; since_best = 0; } else ++since_best;
+    if (!probed || (w >= 5.5f && sp >= 4.6f)) break;   // the fast kind (5.6-6.1 / 4.6-5.4 by box): nothing better to find
+    if (since_best >= 8) break;
   }
+  ctx->last_alloc_peak_bytes = (unsigned long long)tried * bytes;
+  ctx->last_alloc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (best < 0) return fail(ctx, VHP_ERR_HIP, "vhp_alloc_output: out of device memory");
-  for (int k = 0; k < (int)cand.size(); ++k) if (k != best) (void)hipFree(cand[k]);
-  ctx->placed.push_back(cand[best]);
-  *d_buf = cand[best];
+  cand.keep = cand.v[best];
+  ctx->placed.push_back(cand.keep);
+  *d_buf = cand.keep;
   if (whole_lines_TBps) *whole_lines_TBps = best_w;
   if (split_lines_TBps) *split_lines_TBps = best_s;
   if (n_tried) *n_tried = tried;
+  return VHP_OK;
+}
+
+int vhp_alloc_output_cost(const vhp_ctx* ctx, double* search_ms, unsigned long long* peak_bytes) {
+  if (!ctx) return VHP_ERR_ARG;
+  if (search_ms) *search_ms = ctx->last_alloc_ms;
+  if (peak_bytes) *peak_bytes = ctx->last_alloc_peak_bytes;
   return VHP_OK;
 }
 

@@ -92,6 +92,18 @@
 #define VHP_DIAG_TL_RESET
 #endif
 
+// EXPERIMENT (round 5): instruction-arbitration priority by phase -- a strip in its diagonal phase (the chain of its unit) above
+// the strips in their steady phase; the diagonal task of a y-major unit above both
+#if defined(VHP_EXP_PRIO_DIAG) && !defined(VHP_SIM)
+#define VHP_EXP_PRIO_SET(is_diag) wave_priority((is_diag) ? VHP_EXP_PRIO_DIAG : 0);
+#define VHP_EXP_PRIO_TASK_BEGIN wave_priority(VHP_EXP_PRIO_TASK);
+#define VHP_EXP_PRIO_END wave_priority(0);
+#else
+#define VHP_EXP_PRIO_SET(is_diag)
+#define VHP_EXP_PRIO_TASK_BEGIN
+#define VHP_EXP_PRIO_END
+#endif
+
 // back-off of a wavefront that waits (s_sleep units of 64 cycles): measured in round 2, 12 for a hand-off that is not
 // ready, 4 for a dependency that usually is (lesson 3)
 #ifndef VHP_BACKOFF_SLEEP

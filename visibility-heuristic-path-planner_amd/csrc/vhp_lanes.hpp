@@ -226,6 +226,8 @@ inline int lds_and(int* p, int v) { const int old = *p; *p = old & v; return old
 inline int g_add(int* p, int v) { const int old = *p; *p = old + v; return old; }
 inline unsigned long long g_add_u64(unsigned long long* p, unsigned long long v) { const unsigned long long old = *p; *p = old + v; return old; }
 inline unsigned long long g_peek_u64(const unsigned long long* p) { return *p; }
+// four consecutive ints at a uniform index (a 16-byte record that an earlier kernel wrote), as uniform values
+inline void g_load_rec4(const int* base, int idx, int& a, int& b, int& c, int& d) { a = base[4 * idx]; b = base[4 * idx + 1]; c = base[4 * idx + 2]; d = base[4 * idx + 3]; }
 inline void g_store_f64(double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) base[idx.v[l]] = v.v[l]; }
 inline void g_store_f64_if(const vb& p, double* base, const vi& idx, const vd& v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v.v[l]; }
 template <typename T> inline void g_store_scalar_if(const vb& p, T* base, const vi& idx, T v) {
@@ -474,6 +476,14 @@ VHP_LANE_FN unsigned long long g_peek_u64(const unsigned long long* p) {
   const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
+}
+// four consecutive ints at a uniform index (a 16-byte record that an earlier kernel wrote: one load, one round trip), as uniform values
+VHP_LANE_FN void g_load_rec4(const int* base, int idx, int& a, int& b, int& c, int& d) {
+  const int4 v = *reinterpret_cast<const int4*>(base + 4 * (size_t)idx);
+  a = __builtin_amdgcn_readfirstlane(v.x);
+  b = __builtin_amdgcn_readfirstlane(v.y);
+  c = __builtin_amdgcn_readfirstlane(v.z);
+  d = __builtin_amdgcn_readfirstlane(v.w);
 }
 VHP_LANE_FN void g_store_f64(double* base, vi idx, vd v) { base[idx] = v; }
 VHP_LANE_FN void g_store_f64_if(bool p, double* base, vi idx, vd v) { if (p) base[idx] = v; }

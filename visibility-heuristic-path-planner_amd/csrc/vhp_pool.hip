@@ -30,15 +30,16 @@ __global__ void __launch_bounds__(64 * kWaves, 1) vhp_pool_sweep(Args<OutT> a, i
   Worker<OutT, ANYW>::clear(lds, L, (int)threadIdx.x, 64 * W);
   __syncthreads();
   Worker<OutT, ANYW> wk;
-  wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
+  wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)), (int)blockIdx.x);
   wk.run();
 }
 
 // Launch order: one workgroup counting-sorts the 8 n_src units by the length of their march (then by cell count), longest first,
-// zeroes the pull queue, and
-// lays the units' boundary lines out in the scratch (line_base[u]: first 64-entry block of unit u; exclusive prefix sum
-// of UnitGeo::line_blocks in unit order).  Units of out-of-range sources weigh nothing and sort last (they are rejected
-// when they are installed).  If the lines do not fit `capacity_blocks` (the launcher sizes the scratch by an upper
+// sets the pull queue to where the launch starts pulling (queue0: 0, or behind the units that the contexts take by workgroup
+// index, Args::static_round), lays the units' boundary lines out in the scratch (first 64-entry block of unit u: exclusive prefix
+// sum of UnitGeo::line_blocks in unit order) and writes the launch's records: recs[k] = {unit, sx | sy << 16, line base, 0} of the
+// k-th unit in launch order.  Units of out-of-range sources weigh nothing, sort last and carry -1 in place of the source (they
+// are rejected when they are installed).  If the lines do not fit `capacity_blocks` (the launcher sizes the scratch by an upper
 // bound, so they do) nothing is swept and the error flag says so.
 constexpr int kBuckets = 1024;
 constexpr int kOrderLdsUnits = 8192;  // batches of up to 1024 sources keep the per-unit scratch of the ordering in LDS
@@ -71,7 +72,8 @@ __device__ __forceinline__ int block_exclusive_scan_1024(Arr arr, int n, int* wa
 // (PerUnit: int* in LDS, or line_base itself in global memory for batches whose units do not fit there)
 template <typename PerUnit>
 __device__ __forceinline__ void order_units(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order,
-                                            int* __restrict__ line_base, long long capacity_blocks, unsigned long long* __restrict__ queue,
+                                            int* __restrict__ line_base, int* __restrict__ recs, long long capacity_blocks,
+                                            unsigned long long* __restrict__ queue, unsigned long long queue0,
                                             int* __restrict__ err_flag, int* hist, int* wave_tot, PerUnit blocks) {
   const int n_units = n_src * kUnits;
   const double inv_area = 1.0 / ((double)nx * (double)ny), inv_side = 1.0 / (double)(nx > ny ? nx : ny);
@@ -109,24 +111,30 @@ __device__ __forceinline__ void order_units(const int32_t* __restrict__ src_xy, 
   for (int u = threadIdx.x; u < n_units; u += 1024) blocks[u] &= (1 << 20) - 1;
   __syncthreads();
   const int total = block_exclusive_scan_1024(blocks, n_units, wave_tot);
-  if ((const int*)blocks != (const int*)line_base)
-    for (int u = threadIdx.x; u < n_units; u += 1024) line_base[u] = blocks[u];
+  // the records, in launch order (order[] was written by this workgroup before the barriers above)
+  for (int k = threadIdx.x; k < n_units; k += 1024) {
+    const int u = order[k], s = u / kUnits;
+    const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
+    const bool inside = !(sx < 0 || sy < 0 || sx >= nx || sy >= ny);
+    reinterpret_cast<int4*>(recs)[k] = make_int4(u, inside ? (sx | (sy << 16)) : -1, blocks[u], 0);
+  }
   if (threadIdx.x == 0) {
     const bool fits = (long long)total <= capacity_blocks;
-    *queue = fits ? 0ull : (unsigned long long)n_units;
+    *queue = fits ? queue0 : (unsigned long long)n_units;
     if (!fits) atomicOr(err_flag, 4);
   }
 }
 
 __global__ void __launch_bounds__(1024) vhp_pool_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order,
-                                                       int* __restrict__ line_base, long long capacity_blocks,
-                                                       unsigned long long* __restrict__ queue, int* __restrict__ err_flag) {
+                                                       int* __restrict__ line_base, int* __restrict__ recs, long long capacity_blocks,
+                                                       unsigned long long* __restrict__ queue, unsigned long long queue0,
+                                                       int* __restrict__ err_flag) {
   __shared__ int hist[kBuckets];
   __shared__ int wave_tot[16];
   __shared__ int blocks[kOrderLdsUnits];
   VHP_DIAG_TL_RESET
-  if (n_src * kUnits <= kOrderLdsUnits) order_units(src_xy, n_src, nx, ny, order, line_base, capacity_blocks, queue, err_flag, hist, wave_tot, blocks);
-  else order_units(src_xy, n_src, nx, ny, order, line_base, capacity_blocks, queue, err_flag, hist, wave_tot, line_base);
+  if (n_src * kUnits <= kOrderLdsUnits) order_units(src_xy, n_src, nx, ny, order, line_base, recs, capacity_blocks, queue, queue0, err_flag, hist, wave_tot, blocks);
+  else order_units(src_xy, n_src, nx, ny, order, line_base, recs, capacity_blocks, queue, queue0, err_flag, hist, wave_tot, line_base);
 }
 
 }  // namespace pool
@@ -135,9 +143,9 @@ namespace {
 constexpr size_t kLdsLimit = 160 * 1024;
 constexpr int kQueueInts = 16;  // the pull counter (and padding) ahead of the order array
 
-// scratch of a launch: [pull counter, order[n_units], line_base[n_units]] [diagonal lines] [boundary lines]
+// scratch of a launch: [pull counter, recs[4 n_units], order[n_units], line_base[n_units]] [diagonal lines] [boundary lines]
 int diag_stride_of(int nx, int ny) { return ((nx < ny ? nx : ny) + 64 + 15) & ~15; }
-size_t head_bytes(int n_src) { return (((size_t)(kQueueInts + 2 * pool::kUnits * (size_t)n_src) * sizeof(int)) + 255) & ~(size_t)255; }
+size_t head_bytes(int n_src) { return (((size_t)(kQueueInts + 6 * pool::kUnits * (size_t)n_src) * sizeof(int)) + 255) & ~(size_t)255; }
 size_t diag_bytes(int n_src, int nx, int ny) { return (((size_t)n_src * 4 * (size_t)diag_stride_of(nx, ny) * sizeof(double)) + 255) & ~(size_t)255; }
 // 64-entry blocks of boundary lines a source can need, an upper bound: over its four quadrants ni * nj sums to nx * ny;
 // an x-major unit takes at most (min(ni,nj)/64) * (ni/64 + 2) blocks, a y-major one (ni/128 + 1) * (nj/64 + 2)
@@ -179,16 +187,15 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   Args<OutT> g;
   g.m.rows = a.rows; g.m.cols = a.cols; g.m.recip = a.recip;
   g.m.wpr = a.wpr; g.m.wpc = a.wpc; g.m.nx = a.nx; g.m.ny = a.ny;
-  g.src_xy = a.d_src;
   g.out = static_cast<OutT*>(a.d_out);
   g.field_stride = a.field_stride;
   g.err_flag = a.d_err;
   g.queue = reinterpret_cast<unsigned long long*>(a.d_queue);
   g.n_units = a.n_src * kUnits;
-  int* order = a.d_queue + kQueueInts;
+  int* recs = a.d_queue + kQueueInts;  // (16-byte aligned: the scratch is, and kQueueInts is a multiple of 4)
+  int* order = recs + 4 * (size_t)g.n_units;
   int* line_base = order + g.n_units;
-  g.order = order;
-  g.line_base = line_base;
+  g.recs = recs;
   g.diag = reinterpret_cast<double*>(scratch + head_bytes(a.n_src));
   g.diag_stride = diag_stride_of(a.nx, a.ny);
   g.lines = reinterpret_cast<vhp::lanes::Tagged*>(scratch + head_bytes(a.n_src) + diag_bytes(a.n_src, a.nx, a.ny));
@@ -196,6 +203,7 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   g.busy_cap = a.pool_busy_cap > 0 ? a.pool_busy_cap : waves;
   // two contexts take the largest units left, the others the smallest (0.75 against 0.78 ms with one head at 1000^2)
   g.n_head = a.pool_heads > 0 ? a.pool_heads : (sh.n_ctx >= 3 ? 2 : 1);  // (all three from the head: 0.51 / 0.70 ms on two boxes, this: 0.53 / 0.67)
+  if (g.n_head > sh.n_ctx) g.n_head = sh.n_ctx;
   g.tail_limit = (int)((long long)g.n_units * (a.pool_tail_pct > 0 ? a.pool_tail_pct : 15) / 100);  // (100 / 50 / 25 / 15 %: 0.56 / 0.55 / 0.53 / - and - / - / - / 0.67 ms on two boxes; round 4, with non-temporal stores: 5 / 15 / 30 / 60 %: 0.580 / 0.608 / 0.608 / 0.616 ms on a slow buffer, level on a fast one -- within the noise of 1-2 %)
   g.early_ctx = a.pool_early_ctx > 0 ? a.pool_early_ctx : sh.n_ctx;
   g.late_after = (int)((long long)g.n_units * (a.pool_late_pct > 0 ? a.pool_late_pct : 50) / 100);
@@ -203,9 +211,13 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   // slow one 0.583 / 0.582 / 0.597 / 0.589 / 0.591 (bound by the memory there); C5 3.567 / 3.483 / 3.476 / 3.474 / 3.482; 128 sources at
   // 2048^2 1.316 / - / 1.277 / - / 1.238; 512 at 512^2 0.445 / - / 0.419 / - / 0.416
   g.claim_ahead = a.pool_claim_ahead >= 0 ? a.pool_claim_ahead : 48;
+  // the first unit of every context by workgroup index, the queue behind them (Args::static_round)
+  g.n_groups = a.n_cus;
+  g.static_round = a.pool_static_round != 0 && g.early_ctx >= sh.n_ctx && (long long)g.n_units >= (long long)sh.n_ctx * a.n_cus;
+  const unsigned long long queue0 = g.static_round ? ((unsigned long long)(g.n_head * a.n_cus) | ((unsigned long long)((sh.n_ctx - g.n_head) * a.n_cus) << 32)) : 0ull;
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs
-  hipLaunchKernelGGL(vhp_pool_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, order, line_base,
-                     line_blocks_per_source(a.nx, a.ny) * a.n_src, reinterpret_cast<unsigned long long*>(a.d_queue), a.d_err);
+  hipLaunchKernelGGL(vhp_pool_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, order, line_base, recs,
+                     line_blocks_per_source(a.nx, a.ny) * a.n_src, reinterpret_cast<unsigned long long*>(a.d_queue), queue0, a.d_err);
   hipLaunchKernelGGL(k, dim3((unsigned)a.n_cus), dim3(64 * waves), sh.lds, a.stream, g, sh.n_ctx);
   const hipError_t e = hipGetLastError();
   if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);

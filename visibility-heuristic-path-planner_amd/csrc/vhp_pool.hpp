@@ -67,18 +67,19 @@ VHP_DIAG_TL_DECLARE
 // block (66 entries: the block's 64 and the neighbour of its first step on either side), the ring of the boundary values
 // this strip produces (its last 256 steps), a dummy slot; then the scheduler's ints:
 //   [0] queue empty   [2] units installed so far (sequence numbers)   [3] wavefronts sweeping a strip right now
-//   [4] the late contexts are open
+//   [4] the late contexts are open   [5] bit c: context c has taken its first unit (Args::static_round)
 //   [8 + w] header of wavefront w's ring: tag of the strip it belongs to << 14 | steps of it that are in the ring
 //   per context: state (0 free, 1 being installed, 2 active), claim word (seq << 8 | next strip; -1 while not active),
-//   unit, strips, strips not yet finished, sx | sy << 16, diagonal entries ready, (pad), then progress[strip] (steps
-//   swept) and owner[strip] (the wavefront that sweeps it)
+//   unit, strips, strips not yet finished, sx | sy << 16, diagonal entries ready, first block of the unit's boundary lines
+//   (the latency sweep keeps another word there: vhp_lat.hpp kDiagZero), then progress[strip] (steps swept) and owner[strip]
+//   (the wavefront that sweeps it)
 constexpr int kSchedHead = 8 + 16, kCtxHead = 8;
 constexpr int kHdr = 8;
 constexpr int kBin = 72;   // doubles of a boundary-in slab (66 used)
 constexpr int kRing = 256; // entries of a wavefront's boundary ring, indexed by the marching coordinate & 255
 constexpr int kRingSafe = 232;  // a reader trusts ring entries only while the writer is at most this many steps past them
-enum { kQEmpty = 0, kSeq = 2, kBusy = 3, kLateOpen = 4 };
-enum { kState = 0, kWord = 1, kUnit = 2, kNStrips = 3, kLeft = 4, kSxSy = 5, kDiagReady = 6 };
+enum { kQEmpty = 0, kSeq = 2, kBusy = 3, kLateOpen = 4, kFirstDone = 5 };
+enum { kState = 0, kWord = 1, kUnit = 2, kNStrips = 3, kLeft = 4, kSxSy = 5, kDiagReady = 6, kLineBase = 7 };
 struct Layout {
   int W, C, S;
   int tiles, slabs, bins, rings, dummies, sched, ctx_stride, total;
@@ -115,17 +116,25 @@ struct Shared {
 template <typename OutT>
 struct Args {
   Map m;
-  const int32_t* src_xy;
   OutT* out;
   long long field_stride;
   int* err_flag;
-  const int* order;   // unit ids, largest first
+  // The launch order (vhp_pool_order): record k = {unit, sx | sy << 16 (-1: a source outside the grid), first 64-entry block of
+  // the unit's boundary lines, 0} of the k-th unit, longest march first -- one 16-byte load tells a wavefront all it needs to install
+  // a unit (the unit id, then the source, then the line base used to be three dependent loads)
+  const int* recs;
   unsigned long long* queue;  // units taken so far: from the head (low word) and from the tail (high word)
   int n_units;
+  // The first unit of every context is handed out by workgroup index instead of by the queue: context c of workgroup g takes
+  // record c * n_groups + g (c < n_head) or n_units - 1 - ((c - n_head) * n_groups + g), and the queue starts behind them
+  // (n_head * n_groups | (C - n_head) * n_groups << 32: vhp_pool_order writes it).  Only when n_units >= C * n_groups and every
+  // context is open from the start.  Without it a launch opens with C * n_groups atomics on one word, the slowest of which
+  // returns ~10 us after the first.
+  bool static_round;
+  int n_groups;
   double* diag;       // scratch: diag(k) of the y-major unit of (source s, quadrant q) at (4 s + q) * diag_stride + k
   int diag_stride;
-  Tagged* lines;      // scratch: the boundary lines; strip p of unit u at 64 * (line_base[u] + p * blocks(u)) entries
-  const int* line_base;
+  Tagged* lines;      // scratch: the boundary lines; strip p of a unit at 64 * (its line base + p * blocks of its march) entries
   uint64_t epoch;     // the tag of this launch (never 0, never repeated on this scratch)
   int busy_cap;       // a workgroup takes another unit only while fewer than this many of its wavefronts are sweeping
   int n_head;         // contexts 0 .. n_head-1 take the largest unit left, the others the smallest ...
@@ -624,6 +633,7 @@ struct XStrip {
     g.xsteps(nb, lo, hi);
     lo = imax(lo, j0);
     if (lo > hi) return;
+    VHP_EXP_PRIO_SET(lo < j0 + kXRows)
     const int blk = g.X(lo) >> 6;
     {
       vd rv;
@@ -816,6 +826,7 @@ struct YStrip {
     g.ysteps(nb, lo, hi);
     lo = imax(lo, jstart);
     if (lo > hi) return;
+    VHP_EXP_PRIO_SET(lo <= i0 + kYCols - 1)
     const int blk = g.Y(lo) >> 6;
     {
       const vi xa = vmin(vmax(ia, 0), g.ni - 1) * DX + g.sx;
@@ -927,14 +938,16 @@ template <typename OutT, bool ANYW = false>
 struct Worker {
   Args<OutT> a;
   Shared sh;
-  int w;
+  int w, group;
   vi lane;
 
-  VHP_FN void init(const Args<OutT>& a_, double* lds, const Layout& L, int w_) {
+  // (group: the index of the workgroup, 0 .. Args::n_groups - 1)
+  VHP_FN void init(const Args<OutT>& a_, double* lds, const Layout& L, int w_, int group_) {
     a = a_;
     sh.lds = lds;
     sh.L = L;
     w = w_;
+    group = group_;
     lane = lane_id();
   }
 
@@ -955,13 +968,18 @@ struct Worker {
   VHP_FN int find_work(int& c_out, int& p_out, int& qo_out, int& sx_out, int& sy_out) {
     int* sc = sh.sched();
     int best_c = -1, best_seq = 0x7fffffff, best_p = 0, best_word = 0, best_qo = 0, best_sx = 0, best_sy = 0;
-    int free_c = -1;
+    int free_c = -1, free_first = -1;
     bool unclaimed = false, installing = false;
     const bool late_open = a.early_ctx >= sh.L.C || lds_poll(sc + kLateOpen) != 0;  // (raised by this workgroup's own pulls: install)
+    const int first_done = a.static_round ? lds_poll(sc + kFirstDone) : -1;  // (a context's first unit does not come out of the queue)
     for (int c = 0; c < sh.L.C; ++c) {
       int* cx = sh.ctx(c);
       const int st = lds_poll(cx + kState);
-      if (st == 0) { if (c < a.early_ctx || late_open) free_c = c; continue; }
+      if (st == 0) {
+        if (((first_done >> c) & 1) == 0) free_first = c;
+        else if (c < a.early_ctx || late_open) free_c = c;
+        continue;
+      }
       if (st == 1) { installing = true; continue; }
       const int word = lds_poll(cx + kWord);
       if (word < 0) continue;  // being recycled
@@ -994,14 +1012,15 @@ struct Worker {
     // Another unit only while the workgroup is short of work: a CU that holds a large unit (many strips in flight) keeps
     // its whole share of the store path for it -- the march of a full-size octant is the longest dependent chain of the
     // launch, and every other unit on its CU slows each of its steps down.
-    if (free_c >= 0 && !q_empty && lds_poll(sc + kBusy) < a.busy_cap) {
+    if (free_first >= 0) free_c = free_first;
+    if (free_c >= 0 && (!q_empty || free_first >= 0) && lds_poll(sc + kBusy) < a.busy_cap) {
       sim_point();
       if (lds_cas(sh.ctx(free_c) + kState, 0, 1) == 0) {
         install(free_c);
       }
       return kRetry;
     }
-    if (q_empty && !unclaimed && !installing) return kExit;
+    if (q_empty && !unclaimed && !installing && free_first < 0) return kExit;
     return kIdle;
   }
 
@@ -1009,28 +1028,37 @@ struct Worker {
   VHP_FN void install(int c) {
     int* sc = sh.sched();
     int* cx = sh.ctx(c);
-    // (the small end only feeds the gaps beside the large units: once its share is gone, what is left leaves in size order,
-    // largest first, so that the launch ends on its smallest units and not on whatever the two ends met at)
-    bool from_tail = c >= a.n_head;
-    if (from_tail && (int)(g_peek_u64(a.queue) >> 32) >= a.tail_limit) from_tail = false;
-    const unsigned long long old = g_add_u64(a.queue, from_tail ? (1ull << 32) : 1ull);
-    const unsigned taken_head = (unsigned)old, taken_tail = (unsigned)(old >> 32);
-    const int idx = from_tail ? a.n_units - 1 - (int)taken_tail : (int)taken_head;
-    if ((int)(taken_head + taken_tail) >= a.late_after) lds_publish(sc + kLateOpen, 1);
-    sim_progress();
-    if (taken_head + taken_tail >= (unsigned)a.n_units) {
-      lds_publish(sc + kQEmpty, 1);
-      lds_publish(cx + kState, 0);
-      return;
+    int idx;
+    if (a.static_round && ((lds_poll(sc + kFirstDone) >> c) & 1) == 0) {
+      // the context's first unit: by workgroup index (only the wavefront that holds the context in state 1 gets here)
+      lds_or(sc + kFirstDone, 1 << c);
+      idx = c < a.n_head ? c * a.n_groups + group : a.n_units - 1 - ((c - a.n_head) * a.n_groups + group);
+      sim_progress();
+    } else {
+      // (the small end only feeds the gaps beside the large units: once its share is gone, what is left leaves in size order,
+      // largest first, so that the launch ends on its smallest units and not on whatever the two ends met at)
+      bool from_tail = c >= a.n_head;
+      if (from_tail && (int)(g_peek_u64(a.queue) >> 32) >= a.tail_limit) from_tail = false;
+      const unsigned long long old = g_add_u64(a.queue, from_tail ? (1ull << 32) : 1ull);
+      const unsigned taken_head = (unsigned)old, taken_tail = (unsigned)(old >> 32);
+      idx = from_tail ? a.n_units - 1 - (int)taken_tail : (int)taken_head;
+      if ((int)(taken_head + taken_tail) >= a.late_after) lds_publish(sc + kLateOpen, 1);
+      sim_progress();
+      if (taken_head + taken_tail >= (unsigned)a.n_units) {
+        lds_publish(sc + kQEmpty, 1);
+        lds_publish(cx + kState, 0);
+        return;
+      }
     }
-    const int unit = uniform(a.order[idx]);
+    int unit, sxsy, lbase, rsvd;
+    g_load_rec4(a.recs, idx, unit, sxsy, lbase, rsvd);
     const int s = unit / kUnits, qo = unit - s * kUnits;
-    const int sx = uniform(a.src_xy[2 * s]), sy = uniform(a.src_xy[2 * s + 1]);
-    if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
+    if (sxsy < 0) {  // units of a rejected source do nothing
       if (qo == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
       lds_publish(cx + kState, 0);
       return;
     }
+    const int sx = sxsy & 0xffff, sy = sxsy >> 16;
     UnitGeo ug;
     ug.init(a.m.nx, a.m.ny, qo, sx, sy);
     OutT* field = a.out + (size_t)s * a.field_stride;
@@ -1047,8 +1075,9 @@ struct Worker {
     lds_set_int(cx + kUnit, unit);
     lds_set_int(cx + kNStrips, ug.n_strips);
     lds_set_int(cx + kLeft, ug.n_strips);
-    lds_set_int(cx + kSxSy, sx | (sy << 16));
+    lds_set_int(cx + kSxSy, sxsy);
     lds_set_int(cx + kDiagReady, 0);
+    lds_set_int(cx + kLineBase, lbase);
     for (int k0 = 0; k0 < ug.n_strips; k0 += kLanes) lds_store_i_if(lane + k0 < ug.n_strips, sh.prog(c), lane + k0, 0);
     const int seq = lds_add(sc + kSeq, 1) + 1;
     lds_publish(cx + kWord, seq << 8);
@@ -1068,6 +1097,7 @@ struct Worker {
   VHP_FN void run_diag(int* cx, int sx, int sy, double* dline) {
     DiagTask<DX, DY> dt;
     dt.init(a.m, sx, sy, dline);
+    VHP_EXP_PRIO_TASK_BEGIN
     while (!dt.done()) {
       const int ready = dt.run_chunk();
       stores_done();  // the entries are in memory (L2) before the count says so: the strips that load them run on this CU
@@ -1075,6 +1105,7 @@ struct Worker {
       sim_progress();
       sim_point();
     }
+    VHP_EXP_PRIO_END
   }
 
   // A strip of context c is finished: count down, free the context after the last.
@@ -1087,8 +1118,8 @@ struct Worker {
     sim_progress();
   }
 
-  // the boundary line of strip p of `unit`
-  VHP_FN Tagged* line_of(int unit, int p, int nb) const { return a.lines + (size_t)64 * ((size_t)uniform(a.line_base[unit]) + (size_t)p * nb); }
+  // the boundary line of strip p of the unit in context c
+  VHP_FN Tagged* line_of(int c, int p, int nb) const { return a.lines + (size_t)64 * ((size_t)lds_int_at(sh.ctx(c) + kLineBase) + (size_t)p * nb); }
   // tag of strip p of the unit in context c (claim sequence number of the unit, strip)
   VHP_FN int tag_of(int c, int p) const { return (((lds_int_at(sh.ctx(c) + kWord) >> 8) & 0x1ff) << 8) | p; }  // 17 bits: tag << 14 stays positive
 
@@ -1098,7 +1129,7 @@ struct Worker {
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* mine = sh.prog(c) + p;
-    xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(unit, p, g.Nbx) : nullptr,
+    xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(c, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(c, p, g.Nbx) : nullptr,
                a.epoch, p > 0 ? lds_int_at(sh.owner(c) + (p - 1)) : -1, p > 0 ? tag_of(c, p - 1) : 0);
     xs.init(a.m, sx, sy, field, sh, w, p);
     VHP_DIAG_TL_STRIPS(1)
@@ -1119,7 +1150,7 @@ struct Worker {
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* mine = sh.prog(c) + q;
-    ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(unit, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(unit, q, g.Nby) : nullptr,
+    ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(c, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(c, q, g.Nby) : nullptr,
                a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
     ys.init(a.m, sx, sy, field, sh, w, q, dline);
     VHP_DIAG_TL_STRIPS(1)
@@ -1159,6 +1190,7 @@ struct Worker {
       if (r == kRetry) continue;
       lds_add(sh.sched() + kBusy, 1);
       run_strip(c, p, qo, sx, sy);
+      VHP_EXP_PRIO_END
       lds_add(sh.sched() + kBusy, -1);
     }
   }

@@ -223,13 +223,22 @@ struct StoreEmit {
   static constexpr bool kMulti = MULTI;    // fronts may be longer than one round of W strips
   OutT* __restrict__ out;
   int nx;
-  typedef OutT Two __attribute__((ext_vector_type(2)));
-  template <typename T> static __device__ __forceinline__ void put(T* p, T v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+  // A pair is stored with ONE instruction wherever it lies: on an odd pitch, or in a field that starts off the 16-byte grid, every
+  // other pair is aligned to its cells only.  The type says so (aligned to one cell), which keeps the access defined; gfx950 serves
+  // global accesses at any 4-byte alignment (the unaligned access mode ROCm runs the device in), so it stays one global_store.
+  typedef OutT Two __attribute__((ext_vector_type(2), aligned(sizeof(OutT))));
+  static __device__ __forceinline__ void put(OutT* p, OutT v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+  // (not a template over the pointer type: a template argument drops the typedef's alignment)
+  static __device__ __forceinline__ void put2(char* at, OutT a, OutT b) {
+    Two* p = reinterpret_cast<Two*>(at);
+    const Two v = {a, b};
+    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+  }
   __device__ __forceinline__ StoreEmit(OutT* field, int nx_, int) : out(field), nx(nx_) {}
   // both cells valid; off = (y*nx + x) * kCellBytes, maintained incrementally by the caller
   __device__ __forceinline__ void pair_at(uint32_t off, int, int, double v0, double v1) {
     VHP_DIAG_FRONT_STORE_GUARD
-    put(reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off), Two{static_cast<OutT>(v0), static_cast<OutT>(v1)});
+    put2(reinterpret_cast<char*>(out) + off, static_cast<OutT>(v0), static_cast<OutT>(v1));
   }
   // `both`: store the pair; else `one`: store only the cell at off + sel*kCellBytes (value vs)
   __device__ __forceinline__ void pair_or_single_at(uint32_t off, int, int, double v0, double v1, bool both, bool one,
@@ -237,7 +246,7 @@ struct StoreEmit {
     asm volatile("" : "+v"(vs));  // keep the compiler from splitting the 16-byte store to share a half with the single
     VHP_DIAG_FRONT_STORE_GUARD
     if (both)
-      put(reinterpret_cast<Two*>(reinterpret_cast<char*>(out) + off), Two{static_cast<OutT>(v0), static_cast<OutT>(v1)});
+      put2(reinterpret_cast<char*>(out) + off, static_cast<OutT>(v0), static_cast<OutT>(v1));
     else if (one)
       put(reinterpret_cast<OutT*>(reinterpret_cast<char*>(out) + off + (uint32_t)(sel * kCellBytes)), static_cast<OutT>(vs));
   }
