@@ -52,9 +52,13 @@ for name, k in picks:
     st = np.cumsum(h[:, 1].astype(np.int64).sum(0))
     last = int(np.nonzero(by)[0].max()) + 1
     print("%s %s buffer %d: %.3f ms; bytes in the histogram %.3f GB over %d bins of 10 us" % (tag, name, k, ms, by.sum() / 1e9, last), flush=True)
-    print("  t_us   GB/s(10us)  strips running")
+    # per workgroup: wavefronts sweeping a strip at the end of every bin -- how many workgroups have (nearly) all of theirs busy, i.e.
+    # could use a wavefront of another CU, and how many have idle ones
+    per_wg = np.cumsum(h[:, 1].astype(np.int64), axis=1)
+    wmax = int(per_wg.max())
+    print("  t_us   GB/s(10us)  strips running   workgroups with >= %d sweeping   with <= %d" % (wmax - 1, wmax // 2))
     for b in range(last):
-        print("  %4d   %8.0f   %5d" % (10 * b, by[b] / 1e-5 / 1e9, st[b]))
+        print("  %4d   %8.0f   %5d   %5d   %5d" % (10 * b, by[b] / 1e-5 / 1e9, st[b], int((per_wg[:, b] >= wmax - 1).sum()), int((per_wg[:, b] <= wmax // 2).sum())))
     rows[name] = (by[:last], st[:last], ms)
 with open(os.path.join(ROOT, "gpurun_out", "timeline_%s.csv" % tag), "w") as f:
     f.write("# %s: pool sweep, %d sources at %d^2; bytes swept per 10 us bin (GB/s) and strips running; launch ms: %s\n" % (tag, n, side, ", ".join("%s %.3f" % (k, v[2]) for k, v in rows.items())))

@@ -92,11 +92,21 @@
 #define VHP_DIAG_TL_RESET
 #endif
 
-// EXPERIMENT (round 5): instruction-arbitration priority by phase -- a strip in its diagonal phase (the chain of its unit) above
-// the strips in their steady phase; the diagonal task of a y-major unit above both
-#if defined(VHP_EXP_PRIO_DIAG) && !defined(VHP_SIM)
-#define VHP_EXP_PRIO_SET(is_diag) wave_priority((is_diag) ? VHP_EXP_PRIO_DIAG : 0);
-#define VHP_EXP_PRIO_TASK_BEGIN wave_priority(VHP_EXP_PRIO_TASK);
+// Instruction-arbitration priority by phase (s_setprio; round 5): a strip that is growing along its diagonal is the chain of its unit
+// -- the strip above cannot start before it has got there --, so it issues ahead of the strips in their steady phase that share its
+// SIMD; the diagonal task of a y-major unit (every strip of the unit waits for its seeds) ahead of both; idle wavefronts polling for
+// work behind everybody.  Measured (tools/ab_slowfast.py, 256 sources at 1000^2, fast buffer): 0.446 -> 0.432 ms; 128 sources at
+// 2048^2 1.039 -> 1.000; 96 at 1000^2 0.304 -> 0.286; nothing where the memory bounds the launch (slow buffer 0.583, C5 3.53).
+// -DVHP_PRIO_DIAG=0 -DVHP_PRIO_TASK=0: off.
+#ifndef VHP_PRIO_DIAG
+#define VHP_PRIO_DIAG 1
+#endif
+#ifndef VHP_PRIO_TASK
+#define VHP_PRIO_TASK 2
+#endif
+#if !defined(VHP_SIM) && (VHP_PRIO_DIAG != 0 || VHP_PRIO_TASK != 0)
+#define VHP_EXP_PRIO_SET(is_diag) wave_priority((is_diag) ? VHP_PRIO_DIAG : 0);
+#define VHP_EXP_PRIO_TASK_BEGIN wave_priority(VHP_PRIO_TASK);
 #define VHP_EXP_PRIO_END wave_priority(0);
 #else
 #define VHP_EXP_PRIO_SET(is_diag)

@@ -90,7 +90,7 @@ VHP_HD Layout make_layout(int W, int C, int nx, int ny, int tstride = kTStride) 
   L.S = ((imax(nx, ny) + 63) / 64 + 2 + 3) & ~3;  // most strips a unit can have (+ slack)
   int o = 0;
   L.tiles = o; o += W * kXRows * tstride;
-  L.slabs = o; o += W * 2 * kBlock;  // (64 per wavefront here; the latency sweep, vhp_lat.hpp, keeps two blocks per wavefront)
+  L.slabs = o; o += W * 2 * kBlock;  // (two blocks of reciprocals per wavefront: the current one and the next)
   L.bins = o; o += W * kBin;
   L.rings = o; o += W * kRing;
   L.dummies = o; o += W * 16;  // (8 per wavefront here; the latency sweep, vhp_lat.hpp, uses 16)
@@ -313,7 +313,7 @@ struct XStrip {
     m = m_; out = out_;
     g.init(m.nx, m.ny, sx, sy);
     tile = sh.lds + sh.L.tiles + w * kXRows * kTS;
-    slab = sh.lds + sh.L.slabs + w * kBlock;
+    slab = sh.lds + sh.L.slabs + w * (2 * kBlock);  // (two blocks per wavefront: XStrip16 and the latency sweep keep the next block's too)
     bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * 8;
     r_stride = ((m.nx >> 3) & 1) ? 2 : 1;
@@ -670,6 +670,331 @@ struct XStrip {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
+// What a 16-step window reads from the strip below: v[0] = its value one step BEFORE the window's first-marched cell, v[k]
+// (k >= 1) at step k - 1 of the window.  Straight out of the writer's ring, the writer's header read before and after (Link::fetch's
+// check without its copy into the slab); the whole block from global memory if the writer is gone or too far ahead.
+// (cw = lowest coordinate of the window, c_first = its first-marched coordinate.)
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+struct Below16 {
+  static constexpr int NB = 17;
+  bool ring;   // the values came out of the writer's ring and are still to be checked against h1 / h2
+  int h1, h2;
+  vd v[NB];
+
+  VHP_FN void from_ring(const Link<D>& lk, int cw, int c_first) {
+    h1 = lds_peek(lk.rd_hdr);
+    sim_point();
+    v[0] = lds_bcast(lk.rd_ring, (c_first - D) & (kRing - 1));
+    const int rw = cw & (kRing - 1);
+#pragma unroll
+    for (int k = 1; k < NB; ++k) v[k] = lds_bcast(lk.rd_ring, rw + (D > 0 ? k - 1 : 16 - k));
+    sim_point();
+    h2 = lds_peek(lk.rd_hdr);
+    ring = true;
+  }
+  VHP_FN void from_slab(const double* bin, int cw, int c_first) {
+    v[0] = lds_bcast(bin, 1 + (c_first & 63) - D);
+    const int b = 1 + (cw & 63);
+#pragma unroll
+    for (int k = 1; k < NB; ++k) v[k] = lds_bcast(bin, b + (D > 0 ? k - 1 : 16 - k));
+    ring = false;
+  }
+  // the values of steps ia - 1 .. last_needed of the strip below (block nb), waiting for the writer if it has not got there
+  VHP_FN void get(Link<D>& lk, const double* bin, int cw, int c_first, int ia, int last_needed, int nb) {
+    if (!VHP_DIAG_WAITS) { from_slab(bin, cw, c_first); return; }
+    if (lk.bin_block == nb) { from_slab(bin, cw, c_first); return; }
+    from_ring(lk, cw, c_first);
+    for (;;) {
+      const int ha = uniform(h1), hb = uniform(h2);
+      if ((ha >> 14) != lk.rd_tag) break;                         // the writer has finished that strip: its line is (being) stored
+      if ((ha & 0x3fff) <= last_needed) {                          // not swept yet
+        ready_backoff();
+        from_ring(lk, cw, c_first);
+        continue;
+      }
+      // (a writer is at most one window past what it has published: an entry of step s is safe while published - s <= kRingSafe)
+      if ((hb >> 14) != lk.rd_tag || (hb & 0x3fff) - (ia - 1) > kRingSafe) { sim_count(3); break; }
+      sim_count(0);
+      ring = false;
+      return;
+    }
+    lk.fetch(ia, last_needed, nb);
+    from_slab(bin, cw, c_first);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// x-major strip p of a unit in windows of SIXTEEN steps (round 5; widths that are a multiple of 8): rows j = 64p + lane; steps
+// i = 64p .. ni-1; cells (i, j), j <= i.  The window machinery is the latency sweep's (vhp_lat.hpp LatX): a window is 16 adjacent
+// cells of every row, aligned to 16 cells of x; heads, tails and ragged ends are the same window code -- steps that do not
+// exist leave garbage where garbage does no harm (a row is garbage until its diagonal cell switches it on; cells outside
+// j <= i <= i_last are never stored; the reciprocal of a step that does not exist is 0) --, the boundary values of the strip below
+// come straight out of its writer's ring, the ones this strip produces go to its ring once per window out of the tile's last row,
+// and they are published BEFORE the window's own cells are stored.  A steady window is ~ 20 instructions a step all told where
+// the 8-step windows of XStrip took ~ 35 (half of them around the steps: fetch, publish, flush decisions, loop), and a strip that
+// is growing along its diagonal -- the chain of its unit -- hands over every 16 steps at 2/3 of the cost.
+// What the latency sweep does not need and this does: WHOLE LINES.  On a pitch that is an odd multiple of 64 bytes every other row
+// starts half a 128-byte line off the grid: the lines of such a row ("O" rows) are the cells [xw - 8, xw + 8) of two adjacent
+// windows.  The tile stays 16 columns: an O row's line is read out of the tile in the MIDDLE of a window -- after step 7, when the
+// window's first-marched half is new and the other half still holds the window before (the LDS executes a wavefront's
+// instructions in order: the reads are issued before step 8's write) -- and stored with the others at the end; "E" rows (lines on
+// the window grid) are read after step 15.  Every row leaves as whole lines, 8 rows x 128 bytes per store instruction.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY, typename OutT>
+struct XStrip16 {
+  static constexpr int CB = sizeof(OutT);
+  static constexpr int kW = 16;
+  Map m;
+  Quad<DX, DY> g;
+  OutT* out;
+  double* tile;   // 64 rows x 16 columns (pitch kTStride): column c = x - (lowest x of the window)
+  double* slab;   // reciprocals of the step indices of two blocks of 64 coordinates (the current one and the next), indexed by x & 127
+  double* bin;    // = lk.bin
+  Link<DX> lk;
+  int p, j0, rows_here, i_first, i_last;
+  bool below, has_consumer;
+  // The two sets of rows: E (lines on the window grid: n_e = 4 or 8 store instructions a window) and O (lines half a window off:
+  // four store instructions, if there are any): first row and row step.  (Where EVERY row is half a window off -- a pitch that is a
+  // multiple of 128 bytes under fields that start half a line into one: a caller's buffer -- the rows go as E rows, in half lines.)
+  int e_first, o_first, rstep, n_e;
+  bool has_o;
+  int blk;        // the current block (x >> 6): its occupancy words are in ow
+  int pf_blk;     // the block whose operands wait in ow_nx / rv_nx (requested when the current block began), or -1 ...
+  int staged_blk; // ... and the block whose reciprocals were put into the slab last
+  bool pf_wait;   // the loads of ow_nx / rv_nx have not been waited for yet
+  int tl_lo;      // (timeline builds: the first step of the current block that this strip sweeps)
+  vi lane, tile_l, fl_e, fl_o;
+  vu32 fl_off;
+  vd prev, jd;
+  vu64 ow, ow_nx;
+  vd rv_nx;
+
+  // (the caller has initialised lk)
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int p_) {
+    m = m_; out = out_;
+    g.init(m.nx, m.ny, sx, sy);
+    tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
+    slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
+    bin = lk.bin;
+    lane = lane_id();
+    tile_l = lane * kTStride;
+    p = p_;
+    j0 = kXRows * p;
+    rows_here = imin(kXRows, g.rows_total - j0);
+    i_first = j0;
+    i_last = g.ni - 1;
+    below = p > 0;
+    has_consumer = p + 1 < g.Px;
+    {
+      // Which rows start on the line grid?  Row r's first cell is cell (cell0 + y nx) of the buffer; nx = 8 m: bit 3 of that is
+      // (cell0 >> 3) + y m mod 2.  (cell0 is a multiple of 8 wherever the fields start on a line or half a line -- everywhere but in
+      // a caller's buffer at an odd 16-byte offset, where no row has whole lines on any grid.)
+      const int cell0 = (int)((reinterpret_cast<uintptr_t>(out) / CB) & 15);
+      const int mm = (m.nx >> 3) & 1;
+      const int ph0 = ((cell0 >> 3) + (g.sy + DY * j0) * mm) & 1;   // row 0 of the strip: 0 = E, 1 = O
+      if (mm) { rstep = 2; n_e = 4; has_o = true; e_first = ph0; o_first = ph0 ^ 1; }
+      else { rstep = 1; n_e = 8; has_o = false; e_first = o_first = 0; }
+      // flush geometry: lane -> (row slot = lane >> 3, piece = lane & 7 = cells 2 * piece, + 1 of the line's 16); the row slots of a
+      // store instruction are counted upward in y, so that byte offsets from its lowest row are never negative
+      const vi rslot = lane >> 3, pc = lane & 7;
+      const vi rs = DY > 0 ? rslot : 7 - rslot;
+      fl_e = rslot * (rstep * kTStride) + pc * 2;
+      fl_o = rslot * (rstep * kTStride) + ((pc * 2 + 8) & 15);
+      fl_off = to_u32((rs * (rstep * m.nx) + pc * 2) * CB);
+    }
+    prev = vd(0.0);
+    jd = to_f64(lane + j0);
+    pf_blk = -1;
+    pf_wait = false;
+    staged_blk = -0x7fffffff;
+    blk = -0x7fffffff;
+    tl_lo = i_first;
+  }
+
+  // the occupancy word of every lane's row and the reciprocals of the step indices of the 64 coordinates of block blk (x >> 6)
+  VHP_FN void load_ops(int b, vu64& o, vd& rv) {
+    const vi yl = (vmin(lane + j0, g.rows_total - 1)) * DY + g.sy;
+    o = g_load_u64(m.rows, yl * m.wpr + (1 + b));
+    const vi it = (lane + (b * 64 - g.sx)) * DX;
+    const vb ok = (it >= 0) && (it < g.ni);
+    rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
+  }
+  VHP_FN bool block_in_march(int b) const { const int xe = g.X(i_last); return DX > 0 ? 64 * b <= xe : 64 * b + 63 >= xe; }
+  VHP_FN void prefetch_ops(int b) { pf_blk = b; pf_wait = true; load_ops(b, ow_nx, rv_nx); }
+  VHP_FN void stage(int b, vd rv) {
+    wave_sync();
+    lds_store(slab, lane + kBlock * (b & 1), rv);
+    wave_sync();
+    staged_blk = b;
+  }
+  VHP_FN void settle() {
+    if (pf_wait) { pin(ow_nx); pin(rv_nx); pf_wait = false; }
+  }
+  VHP_FN void stage_next() {
+    if (pf_blk != -1 && staged_blk != pf_blk) { settle(); stage(pf_blk, rv_nx); }
+  }
+  // block b becomes the current one (the first block of the strip, or the one after the current)
+  VHP_FN void enter_block(int b) {
+    if (pf_blk == b) { stage_next(); ow = ow_nx; }
+    else { vd rv; load_ops(b, ow, rv); pin(ow); pin(rv); stage(b, rv); }
+    blk = b;
+    if (block_in_march(b + DX)) prefetch_ops(b + DX); else pf_blk = -1;
+  }
+
+  // the lane's pairs of FOUR store instructions' worth of lines out of the tile: instruction u = the rows first + rstep (8 u + row slot);
+  // fl = fl_e (the line = the window's 16 columns) or fl_o (the line = columns 8 .. 15, then 0 .. 7)
+  VHP_FN void load_lines4(int first, const vi& fl, vd (&fa)[4], vd (&fb)[4]) {
+    const vi t0 = fl + first * kTStride;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { fa[u] = lds_load(tile, t0 + u * (8 * rstep * kTStride)); fb[u] = lds_load(tile, t0 + (u * (8 * rstep * kTStride) + 1)); }
+  }
+  // ... and into memory: s_base = the step index of the line's lowest-step cell, xa = its lowest x.  A cell (i', j) exists for
+  // j <= i' <= lim.  An instruction is whole (every cell a cell of a row of this strip: one 16-byte store per lane), skipped (no row of
+  // it has a cell in this line), or goes cell by cell.
+  VHP_FN void store_lines4(int first, int s_base, int xa, int lim, const vd (&fa)[4], const vd (&fb)[4]) {
+    VHP_DIAG_NOXSTORE_RETURN
+    OutT* base = out + (long)(DY > 0 ? g.Y(j0 + first) : g.Y(j0 + first + rstep * 7)) * (long)m.nx + xa;
+    const long base_step = (long)(8 * rstep * DY) * m.nx;
+    if (rows_here == kXRows && s_base >= j0 + kXRows - 1 && s_base + kW - 1 <= lim) {
+      // past every row's diagonal, inside the march, all 64 rows: every instruction whole
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { g_store2(base, fl_off, fa[u], fb[u]); base += base_step; }
+      return;
+    }
+    const int s_hi = imin(s_base + kW - 1, lim);
+    const vi cc = (lane & 7) * 2;
+    const vi s0 = DX > 0 ? cc + s_base : (-cc) + (kW - 1 + s_base), s1 = s0 + DX;  // step indices of the pair's two cells
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r_lo = first + rstep * 8 * u, r_hi = r_lo + rstep * 7;
+      if (r_lo < rows_here && j0 + r_lo <= s_hi) {          // (else: no row of the instruction has a cell in this line)
+        if (r_hi < rows_here && j0 + r_hi <= s_base && s_base + kW - 1 <= lim) {
+          g_store2(base, fl_off, fa[u], fb[u]);             // whole
+        } else {
+          const vi r = (lane >> 3) * rstep + r_lo;
+          const vb row_ok = r < rows_here;
+          const vi jr = r + j0;
+          const vb ok0 = row_ok && (s0 >= jr) && (s0 <= lim);
+          const vb ok1 = row_ok && (s1 >= jr) && (s1 <= lim);
+          g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, fa[u], fb[u]);
+        }
+      }
+      base += base_step;
+    }
+  }
+
+  // One window: steps ia + k, k = 0 .. 15, at x = xw + (k marching up, 15 - k marching down).  DIAG: the strip's diagonal may fall
+  // into it (rows switch on one by one: the diagonal cell of row j takes the NEW value of the row below it times its own
+  // occupancy).
+  template <bool DIAG>
+  VHP_FN void window(int ia, int xw, int nb) {
+    const int k_hi = imin(kW - 1, i_last - ia);
+    vd rr[kW];
+#pragma unroll
+    for (int k = 0; k < kW; ++k) rr[k] = lds_bcast(slab, (xw & (2 * kBlock - 1)) + (DX > 0 ? k : kW - 1 - k));
+    Below16<DX> bl;
+    if (below) bl.get(lk, bin, xw, DX > 0 ? xw : xw + kW - 1, imax(ia, i_first), ia + k_hi, nb);
+    const vu32 hs = half_shifted(ow, xw & 63, xw & 31);  // the window's 16 occupancy bits: bit c = the cell at x = xw + c
+    vd di = vd((double)ia);
+    vd oa[4], ob[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { oa[u] = vd(0.0); ob[u] = vd(0.0); }
+#pragma unroll
+    for (int k = 0; k < kW; ++k) {
+      const int c = DX > 0 ? k : kW - 1 - k;
+      if (k == kW / 2 && has_o) {
+        // the O rows' line [xw - 8, xw + 8) (marching down: [xw + 8, xw + 24)): this window's first-marched half is new, the other
+        // half of the tile still holds the window before
+        wave_sync();
+        load_lines4(o_first, fl_o, oa, ob);
+        wave_sync();
+      }
+      // bl.v[k] = the row below at x(step k) - DX, the OLD neighbour of lane 0 (bl.v[k + 1] the NEW one); strip 0 has none
+      const vd b = shift_up(prev, below ? bl.v[k] : vd(0.0));
+      const vi mk = sbfe1(hs, c);
+      vd v = and_mask(stencil(prev, b, ratio(jd, di, rr[k])), mk);
+      if (DIAG) {
+        const vd up = shift_up(v, below ? bl.v[k + 1] : vd(1.0));  // strip 0: 1.0 = light strength at the origin
+        const vb isd = lane == (ia + k - j0);
+        const vd dcell = and_mask(up, mk);
+        v = select(isd, dcell, v);
+      }
+      prev = v;
+      lds_store(tile, tile_l + c, v);
+      di = di + 1.0;
+    }
+    // ---- the window's boundary values go to the ring; its cells leave ----
+    int lim = i_last;
+    if (DX < 0 && xw == 0) {
+      // Marching down, the march ends at x = 1: column 0 is never swept and reads as zero.  The zero leaves with
+      // the last cells of every row (one step "past" the march) instead of as a lone 8-byte store some other time.
+      wave_sync();
+      lds_store(tile, tile_l, vd(0.0));
+      lim = i_last + 1;
+    }
+    wave_sync();
+    // The boundary values first, the window's own stores after: the strip above -- the one that is growing, the chain of the unit --
+    // is let past its gate a window's worth of loads and stores earlier.
+    if (has_consumer) {
+      const vd bv = lds_load(tile, (lane & (kW - 1)) + (kXRows - 1) * kTStride);  // the last row: what the strip above reads
+      wave_sync();
+      lds_store(lk.ring, (lane & (kW - 1)) + (xw & (kRing - 1)), bv);  // (every lane: the four lanes of an entry write the same value)
+      lk.publish(ia + k_hi + 1);
+    }
+    if (has_o) store_lines4(o_first, ia - kW / 2, DX > 0 ? xw - kW / 2 : xw + kW / 2, i_last, oa, ob);
+    for (int h = 0; h < n_e; h += 4) {   // (four store instructions at a time: four loads in flight, then four stores)
+      vd fa[4], fb[4];
+      const int first = e_first + rstep * 8 * h;
+      load_lines4(first, fl_e, fa, fb);
+      store_lines4(first, ia, xw, lim, fa, fb);
+    }
+  }
+
+  // After the last window (lowest step ia, lowest x xw): the half line of the O rows that no later window completes.
+  VHP_FN void final_flush(int ia, int xw) {
+    if (!has_o) return;
+    int lim = i_last;
+    if (DX < 0 && xw == 0) lim = i_last + 1;   // (the zero of x = 0 is in the tile's column 0: window())
+    if (ia + kW / 2 > lim) return;              // (the march ended in the window's first-marched half: the mid-window lines had it all)
+    wave_sync();
+    vd oa[4], ob[4];
+    load_lines4(o_first, fl_o, oa, ob);
+    store_lines4(o_first, ia + kW / 2, DX > 0 ? xw + kW / 2 : xw - kW / 2, lim, oa, ob);
+  }
+
+  // the window at xw (lowest step ia) is next: if it opens a block, that block's operands become the current ones
+  VHP_FN void open_block(int xw, int ia) {
+    const int b = xw >> 6;
+    if (b == blk) return;
+    if (has_consumer) lk.store_block(g.nbx(ia - 1), blk);
+    VHP_DIAG_TL_XBLOCK(tl_lo, ia - 1, rows_here, j0, CB)
+    tl_lo = ia;
+    VHP_EXP_PRIO_SET(ia <= j0 + kXRows - 1)
+    enter_block(b);
+  }
+  VHP_FN void run() {
+    int xw = g.X(i_first) & ~(kW - 1);
+    int ia = DX > 0 ? xw - g.sx : g.sx - (xw + kW - 1);
+    VHP_EXP_PRIO_SET(true)
+    enter_block(xw >> 6);
+    int ia_l = ia, xw_l = xw;
+    while (ia <= i_last) {
+      open_block(xw, ia);
+      const int nb = DX > 0 ? blk - g.bx0 : g.bx0 - blk;
+      if (ia <= j0 + kXRows - 1) window<true>(ia, xw, nb); else window<false>(ia, xw, nb);
+      ia_l = ia; xw_l = xw;
+      ia += kW; xw += kW * DX;
+      sim_progress();
+      sim_point();
+    }
+    if (has_consumer) lk.store_block(imax(g.nbx(imin(imax(ia - 1, 0), i_last)), 0), blk);
+    VHP_DIAG_TL_XBLOCK(tl_lo, i_last, rows_here, j0, CB)
+    final_flush(ia_l, xw_l);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
 // y-major strip q of a unit: columns i = 128q - ya + 2*lane + {0,1}; steps j = max(i0,0) .. nj-1; cells (i, j), i <= j
 // (the diagonal cell is the seed diag(j), stored again with its neighbour).  the streaming sweep's step code (round 2); the seeds of the
 // lane's two columns wait in registers.
@@ -696,7 +1021,7 @@ struct YStrip {
     m = m_; out = out_;
     odd_pitch = ANYW && ((m.nx & 1) != 0 || (reinterpret_cast<uintptr_t>(out) & (2 * CB - 1)) != 0);
     g.init(m.nx, m.ny, sx, sy);
-    slab = sh.lds + sh.L.slabs + w * kBlock;
+    slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
     bin = lk.bin;
     dummy = sh.lds + sh.L.dummies + w * 8;
     lane = lane_id();
@@ -934,8 +1259,15 @@ VHP_HD bool pool_needs_anyw(int nx, long long field_stride, const OutT* out) {
   return (nx & 7) != 0 || (field_stride & 1) != 0 || (reinterpret_cast<uintptr_t>(out) & (2 * sizeof(OutT) - 1)) != 0;
 }
 
+#ifndef VHP_POOL_X8   // (-DVHP_POOL_X8: the 8-step x-major strips of rounds 3-4 in every build, for A/B)
+#define VHP_POOL_X16 1
+#else
+#define VHP_POOL_X16 0
+#endif
+
 template <typename OutT, bool ANYW = false>
 struct Worker {
+  static constexpr bool kUseX16 = !ANYW && VHP_POOL_X16 != 0;
   Args<OutT> a;
   Shared sh;
   int w, group;
@@ -1125,19 +1457,29 @@ struct Worker {
 
   template <int DX, int DY>
   VHP_FN void run_x(int c, int unit, int p, int sx, int sy, OutT* field) {
-    XStrip<DX, DY, OutT, ANYW> xs;
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* mine = sh.prog(c) + p;
-    xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(c, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(c, p, g.Nbx) : nullptr,
-               a.epoch, p > 0 ? lds_int_at(sh.owner(c) + (p - 1)) : -1, p > 0 ? tag_of(c, p - 1) : 0);
-    xs.init(a.m, sx, sy, field, sh, w, p);
-    VHP_DIAG_TL_STRIPS(1)
-    for (int n = p; n < xs.g.Nbx; ++n) {
-      xs.sweep_block(n);
-      if (n == xs.g.Nbx - 1) xs.end_of_march();
-      sim_progress();
-      sim_point();
+    if (kUseX16) {
+      // (widths that are a multiple of 8: windows of 16 steps)
+      XStrip16<DX, DY, OutT> xs;
+      xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(c, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(c, p, g.Nbx) : nullptr,
+                 a.epoch, p > 0 ? lds_int_at(sh.owner(c) + (p - 1)) : -1, p > 0 ? tag_of(c, p - 1) : 0);
+      xs.init(a.m, sx, sy, field, sh, w, p);
+      VHP_DIAG_TL_STRIPS(1)
+      xs.run();
+    } else {
+      XStrip<DX, DY, OutT, ANYW> xs;
+      xs.lk.init(sh, w, sx, kXRows * p, tag_of(c, p), mine, p > 0 ? line_of(c, p - 1, g.Nbx) : nullptr, p + 1 < g.Px ? line_of(c, p, g.Nbx) : nullptr,
+                 a.epoch, p > 0 ? lds_int_at(sh.owner(c) + (p - 1)) : -1, p > 0 ? tag_of(c, p - 1) : 0);
+      xs.init(a.m, sx, sy, field, sh, w, p);
+      VHP_DIAG_TL_STRIPS(1)
+      for (int n = p; n < xs.g.Nbx; ++n) {
+        xs.sweep_block(n);
+        if (n == xs.g.Nbx - 1) xs.end_of_march();
+        sim_progress();
+        sim_point();
+      }
     }
     lds_publish(mine, 0x3fff);  // finished: whatever the strip above needs to start is there (a march can end before its first window does)
     VHP_DIAG_TL_STRIPS(-1)
