@@ -59,6 +59,16 @@ for name, k in picks:
     print("  t_us   GB/s(10us)  strips running   workgroups with >= %d sweeping   with <= %d" % (wmax - 1, wmax // 2))
     for b in range(last):
         print("  %4d   %8.0f   %5d   %5d   %5d" % (10 * b, by[b] / 1e-5 / 1e9, st[b], int((per_wg[:, b] >= wmax - 1).sum()), int((per_wg[:, b] <= wmax // 2).sum())))
+    # per workgroup: the bytes it swept in all and the bin in which it swept its last -- is the end of the launch a few workgroups with
+    # more than their share, or all of them running out together?
+    wg_bytes = h[:, 0].astype(np.float64).sum(1) / 1e6
+    wg_end = np.array([int(np.nonzero(h[g, 0])[0].max()) if h[g, 0].any() else 0 for g in range(256)]) * 10
+    print("  per workgroup: MB swept min %.2f / mean %.2f / max %.2f; last bin with bytes (us) min %d / median %d / p90 %d / max %d" % (
+        wg_bytes.min(), wg_bytes.mean(), wg_bytes.max(), wg_end.min(), int(np.median(wg_end)), int(np.percentile(wg_end, 90)), wg_end.max()))
+    print("  correlation (MB swept, end time) %.2f; the 8 workgroups that end last: %s" % (
+        float(np.corrcoef(wg_bytes, wg_end)[0, 1]), " ".join("%d:%.1fMB@%dus" % (g, wg_bytes[g], wg_end[g]) for g in np.argsort(-wg_end)[:8])))
+    q = np.argsort(wg_end)
+    print("  mean MB of the 64 workgroups that end first %.2f, of the 64 that end last %.2f" % (wg_bytes[q[:64]].mean(), wg_bytes[q[-64:]].mean()))
     rows[name] = (by[:last], st[:last], ms)
 with open(os.path.join(ROOT, "gpurun_out", "timeline_%s.csv" % tag), "w") as f:
     f.write("# %s: pool sweep, %d sources at %d^2; bytes swept per 10 us bin (GB/s) and strips running; launch ms: %s\n" % (tag, n, side, ", ".join("%s %.3f" % (k, v[2]) for k, v in rows.items())))

@@ -42,8 +42,10 @@
 #endif
 #ifdef VHP_DIAG_NOYSTORE
 #define VHP_DIAG_NOYSTORE_RETURN return;
+#define VHP_DIAG_NOYSTORE_GUARD if (m.nx == 0x7fffffff)
 #else
 #define VHP_DIAG_NOYSTORE_RETURN
+#define VHP_DIAG_NOYSTORE_GUARD
 #endif
 
 // the field stores of the batch kernels without the nt bit
@@ -75,18 +77,21 @@
   constexpr int kPpBins = 256;                                                                                                  \
   static __device__ unsigned long long g_pp_hist[256 * 2 * kPpBins];                                                            \
   static __device__ unsigned long long g_pp_t0;                                                                                 \
+  static __device__ unsigned g_pp_unit[16384 * 2];   /* per unit: installed / finished, in 10 ns ticks since the order pre-kernel */ \
   static __device__ __forceinline__ unsigned long long* pp_slot(int which) {                                                    \
     const unsigned long long b_ = (wall_clock64() - g_pp_t0) / 1000;                                                            \
     return g_pp_hist + ((size_t)(blockIdx.x & 255) * 2 + which) * kPpBins + (b_ < kPpBins - 1 ? b_ : kPpBins - 1);              \
   }
 #define VHP_DIAG_TL_ADD(which, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(pp_slot(which), (unsigned long long)(long long)(n)); } while (0)
 #define VHP_DIAG_TL_STRIPS(d) VHP_DIAG_TL_ADD(1, d);
+#define VHP_DIAG_TL_UNIT(unit, which) do { if ((threadIdx.x & 63) == 0 && (unit) < 16384) g_pp_unit[2 * (unit) + (which)] = (unsigned)(wall_clock64() - g_pp_t0); } while (0);
 #define VHP_DIAG_TL_XBLOCK(lo, hi, rows_here, j0, cb) { long c_ = 0; for (int i_ = (lo); i_ <= (hi); ++i_) c_ += ((rows_here) < i_ - (j0) + 1 ? (rows_here) : i_ - (j0) + 1); VHP_DIAG_TL_ADD(0, c_ * (cb)); }
 #define VHP_DIAG_TL_YBLOCK(lo, hi, i0, ycols, ni, cb) { long c_ = 0; for (int j_ = (lo); j_ <= (hi); ++j_) { int t_ = (i0) + (ycols) - 1; if ((ni) - 1 < t_) t_ = (ni) - 1; if (j_ < t_) t_ = j_; t_ -= ((i0) > 0 ? (i0) : 0) - 1; if (t_ > 0) c_ += t_; } VHP_DIAG_TL_ADD(0, c_ * (cb)); }
 #define VHP_DIAG_TL_RESET for (int k_ = threadIdx.x; k_ < 256 * 2 * kPpBins; k_ += blockDim.x) g_pp_hist[k_] = 0; if (threadIdx.x == 0) g_pp_t0 = wall_clock64();
 #else
 #define VHP_DIAG_TL_DECLARE
 #define VHP_DIAG_TL_STRIPS(d)
+#define VHP_DIAG_TL_UNIT(unit, which)
 #define VHP_DIAG_TL_XBLOCK(lo, hi, rows_here, j0, cb)
 #define VHP_DIAG_TL_YBLOCK(lo, hi, i0, ycols, ni, cb)
 #define VHP_DIAG_TL_RESET
@@ -104,11 +109,19 @@
 #ifndef VHP_PRIO_TASK
 #define VHP_PRIO_TASK 2
 #endif
-#if !defined(VHP_SIM) && (VHP_PRIO_DIAG != 0 || VHP_PRIO_TASK != 0)
+// EXPERIMENT: a steady strip's priority by what is left of its march (steps): the strips that end last issue first
+#if !defined(VHP_SIM) && defined(VHP_PRIO_MARCH)
+#define VHP_EXP_PRIO_SET_LEFT(is_diag, left) wave_priority((is_diag) ? 3 : (left) >= VHP_PRIO_MARCH ? 2 : (left) >= VHP_PRIO_MARCH / 2 ? 1 : 0);
+#define VHP_EXP_PRIO_SET(is_diag) wave_priority((is_diag) ? 3 : 0);
+#define VHP_EXP_PRIO_TASK_BEGIN wave_priority(3);
+#define VHP_EXP_PRIO_END wave_priority(0);
+#elif !defined(VHP_SIM) && (VHP_PRIO_DIAG != 0 || VHP_PRIO_TASK != 0)
+#define VHP_EXP_PRIO_SET_LEFT(is_diag, left) wave_priority((is_diag) ? VHP_PRIO_DIAG : 0);
 #define VHP_EXP_PRIO_SET(is_diag) wave_priority((is_diag) ? VHP_PRIO_DIAG : 0);
 #define VHP_EXP_PRIO_TASK_BEGIN wave_priority(VHP_PRIO_TASK);
 #define VHP_EXP_PRIO_END wave_priority(0);
 #else
+#define VHP_EXP_PRIO_SET_LEFT(is_diag, left)
 #define VHP_EXP_PRIO_SET(is_diag)
 #define VHP_EXP_PRIO_TASK_BEGIN
 #define VHP_EXP_PRIO_END

@@ -239,6 +239,9 @@ bool pool_supported(int nx, int ny) {
 extern "C" int vhp_debug_read_hist(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_pp_hist), (size_t)n_words * 8);
 }
+extern "C" int vhp_debug_read_units(unsigned* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pool::g_pp_unit), (size_t)n_words * 4);
+}
 #endif
 
 hipError_t launch_pool(const BatchArgs& a) {

@@ -970,7 +970,7 @@ struct XStrip16 {
     if (has_consumer) lk.store_block(g.nbx(ia - 1), blk);
     VHP_DIAG_TL_XBLOCK(tl_lo, ia - 1, rows_here, j0, CB)
     tl_lo = ia;
-    VHP_EXP_PRIO_SET(ia <= j0 + kXRows - 1)
+    VHP_EXP_PRIO_SET_LEFT(ia <= j0 + kXRows - 1, i_last - ia)
     enter_block(b);
   }
   VHP_FN void run() {
@@ -1190,6 +1190,192 @@ struct YStrip {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
+// y-major strip q of a unit in windows of SIXTEEN steps (round 5; widths that are a multiple of 8): columns i = 128q - ya + 2 lane
+// + {0, 1}; steps j = max(i0, 0) .. nj - 1; cells (i, j), i <= j.  XStrip16's machinery along y: windows aligned to 16 rows, heads and
+// tails as ordinary windows (a column is garbage until its seed switches it on; a cell is stored from its column's seed step on and
+// never past the march), the boundary values of the strip below straight out of its writer's ring, the next block's occupancy words
+// and reciprocals requested a block ahead.  What a cell's store costs in the growing phase: one compare per column of the lane
+// against a per-lane "first step" (the column's index; never for a column that is not one of the grid) instead of three range
+// checks per cell.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY, typename OutT>
+struct YStrip16 {
+  static constexpr int CB = sizeof(OutT);
+  static constexpr int kW = 16;
+  static constexpr int kNever = 0x7fffffff;
+  Map m;
+  Quad<DX, DY> g;
+  OutT* out;
+  double* slab;   // reciprocals of the step indices of two blocks of 64 coordinates, indexed by y & 127
+  double* bin;    // = lk.bin
+  double* dummy;
+  Link<DY> lk;
+  int q, i0, j_first, j_last;
+  bool below, has_consumer, interior;
+  int blk, pf_blk, staged_blk;
+  bool pf_wait;
+  int tl_lo;
+  vi lane, ia, ib;
+  vi f0, f1;      // the first step at which the lane's cell of column ia / ib is stored (kNever: not a column of the grid)
+  vd prev0, prev1, id0, id1, dg0, dg1;
+  vu64 ow0, ow1, ow0_nx, ow1_nx;
+  vd rv_nx;
+  vu32 xoff;      // byte offset of the lane's pair inside a row
+
+  // (the caller has initialised lk; the seeds of the strip's columns are in `diag`: find_work claims a strip only then)
+  VHP_FN void init(const Map& m_, int sx, int sy, OutT* out_, const Shared& sh, int w, int q_, const double* diag) {
+    m = m_; out = out_;
+    g.init(m.nx, m.ny, sx, sy);
+    slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
+    bin = lk.bin;
+    dummy = sh.lds + sh.L.dummies + w * 8;
+    lane = lane_id();
+    q = q_;
+    i0 = g.ycol0(q);
+    j_first = g.ystart(q);
+    j_last = g.nj - 1;
+    below = q > 0;
+    has_consumer = q + 1 < g.Py;
+    interior = i0 >= 0 && i0 + kYCols - 1 < g.ni;  // every column of the strip is a column of the grid
+    ia = lane * 2 + i0;
+    ib = ia + 1;
+    prev0 = vd(0.0);
+    prev1 = vd(0.0);
+    id0 = to_f64(ia);
+    id1 = to_f64(ib);
+    const vb real0 = (ia >= 0) && (ia < g.ni), real1 = (ib >= 0) && (ib < g.ni);
+    // Marching down in x, the march stops at x = 1: column 0 is never swept and reads as zero.  "Column ni" (x = 0) is
+    // the higher column of its lane's pair -- the pairs start on an even x --: it computes zeros (occupancy 0, seed 0) and is stored
+    // with every row that stores x = 1.
+    const vb zero1 = (DX < 0) ? ((ib == g.ni) && real0) : vb(false);
+    f0 = select(real0, ia, vi(kNever));
+    f1 = select(real1, ib, select(zero1, ia, vi(kNever)));
+    // the seeds of my columns (columns that have none are never seeded: the index is only kept inside the line)
+    dg0 = g_load_f64(diag, vmin(vmax(ia, 0), g.rows_total - 1));
+    dg1 = g_load_f64(diag, vmin(vmax(ib, 0), g.rows_total - 1));
+    pin(dg0);
+    pin(dg1);
+    dg1 = select(zero1, vd(0.0), dg1);
+    const vi xlo = DX > 0 ? ia + g.sx : (-ib) + g.sx;  // the pair's lower x: x(ia) marching up, x(ib) marching down
+    xoff = to_u32(xlo * CB);
+    pf_blk = -1;
+    pf_wait = false;
+    staged_blk = -0x7fffffff;
+    blk = -0x7fffffff;
+    tl_lo = j_first;
+  }
+
+  // the occupancy words of the lane's two columns and the reciprocals of the step indices of the 64 coordinates of block b (y >> 6)
+  VHP_FN void load_ops(int b, vu64& o0, vu64& o1, vd& rv) {
+    const vi xa = vmin(vmax(ia, 0), g.ni - 1) * DX + g.sx;
+    const vi xb = vmin(vmax(ib, 0), g.ni - 1) * DX + g.sx;
+    o0 = g_load_u64(m.cols, xa * m.wpc + (1 + b));
+    o1 = g_load_u64(m.cols, xb * m.wpc + (1 + b));
+    if (DX < 0) o1 = select(ib == g.ni, vu64(0), o1);  // ("column ni" computes zeros: blocked all the way)
+    const vi jt = (lane + (b * 64 - g.sy)) * DY;
+    const vb ok = (jt >= 0) && (jt < g.nj);
+    rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
+  }
+  VHP_FN bool block_in_march(int b) const { const int ye = g.Y(j_last); return DY > 0 ? 64 * b <= ye : 64 * b + 63 >= ye; }
+  VHP_FN void prefetch_ops(int b) { pf_blk = b; pf_wait = true; load_ops(b, ow0_nx, ow1_nx, rv_nx); }
+  VHP_FN void stage(int b, vd rv) {
+    wave_sync();
+    lds_store(slab, lane + kBlock * (b & 1), rv);
+    wave_sync();
+    staged_blk = b;
+  }
+  VHP_FN void settle() {
+    if (pf_wait) { pin(ow0_nx); pin(ow1_nx); pin(rv_nx); pf_wait = false; }
+  }
+  VHP_FN void stage_next() {
+    if (pf_blk != -1 && staged_blk != pf_blk) { settle(); stage(pf_blk, rv_nx); }
+  }
+  VHP_FN void enter_block(int b) {
+    if (pf_blk == b) { stage_next(); ow0 = ow0_nx; ow1 = ow1_nx; }
+    else { vd rv; load_ops(b, ow0, ow1, rv); pin(ow0); pin(ow1); pin(rv); stage(b, rv); }
+    blk = b;
+    if (block_in_march(b + DY)) prefetch_ops(b + DY); else pf_blk = -1;
+  }
+
+  // One window: steps ja + k, k = 0 .. 15, at y = yw + (k marching up, 15 - k marching down).  DIAG: columns may be seeded in it
+  // (implies PRED); PRED: predicated stores (columns that do not exist, or not yet; steps past the march).
+  template <bool DIAG, bool PRED>
+  VHP_FN void window(int ja, int yw, int nb) {
+    const int k_hi = imin(kW - 1, j_last - ja);
+    vd rr[kW];
+#pragma unroll
+    for (int k = 0; k < kW; ++k) rr[k] = lds_bcast(slab, (yw & (2 * kBlock - 1)) + (DY > 0 ? k : kW - 1 - k));
+    Below16<DY> bl;
+    if (below) bl.get(lk, bin, yw, DY > 0 ? yw : yw + kW - 1, imax(ja, j_first), ja + k_hi - 1, nb);
+    const vu32 hs0 = half_shifted(ow0, yw & 63, yw & 31), hs1 = half_shifted(ow1, yw & 63, yw & 31);
+    // every lane writes "its boundary value" each step -- lane 63 into the ring, the others into a dummy slot: one ds_write instead
+    // of an exec-masked region per step
+    double* wbase = has_consumer ? lk.ring + (yw & (kRing - 1)) : dummy;
+    const vi widx = select(lane == 63, vi(0), vi((int)(dummy - wbase)));
+    vd dj = vd((double)ja);
+    OutT* row = out + (long)g.Y(ja) * (long)m.nx;
+    const long rowstep = (long)DY * m.nx;
+#pragma unroll
+    for (int k = 0; k < kW; ++k) {
+      const int c = DY > 0 ? k : kW - 1 - k;
+      const vd b0 = shift_up(prev1, below ? bl.v[k] : vd(0.0));
+      vd v0 = and_mask(stencil(prev0, b0, ratio(id0, dj, rr[k])), sbfe1(hs0, c));
+      vd v1 = and_mask(stencil(prev1, prev0, ratio(id1, dj, rr[k])), sbfe1(hs1, c));
+      if (DIAG) {
+        v0 = select(ia == ja + k, dg0, v0);
+        v1 = select(ib == ja + k, dg1, v1);
+      }
+      VHP_DIAG_NOYSTORE_GUARD
+      {
+        const vd lo = DX > 0 ? v0 : v1, hi = DX > 0 ? v1 : v0;  // in memory order
+        if (PRED) {
+          const int j = ja + k <= j_last ? ja + k : -1;         // (past the march: nothing)
+          const vb ok0 = f0 <= j, ok1 = f1 <= j;
+          const vb oklo = DX > 0 ? ok0 : ok1, okhi = DX > 0 ? ok1 : ok0;
+          g_store2_if(oklo && okhi, oklo, okhi, row, xoff, lo, hi);
+        } else {
+          g_store2(row, xoff, lo, hi);
+        }
+      }
+      prev0 = v0;
+      prev1 = v1;
+      lds_store(wbase, widx + c, v1);
+      dj = dj + 1.0;
+      row += rowstep;
+    }
+    if (has_consumer) lk.publish(ja + k_hi + 1);
+  }
+
+  VHP_FN void open_block(int yw, int ja) {
+    const int b = yw >> 6;
+    if (b == blk) return;
+    if (has_consumer) lk.store_block(g.nby(ja - 1), blk);
+    VHP_DIAG_TL_YBLOCK(tl_lo, ja - 1, i0, kYCols, g.ni, CB)
+    tl_lo = ja;
+    VHP_EXP_PRIO_SET_LEFT(ja <= i0 + kYCols - 1, j_last - ja)
+    enter_block(b);
+  }
+  VHP_FN void run() {
+    int yw = g.Y(j_first) & ~(kW - 1);
+    int ja = DY > 0 ? yw - g.sy : g.sy - (yw + kW - 1);
+    VHP_EXP_PRIO_SET(true)
+    enter_block(yw >> 6);
+    while (ja <= j_last) {
+      open_block(yw, ja);
+      const int nb = DY > 0 ? blk - g.by0 : g.by0 - blk;
+      if (ja <= i0 + kYCols - 1) window<true, true>(ja, yw, nb);
+      else if (!interior || ja + kW - 1 > j_last) window<false, true>(ja, yw, nb);
+      else window<false, false>(ja, yw, nb);
+      ja += kW; yw += kW * DY;
+      sim_progress();
+      sim_point();
+    }
+    if (has_consumer) lk.store_block(imax(g.nby(imin(imax(ja - 1, 0), j_last)), 0), blk);
+    VHP_DIAG_TL_YBLOCK(tl_lo, j_last, i0, kYCols, g.ni, CB)
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
 // The diagonal of a quadrant for its y-major unit (the two-term recurrence below), into the unit's scratch line in global
 // memory, 64 entries per call.  diag(0) = occ(source); for k >= 1:
 //   sub(k)  = V(k, k-1) = (a - c*(a - b)) * occ(k, k-1),  a = diag(k-1), b = sub(k-1), c = (k-1)/k
@@ -1268,6 +1454,11 @@ VHP_HD bool pool_needs_anyw(int nx, long long field_stride, const OutT* out) {
 template <typename OutT, bool ANYW = false>
 struct Worker {
   static constexpr bool kUseX16 = !ANYW && VHP_POOL_X16 != 0;
+#ifdef VHP_POOL_Y8   // (-DVHP_POOL_Y8: the 8-step y-major strips beside the 16-step x-major ones, for A/B)
+  static constexpr bool kUseY16 = false;
+#else
+  static constexpr bool kUseY16 = kUseX16;
+#endif
   Args<OutT> a;
   Shared sh;
   int w, group;
@@ -1391,6 +1582,7 @@ struct Worker {
       return;
     }
     const int sx = sxsy & 0xffff, sy = sxsy >> 16;
+    VHP_DIAG_TL_UNIT(unit, 0)
     UnitGeo ug;
     ug.init(a.m.nx, a.m.ny, qo, sx, sy);
     OutT* field = a.out + (size_t)s * a.field_stride;
@@ -1444,6 +1636,7 @@ struct Worker {
   VHP_FN void strip_done(int c) {
     int* cx = sh.ctx(c);
     if (lds_add(cx + kLeft, -1) == 1) {
+      VHP_DIAG_TL_UNIT(lds_int_at(cx + kUnit), 1)
       lds_publish(cx + kWord, -1);
       lds_publish(cx + kState, 0);
     }
@@ -1488,18 +1681,27 @@ struct Worker {
 
   template <int DX, int DY>
   VHP_FN void run_y(int c, int unit, int q, int sx, int sy, OutT* field, const double* dline) {
-    YStrip<DX, DY, OutT, ANYW> ys;
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* mine = sh.prog(c) + q;
-    ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(c, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(c, q, g.Nby) : nullptr,
-               a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
-    ys.init(a.m, sx, sy, field, sh, w, q, dline);
-    VHP_DIAG_TL_STRIPS(1)
-    for (int n = ys.g.nby(ys.jstart); n < ys.g.Nby; ++n) {
-      ys.sweep_block(n);
-      sim_progress();
-      sim_point();
+    if (kUseY16) {
+      YStrip16<DX, DY, OutT> ys;
+      ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(c, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(c, q, g.Nby) : nullptr,
+                 a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
+      ys.init(a.m, sx, sy, field, sh, w, q, dline);
+      VHP_DIAG_TL_STRIPS(1)
+      ys.run();
+    } else {
+      YStrip<DX, DY, OutT, ANYW> ys;
+      ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(c, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(c, q, g.Nby) : nullptr,
+                 a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
+      ys.init(a.m, sx, sy, field, sh, w, q, dline);
+      VHP_DIAG_TL_STRIPS(1)
+      for (int n = ys.g.nby(ys.jstart); n < ys.g.Nby; ++n) {
+        ys.sweep_block(n);
+        sim_progress();
+        sim_point();
+      }
     }
     lds_publish(mine, 0x3fff);
     VHP_DIAG_TL_STRIPS(-1)
