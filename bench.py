@@ -50,7 +50,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "c1k-empty", "c3-1024", "c3-1016", "c3-512"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "c1-batch", "c-250", "c1k-empty", "c3-1024", "c3-1016", "c3-512"],
+                    help="c3 (default): BASELINE config 3, the configuration the metric is quoted on; c2 / c4 / c5: configs 2, 4, 5 (per-GPU share); "
+                         "c1-batch: the reference's own headline size -- config 1's 101x101 rnd_1 mask -- as a batch of 4096 sources; c-250: a 250x250 "
+                         "random grid, 256 sources (small-grid batches); the others are diagnostics")
     ap.add_argument("--sources", type=int, default=0, help="sources per GPU (default: workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--gather", action="store_true", help="all-gather the fields over RCCL inside the timed region")
@@ -107,6 +110,16 @@ def make_workload(name, rank, n_src):
         if rank:
             src = synth.free_sources(occ, n, seed=11 + 1000 * rank)
         label = "C5: 4096x4096 random grid (50 rectangles 80..400, map seed 1), %d seeded sources per GPU" % n
+    elif name == "c1-batch":
+        n = n_src or 4096
+        occ = synth.c1_rnd1_mask()
+        src = synth.free_sources(occ, n, seed=7 + 1000 * rank)   # (6 909 free cells; a source may repeat: every field is swept all the same)
+        label = "C1 as a batch: 101x101 mask from rnd_1.mat (the reference's headline size), %d seeded sources per GPU" % n
+    elif name == "c-250":
+        n = n_src or 256
+        occ = synth.random_rect_map(250, 250, 50, 5, 25, 5, 25, seed=1)
+        src = synth.free_sources(occ, n, seed=7 + 1000 * rank)
+        label = "250x250 random grid (50 rectangles 5..25, map seed 1), %d seeded sources per GPU" % n
     elif name == "c2":
         n = n_src or 1
         occ = np.ones((1000, 1000), np.uint8)
@@ -228,15 +241,26 @@ def bench_planner(args):
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
-        orc = oracle_lib.Oracle()
+        # the port of solve() built with the flags the reference ships (-O3 -Ofast -march=native), the strict build if that fails
+        flags, fallback = "-O3 -Ofast -march=native", ""
+        try:
+            fast = os.path.join(ROOT, "oracle", "libvhp_oracle_fast.so")
+            if os.path.exists(fast):
+                os.remove(fast)
+            oracle_lib.build(fast=True)
+            orc = oracle_lib.Oracle(fast)
+        except (OSError, AttributeError, subprocess.CalledProcessError) as e:
+            oracle_lib.build()
+            orc = oracle_lib.Oracle()
+            flags, fallback = "-O2 -ffp-contract=off", "; FALLBACK to the strict build because the -Ofast build failed: %r" % (e,)
         ts = []
         t_end = time.time() + min(args.cpu_seconds, 10.0)
         while time.time() < t_end or len(ts) < 3:
             t = time.perf_counter()
             w = orc.solve(occ, start, end, 0.1, 250)
             ts.append(time.perf_counter() - t)
-        out["cpu_baseline"] = {"value": round(w["n_pivots"] / min(ts), 1), "unit": "pivots/s", "cores": 1, "kind": "port",
-                               "sample": "oracle port of solve() (strict IEEE build), best of %d solves of the same maze" % len(ts)}
+        out["cpu_baseline"] = {"value": round(w["n_pivots"] / min(ts), 1), "unit": "pivots/s", "cores": 1, "kind": "port", "flags": flags, "fallback": bool(fallback),
+                               "sample": "oracle port of solve() (%s), best of %d solves of the same maze (the reference's loop is one thread)%s" % (flags, len(ts), fallback)}
     print(json.dumps(out), flush=True)
 
 

@@ -232,6 +232,8 @@ def test_alloc_output_places_a_result_buffer(vhp, oracle):
     assert hip.hipMemcpy(got.data_ptr(), ptr, n_bytes, 3) == 0   # device to device
     assert torch.equal(got, ref)
     _assert_same(got[7].cpu().numpy(), oracle.sweep_full(occ, int(src[7][0]), int(src[7][1])), "placed buffer, source 7")
+    ms, peak = c.alloc_output_cost()   # what the search cost: wall time, and the memory its candidates held at the peak
+    assert ms > 0 and peak == tried * n_bytes
     small, w0, s0, t0 = c.alloc_output(1 << 20, 8)   # below 128 MB nothing can be probed: one allocation, no rates
     assert small and t0 == 1 and w0 == 0.0 and s0 == 0.0
     c.free_output(small)
@@ -240,3 +242,93 @@ def test_alloc_output_places_a_result_buffer(vhp, oracle):
         c.free_output(ptr)
     with pytest.raises(vhp.VhpError):
         c.alloc_output(0, 4)
+
+
+def test_all_256_fields_of_the_bench_launch_on_a_placed_buffer(vhp, oracle):
+    # bench.py's second timed region: the C3 launch into a result buffer from vhp_alloc_output.  All 256 fields equal, byte for byte,
+    # the same launch into an ordinary allocation -- which test_pool_kernel_all_256_fields_of_the_bench_launch holds against the oracle
+    # cell by cell -- and 16 of them are held against the oracle here as well; the search stays inside its budget.
+    import ctypes
+    import torch
+    occ, src = maps.config_c3(256)
+    c = _ctx(vhp, occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    n_bytes = 256 * 1000 * 1000 * 8
+    free_before = torch.cuda.mem_get_info()[0]
+    ptr, whole, split, tried = c.alloc_output(n_bytes, 16)
+    ms, peak = c.alloc_output_cost()
+    assert 1 <= tried <= 16 and peak == tried * n_bytes and peak <= free_before // 4 + n_bytes, (tried, peak, free_before)
+    d_src = torch.from_numpy(src).cuda()
+    ref = torch.full((256, 1000, 1000), float("nan"), dtype=torch.float64, device="cuda")
+    c.sweep_batch_device(d_src.data_ptr(), 256, ref.data_ptr())
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemset(ptr, 0xFF, n_bytes) == 0          # (NaN everywhere: a cell the launch does not write would show)
+    c.sweep_batch_device(d_src.data_ptr(), 256, ptr)
+    c.sync()
+    assert c.last_sweep_kernel() == 3
+    got = torch.empty_like(ref)
+    assert hip.hipMemcpy(got.data_ptr(), ptr, n_bytes, 3) == 0   # device to device
+    assert not bool(torch.isnan(got).any())
+    assert torch.equal(got, ref)
+    for k in range(0, 256, 16):
+        _assert_same(got[k].cpu().numpy(), oracle.sweep_full(occ, int(src[k][0]), int(src[k][1])), "placed buffer, source %d" % k)
+    c.free_output(ptr)
+
+
+def test_static_first_round_and_pulled_units_leave_the_same_bytes(vhp, oracle):
+    # "pool_static_round": the first unit of every context by workgroup index (the default), or every unit pulled from the queue --
+    # the schedule differs, the fields do not; also with fewer units than contexts (the static round is then off by itself)
+    import torch
+    occ, src = maps.config_c3(128)
+    c = _ctx(vhp, occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_option("kernel", 3)
+    d_src = torch.from_numpy(src).cuda()
+    outs = []
+    for static in (1, 0):
+        c.set_option("pool_static_round", static)
+        for n in (128, 40):
+            o = torch.full((n, 1000, 1000), float("nan"), dtype=torch.float64, device="cuda")
+            c.sweep_batch_device(d_src.data_ptr(), n, o.data_ptr())
+            c.sync()
+            assert c.last_sweep_kernel() == 3 and not bool(torch.isnan(o).any())
+            outs.append(o)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3]) and torch.equal(outs[0][:40], outs[1])
+    for k in (0, 39, 127):
+        _assert_same(outs[0][k].cpu().numpy(), oracle.sweep_full(occ, int(src[k][0]), int(src[k][1])), "static round, source %d" % k)
+
+
+def test_field_stride_is_a_property_of_device_buffers(vhp, oracle):
+    # "field_stride" places the fields of a DEVICE batch; the host-buffer entry point copies packed fields out of the library's own
+    # scratch and ignores it; a stride smaller than a field is refused; vhp_set_map resets it
+    import torch
+    nx, ny = 200, 163
+    occ = maps.random_rect_map(nx, ny, 20, 1, nx // 8, 1, ny // 8, 7)
+    src = _sources(occ, 3, 5)[:6]
+    c = vhp.Context(0)
+    c.set_map(occ)
+    want = [oracle.sweep_full(occ, int(sx), int(sy)) for sx, sy in src]
+    c.set_option("field_stride", nx * ny + 24)
+    got = c.sweep_batch(src)                      # host form: packed, whatever the option says
+    for k in range(len(src)):
+        _assert_same(got[k], want[k], "host form with field_stride set, source %d" % k)
+    c.set_option("field_stride", nx * ny - 8)     # the fields would overlap
+    buf = torch.zeros(len(src) * nx * ny, dtype=torch.float64, device="cuda")
+    d_src = torch.from_numpy(src).cuda()
+    with pytest.raises(vhp.VhpError) as e:
+        c.sweep_batch_device(d_src.data_ptr(), len(src), buf.data_ptr())
+    assert e.value.code == vhp.VHP_ERR_ARG
+    got = c.sweep_batch(src)                      # ... which the host form never sees
+    _assert_same(got[0], want[0], "host form with a small field_stride set")
+    c.set_option("field_stride", nx * ny + 24)
+    occ2 = maps.random_rect_map(nx + 8, ny + 5, 20, 1, nx // 8, 1, ny // 8, 8)   # a larger grid: the old stride would overlap its fields
+    c.set_map(occ2)
+    src2 = _sources(occ2, 2, 6)[:3]
+    buf2 = torch.full((len(src2) * (nx + 8) * (ny + 5),), float("nan"), dtype=torch.float64, device="cuda")
+    c.sweep_batch_device(torch.from_numpy(src2).cuda().data_ptr(), len(src2), buf2.data_ptr())
+    c.sync()
+    got2 = buf2.cpu().numpy().reshape(len(src2), ny + 5, nx + 8)
+    for k, (sx, sy) in enumerate(src2):
+        _assert_same(got2[k], oracle.sweep_full(occ2, int(sx), int(sy)), "packed again after set_map, source %d" % k)

@@ -296,11 +296,17 @@ bool use_pool_kernel(const vhp_ctx* c, int n_src) {
     return n_src >= 24;
   }
   // (later in round 4, tools/kernel_ab.py, front / pool, us: 256^2: 192 sources 72 / 113, 384: 91 / 191; 384^2: 192: 124 / 148, 384: 175 / 249;
-  // 512^2: 192: 157 / 184, 384: 284 / 315 -- the other way round by 4 % on another box --; 640^2: 96: 186 / 211, 192: 296 / 247, 384: 477 / 403;
-  // 768^2: 96: 227 / 237, 192: 397 / 329, 384: 747 / 534: the front sweep below a side of 576)
-  if (maxdim < 576) return false;
-  if (maxdim <= 768) return n_src >= 192;
-  if (maxdim <= 1024) return n_src >= 96;
+  // 512^2: 192: 157 / 184, 384: 284 / 315; 640^2: 96: 186 / 211, 192: 296 / 247, 384: 477 / 403; 768^2: 96: 227 / 237, 192: 397 / 329)
+  // Round 5, with the strips in windows of 16 steps (profiles/r05_front_vs_pool_multiples_of_8.txt; front / pool, us): 320^2: 96 sources
+  // 99 / 92, 192: 101 / 108, 1024: 314 / 475; 384^2: 96: 116 / 107, 384: 226 / 209, 1024: 495 / 529; 448^2: 96: 132 / 122, 192: 168 / 142,
+  // 384: 286 / 244, 1024: 521 / 583; 512^2: 48: 135 / 137, 96: 144 / 131, 192: 201 / 168, 1024: 859 / 694; 576^2: 48: 150 / 146, 96: 164 / 142,
+  // 384: 446 / 332; 640^2: 48: 169 / 163, 384: 519 / 384; 768^2: 48: 220 / 193, 96: 248 / 207; 1000^2: 48: 296 / 233, 96: 328 / 257, 384: 1104 / 809.
+  // 256^2 and below: the front sweep at every batch size (256^2 x 4096: 911 / 1734; 104^2 x 4096: 247 / 1483).
+  if (maxdim < 448) return false;
+  if (maxdim < 512) return n_src >= 96 && n_src <= 768;
+  if (maxdim < 576) return n_src >= 96;
+  if (maxdim < 768) return n_src >= 48;
+  if (maxdim <= 1024) return n_src >= 33;
   return n_src >= 24;
 }
 
