@@ -187,8 +187,9 @@ int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n);
  * column grid slid onto 128-byte lines), "pack" (1 = pack short quadrants), "kernel" (1 = front
  * sweep, 3 = pool sweep, 4 = latency sweep; 2 was the streaming sweep, retired in round 4 and refused),
  * "pool_contexts" (1..16: units a workgroup of the pool sweep holds
- * at once), "pool_static_round" (0: every unit of a pool-sweep launch is pulled from its queue; 1, the default: the first unit of
- * every context is handed out by workgroup index), "field_stride" (elements from one field of a DEVICE-pointer batch to the next;
+ * at once), "pool_static_round" (0: every unit of a pool-sweep launch is pulled from its queue; 1: the first unit of
+ * every context is handed out by workgroup index; 2, the default: ... and a workgroup's second unit counts down from the end of the
+ * round, so that the longest units share their CU with the shortest of the round), "field_stride" (elements from one field of a DEVICE-pointer batch to the next;
  * 0 = nx * ny, packed; a value below nx * ny makes vhp_sweep_batch_device fail with VHP_ERR_ARG; the host-buffer entry points
  * ignore it -- their results are packed --, the queue variant refuses it, and vhp_set_map resets it to 0),
  * "alloc_budget_pct" (vhp_alloc_output below).  The

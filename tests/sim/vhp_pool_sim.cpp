@@ -156,6 +156,7 @@ int run_batch_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_sr
   // the first unit of every context by workgroup index wherever the launcher would do so (vhp_pool.hip launch_pool_t), in two runs of three
   a.n_groups = G;
   a.static_round = (seed % 3) != 2 && a.early_ctx >= C && n_units >= C * G;
+  a.static_snake = (seed & 2) != 0;
   if (a.static_round) queue = (unsigned long long)(a.n_head * G) | ((unsigned long long)((C - a.n_head) * G) << 32);
 
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));

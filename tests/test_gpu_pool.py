@@ -287,7 +287,7 @@ def test_static_first_round_and_pulled_units_leave_the_same_bytes(vhp, oracle):
     c.set_option("kernel", 3)
     d_src = torch.from_numpy(src).cuda()
     outs = []
-    for static in (1, 0):
+    for static in (2, 0, 1):
         c.set_option("pool_static_round", static)
         for n in (128, 40):
             o = torch.full((n, 1000, 1000), float("nan"), dtype=torch.float64, device="cuda")
@@ -295,7 +295,8 @@ def test_static_first_round_and_pulled_units_leave_the_same_bytes(vhp, oracle):
             c.sync()
             assert c.last_sweep_kernel() == 3 and not bool(torch.isnan(o).any())
             outs.append(o)
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3]) and torch.equal(outs[0][:40], outs[1])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3]) and torch.equal(outs[0], outs[4]) and torch.equal(outs[1], outs[5])
+    assert torch.equal(outs[0][:40], outs[1])
     for k in (0, 39, 127):
         _assert_same(outs[0][k].cpu().numpy(), oracle.sweep_full(occ, int(src[k][0]), int(src[k][1])), "static round, source %d" % k)
 

@@ -33,7 +33,7 @@ struct BatchArgs {
   int pool_tail_pct = 0;  // pool sweep: share of the units (by count, smallest first) that the filler contexts may take from the small end (0: 50)
   int pool_early_ctx = 0, pool_late_pct = 0;  // pool sweep: contexts >= early_ctx open once late_pct % of the units are taken (0: all open)
   int pool_busy_cap = 0;  // pool sweep: a workgroup takes another unit only while fewer wavefronts than this are sweeping (0: no cap)
-  int pool_static_round = 1;  // pool sweep: every context's first unit by workgroup index, no pull (vhp_pool.hpp Args::static_round); 0: every unit pulled
+  int pool_static_round = 2;  // pool sweep: every context's first unit by workgroup index, no pull (vhp_pool.hpp Args::static_round; 2: odd head contexts count down, Args::static_snake); 0: every unit pulled
   const int* d_src_index = nullptr;  // latency sweep in the planner's loop: sweep source number *d_src_index of d_src (n_src = 1) ...
   const int* d_skip = nullptr;       // ... and nothing at all if *d_skip is set
   bool lat_dead_cells_are_zero = false;  // ... and dead strips store nothing: the field holds +0.0 wherever the launch does not write

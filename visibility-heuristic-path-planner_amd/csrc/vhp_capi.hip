@@ -79,7 +79,7 @@ struct vhp_ctx {
   int opt_pool_tail_pct = 0;   // pool sweep: share of the units the filler contexts take from the small end (0 auto)
   int opt_pool_early_ctx = 0, opt_pool_late_pct = 0;  // pool sweep: late contexts (0 auto)
   int opt_pool_busy_cap = 0;   // pool sweep: no new unit while this many wavefronts of the workgroup are sweeping (0 auto)
-  int opt_pool_static_round = 1;  // pool sweep: every context's first unit by workgroup index (0: every unit pulled from the queue)
+  int opt_pool_static_round = 2;  // pool sweep: every context's first unit by workgroup index (2: the second head context counts down; 0: every unit pulled from the queue)
 
   vhp::PlannerState pl;  // device-resident planner state
   vhp::SpecState spec;   // field cache of the speculative planner
@@ -815,7 +815,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "pool_late_pct") { if (v < 0 || v > 100) return fail(ctx, VHP_ERR_ARG, "pool_late_pct: 0 (automatic) .. 100"); ctx->opt_pool_late_pct = v; }
   else if (k == "pool_busy_cap") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_busy_cap: 0 (automatic) .. 16"); ctx->opt_pool_busy_cap = v; }
   else if (k == "pool_contexts") { if (v < 0 || v > 16) return fail(ctx, VHP_ERR_ARG, "pool_contexts: 0 (automatic) .. 16"); ctx->opt_pool_contexts = v; }
-  else if (k == "pool_static_round") { ctx->opt_pool_static_round = v != 0; }
+  else if (k == "pool_static_round") { if (v < 0 || v > 2) return fail(ctx, VHP_ERR_ARG, "pool_static_round: 0, 1 or 2"); ctx->opt_pool_static_round = v; }
   else if (k == "alloc_budget_pct") { if (v < 1 || v > 90) return fail(ctx, VHP_ERR_ARG, "alloc_budget_pct: 1 .. 90 (per cent of the free device memory)"); ctx->opt_alloc_budget_pct = v; }
   else return fail(ctx, VHP_ERR_ARG, "vhp_set_option: unknown key '" + k + "'");
   return VHP_OK;

@@ -213,6 +213,7 @@ hipError_t launch_pool_t(const BatchArgs& a) {
   g.claim_ahead = a.pool_claim_ahead >= 0 ? a.pool_claim_ahead : 48;
   // the first unit of every context by workgroup index, the queue behind them (Args::static_round)
   g.n_groups = a.n_cus;
+  g.static_snake = a.pool_static_round >= 2;
   g.static_round = a.pool_static_round != 0 && g.early_ctx >= sh.n_ctx && (long long)g.n_units >= (long long)sh.n_ctx * a.n_cus;
   const unsigned long long queue0 = g.static_round ? ((unsigned long long)(g.n_head * a.n_cus) | ((unsigned long long)((sh.n_ctx - g.n_head) * a.n_cus) << 32)) : 0ull;
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);  // the order pre-kernel is part of what a launch costs

@@ -130,7 +130,7 @@ struct Args {
   // (n_head * n_groups | (C - n_head) * n_groups << 32: vhp_pool_order writes it).  Only when n_units >= C * n_groups and every
   // context is open from the start.  Without it a launch opens with C * n_groups atomics on one word, the slowest of which
   // returns ~10 us after the first.
-  bool static_round;
+  bool static_round, static_snake;
   int n_groups;
   double* diag;       // scratch: diag(k) of the y-major unit of (source s, quadrant q) at (4 s + q) * diag_stride + k
   int diag_stride;
@@ -1410,6 +1410,7 @@ struct DiagTask {
     const vu64 wb = g_load_u64(m.rows, yb * m.wpr + ((x >> 6) + 1));
     const vd rk = g_load_f64(m.recip, kk);
     const vi ma = bit_mask_lane(wa, x & 63), mb = bit_mask_lane(wb, x & 63);
+    const vd cv = ratio(to_f64(vmax(kk - 1, 0)), to_f64(kk), rk);  // (k-1)/k of every entry of the chunk: lane work, off the chain
     vd acc = vd(0.0);
     for (int kq = k0; kq < k1; ++kq) {
       const int l = kq - k0;
@@ -1418,7 +1419,7 @@ struct DiagTask {
         dcur = and_mask(vd(1.0), vi(read_lane_i(mb, l)));  // the origin: light strength 1 times its occupancy
         sprev = vd(0.0);
       } else {
-        const vd c = ratio(vd((double)(kq - 1)), (double)kq, read_lane(rk, l));
+        const vd c = vd(read_lane(cv, l));
         const vd sub = and_mask(stencil(dprev, sprev, c), vi(read_lane_i(ma, l)));
         dcur = and_mask(sub, vi(read_lane_i(mb, l)));
         sprev = sub;
@@ -1555,7 +1556,10 @@ struct Worker {
     if (a.static_round && ((lds_poll(sc + kFirstDone) >> c) & 1) == 0) {
       // the context's first unit: by workgroup index (only the wavefront that holds the context in state 1 gets here)
       lds_or(sc + kFirstDone, 1 << c);
-      idx = c < a.n_head ? c * a.n_groups + group : a.n_units - 1 - ((c - a.n_head) * a.n_groups + group);
+      // (odd head contexts count down: workgroup g's second unit is the (2 G - 1 - g)-th longest -- the longest units share their CU,
+      // and its bandwidth, with the shortest of the round, and the round's bytes are spread evenly over the CUs)
+      const int slot = (a.static_snake && (c & 1)) ? a.n_groups - 1 - group : group;
+      idx = c < a.n_head ? c * a.n_groups + slot : a.n_units - 1 - ((c - a.n_head) * a.n_groups + group);
       sim_progress();
     } else {
       // (the small end only feeds the gaps beside the large units: once its share is gone, what is left leaves in size order,
