@@ -1,6 +1,6 @@
 """When every unit of a pool-sweep launch was installed and when its last strip finished (-DVHP_DIAG_TIMELINE build): which units the
 launch ends on, how long a unit of a given march takes, how many generations of units a context runs.  Diagnostic only.
-usage: unit_timeline.py <lib> [n sources] [n candidate buffers]"""
+usage: unit_timeline.py <lib> [n sources] [n candidate buffers] [side] [key=value ...]      (vhp_set_option keys)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,14 +11,18 @@ synth = import_module("visibility-heuristic-path-planner_amd.synth")
 lib = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 nbuf = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-side = 1000
+side = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+opts = [a.split('=') for a in sys.argv[5:]]
 mod.LIB_PATH = os.path.join(ROOT, lib)
-occ = synth.random_rect_map(side, side, 50, 20, 100, 20, 100, seed=1)
+lo_, hi_ = (20, 100) if side >= 1000 else (max(side // 50, 2), max(side // 10, 4))
+occ = synth.random_rect_map(side, side, 50, lo_, hi_, lo_, hi_, seed=1)
 src = synth.free_sources(occ, n, seed=7)
 c = mod.Context(0)
 c.set_stream(torch.cuda.current_stream().cuda_stream)
 c.set_map(occ)
 c.set_option("kernel", 3)
+for k_, v_ in opts:
+    c.set_option(k_, int(v_))
 d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
 hip = C.CDLL("libamdhip64.so")
 hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
@@ -63,16 +67,17 @@ for name, k in (("slowest", int(order[-1])), ("fastest", int(order[0]))):
     geo = np.array(geo, float)
     live = t_out > 0
     print("%s buffer: launch %.3f ms; %d units with strips; last unit finishes at %.0f us" % (name, ms, int(live.sum()), t_out.max()))
-    print("  installs per 50 us:", " ".join("%d" % ((t_in[live] >= a) & (t_in[live] < a + 50)).sum() for a in range(0, 600, 50)))
-    print("  finishes per 50 us:", " ".join("%d" % ((t_out[live] >= a) & (t_out[live] < a + 50)).sum() for a in range(0, 600, 50)))
+    BIN = 50 if side >= 1000 else 10
+    print("  installs per %d us:" % BIN, " ".join("%d" % ((t_in[live] >= a) & (t_in[live] < a + BIN)).sum() for a in range(0, 12 * BIN, BIN)))
+    print("  finishes per %d us:" % BIN, " ".join("%d" % ((t_out[live] >= a) & (t_out[live] < a + BIN)).sum() for a in range(0, 12 * BIN, BIN)))
     print("  duration by march (x-major / y-major), us: median [p90]")
-    for lo in range(0, 1000, 100):
+    for lo in range(0, side, max(side // 10, 1)):
         row = []
         for xm in (1.0, 0.0):
-            sel = live & (geo[:, 0] >= lo) & (geo[:, 0] < lo + 100) & (geo[:, 3] == xm)
+            sel = live & (geo[:, 0] >= lo) & (geo[:, 0] < lo + max(side // 10, 1)) & (geo[:, 3] == xm)
             d = (t_out - t_in)[sel]
             row.append("%6.0f [%6.0f] (%3d)" % (np.median(d), np.percentile(d, 90), sel.sum()) if sel.sum() else "     -")
-        print("    march %4d-%4d: %s   %s" % (lo, lo + 100, row[0], row[1]))
+        print("    march %4d-%4d: %s   %s" % (lo, lo + max(side // 10, 1), row[0], row[1]))
     last = np.argsort(-t_out)[:24]
     print("  the 24 units that finish last: unit, kind, march, rows, Mcells, installed at, finished at, duration")
     for k2 in last:

@@ -1456,18 +1456,29 @@ template <typename OutT, bool ANYW = false>
 struct Worker {
   static constexpr bool kUseX16 = !ANYW && VHP_POOL_X16 != 0;
 #ifdef VHP_POOL_Y8   // (-DVHP_POOL_Y8: the 8-step y-major strips beside the 16-step x-major ones, for A/B)
-  static constexpr bool kUseY16 = false;
+  static constexpr bool kUseY16 = false, kMayY16 = false;
 #else
   static constexpr bool kUseY16 = kUseX16;
+  // The build for the other widths keeps the 8-step strips.  (YStrip16 stores aligned pairs of cells and nothing else about a row's
+  // place in its lines, so it could serve every even width there; measured, 256 sources, 8-step / 16-step y-major strips: 1002^2
+  // 0.686 / 0.700 ms, 1004^2 0.647 / 0.665 -- those launches are bound by the memory's handling of their row pieces, not by
+  // instructions: -DVHP_POOL_ANYW_Y16 builds it.)
+#ifdef VHP_POOL_ANYW_Y16
+  static constexpr bool kMayY16 = ANYW && VHP_POOL_X16 != 0;
+#else
+  static constexpr bool kMayY16 = false;
+#endif
 #endif
   Args<OutT> a;
   Shared sh;
   int w, group;
+  bool pairs_aligned;   // every pair of cells (x even, x + 1) of every field is aligned to its size
   vi lane;
 
   // (group: the index of the workgroup, 0 .. Args::n_groups - 1)
   VHP_FN void init(const Args<OutT>& a_, double* lds, const Layout& L, int w_, int group_) {
     a = a_;
+    pairs_aligned = (a_.m.nx & 1) == 0 && (a_.field_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(a_.out) & (2 * sizeof(OutT) - 1)) == 0;
     sh.lds = lds;
     sh.L = L;
     w = w_;
@@ -1688,7 +1699,7 @@ struct Worker {
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* mine = sh.prog(c) + q;
-    if (kUseY16) {
+    if (kUseY16 || (kMayY16 && pairs_aligned)) {
       YStrip16<DX, DY, OutT> ys;
       ys.lk.init(sh, w, sy, g.ystart(q), tag_of(c, q), mine, q > 0 ? line_of(c, q - 1, g.Nby) : nullptr, q + 1 < g.Py ? line_of(c, q, g.Nby) : nullptr,
                  a.epoch, q > 0 ? lds_int_at(sh.owner(c) + (q - 1)) : -1, q > 0 ? tag_of(c, q - 1) : 0);
