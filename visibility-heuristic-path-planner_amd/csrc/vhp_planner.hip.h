@@ -140,9 +140,22 @@ __device__ __forceinline__ void planner_pick(const DevMap& m, const PlannerDev& 
 // Step 2: the per-cell body of updateVisibility() that follows the store (solver.cpp:417-430)
 // over every cell the sweep visited: max-union into vis_global, first-lit labelling, heuristic
 // of every lit cell, arg-min of (h, push rank).  Embarrassingly parallel and coalesced.
-constexpr int kEpilogueBlocks = 256;  // == the epilogue's workgroup size (the last workgroup merges one partial per thread)
-__global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev d) {
-  __shared__ PlannerKey slots[4];
+// The epilogue's launch shape: kEpilogueBlocks workgroups of kEpilogueThreads (blocks <= threads: the last workgroup merges one partial
+// per thread).  Measured on maze_6 (bench.py --workload c4, us per pivot of the device loop, one box): 256 x 256 31.3, 128 x 512 30.3,
+// 64 x 1024 38.6 (profiles/r05_planner_epilogue_shapes.txt).
+#ifndef VHP_EPI_BLOCKS
+#define VHP_EPI_BLOCKS 128
+#endif
+#ifndef VHP_EPI_THREADS
+#define VHP_EPI_THREADS 512
+#endif
+constexpr int kEpilogueBlocks = VHP_EPI_BLOCKS;
+constexpr int kSpecEpilogueBlocks = 256;  // the speculative solve's epilogue keeps its own shape: 256 workgroups of 256
+constexpr int kEpilogueThreads = VHP_EPI_THREADS;
+constexpr int kEpilogueWaves = kEpilogueThreads / 64;
+static_assert(kEpilogueBlocks <= kEpilogueThreads, "the last workgroup merges one partial per thread");
+__global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap m, PlannerDev d) {
+  __shared__ PlannerKey slots[kEpilogueWaves];
   if (d.ctl->done) return;
   const int nb = d.ctl->nb;
   const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
@@ -226,7 +239,7 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
   __shared__ int is_last;
   if (threadIdx.x == 0) {
     PlannerKey b = slots[0];
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < kEpilogueWaves; ++w)
       if (key_less(slots[w], b)) b = slots[w];
     d.partial[blockIdx.x] = b;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -241,7 +254,8 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
   if (!is_last) return;
   // kEpilogueBlocks == blockDim.x: one partial per thread, agent-scope loads (another CU wrote them)
   PlannerKey k;
-  {
+  k.h = ~0ull; k.rank = ~0ull; k.x = k.y = -1;
+  if (threadIdx.x < gridDim.x) {
     const unsigned long long* p = reinterpret_cast<const unsigned long long*>(d.partial + threadIdx.x);
     k.h = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     k.rank = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -258,7 +272,7 @@ __global__ void __launch_bounds__(256) vhp_planner_epilogue(DevMap m, PlannerDev
   __syncthreads();
   if (threadIdx.x == 0) {
     PlannerKey bb = slots[0];
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < kEpilogueWaves; ++w)
       if (key_less(slots[w], bb)) bb = slots[w];
     *d.ticket = 0;  // for the next iteration (kernels of one stream run in order)
     planner_pick(m, d, bb);
@@ -383,7 +397,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
     VHP_PL_HIP(hipMalloc(&s.label, cells * 4));
     VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
     VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
-    VHP_PL_HIP(hipMalloc(&s.partial, kEpilogueBlocks * sizeof(PlannerKey)));
+    VHP_PL_HIP(hipMalloc(&s.partial, (kEpilogueBlocks > kSpecEpilogueBlocks ? kEpilogueBlocks : kSpecEpilogueBlocks) * sizeof(PlannerKey)));
     VHP_PL_HIP(hipMalloc(&s.ticket, sizeof(unsigned int)));
     s.cells = cells;
   }
@@ -443,7 +457,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
                    : R == 2 ? (multi ? launch_planner_fronts<2, true>(s, m, d, W, stream) : launch_planner_fronts<2, false>(s, m, d, W, stream))
                             : (multi ? launch_planner_fronts<4, true>(s, m, d, W, stream) : launch_planner_fronts<4, false>(s, m, d, W, stream));
       if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
-      hipLaunchKernelGGL(vhp_planner_epilogue, dim3(kEpilogueBlocks), dim3(256), 0, stream, m, d);
+      hipLaunchKernelGGL(vhp_planner_epilogue, dim3(kEpilogueBlocks), dim3(kEpilogueThreads), 0, stream, m, d);
       VHP_PL_HIP(hipGetLastError());
     }
     VHP_PL_HIP(hipMemcpyAsync(&ctl, s.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
@@ -759,7 +773,7 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
     VHP_PL_HIP(hipMalloc(&s.label, cells * 4));
     VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
     VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
-    VHP_PL_HIP(hipMalloc(&s.partial, kEpilogueBlocks * sizeof(PlannerKey)));
+    VHP_PL_HIP(hipMalloc(&s.partial, (kEpilogueBlocks > kSpecEpilogueBlocks ? kEpilogueBlocks : kSpecEpilogueBlocks) * sizeof(PlannerKey)));
     VHP_PL_HIP(hipMalloc(&s.ticket, sizeof(unsigned int)));
     s.cells = cells;
   }
@@ -820,7 +834,7 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
                    : R == 2 ? (multi ? launch_spec_fronts<2, true>(s, m, d, sp, W, stream) : launch_spec_fronts<2, false>(s, m, d, sp, W, stream))
                             : (multi ? launch_spec_fronts<4, true>(s, m, d, sp, W, stream) : launch_spec_fronts<4, false>(s, m, d, sp, W, stream));
       if (e != hipSuccess) { *msg = std::string("speculative planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
-      hipLaunchKernelGGL(vhp_spec_epilogue, dim3(kEpilogueBlocks), dim3(256), 0, stream, m, d, sp);
+      hipLaunchKernelGGL(vhp_spec_epilogue, dim3(kSpecEpilogueBlocks), dim3(256), 0, stream, m, d, sp);
       VHP_PL_HIP(hipGetLastError());
     }
     VHP_PL_HIP(hipMemcpyAsync(&ctl, s.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));

@@ -704,6 +704,15 @@ struct Below16 {
   VHP_FN void get(Link<D>& lk, const double* bin, int cw, int c_first, int ia, int last_needed, int nb) {
     if (!VHP_DIAG_WAITS) { from_slab(bin, cw, c_first); return; }
     if (lk.bin_block == nb) { from_slab(bin, cw, c_first); return; }
+#ifndef VHP_POOL_NO_HDR_POLL   // (-DVHP_POOL_NO_HDR_POLL: every poll reads the 17 values as well, for A/B)
+    {
+      // a strip that follows its writer closely waits here window after window: on the header alone (one LDS read a poll), the
+      // values only once they are there
+      int h = lds_poll(lk.rd_hdr);
+      while ((h >> 14) == lk.rd_tag && (h & 0x3fff) <= last_needed) { ready_backoff(); sim_point(); h = lds_poll(lk.rd_hdr); }
+      lds_acquire();
+    }
+#endif
     from_ring(lk, cw, c_first);
     for (;;) {
       const int ha = uniform(h1), hb = uniform(h2);
