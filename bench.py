@@ -212,7 +212,7 @@ def bench_planner(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     loop_ms = float(np.mean(dev_ms))
-    bytes_per_pivot = 32 * nx * ny  # vis_local 8 W + 8 R, vis_global 8 R + 8 W, labels 4 R + 4 W (DESIGN.md section 5)
+    bytes_per_pivot = 32 * nx * ny  # vis_local 8 W + 8 R, vis_global 8 R + 8 W, labels 4 R + 4 W (DESIGN.md section 7)
     achieved = bytes_per_pivot * n_piv / (loop_ms * 1e-3) / 1e9
     out = {
         "metric": "planner pivots/sec on maze_6 (690x402)", "value": round(n_piv * args.steps / elapsed, 1), "unit": "pivots/s",
@@ -424,7 +424,7 @@ def main():
     overlapped = args.gather and args.gather_mode == "overlapped" and world >= 1 and n_src % args.chunks == 0 and dist.is_initialized()
     # A second result buffer, placed by the library (vhp_alloc_output, include/vhp.h: the memory behind an allocation is of a faster or a
     # slower kind and no allocation API chooses, so the library tries a bounded number of allocations, probes each and keeps the best:
-    # DESIGN.md section 7) -- set up here, before any timed region, like the map and the sources.  --output-buffer first (the default):
+    # DESIGN.md appendix A.7) -- set up here, before any timed region, like the map and the sources.  --output-buffer first (the default):
     # the main region writes into the first allocation and the placed buffer is timed behind it; placed: the other way round.
     placed = None
     d_placed = None
@@ -559,7 +559,7 @@ def main():
             return round(v, 4)
 
         note = ("vhp_probe_stores: 1 KB row pieces in many streams, plain stores; on this device an allocation answers whole lines with "
-                "4.7-5.0 (slow) or 5.6-6.1 TB/s (fast), split lines with 3.5-3.7 or 4.7-5.4, DESIGN.md section 7")
+                "4.7-5.0 (slow) or 5.6-6.1 TB/s (fast), split lines with 3.5-3.7 or 4.7-5.4, DESIGN.md appendix A.7")
         try:
             w, sp = ctx.probe_stores(d_first.data_ptr(), out_bytes)
             placement["first_allocation_of_this_process"] = {"whole_lines_TBps": round(w, 2), "split_lines_TBps": round(sp, 2), "state": state_of(sp), "note": note}

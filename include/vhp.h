@@ -204,7 +204,7 @@ int vhp_last_sweep_kernel(const vhp_ctx* ctx);
  * device buffer takes two store patterns of a sweep launch, in TB/s of bytes stored -- 1 KB row pieces in many concurrent
  * streams, (a) every piece on the 128-byte line grid, (b) every other piece half a line off it, so that two lines per piece
  * are written in halves by different wavefronts at different times, with PLAIN stores.  The same physical memory answers (a)
- * with 4.9-5.0 or 5.9-6.1 and (b) with 3.6-3.7 or 5.2-5.4 depending on where the allocation landed (DESIGN.md section 7);
+ * with 4.9-5.0 or 5.9-6.1 and (b) with 3.6-3.7 or 5.2-5.4 depending on where the allocation landed (DESIGN.md appendix A.7);
  * bench.py reports both for the buffer it timed so that a result can be read against the state of its memory; vhp_alloc_output
  * (below) places a result buffer by it.  d_buf: 128-byte aligned, at least 128 MB; its contents are overwritten with zeros
  * (up to 16 GB of it are used).  Blocks until done. */
@@ -212,7 +212,7 @@ int vhp_probe_stores(vhp_ctx* ctx, void* d_buf, unsigned long long bytes, float*
 
 /* Device memory for results, placed by the library (the reference has no device memory; a maintainer's binding allocates its
  * result fields with this instead of hipMalloc).  The memory behind an allocation is of a faster or a slower kind, and no allocation
- * API chooses (DESIGN.md section 7; a launch of 256 fields at 1000^2 takes 15-20 % longer on the one than on the other): up to
+ * API chooses (DESIGN.md appendix A.7; a launch of 256 fields at 1000^2 takes 15-20 % longer on the one than on the other): up to
  * max_candidates allocations of `bytes` are made, each is probed (vhp_probe_stores; from 128 MB up), the one whose two rates add up
  * highest is kept, the others are freed.  BEST EFFORT: where the fast kind is rare the keeper is merely the best of what was tried.
  * The search is a guest on the device: the candidates -- all held until the choice is made, a freed one would be handed out

@@ -233,7 +233,7 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
     int4* d_desc = reinterpret_cast<int4*>(c->d_order);                      // n_units descriptors first (16-byte aligned)
     int* d_ord = reinterpret_cast<int*>(d_desc + n_units);                   // then the order list
     // Packing short quadrants into one workgroup is implemented and parity-tested, but measured slower
-    // on MI355X (DESIGN.md section 10): off unless VHP_PACK is set.
+    // on MI355X (DESIGN.md appendix A.10): off unless VHP_PACK is set.
     const int pack_w = (!MULTI && W == 8 && pack) ? W : 0;
     hipLaunchKernelGGL(vhp::vhp_order_units, dim3(1), dim3(1024), 0, c->stream, d_src, n_src, c->nx, c->ny, 64 * R, pack_w, d_ord,
                        d_desc);
@@ -934,7 +934,7 @@ int vhp_alloc_output(vhp_ctx* ctx, unsigned long long bytes, int max_candidates,
     // (the two rates move together -- 4.9 / 3.6 on the slow kind, 6.0 / 5.3 on the fast, anything between on a buffer that straddles
     // both --: their sum ranks the candidates; an improvement is more than the probe's own scatter of ~0.05 TB/s)
     if (best < 0 || w + sp > best_w + best_s + 0.05f) { best = k; best_w = w; best_s = sp; since_best = 0; } else ++since_best;
-    if (!probed || (w >= 5.5f && sp >= 4.6f)) break;   // the fast kind (DESIGN.md section 7; 5.6-6.1 / 4.6-5.4 by box): nothing better to find
+    if (!probed || (w >= 5.5f && sp >= 4.6f)) break;   // the fast kind (DESIGN.md appendix A.7; 5.6-6.1 / 4.6-5.4 by box): nothing better to find
     if (since_best >= 8) break;
   }
   ctx->last_alloc_peak_bytes = (unsigned long long)tried * bytes;

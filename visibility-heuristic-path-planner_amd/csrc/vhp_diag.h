@@ -16,12 +16,18 @@
 //   VHP_DIAG_NODEATH    no strip ever declares itself dead: what the early exits are worth                  (latency sweep)
 //   VHP_DIAG_NODIAGSTORE  a strip that is growing along its diagonal stores nothing: the bound on what handing its stores to
 //                       another wavefront could buy (C2: 98.8 -> 79 us)                                     (latency sweep)
+// A/B switches of round 5 (correct results; the product is the build WITHOUT them):
+//   VHP_POOL_X8 / VHP_POOL_Y8   the pool sweep's strips in the 8-step windows of rounds 3-4 (both kinds / the y-major ones only)
+//   VHP_POOL_ANYW_Y16           the 16-step y-major strips also in the build for the other widths (measured slower: vhp_pool.hpp)
+//   VHP_POOL_NO_HDR_POLL        a waiting strip re-reads the 17 boundary values with every poll, not the header alone
+//   VHP_PRIO_DIAG / VHP_PRIO_TASK = 0   no instruction priorities by phase;  VHP_PRIO_MARCH = n: ... and by what is left of a march
+//   VHP_EPI_BLOCKS / VHP_EPI_THREADS    the planner epilogue's launch shape (vhp_planner.hip.h)
 //
 // Experiments that are over were deleted together with their switches.  Round 3: FLATPOLL, MASKPUB, HEAVYSYNC, NOLOAD, YDRAIN,
 // NOREFILL, SLOTTIME, SMALLSTORE, NOSTORE_X/_Y of the front sweep, PRIO, the back-off lengths as -D values.  Round 4: NOPARTIAL, DROP_XPRED / _YPRED / _XRAGGED, WHOLELINES, NOLINES, YALIGNED, NOBANDLOAD / NOBANDTASK (the seam band
 // itself: `git show a1f0eca`), WGTIME (it went with the streaming sweep), the pool sweep's cycle accounts (POOLPROF there: one
-// s_memtime per probe slowed the launch by a third; the timeline took their place).  What they measured is in DESIGN.md
-// sections 4, 4b, 4c and 7.  The kernels' sources contain the macros below and no #if of these switches (the latency sweep's
+// s_memtime per probe slowed the launch by a third; the timeline took their place).  What they measured is in DESIGN.md,
+// appendix A (A.4b, A.4c, A.7) and section 6.  The kernels' sources contain the macros below and no #if of these switches (the latency sweep's
 // stamps and window accounts excepted: vhp_lat.hpp).
 #pragma once
 
@@ -128,7 +134,7 @@
 #endif
 
 // back-off of a wavefront that waits (s_sleep units of 64 cycles): measured in round 2, 12 for a hand-off that is not
-// ready, 4 for a dependency that usually is (DESIGN.md 4b, lesson 3)
+// ready, 4 for a dependency that usually is (DESIGN.md appendix A.4b, lesson 3)
 #ifndef VHP_BACKOFF_SLEEP
 #define VHP_BACKOFF_SLEEP 12
 #endif

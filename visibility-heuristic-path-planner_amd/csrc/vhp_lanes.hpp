@@ -122,7 +122,7 @@ inline void g_load2_f64(const double* base, const vi& idx, vd& a, vd& b) { for (
 // The simulator records every global store (how many, how wide, which 64-byte sectors) for the tests' coverage
 // and store-shape checks.
 // ... and, for stores into the registered output [base, base + bytes), how many 128-byte lines an instruction wrote whole and
-// how many only in part (a line that leaves in pieces costs the memory several whole ones: DESIGN.md section 7).
+// how many only in part (a line that leaves in pieces costs the memory several whole ones: DESIGN.md appendix A.7).
 struct StoreStats {
   long long n16 = 0, n8 = 0, n4 = 0, lines_whole = 0, lines_part = 0, misaligned = 0;  // misaligned: pairs off their own size's grid (must stay 0)
   const char* base = nullptr;
@@ -319,7 +319,7 @@ VHP_LANE_FN vd g_load_f64(const double* base, vi idx) { return base[idx]; }
 VHP_LANE_FN void g_load2_f64(const double* base, vi idx, vd& a, vd& b) { const double2 v = *reinterpret_cast<const double2*>(base + idx); a = v.x; b = v.y; }
 
 // Field stores are NON-TEMPORAL (the nt bit of global_store).  A field is written once and never read by the launch, and --
-// measured, DESIGN.md section 7 -- the memory side charges a plain store that covers only part of a 128-byte line (the two ends
+// measured, DESIGN.md appendix A.7 -- the memory side charges a plain store that covers only part of a 128-byte line (the two ends
 // of a row piece that is half a line off the line grid, the cells next to a diagonal or an axis) several whole lines' worth on
 // two thirds of the device's memory; with nt a partially written line costs what it weighs (tools/policybench.hip: the same
 // bytes, every other row half a line off: 3.65 -> 4.81 TB/s on a slow buffer, 5.27 -> 5.96 on a fast one).
@@ -342,7 +342,7 @@ template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p
     VHP_FIELD_STORE(reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off + (p_lo ? 0u : (uint32_t)sizeof(OutT))), static_cast<OutT>(single));
 }
 // Without the nt bit, whatever the translation unit's VHP_FIELD_STORE is: for 64-byte pieces, which a wavefront's L2 merges into
-// lines when they are plain stores (DESIGN.md section 7: 3.75 TB/s against 3.07 with nt on the slow kind of memory).
+// lines when they are plain stores (DESIGN.md appendix A.7: 3.75 TB/s against 3.07 with nt on the slow kind of memory).
 template <typename OutT> VHP_LANE_FN void g_store2_plain(OutT* base, vu32 off, vd a, vd b) {
   VHP_DIAG_STORE_GUARD(a, b, off)
   *reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off) = Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)};

@@ -2,40 +2,35 @@
 // batches of sources, organised as a pool of wavefronts per CU that pull STRIPS.
 //
 // A quadrant is an x-major octant whose fronts are columns and a y-major octant whose fronts are rows (vhp_geom.hpp); a unit
-// is one octant; a strip is 64 rows / 128 columns of it; a block is 64 steps of a strip.  The per-step code is that of round
-// 2's streaming sweep (retired: DESIGN.md section 4b), the machine around it is not.  There a workgroup swept ONE unit with a
-// fixed team, wavefront w owned strips w, w+W, ... one after the other (wavefront 0 of a full-size octant: 2424 dependent
-// steps), half of an x-major team only flushed, a y-major team kept 2 of 7 wavefronts busy, and so a launch without stores
-// still took 0.46 ms for 0.1 ms of arithmetic.  Here
+// is one octant; a strip is 64 rows / 128 columns of it; a block is 64 steps of a strip.  (Round 2's streaming sweep, retired --
+// DESIGN.md appendix A.4b --, swept ONE unit per workgroup with a fixed team: wavefront 0 of a full-size octant had 2424
+// dependent steps, and a launch without stores took 0.46 ms for 0.1 ms of arithmetic.)  Here
 //
 //   * ONE workgroup of W wavefronts per CU, persistent, holds up to C units at once (contexts in LDS);
 //   * every wavefront is a worker: it claims the next strip of a context whose predecessor strip has got far enough
-//     (compare-and-swap on the context's claim word), sweeps it from its first block to the end of the march, and
-//     looks for the next.  A full-size octant has all of its strips in flight at once, a window apart; small units fill
-//     the wavefronts the large ones leave.  When no strip is ready and a context is free, the wavefront installs a unit
-//     of the launch's queue (units sorted by cell count: vhp_pool_order): context 0 takes the LARGEST unit left, the
-//     other contexts the SMALLEST -- a strip occupies its wavefront until its march ends, so what runs beside a large
-//     unit must be short, or that unit's next strip finds no wavefront when it becomes ready (with every context pulling
-//     from the head the largest octants took the whole launch, 0.7 ms, waiting for wavefronts);
+//     (compare-and-swap on the context's claim word), sweeps it from its first step to the end of the march, and looks for the
+//     next.  A full-size octant has all of its strips in flight at once, a window apart; small units fill the wavefronts the
+//     large ones leave.  When no strip is ready and a context is free, the wavefront installs a unit of the launch's queue
+//     (vhp_pool_order: units sorted by the length of their march): the head contexts take the LONGEST unit left, the filler
+//     context the SHORTEST -- a strip occupies its wavefront until its march ends, so what runs beside a large unit must be
+//     short.  The first unit of every context is handed out by workgroup index, no pull (Args::static_round);
 //   * the boundary line of strip p goes to strip p+1 twice.  DURABLY through global memory (the L2), a block of 64 entries
 //     at a time: 16-byte entries {value, tag}, the tag being the launch's epoch, so that a reader can tell an entry of
-//     this launch from whatever the scratch held before -- no fence, no wait for the producer's stores (a workgroup-scope
-//     release drains every store the wavefront has in flight: DESIGN.md 4b).  And FAST through a 256-entry ring in LDS
-//     that belongs to the writing wavefront and that it overwrites without ever waiting for anybody: a reader that
-//     follows closely (the normal case) copies the few entries of its next window out of the ring and checks the
-//     writer's header word -- which strip the ring belongs to, how far it has got -- before and after; if the writer is
+//     this launch from whatever the scratch held before -- no fence, no wait for the producer's stores.  And FAST through a
+//     256-entry ring in LDS that belongs to the writing wavefront and that it overwrites without ever waiting for anybody: a
+//     reader that follows closely (the normal case) reads the values of its next window straight out of the ring and checks
+//     the writer's header word -- which strip the ring belongs to, how far it has got -- before and after; if the writer is
 //     more than ~240 steps ahead, or has moved on to another strip, the reader takes the whole block from global memory
-//     instead.  So a strip follows the strip below it by one 8-step window instead of a 64-step block (the launch is
-//     as long as the pipelines of its largest units: with block hand-offs a full-size octant needs 31 block times for
-//     16 blocks of march), and a strip still waits only for strips claimed before it: the machine cannot deadlock,
-//     whatever the number of wavefronts, contexts and strips.  (A first version had rings that were never overwritten:
-//     with the reader of a ring not yet claimed its writer stalls, and on marches longer than ~4 W blocks every
-//     wavefront can end up stalled behind an unclaimed reader -- the simulator found it);
-//   * an x-major strip flushes its own staging tile: after every 8-step window the rows whose 128-byte line is
-//     complete leave as whole lines, 8 rows per store instruction, issued by the wavefront that computed them (a
-//     wavefront stalled in a store is covered by the other wavefronts of its SIMD: that is what a pool is for);
-//     two builds: widths that are a multiple of 8 (a row's lines start at one of two places: a tile of two windows), and every
-//     other width, padded or unaligned field (ANYW: the lines of a row start anywhere, a tile of three windows; XStrip::flush_rows);
+//     instead.  So a strip follows the strip below it by one window instead of a 64-step block, and a strip still waits only
+//     for strips claimed before it: the machine cannot deadlock, whatever the number of wavefronts, contexts and strips.
+//     (A first version had rings that were never overwritten: with the reader of a ring not yet claimed its writer stalls,
+//     and on marches longer than ~4 W blocks every wavefront can end up stalled behind an unclaimed reader -- the simulator
+//     found it);
+//   * the strips (round 5): windows of SIXTEEN steps, XStrip16 / YStrip16 below -- the latency sweep's window machinery
+//     (vhp_lat.hpp) with whole-line stores: an x-major strip flushes its own 16-column staging tile, 8 rows x 128 bytes per
+//     store instruction, the rows that lie half a line off the grid out of a read in mid-window.  The build for widths that are
+//     not a multiple of 8, for padded or unaligned fields (ANYW) keeps the 8-step strips of rounds 3-4, XStrip / YStrip: the lines
+//     of a row start anywhere there, the tile is a ring of three 8-column windows (XStrip::flush_rows);
 //   * the stale diagonal of a y-major unit is produced by the wavefront that installed the unit -- the serial
 //     two-term recurrence of DiagTask -- into a scratch line in global memory, 64 entries at a time; a strip
 //     loads the seeds of its own columns into registers when it starts.

@@ -214,7 +214,7 @@ __device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
 // ~60-80 cycles whether or not its lanes are dropped.)
 // NT: non-temporal stores (the nt bit) -- the batch sweeps, whose fields nobody reads back during the launch: a plain store
 // that covers part of a 128-byte line costs the memory side several whole lines' worth on most of the device's memory, an nt
-// store what it weighs (DESIGN.md section 7; vhp_lanes.hpp VHP_FIELD_STORE).  The planner's sweeps, whose field the epilogue
+// store what it weighs (DESIGN.md appendix A.7; vhp_lanes.hpp VHP_FIELD_STORE).  The planner's sweeps, whose field the epilogue
 // reads right away, keep plain stores.
 template <typename OutT, bool MULTI = false, bool NT = false>
 struct StoreEmit {
