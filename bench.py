@@ -494,6 +494,24 @@ def main():
     other = None
     if d_other is not None:
         other = timed_region(d_other)
+    # Not a parity test (tests/test_gpu_*.py hold these very launches against the oracle field by field), a tripwire: the first fields
+    # the timed launches left in the first allocation, byte for byte against ANOTHER kernel's -- the front sweep's -- on the same
+    # sources.  Behind both timed regions, before anything else writes the buffer.
+    self_check = None
+    if rank == 0 and not overlapped:
+        try:
+            n_chk = min(8, n_src)
+            ref = torch.empty((n_chk, ny, nx), dtype=tdt, device=dev)
+            timed_kernel = ctx.last_sweep_kernel()
+            ctx.set_option("kernel", 1)
+            ctx.sweep_batch_device(d_src.data_ptr(), n_chk, ref.data_ptr(), dtype=vdt)
+            ctx.sync()
+            ctx.set_option("kernel", args.kernel)
+            self_check = {"fields_compared": n_chk, "timed_kernel": timed_kernel, "against_kernel": 1,
+                          "equal": bool(torch.equal(ref, d_first[:n_chk]))}
+            ref = None
+        except Exception as e:
+            self_check = {"error": repr(e)}
 
     # ---- behind the timed region: the job with its collective (N > 1), then what memory the timed buffer was -----------------
     with_coll = None
@@ -615,6 +633,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "grid": [nx, ny], "sources_per_gpu": n_src, "sharding": "sources/%d" % world,
                        "kernel_option": args.kernel,
+                       "self_check": self_check,
                        "output_placement": placement,
                        "collective": ("rccl all_gather of fields (%s%s)" % (args.gather_mode if gathered is not None else "", ", %d chunks per shard" % args.chunks if overlapped else "")
                                       if gathered is not None else "none (independent sources)"),
