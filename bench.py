@@ -76,7 +76,11 @@ def parse():
     ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 3, 4],
                     help="0 = the library's own choice, 1 = front sweep, 3 = pool sweep, 4 = latency sweep (vhp_set_option \"kernel\")")
     ap.add_argument("--pool-contexts", type=int, default=0, help="pool sweep: units a workgroup holds at once (0 = automatic)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo only with --dry-run)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (gloo only with --dry-run or --share-device)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="TEST ONLY: every rank on cuda:0 with the gloo backend, so that the N > 1 code path (broadcast map, barriers, "
+                         "max over ranks, the collectives behind the region) runs for real on a one-GPU box; never a result")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the launcher, the rendezvous, the barriers and the max-over-ranks timing with a CPU stub in "
                          "place of the sweep (no GPU, no library): for the CPU test of `bench.py --gpus N`; never a result")
@@ -346,11 +350,13 @@ def main():
         print("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is what runs" % (args.gpus, world), file=sys.stderr)
     if args.dry_run:
         return bench_dry_run(args, rank, world)
-    if args.backend != "nccl":
-        raise SystemExit("bench.py: --backend gloo exists for --dry-run only (the sweep runs on the GPU, RCCL is its collective)")
+    if args.backend != "nccl" and not args.share_device:
+        raise SystemExit("bench.py: --backend gloo exists for --dry-run and --share-device only (the sweep runs on the GPU, RCCL is its collective)")
+    if args.share_device and args.backend != "gloo":
+        raise SystemExit("bench.py: --share-device needs --backend gloo (RCCL refuses two ranks on one device)")
     if args.workload == "c4":
         return bench_planner(args)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
@@ -363,7 +369,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     from importlib import import_module
@@ -445,6 +454,13 @@ def main():
             placed = None
             d_placed = None
             sys.stderr.write("vhp_alloc_output failed (%r): the first allocation only\n" % (e,))
+    if world > 1:
+        # every rank runs the same regions with the same barriers: a placed buffer on all of them, or on none
+        have = torch.tensor([1 if d_placed is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if int(have.item()) == 0 and d_placed is not None:
+            ctx.free_output(d_placed.data_ptr())
+            d_placed, placed = None, None
     d_out = d_placed if (args.output_buffer == "placed" and d_placed is not None) else d_first
     d_other = None if d_placed is None else (d_first if d_out is d_placed else d_placed)
     if args.gather and (world > 1 or overlapped):
@@ -637,7 +653,8 @@ def main():
                        "output_placement": placement,
                        "collective": ("rccl all_gather of fields (%s%s)" % (args.gather_mode if gathered is not None else "", ", %d chunks per shard" % args.chunks if overlapped else "")
                                       if gathered is not None else "none (independent sources)"),
-                       "map": "rccl broadcast from rank 0" if world > 1 else "uploaded by the only rank"},
+                       "map": "rccl broadcast from rank 0" if world > 1 else "uploaded by the only rank",
+                       **({"share_device": "TEST MODE: every rank on cuda:0, gloo collectives -- not a result"} if args.share_device else {})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": round(kern_ms, 4),

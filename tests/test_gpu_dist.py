@@ -73,3 +73,28 @@ def test_sharded_hip_sweep_under_rccl_single_rank(oracle):
         assert np.array_equal(out.cpu().numpy()[rows], full)
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_on_one_device():
+    # bench.py's N > 1 path for real (not --dry-run): two ranks, both on cuda:0 (--share-device: gloo collectives, since RCCL refuses two
+    # ranks on one device), the map broadcast from rank 0, both timed regions with their barriers, the collectives behind them, the
+    # max over ranks, one JSON line from rank 0.  What the driver's 8-GPU run walks, minus RCCL itself (test above).
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node=2",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3", "--warmup", "1",
+           "--sources", "48", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["sources_per_gpu"] == 48 and d["config"]["sharding"] == "sources/2"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 48 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-3 * d["value"]
+    assert d["value_first_allocation"] == d["value"] and d["roofline"]["kernel"] in ("vhp_pool_sweep", "vhp_sweep_fronts")
+    assert d["config"]["self_check"]["equal"] is True
+    wc = d["value_with_collective"]
+    assert "error" not in wc and wc["allgather_f32"]["value"] > 0 and wc["union_fields"]["value"] > 0, wc
