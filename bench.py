@@ -23,7 +23,8 @@ section 7) and the same launch takes 15-20 % longer on the one than on the other
   * `value_placed_buffer` / `roofline.frac_placed_buffer` -- the same K steps, same barriers, behind the main region, into a result
     buffer placed by the library's own allocator (vhp_alloc_output: a bounded number of allocations probed, the best kept; what
     the search cost is in `config.output_placement.search_ms` / `.search_bytes_peak`).
-`--output-buffer placed` swaps the roles (the main region on the placed buffer).  `config.output_placement` also says what kind of
+`--output-buffer placed` swaps the roles (the main region on the placed buffer).  Where the main region is short (the driver's 20
+steps are 10 ms of work) `value_200_steps` / `roofline.kernel_ms_200_steps` repeat it over 200 steps on the same buffer.  `config.output_placement` also says what kind of
 memory both buffers and three more allocations of the process are on (vhp_probe_stores), with the launch timed on each.
 
 The defaults (100 steps after 10 warm-up launches, ~0.1 s of GPU time) report the sustained rate.
@@ -485,31 +486,37 @@ def main():
 
     launches_per_step = args.chunks if overlapped else 1
 
-    def timed_region(dst=None):
+    def timed_region(dst=None, steps=None):
         """W warm-up steps, barrier, K timed steps, barrier: (seconds -- max over ranks --, this rank's kernel ms per step)."""
+        steps = steps or args.steps
         for _ in range(args.warmup):
             step(dst)
         barrier()
-        ctx.timing(True, prealloc=args.steps * launches_per_step + 2)  # HIP events around every sweep kernel, on the stream it is launched on;
+        ctx.timing(True, prealloc=steps * launches_per_step + 2)  # HIP events around every sweep kernel, on the stream it is launched on;
         #                                              the event pairs exist before the timed region starts
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step(dst)
         barrier()
         el = time.perf_counter() - t0
         ctx.sync()  # surfaces device-side validation errors
-        k = ctx.timing_collect(args.steps * launches_per_step)
+        k = ctx.timing_collect(steps * launches_per_step)
         ctx.timing(False)
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), float(k.sum()) / args.steps
+        return float(t.item()), float(k.sum()) / steps
 
     elapsed, kern_ms = timed_region()
     # the same K steps into the OTHER result buffer (the library-placed one, or with --output-buffer placed the first allocation)
     other = None
     if d_other is not None:
         other = timed_region(d_other)
+    # ... and, where the main region is short (the driver's 20 steps are 10 ms of work), the same buffer again over 200 steps: the
+    # sustained rate beside the line's own (reported, never `value`)
+    sustained = None
+    if args.steps < 200 and not args.gather:
+        sustained = timed_region(None, 200)
     # Not a parity test (tests/test_gpu_*.py hold these very launches against the oracle field by field), a tripwire: the first fields
     # the timed launches left in the first allocation, byte for byte against ANOTHER kernel's -- the front sweep's -- on the same
     # sources.  Behind both timed regions, before anything else writes the buffer.
@@ -637,6 +644,7 @@ def main():
             "value": round(fields / elapsed, 2),
             "value_first_allocation": (round(fields / first_reg[0], 2) if first_reg else None),
             "value_placed_buffer": (round(fields / placed_reg[0], 2) if placed_reg else None),
+            "value_200_steps": (round(world * n_src * 200 / sustained[0], 2) if sustained else None),
             "unit": "fields/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -662,6 +670,7 @@ def main():
                          "kernel_ms_first_allocation": (round(first_reg[1], 4) if first_reg else None),
                          "frac_placed_buffer": (round(alg_bytes / (placed_reg[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if placed_reg else None),
                          "kernel_ms_placed_buffer": (round(placed_reg[1], 4) if placed_reg else None),
+                         "kernel_ms_200_steps": (round(sustained[1], 4) if sustained else None),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          # the same rate counting only the field bytes written (the occupancy maps are read at 2 bits/cell)
                          "frac_field_bytes": round((alg_bytes - nx * ny * n_src) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
