@@ -290,10 +290,14 @@ bool use_pool_kernel(const vhp_ctx* c, int n_src) {
     // 250^2: 192: 94 / 123, 512: 220 / 259; 101^2: 512: 50 / 191.
     // (with the whole-line build: 1002x1000: 32: 309 / 329, 48: 365 / 320, 96: 621 / 394, 192: 1116 / 604; 690x402: 48: 152 / 189, 96: 240 / 195;
     // 500^2: 96: 167 / 185, 192: 285 / 208; 398^2: 96: 132 / 150, 192: 213 / 174)
-    if (maxdim < 384) return false;
-    if (maxdim <= 600) return n_src >= 192;
-    if (maxdim <= 768) return n_src >= 96;
-    if (maxdim <= 1100) return n_src >= 48;
+    // Round 5, the front sweep with plain stores (1.5-1.9 x faster on these widths: vhp_sweep.hip.h StoreEmit; front / pool, us,
+    // profiles/r05_front_vs_pool_plain_front_stores.txt): 1002x1000: 48 sources 298 / 321, 96: 438 / 322, 256: 1013 / 626; 1001x971: 48: 281 /
+    // 337, 96: 425 / 353; 690x402: 96: 170 / 176, 192: 235 / 208, 256: 325 / 244; 500^2: 192: 171 / 182, 256: 265 / 238, 512: 521 / 438;
+    // 398^2: 256: 139 / 199, 512: 356 / 353; 250^2: 512: 108 / 248.
+    if (maxdim < 450) return false;
+    if (maxdim <= 600) return n_src >= 256;
+    if (maxdim <= 768) return n_src >= 128;
+    if (maxdim <= 1100) return n_src >= 64;
     return n_src >= 24;
   }
   // (later in round 4, tools/kernel_ab.py, front / pool, us: 256^2: 192 sources 72 / 113, 384: 91 / 191; 384^2: 192: 124 / 148, 384: 175 / 249;
@@ -303,8 +307,10 @@ bool use_pool_kernel(const vhp_ctx* c, int n_src) {
   // 384: 286 / 244, 1024: 521 / 583; 512^2: 48: 135 / 137, 96: 144 / 131, 192: 201 / 168, 1024: 859 / 694; 576^2: 48: 150 / 146, 96: 164 / 142,
   // 384: 446 / 332; 640^2: 48: 169 / 163, 384: 519 / 384; 768^2: 48: 220 / 193, 96: 248 / 207; 1000^2: 48: 296 / 233, 96: 328 / 257, 384: 1104 / 809.
   // 256^2 and below: the front sweep at every batch size (256^2 x 4096: 911 / 1734; 104^2 x 4096: 247 / 1483).
+  // Again with the front sweep's plain stores (same file as above): 384^2: 96 sources 115 / 102, 192: 126 / 121, 384: 189 / 202; 448^2: 48:
+  // 118 / 124, 96: 133 / 118, 384: 274 / 242, 1024: 655 / 587; 512^2: 48: 136 / 135, 96: 145 / 128, 1024: 823 / 691; 576^2: 48: 152 / 147;
+  // 640^2: 48: 172 / 162; 768^2: 48: 216 / 198; 1000^2: 48: 300 / 233.
   if (maxdim < 448) return false;
-  if (maxdim < 512) return n_src >= 96 && n_src <= 768;
   if (maxdim < 576) return n_src >= 96;
   if (maxdim < 768) return n_src >= 48;
   if (maxdim <= 1024) return n_src >= 33;

@@ -212,10 +212,15 @@ __device__ __forceinline__ void chunk_steps(int s, int n, int* lo, int* hi) {
 // (Raw buffer stores with out-of-range offsets as predication were measured slower than
 // exec-masked global stores here: every store instruction costs the issuing wavefront
 // ~60-80 cycles whether or not its lanes are dropped.)
-// NT: non-temporal stores (the nt bit) -- the batch sweeps, whose fields nobody reads back during the launch: a plain store
-// that covers part of a 128-byte line costs the memory side several whole lines' worth on most of the device's memory, an nt
-// store what it weighs (vhp_lanes.hpp VHP_FIELD_STORE).  The planner's sweeps, whose field the epilogue
-// reads right away, keep plain stores.
+// NT: non-temporal stores (the nt bit).  The POOL sweep's field stores carry it (vhp_lanes.hpp VHP_FIELD_STORE: its x-major strips
+// flush whole 128-byte lines, and on most of the device's memory a plain store that covers part of a line costs several lines'
+// worth: DESIGN.md appendix A.7).  THIS kernel's do not, since round 5: it flushes 64-byte row segments, which a wavefront's L2
+// merges into lines when they are plain stores, and it runs the small and the unaligned grids, where rows are short and segments
+// straddle sectors.  Measured, nt / plain, ms (profiles/r05_front_sweep_nt_vs_plain.txt): 101^2 x 4096 sources 0.368 / 0.192,
+// 250^2 x 256 0.121 / 0.081, 250^2 x 1024 0.426 / 0.245, 398^2 x 192 0.209 / 0.133, 128^2 x 4096 0.307 / 0.252, 384^2 x 256 0.156 /
+// 0.135, 512^2 x 256 0.242 / 0.222, 1002^2 x 40 0.337 / 0.295; level (+-1 %) at 248^2 x 256, 640^2 x 48, 768^2 x 48, 1000^2 x 40.
+// (Round 4 had set the bit for every batch launch on the strength of 1000^2 x 256 -- 0.766 -> 0.747 ms --, a launch the pool sweep
+// takes.)  -DVHP_FRONT_NT=true builds the round-4 behaviour.
 template <typename OutT, bool MULTI = false, bool NT = false>
 struct StoreEmit {
   static constexpr int kCellBytes = sizeof(OutT);
@@ -1168,7 +1173,10 @@ __device__ __forceinline__ void sweep_slot(const DevMap& m, const int32_t* __res
     for (int t = 0; t <= sg.tmax_floor; ++t) __syncthreads();
     return;
   }
-  StoreEmit<OutT, MULTI, true> emit(out + (size_t)s * field_stride, m.nx, m.ny);
+#ifndef VHP_FRONT_NT
+#define VHP_FRONT_NT false
+#endif
+  StoreEmit<OutT, MULTI, VHP_FRONT_NT> emit(out + (size_t)s * field_stride, m.nx, m.ny);
   sweep_quadrant<R>(m, emit, sx, sy, q, lds + (size_t)sub * sweep_lds_doubles(R, sg.W, MULTI), sg);
 }
 
