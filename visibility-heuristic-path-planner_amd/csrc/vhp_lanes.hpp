@@ -333,13 +333,24 @@ template <typename OutT> VHP_LANE_FN void g_store2(OutT* base, vu32 off, vd a, v
   VHP_DIAG_STORE_GUARD(a, b, off)
   VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
 }
+// The PREDICATED stores -- the ragged ends at diagonals, axes and the ends of a march: 8- and 16-byte pieces of sectors that other
+// wavefronts complete later -- are PLAIN stores (round 5): a non-temporal store of part of a 64-byte sector goes to the memory as it
+// is and costs it a read-modify-write, a plain one is merged with its neighbours in the L2 first.  (The unpredicated field stores
+// cover whole sectors -- 1 KB row pieces, 128-byte lines -- and keep the nt bit, above.)  Measured, 256 sources at 1000^2, all nt /
+// predicated plain: slow buffer 0.578 -> 0.554 ms, fast 0.422 -> 0.416; 640^2 0.228 -> 0.222; 1002^2 0.586 -> 0.573; level at 2048^2
+// and 4096^2 (profiles/r05_ab_predicated_stores_plain.txt).  -DVHP_PRED_STORE_NT: the round-4 behaviour.
+#if defined(VHP_PRED_STORE_NT) && !defined(VHP_FIELD_STORE_PLAIN)
+#define VHP_PRED_FIELD_STORE(ptr, val) VHP_FIELD_STORE(ptr, val)
+#else
+#define VHP_PRED_FIELD_STORE(ptr, val) (*(ptr) = (val))
+#endif
 template <typename OutT> VHP_LANE_FN void g_store2_if(bool p2, bool p_lo, bool p_hi, OutT* base, vu32 off, vd a, vd b) {
   VHP_DIAG_STORE_GUARD(a, b, off)
   vd single = p_lo ? a : b;
   asm volatile("" : "+v"(single));  // keep the compiler from splitting the 16-byte store to share a half with the single
-  if (p2) VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
+  if (p2) VHP_PRED_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
   else if (p_lo || p_hi)
-    VHP_FIELD_STORE(reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off + (p_lo ? 0u : (uint32_t)sizeof(OutT))), static_cast<OutT>(single));
+    VHP_PRED_FIELD_STORE(reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off + (p_lo ? 0u : (uint32_t)sizeof(OutT))), static_cast<OutT>(single));
 }
 // Without the nt bit, whatever the translation unit's VHP_FIELD_STORE is: for 64-byte pieces, which a wavefront's L2 merges into
 // lines when they are plain stores (3.75 TB/s against 3.07 with nt on the slow kind of memory).
@@ -362,7 +373,7 @@ template <typename OutT> VHP_LANE_FN void g_store2_mask(bool p, OutT* base, vu32
   if (p) VHP_FIELD_STORE(reinterpret_cast<Pair<OutT>*>(reinterpret_cast<char*>(base) + off), (Pair<OutT>{static_cast<OutT>(a), static_cast<OutT>(b)}));
 }
 template <typename OutT> VHP_LANE_FN void g_store1_if(bool p1, OutT* base, vu32 off, vd a) {
-  if (p1) VHP_FIELD_STORE(reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off), static_cast<OutT>(a));
+  if (p1) VHP_PRED_FIELD_STORE(reinterpret_cast<OutT*>(reinterpret_cast<char*>(base) + off), static_cast<OutT>(a));   // (a single cell: part of a sector)
 }
 // Orders this wavefront's LDS writes before its later LDS reads of other lanes' data.  The LDS executes the DS
 // instructions of one wavefront in issue order, so a read issued after a write sees it without an s_waitcnt in between:
