@@ -266,7 +266,6 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   LatArgs<OutT> a;
   a.m = h.m;
   a.src_xy = src;
-  a.pivot_rec = nullptr;
   a.out = out;
   a.field_stride = (long long)nx * ny;
   a.err_flag = &err;

@@ -69,7 +69,6 @@ struct vhp_ctx {
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
   const int* lat_src_index = nullptr;  // set around a latency-sweep launch of the planner's loop (vhp_planner_solve)
   const int* lat_skip = nullptr;
-  const int* lat_pivot_rec = nullptr;  // ... {skip, x, y, -} of the planner's current pivot as one 16-byte record (PlannerCtl::cur)
   bool lat_dark_unwritten = false;
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 3 pool sweep (vhp_pool), 4 latency sweep (vhp_lat); 2 was the streaming sweep (retired in round 4)
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 3 pool sweep, 4 latency sweep
@@ -348,7 +347,6 @@ hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT*
   a.pool_epoch = ++c->pool_epoch;
   a.d_src_index = lat ? c->lat_src_index : nullptr;
   a.d_skip = lat ? c->lat_skip : nullptr;
-  a.d_pivot_rec = lat ? c->lat_pivot_rec : nullptr;
   a.lat_dead_cells_are_zero = lat && c->lat_dark_unwritten;
   a.n_cus = c->n_cus;
   a.stream = c->stream;
@@ -1006,13 +1004,12 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
     ctx->pl.lat_sweep = nullptr;
     ctx->last_kernel = use_lat_kernel(ctx, 1) ? 4 : 1;  // (vhp_last_sweep_kernel after a solve: what swept its iterations)
     if (use_lat_kernel(ctx, 1))
-      ctx->pl.lat_sweep = [ctx](const int32_t* pivots, const int* nb, const int* done, const int* pivot_rec, double* out, bool dark_unwritten) {
+      ctx->pl.lat_sweep = [ctx](const int32_t* pivots, const int* nb, const int* done, double* out, bool dark_unwritten) {
         ctx->lat_src_index = nb;
         ctx->lat_skip = done;
-        ctx->lat_pivot_rec = pivot_rec;
         ctx->lat_dark_unwritten = dark_unwritten;
         const hipError_t e = launch_batch_sweep<double>(ctx, pivots, 1, out, true);
-        ctx->lat_src_index = ctx->lat_skip = ctx->lat_pivot_rec = nullptr;
+        ctx->lat_src_index = ctx->lat_skip = nullptr;
         ctx->lat_dark_unwritten = false;
         return e;
       };

@@ -31,15 +31,11 @@ __global__ void __launch_bounds__(64 * kLatWaves, 1) vhp_lat_sweep(LatArgs<OutT>
 #ifdef VHP_DIAG_POOLPROF
   const unsigned long long t_begin = wall_clock64();
 #endif
-  // (the planner's loop: what to sweep, requested before the LDS is cleared -- the load's round trip runs beside the clearing)
-  int rec_skip = 0, rec_x = 0, rec_y = 0, rec_pad = 0;
-  if (a.pivot_rec) g_load_rec4(a.pivot_rec, 0, rec_skip, rec_x, rec_y, rec_pad);
   LatWorker<OutT, ODD>::clear(lds, L, (int)threadIdx.x, 64 * kLatWaves);
   __syncthreads();
   LatWorker<OutT, ODD> wk;
   wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
-  if (a.pivot_rec) { if (rec_skip == 0) wk.run_at((int)blockIdx.x, rec_x, rec_y); }
-  else wk.run((int)blockIdx.x);
+  wk.run((int)blockIdx.x);
 #ifdef VHP_DIAG_POOLPROF
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {
     unsigned long long* o = g_latprof + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 20;
@@ -79,7 +75,6 @@ hipError_t launch_lat_t(const BatchArgs& a) {
   g.epoch = a.pool_epoch;
   g.src_index = a.d_src_index;
   g.skip = a.d_skip;
-  g.pivot_rec = a.d_pivot_rec;
   g.dead_cells_are_zero = a.lat_dead_cells_are_zero;
   g.strip_times = nullptr;
 #ifdef VHP_DIAG_POOLPROF

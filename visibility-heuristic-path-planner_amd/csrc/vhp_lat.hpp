@@ -52,7 +52,6 @@ struct LatArgs {
   // or nothing at all if *skip is set (the loop has ended: launches are enqueued ahead of the host's polls); both may be null
   const int* src_index;
   const int* skip;
-  const int* pivot_rec;   // or: one 16-byte record {skip, x, y, -} that says both (read by the kernel before it clears its LDS); may be null
   // the field is known to hold +0.0 wherever this launch does not write: dead strips store nothing (the planner's loop keeps two
   // local fields and clears the one that is not in use while it reads the other: vhp_planner.hip.h)
   bool dead_cells_are_zero;
@@ -1002,14 +1001,10 @@ struct LatWorker {
 
   // the whole life of this wavefront: its strips of unit `unit` (8 * source + 2 * quadrant + {0: x-major, 1: y-major})
   VHP_FN void run(int unit) {
-    const int s = unit / kUnits;
+    const int s = unit / kUnits, qo = unit - s * kUnits;
     if (a.skip && uniform(*a.skip) != 0) return;
     const int si = a.src_index ? uniform(*a.src_index) : s;
-    run_at(unit, uniform(a.src_xy[2 * si]), uniform(a.src_xy[2 * si + 1]));
-  }
-  // ... its strips of unit `unit`, the source given
-  VHP_FN void run_at(int unit, int sx, int sy) {
-    const int s = unit / kUnits, qo = unit - s * kUnits;
+    const int sx = uniform(a.src_xy[2 * si]), sy = uniform(a.src_xy[2 * si + 1]);
     if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
       if (qo == 0 && w == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
       return;

@@ -36,15 +36,11 @@ namespace vhp {
 
 constexpr uint32_t kUnlabelled32 = 0xffffffffu;
 
-struct alignas(16) PlannerCtl {
+struct PlannerCtl {
   int nb;        // nb_of_sources_
   int done;      // loop finished (any reason)
   int status;    // vhp_status of the solve
   int iters;     // planner steps executed
-  // What the next sweep needs, as ONE 16-byte record (the latency sweep reads it with one load before it clears its LDS, instead of
-  // `done`, then `nb`, then pivots[nb]: two dependent round trips to memory at the head of every iteration): {done, x, y, nb} of the
-  // current pivot.  Written by vhp_planner_init and by the epilogue's last workgroup (planner_pick).
-  int cur[4];
 };
 
 struct PlannerKey {
@@ -119,18 +115,15 @@ __device__ __forceinline__ void planner_pick(const DevMap& m, const PlannerDev& 
   if (b.x < 0) {  // nothing reached the threshold: the reference would call top() on an empty heap
     d.ctl->status = VHP_ERR_NOTHING_LIT;
     d.ctl->done = 1;
-    d.ctl->cur[0] = 1;
     return;
   }
   const int nb = d.ctl->nb + 1;  // ls_ = top(); ++nb_of_sources_; lightSources_[nb] = ls_   (solver.cpp:130-133)
   d.ctl->nb = nb;
   d.pivots[2 * nb] = b.x;
   d.pivots[2 * nb + 1] = b.y;
-  *reinterpret_cast<int4*>(d.ctl->cur) = make_int4(0, b.x, b.y, nb);
   if ((unsigned long long)nb > d.max_iter) {  // :134-139
     d.ctl->status = VHP_ERR_MAX_ITER;
     d.ctl->done = 1;
-    d.ctl->cur[0] = 1;
     return;
   }
   // the loop condition, :127.  vis_global(end) was written by some workgroup of this kernel: agent-scope load
@@ -141,7 +134,6 @@ __device__ __forceinline__ void planner_pick(const DevMap& m, const PlannerDev& 
     d.pivots[2 * nb + 1] = d.end_y;
     d.ctl->status = VHP_OK;
     d.ctl->done = 1;
-    d.ctl->cur[0] = 1;
   }
 }
 
@@ -164,13 +156,25 @@ constexpr int kEpilogueWaves = kEpilogueThreads / 64;
 static_assert(kEpilogueBlocks <= kEpilogueThreads, "the last workgroup merges one partial per thread");
 __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap m, PlannerDev d) {
   __shared__ PlannerKey slots[kEpilogueWaves];
+  if (d.ctl->done) return;
+  const int nb = d.ctl->nb;
+  const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
   const int nx = m.nx, ny = m.ny;
+  PlannerKey best;
+  best.h = ~0ull;
+  best.rank = ~0ull;
+  best.x = best.y = -1;
   const size_t cells = (size_t)nx * ny;
+  // The pivots a label can name (lightSources_[0 .. nb]) into LDS, beside the first batch of loads: a lit cell's parent then
+  // costs no round trip to memory of its own (beyond kPivLds entries: from global memory as before).
+  constexpr int kPivLds = 1024;
+  __shared__ int piv_lds[2 * kPivLds];
+  const int n_piv = nb + 1 < kPivLds ? nb + 1 : kPivLds;
+  for (int t = threadIdx.x; t < 2 * n_piv; t += blockDim.x) piv_lds[t] = d.pivots[t];
   // Four cells of a thread at a time, their loads issued together -- the label's too, whether or not the cell turns out lit: the
-  // kernel is a chain of memory latencies, not of bytes.  The first batch is requested BEFORE the control block is read (the cells'
-  // addresses do not depend on it): one round trip to memory for both.
+  // kernel is a chain of memory latencies, not of bytes.
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  double vv[4], oo[4], ot[4];
+  double vv[4], oo[4];
   uint32_t ll[4];
   auto load_batch = [&](size_t k0) {
 #pragma unroll
@@ -180,35 +184,12 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap 
       vv[u] = in ? d.vis_local[k] : 0.0;
       oo[u] = in ? d.vis_global[k] : 0.0;
       ll[u] = in ? d.label[k] : 0u;
-      ot[u] = (d.vis_other && in) ? d.vis_other[k] : 0.0;
-    }
-  };
-  // (the other local field is cleared for the next sweep only by an iteration that runs: past the end of the loop it holds the
-  // solve's result)
-  auto clear_other = [&](size_t k0) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t k = k0 + u * stride;
-      if (d.vis_other && k < cells && ot[u] != 0.0) d.vis_other[k] = 0.0;
+      if (d.vis_other && in && d.vis_other[k] != 0.0) d.vis_other[k] = 0.0;
     }
   };
   size_t k0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  load_batch(k0);
-  if (d.ctl->done) return;
-  const int nb = d.ctl->nb;
-  const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
-  PlannerKey best;
-  best.h = ~0ull;
-  best.rank = ~0ull;
-  best.x = best.y = -1;
-  // The pivots a label can name (lightSources_[0 .. nb]) into LDS, beside the first batch of loads: a lit cell's parent then
-  // costs no round trip to memory of its own (beyond kPivLds entries: from global memory as before).
-  constexpr int kPivLds = 1024;
-  __shared__ int piv_lds[2 * kPivLds];
-  const int n_piv = nb + 1 < kPivLds ? nb + 1 : kPivLds;
-  for (int t = threadIdx.x; t < 2 * n_piv; t += blockDim.x) piv_lds[t] = d.pivots[t];
+  load_batch(k0);   // (issued before the barrier that the staged pivots need: one round trip to memory for both)
   __syncthreads();
-  clear_other(k0);
   for (;;) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -242,7 +223,6 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap 
     k0 += 4 * stride;
     if (k0 >= cells) break;
     load_batch(k0);
-    clear_other(k0);
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
@@ -307,7 +287,6 @@ __global__ void vhp_planner_init(PlannerDev d, int nx, int start_x, int start_y)
     d.ctl->iters = 0;
     d.pivots[0] = start_x;  // lightSources_[0] = start; cameFrom_(start) = 0   (solver.cpp:121-122)
     d.pivots[1] = start_y;
-    *reinterpret_cast<int4*>(d.ctl->cur) = make_int4(0.0 > d.threshold ? 1 : 0, start_x, start_y, 0);
     d.label[(size_t)start_y * nx + start_x] = 0;
     // while (visibility_global_(end) <= threshold), solver.cpp:127: visibility_global_ is all zero here, so a
     // negative threshold skips the loop altogether; lightSources_[0] = end then (:141)
@@ -345,7 +324,7 @@ struct PlannerState {
   // set by the caller when the latency sweep (vhp_lat.hpp) can sweep this grid: launches it for source number *nb of pivots into
   // out unless *done is set (the same contract as vhp_planner_sweep: everything read on the device when the launch runs)
   // (dark_unwritten: the field holds +0.0 wherever the sweep does not write, dead strips store nothing)
-  std::function<hipError_t(const int32_t* pivots, const int* nb, const int* done, const int* pivot_rec, double* out, bool dark_unwritten)> lat_sweep;
+  std::function<hipError_t(const int32_t* pivots, const int* nb, const int* done, double* out, bool dark_unwritten)> lat_sweep;
 };
 
 inline void planner_free(PlannerState& s) {
@@ -473,7 +452,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
         d.vis_local = (launches & 1) ? s.vis_local2 : s.vis_local;
         d.vis_other = (launches & 1) ? s.vis_local : s.vis_local2;
       }
-      hipError_t e = s.lat_sweep ? s.lat_sweep(d.pivots, &s.ctl->nb, &s.ctl->done, s.ctl->cur, d.vis_local, true)
+      hipError_t e = s.lat_sweep ? s.lat_sweep(d.pivots, &s.ctl->nb, &s.ctl->done, d.vis_local, true)
                    : R == 1 ? (multi ? launch_planner_fronts<1, true>(s, m, d, W, stream) : launch_planner_fronts<1, false>(s, m, d, W, stream))
                    : R == 2 ? (multi ? launch_planner_fronts<2, true>(s, m, d, W, stream) : launch_planner_fronts<2, false>(s, m, d, W, stream))
                             : (multi ? launch_planner_fronts<4, true>(s, m, d, W, stream) : launch_planner_fronts<4, false>(s, m, d, W, stream));
