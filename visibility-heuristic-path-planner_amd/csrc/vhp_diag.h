@@ -18,6 +18,7 @@
 //                       another wavefront could buy (C2: 98.8 -> 79 us)                                     (latency sweep)
 // A/B switches of round 5 (correct results; the product is the build WITHOUT them):
 //   VHP_POOL_X8 / VHP_POOL_Y8   the pool sweep's strips in the 8-step windows of rounds 3-4 (both kinds / the y-major ones only)
+//   VHP_POOL_SPLIT_ENDS=0         the ANYW build's unpredicated y-major stores all with the nt bit (the ends of a row piece too)
 //   VHP_POOL_ANYW_Y16           the 16-step y-major strips also in the build for the other widths (measured slower: vhp_pool.hpp)
 //   VHP_POOL_NO_HDR_POLL        a waiting strip re-reads the 17 boundary values with every poll, not the header alone
 //   VHP_PRIO_DIAG / VHP_PRIO_TASK = 0   no instruction priorities by phase;  VHP_PRIO_MARCH = n: ... and by what is left of a march

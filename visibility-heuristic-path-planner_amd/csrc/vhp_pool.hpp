@@ -1003,6 +1003,9 @@ struct XStrip16 {
 // (the diagonal cell is the seed diag(j), stored again with its neighbour).  the streaming sweep's step code (round 2); the seeds of the
 // lane's two columns wait in registers.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef VHP_POOL_SPLIT_ENDS   // (the ends of a row piece that starts inside a sector stored plain: -DVHP_POOL_SPLIT_ENDS=0 for A/B)
+#define VHP_POOL_SPLIT_ENDS 1
+#endif
 template <int DX, int DY, typename OutT, bool ANYW>
 struct YStrip {
   static constexpr int CB = sizeof(OutT);
@@ -1012,6 +1015,7 @@ struct YStrip {
   double* slab;   // reciprocals of the current block's 64 steps, indexed by y & 63
   double* dummy;
   int q, i0, jstart;
+  int piece_lo;       // the lowest x of the strip's columns
   bool has_consumer, interior, odd_pitch;
   Link<DY> lk;        // the boundary lines, along y
   double* bin;        // = lk.bin
@@ -1047,6 +1051,7 @@ struct YStrip {
     pin(dg1);
     const vi xlo = DX > 0 ? ia + g.sx : (-ib) + g.sx;  // the pair's lower x: x(ia) marching up, x(ib) marching down
     xoff = to_u32(xlo * CB);
+    piece_lo = DX > 0 ? i0 + g.sx : g.sx - (i0 + kYCols - 1);
   }
 
   // is column c a column of the grid at or below the diagonal at step j?
@@ -1075,13 +1080,36 @@ struct YStrip {
       if (PRED) oknb = oknb && lo_ok(DX > 0 ? ia + 2 : ia - 2, j);
       // (offsets from two cells before the row: marching down, the lane past x = 1 stores the x = 0 of its neighbour, and its own
       // xoff is "negative" -- the 32-bit sum wraps back)
-      g_store2_if(okhi && oknb, okhi, oknb, row - 2, xoff + (uint32_t)(3 * CB), hi, nb);
+      if (!PRED && VHP_POOL_SPLIT_ENDS && CB == 8) {
+        // (the 63 pairs between the piece's first and last cell: those of whole sectors with the nt bit -- see below; fp32
+        // fields: 1 % slower that way at 1001^2, left as they were)
+        const uint32_t kk = (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(row)) + static_cast<uint32_t>((piece_lo + 1) * CB)) & 63u;
+        const int head = (int)(((64u - kk) & 63u) / (2 * CB)), tail = 63 - (int)(((kk + 63u * (2 * CB)) & 63u) / (2 * CB));
+        const vi mp = DX > 0 ? lane : 63 - lane;   // the pair's index in memory order; 63: the lane without a neighbour
+        const vb end = (mp < head) || (mp >= tail);
+        g_store2_mask(!end, row - 2, xoff + (uint32_t)(3 * CB), hi, nb);
+        g_store2_if(end && oknb, end && !oknb, vb(false), row - 2, xoff + (uint32_t)(3 * CB), hi, nb);
+      } else
+        g_store2_if(okhi && oknb, okhi, oknb, row - 2, xoff + (uint32_t)(3 * CB), hi, nb);
       g_store1_if((lane == (DX > 0 ? 0 : 63)) && oklo, row, xoff, lo);
       return;
     }
     if (PRED) g_store2_if(oklo && okhi, oklo, okhi, row, xoff, lo, hi);
     // (on the other widths a row piece starts anywhere in a sector, so its two ends are parts of sectors as well: every unpredicated
     // y-major store of that build plain, measured: 1002^2 0.658 -> 0.670 ms, 1004^2 0.648 -> 0.668 -- the interior wants the nt bit)
+    else if (ANYW && VHP_POOL_SPLIT_ENDS) {
+      // The piece starts k bytes into a sector and ends k bytes into one (it is 8 or 16 sectors long): the lanes of those two
+      // sectors store plain, as parts of sectors do everywhere else, the whole sectors between them with the nt bit.  256 sources,
+      // fp64: 1002^2 0.670 -> 0.649 ms, 1500^2 1.274 -> 1.233, 1001^2 0.674 -> 0.658, 1501^2 1.278 -> 1.227
+      // (profiles/r05_ab_row_piece_ends_plain.txt).
+      const uint32_t k = (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(row)) + static_cast<uint32_t>(piece_lo * CB)) & 63u;
+      if (k == 0) { g_store2(row, xoff, lo, hi); return; }
+      const int head = (int)((64u - k) / (2 * CB)), tail = 64 - (int)(k / (2 * CB));  // lanes, in memory order
+      const vi ml = DX > 0 ? lane : 63 - lane;
+      const vb end = (ml < head) || (ml >= tail);
+      g_store2_mask(!end, row, xoff, lo, hi);
+      g_store2_if(end, vb(false), vb(false), row, xoff, lo, hi);
+    }
     else g_store2(row, xoff, lo, hi);
   }
   // (a strip's pairs start on an even x: a row is aligned or not as a whole)
