@@ -122,3 +122,66 @@ def test_fast_mode_gives_a_valid_plan_in_fewer_launches(vhp, oracle, k):
         lab = int(r["came_from"][y, x])
         f = oracle.sweep_full(occ, int(r["pivots"][lab][0]), int(r["pivots"][lab][1]))
         assert f[y, x] >= 0.1
+
+
+def _union_of_the_pivots_fields(oracle, occ, r, thr, start):
+    """What mode 1 must leave behind, from the oracle's sweeps of the pivots it committed: the max-union, the label of the first
+    pivot (in commit order) that lights a cell, and the last committed pivot's own field."""
+    n = r["n_pivots"]
+    union = np.zeros(occ.shape, np.float64)
+    label = np.full(occ.shape, -1, np.int64)
+    label[start[1], start[0]] = 0
+    f = None
+    for j in range(n):
+        f = oracle.sweep_full(occ, int(r["pivots"][j][0]), int(r["pivots"][j][1]))
+        np.maximum(union, f, out=union)
+        label[(label < 0) & (f >= thr)] = j
+    return union, label, f
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_fast_mode_fields_are_its_pivots_own(vhp, oracle, k):
+    """Mode 1's slots take turns and are put back to +0.0 by the epilogue that read them, and its sweeps store nothing for dead strips:
+    one stale cell would show up in the union, the labels or the local field.  The cache is left dirty by an exact-mode solve
+    first, and the fast solve runs twice."""
+    occ = maps.maze_6()
+    ny = occ.shape[0]
+    start, end = (345, ny - 1 - 391), (341, ny - 1 - 10)
+    c = _ctx(vhp, occ)
+    c.planner_solve_speculative(start, end, 0.1, 250, k=8, mode=0)
+    for rep in range(2):
+        r = c.planner_solve_speculative(start, end, 0.1, 400, k=k, mode=1)
+        assert r["status"] == 0
+        union, label, last = _union_of_the_pivots_fields(oracle, occ, r, 0.1, start)
+        assert np.array_equal(r["vis_global"], union), "repetition %d" % rep
+        assert np.array_equal(r["vis_local"], last), "repetition %d" % rep
+        got = np.where(r["came_from"] == vhp.UNLABELLED, -1, r["came_from"].astype(np.int64))
+        assert np.array_equal(got, label), "repetition %d" % rep
+
+
+def test_fast_mode_fields_on_a_random_map_and_an_odd_width(vhp, oracle):
+    checked = 0
+    for (nx, ny, seed, k) in ((301, 200, 3, 4), (256, 300, 5, 2)):
+        occ = maps.random_rect_map(nx, ny, 25, 4, 40, 4, 40, seed=seed)
+        free = np.argwhere(occ == 1)
+        start = (int(free[0][1]), int(free[0][0]))
+        end = (int(free[-1][1]), int(free[-1][0]))
+        c = _ctx(vhp, occ)
+        r = c.planner_solve_speculative(start, end, 0.3, 200, k=k, mode=1)
+        if r["status"] not in (0, vhp.VHP_ERR_MAX_ITER):
+            continue
+        checked += 1
+        union, label, last = _union_of_the_pivots_fields(oracle, occ, r, 0.3, start)
+        assert np.array_equal(r["vis_global"], union)
+        assert np.array_equal(r["vis_local"], last)
+        got = np.where(r["came_from"] == vhp.UNLABELLED, -1, r["came_from"].astype(np.int64))
+        assert np.array_equal(got, label)
+    assert checked >= 1
+
+
+def test_speculative_launches_take_the_latency_sweep(vhp):
+    occ = maps.maze_6()
+    ny = occ.shape[0]
+    c = _ctx(vhp, occ)
+    c.planner_solve_speculative((345, ny - 1 - 391), (341, ny - 1 - 10), 0.1, 250, k=4, mode=0, outputs=False)
+    assert c.last_sweep_kernel() == 4

@@ -36,6 +36,8 @@ struct BatchArgs {
   int pool_static_round = 2;  // pool sweep: every context's first unit by workgroup index, no pull (vhp_pool.hpp Args::static_round; 2: odd head contexts count down, Args::static_snake); 0: every unit pulled
   const int* d_src_index = nullptr;  // latency sweep in the planner's loop: sweep source number *d_src_index of d_src (n_src = 1) ...
   const int* d_skip = nullptr;       // ... and nothing at all if *d_skip is set
+  const int* d_slot_base = nullptr;  // the speculative planner's launches (LatArgs::slot_base, run_if)
+  const int* d_run_if = nullptr;
   bool lat_dead_cells_are_zero = false;  // ... and dead strips store nothing: the field holds +0.0 wherever the launch does not write
   unsigned long long pool_epoch = 0;  // pool sweep: the tag of this launch's boundary-line entries: never 0, never reused on this scratch
 };

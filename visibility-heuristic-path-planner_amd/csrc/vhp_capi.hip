@@ -69,6 +69,8 @@ struct vhp_ctx {
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
   const int* lat_src_index = nullptr;  // set around a latency-sweep launch of the planner's loop (vhp_planner_solve)
   const int* lat_skip = nullptr;
+  const int* lat_slot_base = nullptr;  // ... of the speculative planner's (vhp_planner_solve_speculative)
+  const int* lat_run_if = nullptr;
   bool lat_dark_unwritten = false;
   int opt_kernel = 0;         // 0 auto, 1 front sweep (vhp_sweep_fronts), 3 pool sweep (vhp_pool), 4 latency sweep (vhp_lat); 2 was the streaming sweep (retired in round 4)
   int last_kernel = 0;         // what the last batch sweep launched: 1 front sweep, 3 pool sweep, 4 latency sweep
@@ -347,6 +349,8 @@ hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT*
   a.pool_epoch = ++c->pool_epoch;
   a.d_src_index = lat ? c->lat_src_index : nullptr;
   a.d_skip = lat ? c->lat_skip : nullptr;
+  a.d_slot_base = lat ? c->lat_slot_base : nullptr;
+  a.d_run_if = lat ? c->lat_run_if : nullptr;
   a.lat_dead_cells_are_zero = lat && c->lat_dark_unwritten;
   a.n_cus = c->n_cus;
   a.stream = c->stream;
@@ -1039,6 +1043,23 @@ int vhp_planner_solve_speculative(vhp_ctx* ctx, int start_x, int start_y, int en
     ctx->pl.W = W;
     ctx->pl.multi = multi;
     ctx->pl.raise_lds = [ctx](const void* fn, size_t bytes) { return raise_lds_limit(ctx, fn, bytes); };
+    // k sources per launch: the latency sweep (8 k workgroups) wherever a batch of k would take it
+    ctx->pl.lat_sweep_k = nullptr;
+    ctx->last_kernel = use_lat_kernel(ctx, k) ? 4 : 1;
+    if (use_lat_kernel(ctx, k))
+      ctx->pl.lat_sweep_k = [ctx](const int32_t* cand, int n, const int* slot_base, const int* run_if, const int* done, double* cache, bool dark_unwritten) {
+        ctx->lat_skip = done;
+        ctx->lat_slot_base = slot_base;
+        ctx->lat_run_if = run_if;
+        ctx->lat_dark_unwritten = dark_unwritten;
+        const long long stride = ctx->opt_field_stride;
+        ctx->opt_field_stride = 0;  // (the cache holds packed fields)
+        const hipError_t e = launch_batch_sweep<double>(ctx, cand, n, cache, true);
+        ctx->opt_field_stride = stride;
+        ctx->lat_skip = ctx->lat_slot_base = ctx->lat_run_if = nullptr;
+        ctx->lat_dark_unwritten = false;
+        return e;
+      };
   }
   int st[3] = {0, 0, 0};
   int rc = vhp::planner_solve_speculative(ctx->pl, ctx->spec, pm, ctx->d_occ, ctx->stream, ctx->ev0, ctx->ev1, start_x, start_y, end_x, end_y,

@@ -75,6 +75,8 @@ hipError_t launch_lat_t(const BatchArgs& a) {
   g.epoch = a.pool_epoch;
   g.src_index = a.d_src_index;
   g.skip = a.d_skip;
+  g.slot_base = a.d_slot_base;
+  g.run_if = a.d_run_if;
   g.dead_cells_are_zero = a.lat_dead_cells_are_zero;
   g.strip_times = nullptr;
 #ifdef VHP_DIAG_POOLPROF

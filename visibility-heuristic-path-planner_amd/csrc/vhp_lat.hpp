@@ -52,6 +52,10 @@ struct LatArgs {
   // or nothing at all if *skip is set (the loop has ended: launches are enqueued ahead of the host's polls); both may be null
   const int* src_index;
   const int* skip;
+  // the speculative planner's launches: field s of the launch is field *slot_base + s of `out`, a source with a negative x is no
+  // source (its units do nothing, no error), and the launch sweeps nothing unless *run_if is set; both may be null
+  const int* slot_base = nullptr;
+  const int* run_if = nullptr;
   // the field is known to hold +0.0 wherever this launch does not write: dead strips store nothing (the planner's loop keeps two
   // local fields and clears the one that is not in use while it reads the other: vhp_planner.hip.h)
   bool dead_cells_are_zero;
@@ -1003,13 +1007,15 @@ struct LatWorker {
   VHP_FN void run(int unit) {
     const int s = unit / kUnits, qo = unit - s * kUnits;
     if (a.skip && uniform(*a.skip) != 0) return;
+    if (a.run_if && uniform(*a.run_if) == 0) return;
     const int si = a.src_index ? uniform(*a.src_index) : s;
     const int sx = uniform(a.src_xy[2 * si]), sy = uniform(a.src_xy[2 * si + 1]);
+    if (a.slot_base && sx < 0) return;
     if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
       if (qo == 0 && w == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
       return;
     }
-    OutT* field = a.out + (size_t)s * a.field_stride;
+    OutT* field = a.out + (size_t)(s + (a.slot_base ? uniform(*a.slot_base) : 0)) * a.field_stride;
     if (qo == 0 && w == W - 1 && sy > 0) {
       // rows/columns no quadrant covers read as zero; the x-major unit of quadrant 0 always exists
       // (column 0, x = 0, y >= 1: written as zero by the units that march down to x = 1, with their last store of the row)

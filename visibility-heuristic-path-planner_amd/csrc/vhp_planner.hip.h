@@ -88,6 +88,24 @@ __device__ __forceinline__ unsigned long long push_rank(int nx, int ny, int sx, 
   return ((unsigned long long)q << 40) | (unsigned long long)r;
 }
 
+// The minimum over a whole wavefront (every lane active), in every lane: four DPP steps inside the rows of 16 (pairs, quads, the
+// half-row and the row mirrored), the four rows' results through scalar registers.  (A butterfly of ds_bpermute takes 12 trips through
+// the LDS crossbar per 64-bit value: 0.9 us per round of the speculative epilogue's pick.)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));  // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), e = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, e));
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+  const unsigned hi = wave_min_u32((unsigned)(v >> 32));
+  const unsigned lo = wave_min_u32((unsigned)(v >> 32) == hi ? (unsigned)v : 0xffffffffu);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ PlannerKey key_shuffle_xor(const PlannerKey& k, int mask) {
   PlannerKey o;
   o.h = ((unsigned long long)(unsigned)__shfl_xor((int)(k.h >> 32), mask) << 32) | (unsigned)__shfl_xor((int)k.h, mask);
@@ -150,9 +168,9 @@ __device__ __forceinline__ void planner_pick(const DevMap& m, const PlannerDev& 
 #define VHP_EPI_THREADS 512
 #endif
 constexpr int kEpilogueBlocks = VHP_EPI_BLOCKS;
-constexpr int kSpecEpilogueBlocks = 256;  // the speculative solve's epilogue keeps its own shape: 256 workgroups of 256
 constexpr int kEpilogueThreads = VHP_EPI_THREADS;
 constexpr int kEpilogueWaves = kEpilogueThreads / 64;
+constexpr int kSpecPartials = kEpilogueBlocks * kEpilogueWaves;  // the speculative solve's epilogue (same launch shape) leaves one partial per wavefront
 static_assert(kEpilogueBlocks <= kEpilogueThreads, "the last workgroup merges one partial per thread");
 __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap m, PlannerDev d) {
   __shared__ PlannerKey slots[kEpilogueWaves];
@@ -325,6 +343,8 @@ struct PlannerState {
   // out unless *done is set (the same contract as vhp_planner_sweep: everything read on the device when the launch runs)
   // (dark_unwritten: the field holds +0.0 wherever the sweep does not write, dead strips store nothing)
   std::function<hipError_t(const int32_t* pivots, const int* nb, const int* done, double* out, bool dark_unwritten)> lat_sweep;
+  // ... of the speculative loop: the n candidates of `cand` into fields *slot_base .. of `cache`, if *run_if and not *done
+  std::function<hipError_t(const int32_t* cand, int n, const int* slot_base, const int* run_if, const int* done, double* cache, bool dark_unwritten)> lat_sweep_k;
 };
 
 inline void planner_free(PlannerState& s) {
@@ -397,7 +417,7 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
     VHP_PL_HIP(hipMalloc(&s.label, cells * 4));
     VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
     VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
-    VHP_PL_HIP(hipMalloc(&s.partial, (kEpilogueBlocks > kSpecEpilogueBlocks ? kEpilogueBlocks : kSpecEpilogueBlocks) * sizeof(PlannerKey)));
+    VHP_PL_HIP(hipMalloc(&s.partial, kSpecPartials * sizeof(PlannerKey)));
     VHP_PL_HIP(hipMalloc(&s.ticket, sizeof(unsigned int)));
     s.cells = cells;
   }
@@ -513,6 +533,10 @@ struct SpecCtl {
   int sweep;                     // this iteration sweeps (a miss, or mode 1)
   int n_commit;                  // pivots this iteration commits (1 in mode 0)
   int hits, misses, fields_swept;
+#ifdef VHP_DIAG_SPEC_TAIL  // (diagnostic builds: where the last epilogue workgroup's time goes, 10 ns units, summed over the iterations)
+  unsigned long long tail_t[8];
+#endif
+  int prev_last;                 // mode 1: the slot of the previous iteration's last committed field (-1: none), see vhp_spec_epilogue
 };
 
 struct SpecDev {
@@ -522,36 +546,43 @@ struct SpecDev {
   int K, mode;
 };
 
-__global__ void vhp_spec_init(SpecDev sp, int start_x, int start_y) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Before the sweep of an iteration: is the pivot's field cached?  Otherwise the launch's slots are named after its sources.  One
+// wavefront (all 64 lanes call it; lane 0 writes): vhp_spec_init's for the first iteration, wavefront 0 of the epilogue's last
+// workgroup -- the one that has just picked the pivot -- for every other (a kernel of its own until round 5: 4.9 us per iteration).
+__device__ inline void spec_lookup(const PlannerDev& d, const SpecDev& sp) {
+  const int lane = (int)(threadIdx.x & 63);
   SpecCtl* c = sp.sc;
-  for (int k = 0; k < 2 * kSpecMaxK; ++k) c->cand[k] = -1;
-  for (int k = 0; k < 2 * kSpecSlots; ++k) c->slot_key[k] = -1;
-  c->cand[0] = start_x;
-  c->cand[1] = start_y;
-  c->head = c->cur_slot = c->sweep = 0;
-  c->n_commit = 1;
-  c->hits = c->misses = c->fields_swept = 0;
-}
-
-// Before the sweep of an iteration: is the pivot's field cached?  Otherwise the launch's slots are named after its sources.
-__global__ void vhp_spec_lookup(PlannerDev d, SpecDev sp) {
-  if (threadIdx.x != 0 || blockIdx.x != 0 || d.ctl->done) return;
-  SpecCtl* c = sp.sc;
-  const int nb = d.ctl->nb;
-  const int px = d.pivots[2 * nb], py = d.pivots[2 * nb + 1];
-  c->n_commit = 1;
+  // (what lane 0 has just written -- the control block, the pivot -- the other lanes get from it)
+  int done = 0, nb = 0, px = 0, py = 0;
+  if (lane == 0) {
+    done = d.ctl->done;
+    nb = d.ctl->nb;
+    px = d.pivots[2 * nb];
+    py = d.pivots[2 * nb + 1];
+  }
+  done = __shfl(done, 0);
+  nb = __shfl(nb, 0);
+  px = __shfl(px, 0);
+  py = __shfl(py, 0);
+  if (done) return;
+  int hit = -1;
   if (sp.mode == 0) {
-    for (int s = 0; s < kSpecSlots; ++s)
-      if (c->slot_key[2 * s] == px && c->slot_key[2 * s + 1] == py) {
-        c->cur_slot = s;
-        c->sweep = 0;
-        c->hits += 1;
-        return;
-      }
+    // (agent-scope loads: in vhp_spec_init the keys were written by lane 0 a moment ago)
+    const bool mine = lane < kSpecSlots && __hip_atomic_load(&c->slot_key[2 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == px &&
+                      __hip_atomic_load(&c->slot_key[2 * lane + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == py;
+    const unsigned long long found = __ballot(mine);
+    if (found) hit = __ffsll((long long)found) - 1;  // (the lowest slot, as the scan found it)
+  }
+  if (lane != 0) return;
+  c->n_commit = 1;
+  if (hit >= 0) {
+    c->cur_slot = hit;
+    c->sweep = 0;
+    c->hits += 1;
+    return;
   }
   const int base = c->head;
-  c->head = (base + sp.K) % kSpecSlots;
+  c->head = (base + sp.K) % (sp.mode == 1 ? 2 * sp.K : kSpecSlots);  // (mode 1: two groups take turns, vhp_spec_epilogue)
   c->cand[0] = px;  // (it is: the pick wrote both)
   c->cand[1] = py;
   int n = 0, committed = 1;
@@ -575,7 +606,29 @@ __global__ void vhp_spec_lookup(PlannerDev d, SpecDev sp) {
   c->fields_swept += n;
 }
 
-// The sweep launch of an iteration: workgroup b sweeps quadrant b & 3 of candidate b >> 2 into its cache slot.
+// (behind vhp_planner_init on the stream: the control block is set)
+__global__ void __launch_bounds__(64) vhp_spec_init(PlannerDev d, SpecDev sp, int start_x, int start_y) {
+  if (blockIdx.x != 0) return;
+  SpecCtl* c = sp.sc;
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 2 * kSpecMaxK; ++k) c->cand[k] = -1;
+    for (int k = 0; k < 2 * kSpecSlots; ++k) c->slot_key[k] = -1;
+    c->cand[0] = start_x;
+    c->cand[1] = start_y;
+    c->head = c->cur_slot = c->sweep = 0;
+    c->n_commit = 1;
+    c->hits = c->misses = c->fields_swept = 0;
+    c->prev_last = -1;
+#ifdef VHP_DIAG_SPEC_TAIL
+    for (int k = 0; k < 8; ++k) c->tail_t[k] = 0;
+#endif
+    __threadfence();  // (the other lanes read the slot keys)
+  }
+  spec_lookup(d, sp);
+}
+
+// The sweep launch of an iteration where the latency sweep does not take it (PlannerState::lat_sweep_k): workgroup b sweeps quadrant
+// b & 3 of candidate b >> 2 into its cache slot.
 template <int R, bool MULTI>
 __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : ((MULTI && R == 2) ? 6 : 8)) vhp_spec_sweep(DevMap m, PlannerDev d, SpecDev sp) {
   extern __shared__ double lds[];
@@ -587,48 +640,100 @@ __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (
   sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x & 3, lds, whole_workgroup());
 }
 
-// updateVisibility()'s per-cell body over the committed field(s), the arg-min, and -- in the last workgroup -- the next
-// pivot and the runner-ups.  With one committed field (mode 0) this is vhp_planner_epilogue operation for operation.
-__global__ void __launch_bounds__(256) vhp_spec_epilogue(DevMap m, PlannerDev d, SpecDev sp) {
-  __shared__ PlannerKey slots[4];
-  __shared__ int chosen[2 * kSpecMaxK];
+// updateVisibility()'s per-cell body over the committed field(s), the arg-min, and -- in the last workgroup -- the next pivot, the
+// runner-ups and the look-up of the next iteration.  With one committed field (mode 0) the cells see vhp_planner_epilogue's operations
+// one for one, in its launch shape; every wavefront leaves a partial minimum (kSpecPartials of them: the runner-ups are picked
+// among those).
+static_assert(kSpecPartials <= 2 * kEpilogueThreads, "the last workgroup merges two partials per thread");
+// NF = the committed fields a launch can have (mode 0: 1; mode 1: k).  CLEAN (mode 1): a field is read exactly once, by the epilogue
+// of the iteration that swept it, so that epilogue puts +0.0 back wherever it read something else -- except into the iteration's
+// last field, which is the solve's local field if the loop ends here: the next epilogue clears that one (one more load per cell).
+// Two groups of k slots take turns, both zero when the solve starts: every sweep finds +0.0 wherever it will not write, and its dead
+// strips store nothing (LatArgs::dead_cells_are_zero) -- k fields of zeros per launch were 10 us of the sweep and as much of the
+// epilogue behind it, whose loads queued behind their write-back.
+template <int NF, bool CLEAN>
+__global__ void __launch_bounds__(kEpilogueThreads) vhp_spec_epilogue(DevMap m, PlannerDev d, SpecDev sp) {
+#ifdef VHP_DIAG_SPEC_TAIL
+  unsigned long long tt[8];
+  tt[0] = wall_clock64();
+#define VHP_SPEC_STAMP(i) tt[i] = wall_clock64()
+#else
+#define VHP_SPEC_STAMP(i)
+#endif
   if (d.ctl->done) return;
   const int nb = d.ctl->nb;
   const int nc = sp.sc->n_commit;
   const int nx = m.nx, ny = m.ny;
-  const int sx0 = d.pivots[2 * nb], sy0 = d.pivots[2 * nb + 1];
-  const double* field0 = sp.cache + (size_t)sp.sc->cur_slot * sp.cells;
+  const int cur = sp.sc->cur_slot;
+  double* field0 = sp.cache + (size_t)cur * sp.cells;
+  const int prev_last = CLEAN ? sp.sc->prev_last : -1;
+  double* prev_field = sp.cache + (size_t)(prev_last < 0 ? 0 : prev_last) * sp.cells;
   PlannerKey best;
   best.h = ~0ull;
   best.rank = ~0ull;
   best.x = best.y = -1;
   const size_t cells = (size_t)nx * ny;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < cells; k += (size_t)gridDim.x * blockDim.x) {
-    const int y = (int)(k / nx), x = (int)(k - (size_t)y * nx);
-    double g = d.vis_global[k];
-    uint32_t lab = d.label[k];
-    bool visited = false;
-    for (int j = 0; j < nc; ++j) {
-      const int sx = d.pivots[2 * (nb + j)], sy = d.pivots[2 * (nb + j) + 1];
-      if ((x == 0 && sx > 0) || (y == 0 && sy > 0)) continue;  // not swept from this pivot
-      visited = true;
-      const double v = field0[(size_t)j * sp.cells + k];
-      g = fmax(v, g);  // :417-418
-      if (v >= d.threshold && lab == kUnlabelled32) lab = (uint32_t)(nb + j);  // :419-423
+  constexpr int kPivLds = 1024;
+  __shared__ int piv_lds[2 * kPivLds];
+  const int n_piv = nb + nc < kPivLds ? nb + nc : kPivLds;   // (a label can name the pivots this iteration commits)
+  for (int t = threadIdx.x; t < 2 * n_piv; t += blockDim.x) piv_lds[t] = d.pivots[t];
+  auto pivot_x = [&](uint32_t i) { return i < (uint32_t)kPivLds ? piv_lds[2 * i] : d.pivots[2 * i]; };
+  auto pivot_y = [&](uint32_t i) { return i < (uint32_t)kPivLds ? piv_lds[2 * i + 1] : d.pivots[2 * i + 1]; };
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double vv[NF][4], oo[4];   // (every committed field's cell with the batch: the kernel is a chain of latencies)
+  uint32_t ll[4];
+  auto load_batch = [&](size_t k0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t k = k0 + u * stride;
+      const bool in = k < cells;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) vv[j][u] = (in && (NF == 1 || j < nc)) ? field0[(size_t)j * sp.cells + k] : 0.0;
+      if (CLEAN && in && prev_last >= 0 && prev_field[k] != 0.0) prev_field[k] = 0.0;
+      oo[u] = in ? d.vis_global[k] : 0.0;
+      ll[u] = in ? d.label[k] : 0u;
     }
-    if (!visited) continue;
-    d.vis_global[k] = g;
-    d.label[k] = lab;
-    if (g >= d.threshold) {  // :424-430
-      const int px = d.pivots[2 * lab], py = d.pivots[2 * lab + 1];
-      const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, px, py));
-      PlannerKey c;
-      c.h = (unsigned long long)__double_as_longlong(h);
-      c.rank = push_rank(nx, ny, sx0, sy0, x, y);
-      c.x = x;
-      c.y = y;
-      if (key_less(c, best)) best = c;
+  };
+  size_t k0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  load_batch(k0);
+  __syncthreads();
+  const int sx0 = pivot_x((uint32_t)nb), sy0 = pivot_y((uint32_t)nb);
+  for (;;) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t k = k0 + u * stride;
+      if (k >= cells) continue;
+      const int y = (int)((unsigned)k / (unsigned)nx), x = (int)((unsigned)k - (unsigned)y * (unsigned)nx);
+      double g = oo[u];
+      uint32_t lab = ll[u];
+      bool visited = false;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        if (NF > 1 && j >= nc) continue;
+        if (CLEAN && j < nc - 1 && vv[j][u] != 0.0) field0[(size_t)j * sp.cells + k] = 0.0;
+        const int sx = j == 0 ? sx0 : pivot_x((uint32_t)(nb + j)), sy = j == 0 ? sy0 : pivot_y((uint32_t)(nb + j));
+        if ((x == 0 && sx > 0) || (y == 0 && sy > 0)) continue;  // not swept from this pivot
+        visited = true;
+        const double v = vv[j][u];
+        g = fmax(v, g);  // :417-418
+        if (v >= d.threshold && lab == kUnlabelled32) lab = (uint32_t)(nb + j);  // :419-423
+      }
+      if (!visited) continue;
+      if (g != oo[u]) d.vis_global[k] = g;
+      if (lab != ll[u]) d.label[k] = lab;
+      if (g >= d.threshold) {  // :424-430
+        const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, pivot_x(lab), pivot_y(lab)));
+        PlannerKey c;
+        c.h = (unsigned long long)__double_as_longlong(h);
+        c.rank = push_rank(nx, ny, sx0, sy0, x, y);
+        c.x = x;
+        c.y = y;
+        if (key_less(c, best)) best = c;
+      }
     }
+    k0 += 4 * stride;
+    if (k0 >= cells) break;
+    load_batch(k0);
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
@@ -636,15 +741,13 @@ __global__ void __launch_bounds__(256) vhp_spec_epilogue(DevMap m, PlannerDev d,
     if (key_less(o, best)) best = o;
   }
   const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) slots[wave] = best;
+  if ((threadIdx.x & 63) == 0) d.partial[blockIdx.x * kEpilogueWaves + wave] = best;
+  // (the hand-off of vhp_planner_epilogue: every wavefront drains its stores -- its partial among them --, the barrier, one lane:
+  // agent-scope release, ticket)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   __shared__ int is_last;
   if (threadIdx.x == 0) {
-    PlannerKey b = slots[0];
-    for (int w = 1; w < 4; ++w)
-      if (key_less(slots[w], b)) b = slots[w];
-    d.partial[blockIdx.x] = b;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     is_last = __hip_atomic_fetch_add(d.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
@@ -655,57 +758,136 @@ __global__ void __launch_bounds__(256) vhp_spec_epilogue(DevMap m, PlannerDev d,
   }
   __syncthreads();
   if (!is_last) return;
-  PlannerKey mine;
-  {
-    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(d.partial + threadIdx.x);
-    mine.h = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mine.rank = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long xy = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mine.x = (int)(unsigned)xy;
-    mine.y = (int)(unsigned)(xy >> 32);
-  }
-  // round 0: the arg-min (the next pivot, exactly); rounds 1 .. K-1: the best partial minima at least kSpecSep away from
-  // what has been chosen
-  for (int r = 0; r < sp.K; ++r) {
-    PlannerKey k = mine;
-    for (int c = 0; c < r; ++c) {
-      const int cx = chosen[2 * c], cy = chosen[2 * c + 1];
-      if (cx >= 0 && k.x >= 0 && abs(k.x - cx) < kSpecSep && abs(k.y - cy) < kSpecSep) { k.h = ~0ull; k.rank = ~0ull; k.x = k.y = -1; }
-    }
+  VHP_SPEC_STAMP(1);
+  // Wavefront 0 picks alone -- no barrier and no trip through one thread per round (round 5: 2.4 us per round that way).  What the
+  // pick and the look-up need from memory is asked for now, together -- the partials (agent scope: other CUs wrote them), the loop
+  // condition's cell (written by some workgroup of this kernel), the control words, the slot keys (lane s: slot s) --, so that the
+  // serial part below runs on registers: a trip to memory per word, one after the other, was 10 us of this kernel at k = 4 and 20 at
+  // k = 8.
+  if (wave != 0) return;
+  VHP_SPEC_STAMP(2);
+  SpecCtl* c = sp.sc;
+  const int lane = (int)threadIdx.x;
+  const double ge = __longlong_as_double((long long)__hip_atomic_load(
+      reinterpret_cast<const unsigned long long*>(d.vis_global + (size_t)d.end_y * m.nx + d.end_x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const int iters = d.ctl->iters;
+  const int head = c->head;
+  const int key_x = lane < kSpecSlots ? c->slot_key[2 * lane] : -1, key_y = lane < kSpecSlots ? c->slot_key[2 * lane + 1] : -1;
+  constexpr int kPerLane = kSpecPartials / 64;   // (16 candidates per lane: every wavefront's partial minimum is one)
+  static_assert(kSpecPartials % 64 == 0 && kPerLane <= 32, "one bit per candidate");
+  PlannerKey cand[kPerLane];
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-      const PlannerKey o = key_shuffle_xor(k, s);
-      if (key_less(o, k)) k = o;
-    }
-    if ((threadIdx.x & 63) == 0) slots[wave] = k;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      PlannerKey bb = slots[0];
-      for (int w = 1; w < 4; ++w)
-        if (key_less(slots[w], bb)) bb = slots[w];
-      chosen[2 * r] = bb.x;
-      chosen[2 * r + 1] = bb.y;
-      if (r == 0) {
-        *d.ticket = 0;
-        d.ctl->nb += nc - 1;  // the runner-ups this iteration committed (mode 1) are pivots nb+1 .. nb+nc-1
-        planner_pick(m, d, bb);
-      }
-    }
-    __syncthreads();
+  for (int t = 0; t < kPerLane; ++t) {
+    const int i = lane + 64 * t;
+    const bool in = i < (int)gridDim.x * kEpilogueWaves;
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(d.partial + (in ? i : 0));
+    cand[t].h = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cand[t].rank = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long xy = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cand[t].x = in ? (int)(unsigned)xy : -1;
+    cand[t].y = in ? (int)(unsigned)(xy >> 32) : -1;
+    if (!in) { cand[t].h = ~0ull; cand[t].rank = ~0ull; }
   }
-  if (threadIdx.x == 0) {
-    SpecCtl* c = sp.sc;
-    const int nbn = d.ctl->nb;
-    c->cand[0] = d.pivots[2 * nbn];  // (the end point if the loop is over: nothing sweeps it)
-    c->cand[1] = d.pivots[2 * nbn + 1];
-    int n = 1;
-    for (int r = 1; r < kSpecMaxK; ++r) {
-      const bool ok = r < sp.K && chosen[2 * r] >= 0;
-      if (ok) { c->cand[2 * n] = chosen[2 * r]; c->cand[2 * n + 1] = chosen[2 * r + 1]; ++n; }
+  // round 0: the arg-min (the next pivot, exactly: every partial is somebody's); rounds 1 .. K-1: the best of the rest at least
+  // kSpecSep away from what has been chosen (guesses).  A candidate too close to
+  // a choice is struck off when the choice is made; the choices go to LDS (nothing here is an array the compiler would index at
+  // run time: such arrays lived in scratch memory, 2.6 us per round at k = 8).
+  __shared__ int next_src[2 * kSpecMaxK];   // the sources of the next sweep launch, packed: [0] the pivot, then the runner-ups
+  VHP_SPEC_STAMP(3);
+  // (the rounds run on ONE candidate per lane, the best of its 16 partials: 800 instructions per round on all of them, by a lone
+  // wavefront, were 1.4 us per round)
+  PlannerKey mine = cand[0];
+#pragma unroll
+  for (int t = 1; t < kPerLane; ++t)
+    if (key_less(cand[t], mine)) mine = cand[t];
+  int first_x = -1, first_y = -1, n_c = 1;
+  for (int r = 0; r < sp.K; ++r) {
+    // the wavefront's minimum of h, of the rank among the lanes that hold it (round 0: the arg-min must be the reference's; a guess
+    // takes the lowest lane), and the cell from the lane that has both
+    const unsigned long long hmin = wave_min_u64(mine.h);
+    unsigned long long rk = mine.h == hmin ? mine.rank : ~0ull;
+    if (r == 0) { const unsigned long long rmin = wave_min_u64(rk); rk = rk == rmin ? 0ull : ~0ull; }
+    const unsigned long long holders = __ballot(mine.h == hmin && rk != ~0ull);
+    const int wl = holders ? __ffsll((long long)holders) - 1 : 0;
+    const int wx = __builtin_amdgcn_readlane(mine.x, wl), wy = __builtin_amdgcn_readlane(mine.y, wl);  // (-1 from every lane when nothing is left)
+    if (wx < 0) break;
+    if (r == 0) { first_x = wx; first_y = wy; }
+    else {
+      if (lane == 0) { next_src[2 * n_c] = wx; next_src[2 * n_c + 1] = wy; }
+      ++n_c;
     }
-    for (int r = n; r < kSpecMaxK; ++r) { c->cand[2 * r] = -1; c->cand[2 * r + 1] = -1; }
+    if (abs(mine.x - wx) < kSpecSep && abs(mine.y - wy) < kSpecSep) { mine.h = ~0ull; mine.rank = ~0ull; mine.x = mine.y = -1; }
+  }
+  VHP_SPEC_STAMP(4);
+  // planner_pick, on registers (every lane computes, lane 0 stores): ls_ = top(); ++nb_of_sources_; the loop condition
+  // (solver.cpp:127-141).  The runner-ups this iteration committed (mode 1) are pivots nb+1 .. nb+nc-1.
+  const bool st = lane == 0;
+  if (st) { *d.ticket = 0; d.ctl->iters = iters + 1; if (CLEAN) c->prev_last = cur + nc - 1; }
+  int nbn = nb + nc - 1;
+  bool done = false;
+  int px = first_x, py = first_y;
+  if (px < 0) {  // nothing reached the threshold: the reference would call top() on an empty heap
+    if (st) { d.ctl->nb = nbn; d.ctl->status = VHP_ERR_NOTHING_LIT; d.ctl->done = 1; }
+    done = true;
+    // (next_src[0] below: the pivot as it stands)
+    px = pivot_x((uint32_t)nbn);
+    py = pivot_y((uint32_t)nbn);
+  } else {
+    nbn += 1;
+    int status = -1;
+    if ((unsigned long long)nbn > d.max_iter) status = VHP_ERR_MAX_ITER;  // :134-139
+    else if (ge > d.threshold) { px = d.end_x; py = d.end_y; status = VHP_OK; }  // :127, :141
+    done = status >= 0;
+    if (st) {
+      d.ctl->nb = nbn;
+      d.pivots[2 * nbn] = px;
+      d.pivots[2 * nbn + 1] = py;
+      if (done) { d.ctl->status = status; d.ctl->done = 1; }
+    }
+  }
+  // the sources of the next sweep launch: the pivot (the end point if the loop is over: nothing sweeps it), the runner-ups, then none
+  if (lane < 2 * kSpecMaxK && (lane < 2 || lane >= 2 * n_c)) next_src[lane] = lane == 0 ? px : lane == 1 ? py : -1;
+  __builtin_amdgcn_wave_barrier();
+  const int my_src = lane < 2 * kSpecMaxK ? next_src[lane] : -1;   // (lane l: word l)
+  if (lane < 2 * kSpecMaxK) c->cand[lane] = my_src;
+  VHP_SPEC_STAMP(5);
+#ifdef VHP_DIAG_SPEC_TAIL
+  if (st) for (int i = 1; i <= 5; ++i) c->tail_t[i] += tt[i] - tt[i - 1];
+#endif
+  if (done) return;
+  // the look-up of the next iteration (spec_lookup, on registers)
+  int hit = -1;
+  if (sp.mode == 0) {
+    const unsigned long long found = __ballot(key_x == px && key_y == py && lane < kSpecSlots);
+    if (found) hit = __ffsll((long long)found) - 1;
+  }
+  if (hit >= 0) {
+    if (st) {
+      c->n_commit = 1;
+      c->cur_slot = hit;
+      c->sweep = 0;
+      atomicAdd(&c->hits, 1);
+    }
+    return;
+  }
+  // a miss: the launch's slots are named after its sources (lane l: word l of the k pairs); mode 1 commits the runner-ups in rank
+  // order as lightSources_[nb + j] -- they are packed, so those are sources 1 .. committed-1; a candidate past max_iter + 1 is
+  // swept but not committed
+  const int n_src = n_c < sp.K ? n_c : sp.K;
+  long long room = (long long)d.max_iter + 2 - nbn;   // j <= max_iter + 1 - nb
+  const int committed = sp.mode == 1 ? (int)(room < 1 ? 1 : (room < n_src ? room : n_src)) : 1;
+  if (lane < 2 * sp.K) c->slot_key[2 * head + lane] = my_src;
+  if (sp.mode == 1 && lane >= 2 && lane < 2 * committed) d.pivots[2 * nbn + lane] = my_src;
+  if (st) {
+    c->head = (head + sp.K) % (CLEAN ? 2 * sp.K : kSpecSlots);
+    c->n_commit = committed;
+    c->cur_slot = head;
+    c->sweep = 1;
+    atomicAdd(&c->misses, 1);
+    atomicAdd(&c->fields_swept, n_src);
   }
 }
+#undef VHP_SPEC_STAMP
 
 // the last committed pivot's field becomes vis_local; cells its sweep does not visit read as zero (visibility_.reset(), :386)
 __global__ void vhp_spec_export_local(DevMap m, PlannerDev d, SpecDev sp) {
@@ -773,7 +955,7 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
     VHP_PL_HIP(hipMalloc(&s.label, cells * 4));
     VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
     VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
-    VHP_PL_HIP(hipMalloc(&s.partial, (kEpilogueBlocks > kSpecEpilogueBlocks ? kEpilogueBlocks : kSpecEpilogueBlocks) * sizeof(PlannerKey)));
+    VHP_PL_HIP(hipMalloc(&s.partial, kSpecPartials * sizeof(PlannerKey)));
     VHP_PL_HIP(hipMalloc(&s.ticket, sizeof(unsigned int)));
     s.cells = cells;
   }
@@ -793,6 +975,7 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
   VHP_PL_HIP(hipMemsetAsync(s.label, 0xff, cells * 4, stream));
   VHP_PL_HIP(hipMemsetAsync(s.pivots, 0, s.pivot_cap * sizeof(int32_t), stream));
   VHP_PL_HIP(hipMemsetAsync(s.ticket, 0, sizeof(unsigned int), stream));
+  if (mode == 1) VHP_PL_HIP(hipMemsetAsync(ss.cache, 0, (size_t)2 * K * cells * 8, stream));  // (the two groups of k slots that take turns: vhp_spec_epilogue)
 
   PlannerDev d;
   d.vis_global = s.vis_global;
@@ -823,18 +1006,20 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
   const bool multi = s.multi;
   VHP_PL_HIP(hipEventRecord(ev0, stream));
   hipLaunchKernelGGL(vhp_planner_init, dim3(1), dim3(64), 0, stream, d, nx, start_x, start_y);
-  hipLaunchKernelGGL(vhp_spec_init, dim3(1), dim3(64), 0, stream, sp, start_x, start_y);
+  hipLaunchKernelGGL(vhp_spec_init, dim3(1), dim3(64), 0, stream, d, sp, start_x, start_y);
   VHP_PL_HIP(hipGetLastError());
   PlannerCtl ctl{};
   const int batch = 8;
   for (;;) {
     for (int b = 0; b < batch; ++b) {
-      hipLaunchKernelGGL(vhp_spec_lookup, dim3(1), dim3(64), 0, stream, d, sp);
-      hipError_t e = R == 1 ? (multi ? launch_spec_fronts<1, true>(s, m, d, sp, W, stream) : launch_spec_fronts<1, false>(s, m, d, sp, W, stream))
+      hipError_t e = s.lat_sweep_k ? s.lat_sweep_k(ss.sc->cand, K, &ss.sc->cur_slot, &ss.sc->sweep, &s.ctl->done, ss.cache, mode == 1)
+                   : R == 1 ? (multi ? launch_spec_fronts<1, true>(s, m, d, sp, W, stream) : launch_spec_fronts<1, false>(s, m, d, sp, W, stream))
                    : R == 2 ? (multi ? launch_spec_fronts<2, true>(s, m, d, sp, W, stream) : launch_spec_fronts<2, false>(s, m, d, sp, W, stream))
                             : (multi ? launch_spec_fronts<4, true>(s, m, d, sp, W, stream) : launch_spec_fronts<4, false>(s, m, d, sp, W, stream));
       if (e != hipSuccess) { *msg = std::string("speculative planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
-      hipLaunchKernelGGL(vhp_spec_epilogue, dim3(kSpecEpilogueBlocks), dim3(256), 0, stream, m, d, sp);
+      auto epi = mode == 0 ? vhp_spec_epilogue<1, false> : K == 1 ? vhp_spec_epilogue<1, true> : K == 2 ? vhp_spec_epilogue<2, true>
+                         : K == 4 ? vhp_spec_epilogue<4, true> : vhp_spec_epilogue<8, true>;
+      hipLaunchKernelGGL(epi, dim3(kEpilogueBlocks), dim3(kEpilogueThreads), 0, stream, m, d, sp);
       VHP_PL_HIP(hipGetLastError());
     }
     VHP_PL_HIP(hipMemcpyAsync(&ctl, s.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
@@ -859,6 +1044,10 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
   if (vis_local) VHP_PL_HIP(hipMemcpyAsync(vis_local, s.vis_local, cells * 8, hipMemcpyDeviceToHost, stream));
   VHP_PL_HIP(hipStreamSynchronize(stream));
   if (stats) { stats[0] = hc.hits; stats[1] = hc.misses; stats[2] = hc.fields_swept; }
+#ifdef VHP_DIAG_SPEC_TAIL
+  fprintf(stderr, "spec tail (us, summed over the solve): start->last %.1f  gather %.1f  loads %.1f  rounds %.1f  pick %.1f\n", hc.tail_t[1] / 100.0,
+          hc.tail_t[2] / 100.0, hc.tail_t[3] / 100.0, hc.tail_t[4] / 100.0, hc.tail_t[5] / 100.0);
+#endif
   if (ctl.status == VHP_ERR_MAX_ITER) *msg = "Max iters hit. Solution could not be found. Try lowering visibility threshold.";
   if (ctl.status == VHP_ERR_NOTHING_LIT) *msg = "no cell reached the visibility threshold";
   return ctl.status;
