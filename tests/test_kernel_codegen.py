@@ -29,7 +29,8 @@ def _asm(src, tmp_path):
 def _kernels(asm, name):
     """{mangled name: body} of the kernels whose name contains `name`"""
     out = {}
-    for m in re.finditer(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % name, asm, re.S | re.M):
+    # (up to the end of the function, not to the first s_endpgm: an early return may have one of its own)
+    for m in re.finditer(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\.Lfunc_end\d+:" % name, asm, re.S | re.M):
         out[m.group(1)] = m.group(2)
     return out
 

@@ -1006,16 +1006,18 @@ struct LatWorker {
   // the whole life of this wavefront: its strips of unit `unit` (8 * source + 2 * quadrant + {0: x-major, 1: y-major})
   VHP_FN void run(int unit) {
     const int s = unit / kUnits, qo = unit - s * kUnits;
-    if (a.skip && uniform(*a.skip) != 0) return;
-    if (a.run_if && uniform(*a.run_if) == 0) return;
-    const int si = a.src_index ? uniform(*a.src_index) : s;
+    // (the planners' control words together, before any of them is looked at: one trip to memory, then the source's)
+    const int skip = a.skip ? *a.skip : 0, run = a.run_if ? *a.run_if : 1, si0 = a.src_index ? *a.src_index : s;
+    const int slot0 = a.slot_base ? *a.slot_base : 0;
+    if (uniform(skip) != 0 || uniform(run) == 0) return;
+    const int si = uniform(si0);
     const int sx = uniform(a.src_xy[2 * si]), sy = uniform(a.src_xy[2 * si + 1]);
     if (a.slot_base && sx < 0) return;
     if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
       if (qo == 0 && w == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
       return;
     }
-    OutT* field = a.out + (size_t)(s + (a.slot_base ? uniform(*a.slot_base) : 0)) * a.field_stride;
+    OutT* field = a.out + (size_t)(s + uniform(slot0)) * a.field_stride;
     if (qo == 0 && w == W - 1 && sy > 0) {
       // rows/columns no quadrant covers read as zero; the x-major unit of quadrant 0 always exists
       // (column 0, x = 0, y >= 1: written as zero by the units that march down to x = 1, with their last store of the row)

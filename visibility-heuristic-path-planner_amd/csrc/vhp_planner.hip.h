@@ -12,7 +12,7 @@
 //   vhp_planner_epilogue : per visited cell max-union into vis_global, first-lit labelling,
 //                          heuristic h of every lit cell, block arg-min of (h, push rank);
 //                          (the workgroup that finishes last merges the block partials, appends the
-//                          next pivot, evaluates the loop condition and raises `done`: planner_pick)
+//                          next pivot, evaluates the loop condition and raises `done`)
 // The host enqueues a few iterations at a time and polls the control block; kernels
 // of iterations queued past the end see `done` and return at once.
 //
@@ -106,13 +106,13 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ PlannerKey key_shuffle_xor(const PlannerKey& k, int mask) {
-  PlannerKey o;
-  o.h = ((unsigned long long)(unsigned)__shfl_xor((int)(k.h >> 32), mask) << 32) | (unsigned)__shfl_xor((int)k.h, mask);
-  o.rank = ((unsigned long long)(unsigned)__shfl_xor((int)(k.rank >> 32), mask) << 32) | (unsigned)__shfl_xor((int)k.rank, mask);
-  o.x = __shfl_xor(k.x, mask);
-  o.y = __shfl_xor(k.y, mask);
-  return o;
+// Is this lane the one that holds the wavefront's minimum of (h, rank)?  (The lowest such lane: ranks of lit cells are distinct, keys
+// of lanes that found nothing are all alike.)  Every lane of the wavefront calls it.
+__device__ __forceinline__ bool wave_holds_min(const PlannerKey& k) {
+  const unsigned long long hmin = wave_min_u64(k.h);
+  const unsigned long long rmin = wave_min_u64(k.h == hmin ? k.rank : ~0ull);
+  const unsigned long long holders = __ballot(k.h == hmin && k.rank == rmin);
+  return (int)(threadIdx.x & 63) == __ffsll((long long)holders) - 1;
 }
 
 // Step 1 of a planner iteration: the plain front sweep (vhp_sweep.hip.h, fast path) from the
@@ -125,34 +125,6 @@ __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (
   const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
   StoreEmit<double, MULTI> emit(d.vis_local, m.nx, m.ny);
   sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x, lds, whole_workgroup());
-}
-
-// ls_ = heap_->top(); ++nb_of_sources_; the loop condition (solver.cpp:127-141), by the one thread that holds the minimum
-__device__ __forceinline__ void planner_pick(const DevMap& m, const PlannerDev& d, const PlannerKey& b) {
-  d.ctl->iters += 1;
-  if (b.x < 0) {  // nothing reached the threshold: the reference would call top() on an empty heap
-    d.ctl->status = VHP_ERR_NOTHING_LIT;
-    d.ctl->done = 1;
-    return;
-  }
-  const int nb = d.ctl->nb + 1;  // ls_ = top(); ++nb_of_sources_; lightSources_[nb] = ls_   (solver.cpp:130-133)
-  d.ctl->nb = nb;
-  d.pivots[2 * nb] = b.x;
-  d.pivots[2 * nb + 1] = b.y;
-  if ((unsigned long long)nb > d.max_iter) {  // :134-139
-    d.ctl->status = VHP_ERR_MAX_ITER;
-    d.ctl->done = 1;
-    return;
-  }
-  // the loop condition, :127.  vis_global(end) was written by some workgroup of this kernel: agent-scope load
-  const double ge = __longlong_as_double((long long)__hip_atomic_load(
-      reinterpret_cast<const unsigned long long*>(d.vis_global + (size_t)d.end_y * m.nx + d.end_x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  if (ge > d.threshold) {
-    d.pivots[2 * nb] = d.end_x;  // :141
-    d.pivots[2 * nb + 1] = d.end_y;
-    d.ctl->status = VHP_OK;
-    d.ctl->done = 1;
-  }
 }
 
 // Step 2: the per-cell body of updateVisibility() that follows the store (solver.cpp:417-430)
@@ -171,28 +143,15 @@ constexpr int kEpilogueBlocks = VHP_EPI_BLOCKS;
 constexpr int kEpilogueThreads = VHP_EPI_THREADS;
 constexpr int kEpilogueWaves = kEpilogueThreads / 64;
 constexpr int kSpecPartials = kEpilogueBlocks * kEpilogueWaves;  // the speculative solve's epilogue (same launch shape) leaves one partial per wavefront
-static_assert(kEpilogueBlocks <= kEpilogueThreads, "the last workgroup merges one partial per thread");
 __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap m, PlannerDev d) {
   __shared__ PlannerKey slots[kEpilogueWaves];
-  if (d.ctl->done) return;
-  const int nb = d.ctl->nb;
-  const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
   const int nx = m.nx, ny = m.ny;
-  PlannerKey best;
-  best.h = ~0ull;
-  best.rank = ~0ull;
-  best.x = best.y = -1;
   const size_t cells = (size_t)nx * ny;
-  // The pivots a label can name (lightSources_[0 .. nb]) into LDS, beside the first batch of loads: a lit cell's parent then
-  // costs no round trip to memory of its own (beyond kPivLds entries: from global memory as before).
-  constexpr int kPivLds = 1024;
-  __shared__ int piv_lds[2 * kPivLds];
-  const int n_piv = nb + 1 < kPivLds ? nb + 1 : kPivLds;
-  for (int t = threadIdx.x; t < 2 * n_piv; t += blockDim.x) piv_lds[t] = d.pivots[t];
   // Four cells of a thread at a time, their loads issued together -- the label's too, whether or not the cell turns out lit: the
-  // kernel is a chain of memory latencies, not of bytes.
+  // kernel is a chain of memory latencies, not of bytes.  The first batch is asked for with the control block, before anybody knows
+  // what that says (the loads are harmless if the loop has ended; the stores wait): one trip to memory less per iteration.
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  double vv[4], oo[4];
+  double vv[4], oo[4], ot[4];
   uint32_t ll[4];
   auto load_batch = [&](size_t k0) {
 #pragma unroll
@@ -202,17 +161,31 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap 
       vv[u] = in ? d.vis_local[k] : 0.0;
       oo[u] = in ? d.vis_global[k] : 0.0;
       ll[u] = in ? d.label[k] : 0u;
-      if (d.vis_other && in && d.vis_other[k] != 0.0) d.vis_other[k] = 0.0;
+      ot[u] = (d.vis_other && in) ? d.vis_other[k] : 0.0;
     }
   };
   size_t k0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  load_batch(k0);   // (issued before the barrier that the staged pivots need: one round trip to memory for both)
+  const int done = d.ctl->done, nb = d.ctl->nb;
+  load_batch(k0);
+  if (done) return;
+  const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
+  PlannerKey best;
+  best.h = ~0ull;
+  best.rank = ~0ull;
+  best.x = best.y = -1;
+  // The pivots a label can name (lightSources_[0 .. nb]) into LDS, beside the first batch of loads: a lit cell's parent then
+  // costs no round trip to memory of its own (beyond kPivLds entries: from global memory as before).
+  constexpr int kPivLds = 1024;
+  __shared__ int piv_lds[2 * kPivLds];
+  const int n_piv = nb + 1 < kPivLds ? nb + 1 : kPivLds;
+  for (int t = threadIdx.x; t < 2 * n_piv; t += blockDim.x) piv_lds[t] = d.pivots[t];
   __syncthreads();
   for (;;) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t k = k0 + u * stride;
       if (k >= cells) continue;
+      if (ot[u] != 0.0) d.vis_other[k] = 0.0;   // (what iteration n - 1 left in the field the next sweep writes)
       const int y = (int)((unsigned)k / (unsigned)nx), x = (int)((unsigned)k - (unsigned)y * (unsigned)nx);  // (cells < 2^31: VHP_MAX_SIDE^2)
       // column 0 / row 0 are swept only when the pivot lies on them: unvisited cells are
       // neither united, labelled nor pushed
@@ -242,13 +215,8 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap 
     if (k0 >= cells) break;
     load_batch(k0);
   }
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-    const PlannerKey o = key_shuffle_xor(best, s);
-    if (key_less(o, best)) best = o;
-  }
   const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) slots[wave] = best;
+  if (wave_holds_min(best)) slots[wave] = best;   // (the one lane that holds the wavefront's minimum of (h, rank))
   // The workgroup whose partial arrives last merges them all and picks the next pivot: no third kernel, no single-thread
   // walk over the partials.  Cross-CU hand-off (MI355X_MICROARCH "Valid forms"): every storing wavefront drains its
   // stores, the workgroup's barrier, then one lane: partial, agent-scope release, drained again, ticket.
@@ -270,31 +238,53 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap 
   }
   __syncthreads();
   if (!is_last) return;
-  // kEpilogueBlocks == blockDim.x: one partial per thread, agent-scope loads (another CU wrote them)
+  // Wavefront 0 alone, on registers: the partials (agent-scope loads: other CUs wrote them), the loop condition's cell (written by
+  // some workgroup of this kernel) and the iteration count are asked for together; the minimum of (h, rank) by DPP; lane 0 stores
+  // the pick -- ls_ = top(); ++nb_of_sources_; lightSources_[nb] = ls_; the loop condition (solver.cpp:127-141).
+  // (Until round 5: a partial per thread, a butterfly of ds_bpermute per wavefront, a barrier, one thread over the wavefronts'
+  // minima and then the pick's trips to memory one after the other.)
+  if (wave != 0) return;
+  const int lane = (int)threadIdx.x;
+  const double ge = __longlong_as_double((long long)__hip_atomic_load(
+      reinterpret_cast<const unsigned long long*>(d.vis_global + (size_t)d.end_y * m.nx + d.end_x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const int iters = d.ctl->iters;
+  constexpr int kPerLane = (kEpilogueBlocks + 63) / 64;
   PlannerKey k;
   k.h = ~0ull; k.rank = ~0ull; k.x = k.y = -1;
-  if (threadIdx.x < gridDim.x) {
-    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(d.partial + threadIdx.x);
-    k.h = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    k.rank = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long xy = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    k.x = (int)(unsigned)xy;
-    k.y = (int)(unsigned)(xy >> 32);
-  }
 #pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-    const PlannerKey o = key_shuffle_xor(k, s);
-    if (key_less(o, k)) k = o;
+  for (int t = 0; t < kPerLane; ++t) {
+    const int i = lane + 64 * t;
+    const bool in = i < (int)gridDim.x;
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(d.partial + (in ? i : 0));
+    PlannerKey o;
+    o.h = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    o.rank = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long xy = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    o.x = (int)(unsigned)xy;
+    o.y = (int)(unsigned)(xy >> 32);
+    if (in && key_less(o, k)) k = o;
   }
-  if ((threadIdx.x & 63) == 0) slots[wave] = k;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    PlannerKey bb = slots[0];
-    for (int w = 1; w < kEpilogueWaves; ++w)
-      if (key_less(slots[w], bb)) bb = slots[w];
-    *d.ticket = 0;  // for the next iteration (kernels of one stream run in order)
-    planner_pick(m, d, bb);
+  const unsigned long long hmin = wave_min_u64(k.h);
+  const unsigned long long rmin = wave_min_u64(k.h == hmin ? k.rank : ~0ull);
+  const unsigned long long holders = __ballot(k.h == hmin && k.rank == rmin);
+  const int wl = holders ? __ffsll((long long)holders) - 1 : 0;
+  const int wx = __builtin_amdgcn_readlane(k.x, wl), wy = __builtin_amdgcn_readlane(k.y, wl);  // (-1: nothing reached the threshold)
+  if (lane != 0) return;
+  *d.ticket = 0;  // for the next iteration (kernels of one stream run in order)
+  d.ctl->iters = iters + 1;
+  if (wx < 0) {  // the reference would call top() on an empty heap
+    d.ctl->status = VHP_ERR_NOTHING_LIT;
+    d.ctl->done = 1;
+    return;
   }
+  const int nbn = nb + 1;
+  int px = wx, py = wy, status = -1;
+  if ((unsigned long long)nbn > d.max_iter) status = VHP_ERR_MAX_ITER;  // :134-139
+  else if (ge > d.threshold) { px = d.end_x; py = d.end_y; status = VHP_OK; }  // :127, :141
+  d.ctl->nb = nbn;
+  d.pivots[2 * nbn] = px;
+  d.pivots[2 * nbn + 1] = py;
+  if (status >= 0) { d.ctl->status = status; d.ctl->done = 1; }
 }
 
 __global__ void vhp_planner_init(PlannerDev d, int nx, int start_x, int start_y) {
@@ -660,13 +650,12 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_spec_epilogue(DevMap m, 
 #else
 #define VHP_SPEC_STAMP(i)
 #endif
-  if (d.ctl->done) return;
-  const int nb = d.ctl->nb;
-  const int nc = sp.sc->n_commit;
-  const int nx = m.nx, ny = m.ny;
-  const int cur = sp.sc->cur_slot;
-  double* field0 = sp.cache + (size_t)cur * sp.cells;
+  // (the control words together, and nobody waits for `done` before the others are on their way: a trip to memory less)
+  const int done_now = d.ctl->done, nb = d.ctl->nb, nc = sp.sc->n_commit, cur = sp.sc->cur_slot;
   const int prev_last = CLEAN ? sp.sc->prev_last : -1;
+  if (done_now) return;
+  const int nx = m.nx, ny = m.ny;
+  double* field0 = sp.cache + (size_t)cur * sp.cells;
   double* prev_field = sp.cache + (size_t)(prev_last < 0 ? 0 : prev_last) * sp.cells;
   PlannerKey best;
   best.h = ~0ull;
@@ -735,13 +724,8 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_spec_epilogue(DevMap m, 
     if (k0 >= cells) break;
     load_batch(k0);
   }
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-    const PlannerKey o = key_shuffle_xor(best, s);
-    if (key_less(o, best)) best = o;
-  }
   const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) d.partial[blockIdx.x * kEpilogueWaves + wave] = best;
+  if (wave_holds_min(best)) d.partial[blockIdx.x * kEpilogueWaves + wave] = best;
   // (the hand-off of vhp_planner_epilogue: every wavefront drains its stores -- its partial among them --, the barrier, one lane:
   // agent-scope release, ticket)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -819,7 +803,7 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_spec_epilogue(DevMap m, 
     if (abs(mine.x - wx) < kSpecSep && abs(mine.y - wy) < kSpecSep) { mine.h = ~0ull; mine.rank = ~0ull; mine.x = mine.y = -1; }
   }
   VHP_SPEC_STAMP(4);
-  // planner_pick, on registers (every lane computes, lane 0 stores): ls_ = top(); ++nb_of_sources_; the loop condition
+  // the pick of vhp_planner_epilogue, on registers (every lane computes, lane 0 stores): ls_ = top(); ++nb_of_sources_; the loop condition
   // (solver.cpp:127-141).  The runner-ups this iteration committed (mode 1) are pivots nb+1 .. nb+nc-1.
   const bool st = lane == 0;
   if (st) { *d.ticket = 0; d.ctl->iters = iters + 1; if (CLEAN) c->prev_last = cur + nc - 1; }
