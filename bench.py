@@ -230,9 +230,9 @@ def bench_planner(args):
                      "note": "latency case by construction: one source per pivot, pivots are sequential (SURVEY 8d expectation management)"},
     }
     # the speculative planner (vhp_planner_solve_speculative): exact mode (same pivots, cached fields) and fast mode (all k
-    # candidates of a launch committed: NOT the reference's result), device loop only
+    # candidates of a launch committed: NOT the reference's result), device loop only; "vs_plain_loop" = the plain loop's time / theirs
     spec = {}
-    for name, k, mode in (("exact_k4", 4, 0), ("exact_k8", 8, 0), ("fast_k4", 4, 1), ("fast_k8", 8, 1)):
+    for name, k, mode in (("exact_k2", 2, 0), ("exact_k4", 4, 0), ("fast_k2", 2, 1), ("fast_k4", 4, 1), ("fast_k8", 8, 1)):
         r = None
         ms = []
         for it in range(1 + min(args.steps, 5)):
@@ -241,7 +241,8 @@ def bench_planner(args):
                 ms.append(ctx.last_elapsed_ms())
         spec[name] = {"status": r["status"], "pivots": r["n_pivots"], "sweep_launches": r["sweeps"], "cache_hits": r["hits"], "fields_swept": r["fields_swept"],
                       "device_loop_ms": round(float(np.mean(ms)), 4), "us_per_pivot_device_loop": round(float(np.mean(ms)) * 1e3 / max(r["n_pivots"], 1), 2),
-                      "us_per_launch": round(float(np.mean(ms)) * 1e3 / max(r["sweeps"] + r["hits"], 1), 2)}
+                      "us_per_launch": round(float(np.mean(ms)) * 1e3 / max(r["sweeps"] + r["hits"], 1), 2),
+                      "vs_plain_loop": round(loop_ms / float(np.mean(ms)), 3)}   # > 1: faster than vhp_planner_solve's device loop
     out["config"]["speculative"] = spec
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
