@@ -122,10 +122,10 @@ int vhp_planner_results_device(vhp_ctx* ctx, const uint32_t** labels, const doub
  * stats (may be NULL): [0] iterations whose pivot was cached, [1] iterations that swept, [2] fields swept.
  * pivots_xy: at least 2*(max_iter+2+8) ints -- in mode 1 an iteration commits up to k pivots before the max_iter test, so
  * *n_pivots can reach max_iter + 8.  Their launches take the latency sweep (8 k workgroups) wherever a batch of k would.  Measured
- * on maze_6 (threshold 0.1, 64 pivots; vhp_planner_solve 1.92 ms): mode 1 with k = 4 1.54 ms -- 149 pivots in 38 launches --, k = 2
- * 1.77; mode 0 2.55 ms: it sweeps k fields where the plain loop sweeps one and skips 13 of 64 sweeps, which does not pay there.  It
- * pays where pivots repeat (the reference's live-lock, threshold 0.25 on the same map: 4.3 ms against 6.3 until max_iter = 250; mode
- * 1 SOLVES that instance, 157 pivots in 1.56 ms).  DESIGN.md section 7.
+ * on maze_6 (threshold 0.1, 64 pivots; vhp_planner_solve 1.70 ms): mode 1 with k = 4 1.44 ms -- 149 pivots in 38 launches --, k = 2
+ * 1.62; mode 0 2.44 ms: it sweeps k fields where the plain loop sweeps one and skips 13 of 64 sweeps, which does not pay there.  It
+ * pays where pivots repeat (the reference's live-lock, threshold 0.25 on the same map: 3.8 ms against 5.6 until max_iter = 250; mode
+ * 1 SOLVES that instance, 157 pivots in 1.51 ms).  DESIGN.md section 7.
  * Results stay on the device as with vhp_planner_solve_device (vhp_planner_results_device); host outputs may be NULL. */
 int vhp_planner_solve_speculative(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end_y, double threshold, uint64_t max_iter,
                                   int k, int mode, uint64_t* came_from, double* vis_global, double* vis_local, int32_t* pivots_xy,

@@ -325,6 +325,10 @@ struct PlannerState {
   PlannerCtl* ctl = nullptr;
   PlannerKey* partial = nullptr;
   unsigned int* ticket = nullptr;
+  // the host's polls of the control block: two pinned copies and their events, so that the next batch of iterations is enqueued
+  // before the host waits for the last one's copy (planner_poll)
+  PlannerCtl* h_ctl = nullptr;
+  hipEvent_t poll_ev[2] = {nullptr, nullptr};
   // launch shape of the front sweep and the per-device dynamic-LDS bookkeeping, set by the caller (vhp_capi.hip)
   int R = 2, W = 8;
   bool multi = false;
@@ -349,6 +353,9 @@ inline void planner_free(PlannerState& s) {
   if (s.partial) (void)hipFree(s.partial);
   if (s.ticket) (void)hipFree(s.ticket);
   s.ticket = nullptr;
+  if (s.h_ctl) (void)hipHostFree(s.h_ctl);
+  s.h_ctl = nullptr;
+  for (auto& e : s.poll_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   s.cells = 0;
   s.pivot_cap = 0;
   s.vis_global = s.vis_local = nullptr;
@@ -367,6 +374,34 @@ inline void planner_free(PlannerState& s) {
       return (int)VHP_ERR_HIP;                                                \
     }                                                                         \
   } while (0)
+
+// The loop both solves run on the host: `enqueue` puts one batch of iterations on the stream (kernels of iterations past the end see
+// `done` and return at once); the control block is copied out behind every batch, and the host waits for the copy of batch n only
+// after batch n + 1 is on the stream -- the GPU does not idle while the host looks (until round 5 it did: 10-20 us per poll); the price is
+// one batch of kernels that return at once when the loop ends.  maze_6: 1.87 -> 1.71 ms per solve (batches of 4 or 16: no better).
+template <typename Enqueue>
+inline int planner_poll(PlannerState& s, hipStream_t stream, Enqueue enqueue, PlannerCtl* out, std::string* msg) {
+  if (!s.h_ctl) {
+    VHP_PL_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_ctl), 2 * sizeof(PlannerCtl)));
+    for (auto& e : s.poll_ev) VHP_PL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  auto post = [&](int slot) -> int {
+    // (on the solve's own stream: the copy on a second stream behind an event of this one measured 6 % slower)
+    VHP_PL_HIP(hipMemcpyAsync(&s.h_ctl[slot], s.ctl, sizeof(PlannerCtl), hipMemcpyDeviceToHost, stream));
+    VHP_PL_HIP(hipEventRecord(s.poll_ev[slot], stream));
+    return VHP_OK;
+  };
+  int rc = enqueue();
+  if (rc != VHP_OK) return rc;
+  if ((rc = post(0)) != VHP_OK) return rc;
+  for (int q = 0;; ++q) {
+    if ((rc = enqueue()) != VHP_OK) return rc;
+    if ((rc = post((q + 1) & 1)) != VHP_OK) return rc;
+    VHP_PL_HIP(hipEventSynchronize(s.poll_ev[q & 1]));
+    *out = s.h_ctl[q & 1];
+    if (out->done) return VHP_OK;
+  }
+}
 
 template <int R, bool MULTI>
 inline hipError_t launch_planner_fronts(PlannerState& s, const DevMap& m, const PlannerDev& d, int W, hipStream_t stream) {
@@ -455,24 +490,28 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   hipLaunchKernelGGL(vhp_planner_init, dim3(1), dim3(64), 0, stream, d, nx, start_x, start_y);
   VHP_PL_HIP(hipGetLastError());
   PlannerCtl ctl{};
-  const int batch = 8;  // iterations enqueued per host poll (those past the end see `done` and return at once)
-  for (;;) {
-    for (int b = 0; b < batch; ++b, ++launches) {
-      if (two_fields) {
-        d.vis_local = (launches & 1) ? s.vis_local2 : s.vis_local;
-        d.vis_other = (launches & 1) ? s.vis_local : s.vis_local2;
+#ifndef VHP_PLANNER_BATCH
+#define VHP_PLANNER_BATCH 8
+#endif
+  const int batch = VHP_PLANNER_BATCH;  // iterations enqueued per host poll (those past the end see `done` and return at once)
+  {
+    const int rc = planner_poll(s, stream, [&]() -> int {
+      for (int b = 0; b < batch; ++b, ++launches) {
+        if (two_fields) {
+          d.vis_local = (launches & 1) ? s.vis_local2 : s.vis_local;
+          d.vis_other = (launches & 1) ? s.vis_local : s.vis_local2;
+        }
+        hipError_t e = s.lat_sweep ? s.lat_sweep(d.pivots, &s.ctl->nb, &s.ctl->done, d.vis_local, true)
+                     : R == 1 ? (multi ? launch_planner_fronts<1, true>(s, m, d, W, stream) : launch_planner_fronts<1, false>(s, m, d, W, stream))
+                     : R == 2 ? (multi ? launch_planner_fronts<2, true>(s, m, d, W, stream) : launch_planner_fronts<2, false>(s, m, d, W, stream))
+                              : (multi ? launch_planner_fronts<4, true>(s, m, d, W, stream) : launch_planner_fronts<4, false>(s, m, d, W, stream));
+        if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
+        hipLaunchKernelGGL(vhp_planner_epilogue, dim3(kEpilogueBlocks), dim3(kEpilogueThreads), 0, stream, m, d);
+        VHP_PL_HIP(hipGetLastError());
       }
-      hipError_t e = s.lat_sweep ? s.lat_sweep(d.pivots, &s.ctl->nb, &s.ctl->done, d.vis_local, true)
-                   : R == 1 ? (multi ? launch_planner_fronts<1, true>(s, m, d, W, stream) : launch_planner_fronts<1, false>(s, m, d, W, stream))
-                   : R == 2 ? (multi ? launch_planner_fronts<2, true>(s, m, d, W, stream) : launch_planner_fronts<2, false>(s, m, d, W, stream))
-                            : (multi ? launch_planner_fronts<4, true>(s, m, d, W, stream) : launch_planner_fronts<4, false>(s, m, d, W, stream));
-      if (e != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
-      hipLaunchKernelGGL(vhp_planner_epilogue, dim3(kEpilogueBlocks), dim3(kEpilogueThreads), 0, stream, m, d);
-      VHP_PL_HIP(hipGetLastError());
-    }
-    VHP_PL_HIP(hipMemcpyAsync(&ctl, s.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
-    VHP_PL_HIP(hipStreamSynchronize(stream));
-    if (ctl.done) break;
+      return VHP_OK;
+    }, &ctl, msg);
+    if (rc != VHP_OK) return rc;
   }
   VHP_PL_HIP(hipEventRecord(ev1, stream));
 
@@ -993,22 +1032,23 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
   hipLaunchKernelGGL(vhp_spec_init, dim3(1), dim3(64), 0, stream, d, sp, start_x, start_y);
   VHP_PL_HIP(hipGetLastError());
   PlannerCtl ctl{};
-  const int batch = 8;
-  for (;;) {
-    for (int b = 0; b < batch; ++b) {
-      hipError_t e = s.lat_sweep_k ? s.lat_sweep_k(ss.sc->cand, K, &ss.sc->cur_slot, &ss.sc->sweep, &s.ctl->done, ss.cache, mode == 1)
-                   : R == 1 ? (multi ? launch_spec_fronts<1, true>(s, m, d, sp, W, stream) : launch_spec_fronts<1, false>(s, m, d, sp, W, stream))
-                   : R == 2 ? (multi ? launch_spec_fronts<2, true>(s, m, d, sp, W, stream) : launch_spec_fronts<2, false>(s, m, d, sp, W, stream))
-                            : (multi ? launch_spec_fronts<4, true>(s, m, d, sp, W, stream) : launch_spec_fronts<4, false>(s, m, d, sp, W, stream));
-      if (e != hipSuccess) { *msg = std::string("speculative planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
-      auto epi = mode == 0 ? vhp_spec_epilogue<1, false> : K == 1 ? vhp_spec_epilogue<1, true> : K == 2 ? vhp_spec_epilogue<2, true>
-                         : K == 4 ? vhp_spec_epilogue<4, true> : vhp_spec_epilogue<8, true>;
-      hipLaunchKernelGGL(epi, dim3(kEpilogueBlocks), dim3(kEpilogueThreads), 0, stream, m, d, sp);
-      VHP_PL_HIP(hipGetLastError());
-    }
-    VHP_PL_HIP(hipMemcpyAsync(&ctl, s.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
-    VHP_PL_HIP(hipStreamSynchronize(stream));
-    if (ctl.done) break;
+  const int batch = VHP_PLANNER_BATCH;
+  {
+    const int rc = planner_poll(s, stream, [&]() -> int {
+      for (int b = 0; b < batch; ++b) {
+        hipError_t e = s.lat_sweep_k ? s.lat_sweep_k(ss.sc->cand, K, &ss.sc->cur_slot, &ss.sc->sweep, &s.ctl->done, ss.cache, mode == 1)
+                     : R == 1 ? (multi ? launch_spec_fronts<1, true>(s, m, d, sp, W, stream) : launch_spec_fronts<1, false>(s, m, d, sp, W, stream))
+                     : R == 2 ? (multi ? launch_spec_fronts<2, true>(s, m, d, sp, W, stream) : launch_spec_fronts<2, false>(s, m, d, sp, W, stream))
+                              : (multi ? launch_spec_fronts<4, true>(s, m, d, sp, W, stream) : launch_spec_fronts<4, false>(s, m, d, sp, W, stream));
+        if (e != hipSuccess) { *msg = std::string("speculative planner launch: ") + hipGetErrorString(e); return VHP_ERR_HIP; }
+        auto epi = mode == 0 ? vhp_spec_epilogue<1, false> : K == 1 ? vhp_spec_epilogue<1, true> : K == 2 ? vhp_spec_epilogue<2, true>
+                           : K == 4 ? vhp_spec_epilogue<4, true> : vhp_spec_epilogue<8, true>;
+        hipLaunchKernelGGL(epi, dim3(kEpilogueBlocks), dim3(kEpilogueThreads), 0, stream, m, d, sp);
+        VHP_PL_HIP(hipGetLastError());
+      }
+      return VHP_OK;
+    }, &ctl, msg);
+    if (rc != VHP_OK) return rc;
   }
   hipLaunchKernelGGL(vhp_spec_export_local, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, m, d, sp);
   VHP_PL_HIP(hipGetLastError());

@@ -174,6 +174,9 @@ struct UnitGeo {
 // ---------------------------------------------------------------------------------------------------------------
 template <int D>
 struct Link {
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
+  unsigned long long* pp;  // diagnostic builds (tools/lat_timeline.py): the wavefront's cycle accounts
+#endif
   // reading side (nothing of it is used by the first strip of a unit)
   double* bin;             // entry of coordinate x of the current block at 1 + (x & 63); 0 / 65: the neighbours of the block
   const double* rd_ring;   // the ring of the wavefront that sweeps the strip below
