@@ -142,20 +142,26 @@ __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (
 constexpr int kEpilogueBlocks = VHP_EPI_BLOCKS;
 constexpr int kEpilogueThreads = VHP_EPI_THREADS;
 constexpr int kEpilogueWaves = kEpilogueThreads / 64;
+// cells of a thread per batch of loads in vhp_planner_epilogue (measured on maze_6 -- 277 380 cells, 65 536 threads: 4.2 cells each --,
+// us per pivot: 4: 26.4-26.6, 5 -- one batch instead of a full one and a quarter of a second --: 26.9, 6: 27.0)
+#ifndef VHP_EPI_CELLS
+#define VHP_EPI_CELLS 4
+#endif
+constexpr int kEpiCells = VHP_EPI_CELLS;
 constexpr int kSpecPartials = kEpilogueBlocks * kEpilogueWaves;  // the speculative solve's epilogue (same launch shape) leaves one partial per wavefront
 __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap m, PlannerDev d) {
   __shared__ PlannerKey slots[kEpilogueWaves];
   const int nx = m.nx, ny = m.ny;
   const size_t cells = (size_t)nx * ny;
-  // Four cells of a thread at a time, their loads issued together -- the label's too, whether or not the cell turns out lit: the
+  // kEpiCells cells of a thread at a time, their loads issued together -- the label's too, whether or not the cell turns out lit: the
   // kernel is a chain of memory latencies, not of bytes.  The first batch is asked for with the control block, before anybody knows
   // what that says (the loads are harmless if the loop has ended; the stores wait): one trip to memory less per iteration.
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  double vv[4], oo[4], ot[4];
-  uint32_t ll[4];
+  double vv[kEpiCells], oo[kEpiCells], ot[kEpiCells];
+  uint32_t ll[kEpiCells];
   auto load_batch = [&](size_t k0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kEpiCells; ++u) {
       const size_t k = k0 + u * stride;
       const bool in = k < cells;
       vv[u] = in ? d.vis_local[k] : 0.0;
@@ -182,7 +188,7 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap 
   __syncthreads();
   for (;;) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kEpiCells; ++u) {
       const size_t k = k0 + u * stride;
       if (k >= cells) continue;
       if (ot[u] != 0.0) d.vis_other[k] = 0.0;   // (what iteration n - 1 left in the field the next sweep writes)
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap 
         if (key_less(c, best)) best = c;
       }
     }
-    k0 += 4 * stride;
+    k0 += kEpiCells * stride;
     if (k0 >= cells) break;
     load_batch(k0);
   }
