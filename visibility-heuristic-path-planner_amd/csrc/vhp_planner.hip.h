@@ -132,7 +132,8 @@ __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (
 // of every lit cell, arg-min of (h, push rank).  Embarrassingly parallel and coalesced.
 // The epilogue's launch shape: kEpilogueBlocks workgroups of kEpilogueThreads (blocks <= threads: the last workgroup merges one partial
 // per thread).  Measured on maze_6 (bench.py --workload c4, us per pivot of the device loop, one box): 256 x 256 31.3, 128 x 512 30.3,
-// 64 x 1024 38.6 (profiles/r05_planner_epilogue_shapes.txt).
+// 64 x 1024 38.6 (profiles/r05_planner_epilogue_shapes.txt); later in round 5, with the polls overlapped: 96 x 512 27.2, 128 x 512 26.5,
+// 192 x 512 27.3, 256 x 512 28.8.
 #ifndef VHP_EPI_BLOCKS
 #define VHP_EPI_BLOCKS 128
 #endif
@@ -679,7 +680,6 @@ __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (
 // runner-ups and the look-up of the next iteration.  With one committed field (mode 0) the cells see vhp_planner_epilogue's operations
 // one for one, in its launch shape; every wavefront leaves a partial minimum (kSpecPartials of them: the runner-ups are picked
 // among those).
-static_assert(kSpecPartials <= 2 * kEpilogueThreads, "the last workgroup merges two partials per thread");
 // NF = the committed fields a launch can have (mode 0: 1; mode 1: k).  CLEAN (mode 1): a field is read exactly once, by the epilogue
 // of the iteration that swept it, so that epilogue puts +0.0 back wherever it read something else -- except into the iteration's
 // last field, which is the solve's local field if the loop ends here: the next epilogue clears that one (one more load per cell).
