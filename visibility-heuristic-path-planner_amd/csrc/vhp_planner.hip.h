@@ -559,7 +559,11 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kSpecMaxK = 8;
 constexpr int kSpecSlots = 32;  // cached fields (a multiple of every K)
-constexpr int kSpecSep = 8;     // Chebyshev distance between candidates of one launch
+#ifndef VHP_SPEC_SEP
+#define VHP_SPEC_SEP 8
+#endif
+constexpr int kSpecSep = VHP_SPEC_SEP;     // Chebyshev distance between candidates of one launch (maze_6, fast k = 4, iterations at threshold
+                                           // 0.1 / 0.25: 4: 43 / max_iter, 8: 38 / 40, 16: 39 / 42, 32: 36 / max_iter, 64: 51 / max_iter)
 
 struct SpecCtl {
   int cand[2 * kSpecMaxK];       // sources of the next sweep launch: [0] the pivot, then runner-ups (x < 0: none)
