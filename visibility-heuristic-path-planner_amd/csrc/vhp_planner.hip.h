@@ -718,11 +718,12 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_spec_epilogue(DevMap m, 
   auto pivot_x = [&](uint32_t i) { return i < (uint32_t)kPivLds ? piv_lds[2 * i] : d.pivots[2 * i]; };
   auto pivot_y = [&](uint32_t i) { return i < (uint32_t)kPivLds ? piv_lds[2 * i + 1] : d.pivots[2 * i + 1]; };
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  double vv[NF][4], oo[4];   // (every committed field's cell with the batch: the kernel is a chain of latencies)
-  uint32_t ll[4];
+  constexpr int CB = NF > 4 ? 2 : 4;   // cells of a thread per batch of loads (8 fields x 4 cells spilled: 348 bytes of scratch per lane)
+  double vv[NF][CB], oo[CB];   // (every committed field's cell with the batch: the kernel is a chain of latencies)
+  uint32_t ll[CB];
   auto load_batch = [&](size_t k0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CB; ++u) {
       const size_t k = k0 + u * stride;
       const bool in = k < cells;
 #pragma unroll
@@ -738,7 +739,7 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_spec_epilogue(DevMap m, 
   const int sx0 = pivot_x((uint32_t)nb), sy0 = pivot_y((uint32_t)nb);
   for (;;) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CB; ++u) {
       const size_t k = k0 + u * stride;
       if (k >= cells) continue;
       const int y = (int)((unsigned)k / (unsigned)nx), x = (int)((unsigned)k - (unsigned)y * (unsigned)nx);
@@ -769,7 +770,7 @@ __global__ void __launch_bounds__(kEpilogueThreads) vhp_spec_epilogue(DevMap m, 
         if (key_less(c, best)) best = c;
       }
     }
-    k0 += 4 * stride;
+    k0 += CB * stride;
     if (k0 >= cells) break;
     load_batch(k0);
   }
