@@ -39,6 +39,7 @@ struct vhp_ctx {
   int opt_alloc_budget_pct = 25;  // vhp_alloc_output: share of the free device memory its candidates may hold at once
   int nx = 0, ny = 0;
   uint8_t* d_occ = nullptr;    // uint8 map (kept for the planner's validation and packing)
+  std::vector<uint8_t> h_occ;  // ... its host copy when vhp_set_map brought it (empty after vhp_set_map_device)
   uint64_t* d_rows = nullptr;  // packed along x
   uint64_t* d_cols = nullptr;  // packed along y
   double* d_recip = nullptr;
@@ -182,6 +183,8 @@ void free_map(vhp_ctx* c) {
   if (c->d_cols) hipFree(c->d_cols);
   if (c->d_recip) hipFree(c->d_recip);
   c->d_occ = nullptr; c->d_rows = nullptr; c->d_cols = nullptr; c->d_recip = nullptr;
+  c->h_occ.clear();
+  c->pl.h_occ = nullptr;
   vhp::planner_free(c->pl);
   vhp::spec_free(c->spec);
   vhp::queue_scratch_free(c->qs);
@@ -522,6 +525,8 @@ static int set_map_common(vhp_ctx* ctx, const uint8_t* src, int nx, int ny, bool
   const size_t n = (size_t)nx * ny;
   VHP_HIP(hipMalloc(&ctx->d_occ, n));
   VHP_HIP(hipMemcpyAsync(ctx->d_occ, src, n, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  if (from_device) ctx->h_occ.clear(); else ctx->h_occ.assign(src, src + n);
+  ctx->pl.h_occ = ctx->h_occ.empty() ? nullptr : ctx->h_occ.data();
   return finish_set_map(ctx, nx, ny);
 }
 

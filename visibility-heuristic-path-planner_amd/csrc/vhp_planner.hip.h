@@ -336,6 +336,7 @@ struct PlannerState {
   // before the host waits for the last one's copy (planner_poll)
   PlannerCtl* h_ctl = nullptr;
   hipEvent_t poll_ev[2] = {nullptr, nullptr};
+  const uint8_t* h_occ = nullptr;   // the caller's host copy of the map if it has one (vhp_set_map), for the start / end validation
   // launch shape of the front sweep and the per-device dynamic-LDS bookkeeping, set by the caller (vhp_capi.hip)
   int R = 2, W = 8;
   bool multi = false;
@@ -433,9 +434,14 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   if (!valid(start_x, start_y)) { *msg = "Start point is out of bounds."; return VHP_ERR_START_OOB; }
   if (!valid(end_x, end_y)) { *msg = "End point is out of bounds."; return VHP_ERR_END_OOB; }
   uint8_t occ_s = 0, occ_e = 0;
-  VHP_PL_HIP(hipMemcpyAsync(&occ_s, d_occ + (size_t)start_y * nx + start_x, 1, hipMemcpyDeviceToHost, stream));
-  VHP_PL_HIP(hipMemcpyAsync(&occ_e, d_occ + (size_t)end_y * nx + end_x, 1, hipMemcpyDeviceToHost, stream));
-  VHP_PL_HIP(hipStreamSynchronize(stream));
+  if (s.h_occ) {  // (the map came from the host: its copy answers, no trip to the device)
+    occ_s = s.h_occ[(size_t)start_y * nx + start_x];
+    occ_e = s.h_occ[(size_t)end_y * nx + end_x];
+  } else {
+    VHP_PL_HIP(hipMemcpyAsync(&occ_s, d_occ + (size_t)start_y * nx + start_x, 1, hipMemcpyDeviceToHost, stream));
+    VHP_PL_HIP(hipMemcpyAsync(&occ_e, d_occ + (size_t)end_y * nx + end_x, 1, hipMemcpyDeviceToHost, stream));
+    VHP_PL_HIP(hipStreamSynchronize(stream));
+  }
   if (!occ_s) { *msg = "Start point is not valid (occupied)"; return VHP_ERR_START_OCCUPIED; }
   if (!occ_e) { *msg = "End point is not valid (occupied)"; return VHP_ERR_END_OCCUPIED; }
   if (max_iter > (1u << 24)) { *msg = "max_iter too large"; return VHP_ERR_ARG; }
@@ -973,9 +979,14 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
   if (!valid(start_x, start_y)) { *msg = "Start point is out of bounds."; return VHP_ERR_START_OOB; }
   if (!valid(end_x, end_y)) { *msg = "End point is out of bounds."; return VHP_ERR_END_OOB; }
   uint8_t occ_s = 0, occ_e = 0;
-  VHP_PL_HIP(hipMemcpyAsync(&occ_s, d_occ + (size_t)start_y * nx + start_x, 1, hipMemcpyDeviceToHost, stream));
-  VHP_PL_HIP(hipMemcpyAsync(&occ_e, d_occ + (size_t)end_y * nx + end_x, 1, hipMemcpyDeviceToHost, stream));
-  VHP_PL_HIP(hipStreamSynchronize(stream));
+  if (s.h_occ) {  // (the map came from the host: its copy answers, no trip to the device)
+    occ_s = s.h_occ[(size_t)start_y * nx + start_x];
+    occ_e = s.h_occ[(size_t)end_y * nx + end_x];
+  } else {
+    VHP_PL_HIP(hipMemcpyAsync(&occ_s, d_occ + (size_t)start_y * nx + start_x, 1, hipMemcpyDeviceToHost, stream));
+    VHP_PL_HIP(hipMemcpyAsync(&occ_e, d_occ + (size_t)end_y * nx + end_x, 1, hipMemcpyDeviceToHost, stream));
+    VHP_PL_HIP(hipStreamSynchronize(stream));
+  }
   if (!occ_s) { *msg = "Start point is not valid (occupied)"; return VHP_ERR_START_OCCUPIED; }
   if (!occ_e) { *msg = "End point is not valid (occupied)"; return VHP_ERR_END_OCCUPIED; }
   if (max_iter > (1u << 24)) { *msg = "max_iter too large"; return VHP_ERR_ARG; }
