@@ -549,7 +549,8 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
 // ---------------------------------------------------------------------------------------------------------------------
 // The speculative planner (second half).  The planner loop is sequential in its pivots -- pivot k+1 is the
 // arg-min of a heuristic that needs the union after pivot k -- but a sweep depends on nothing but its pivot, and one
-// launch sweeps K sources in the time it sweeps one (a single-source sweep is latency-bound: 4 workgroups on 256 CUs).
+// launch sweeps K sources in the time it sweeps one (a single-source sweep is latency-bound: 8 workgroups on 256 CUs; the launches
+// take the latency sweep where a batch of K would: PlannerState::lat_sweep_k).
 // So every sweep launch takes the next pivot AND the K-1 best other candidates of the last heuristic evaluation along,
 // into a cache of fields keyed by the source cell:
 //   mode 0 (exact): an iteration whose pivot is already in the cache skips its sweep.  Pivots, labels, union and the
@@ -560,8 +561,9 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
 //     iteration, in rank order -- what the reference would do if its heap handed out its K best entries before it
 //     re-evaluated the heuristic.  Fewer, fatter iterations; the labels still form a valid parent table (every pivot
 //     was lit by an earlier one), the path and the pivot list differ from the reference's.
-// Candidates: the committed pivot is the exact arg-min; the runner-ups are the best cells of the other 255 epilogue
-// workgroups' partial minima (a guess is allowed to be a guess), at least kSpecSep cells apart.
+// Candidates: the committed pivot is the exact arg-min of the epilogue's 1024 wavefront minima; the runner-ups are picked among the
+// 64 lanes' best of 16 of those each (a guess is allowed to be a guess), at least kSpecSep cells apart.  Mode 1 keeps its slots
+// clean (two groups of K take turns, vhp_spec_epilogue) so that its sweeps store nothing for dead strips.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kSpecMaxK = 8;
 constexpr int kSpecSlots = 32;  // cached fields (a multiple of every K)
