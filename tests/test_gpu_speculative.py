@@ -185,3 +185,25 @@ def test_speculative_launches_take_the_latency_sweep(vhp):
     c = _ctx(vhp, occ)
     c.planner_solve_speculative((345, ny - 1 - 391), (341, ny - 1 - 10), 0.1, 250, k=4, mode=0, outputs=False)
     assert c.last_sweep_kernel() == 4
+
+
+def test_edge_cases_of_the_loop_end_plain_and_exact(vhp, oracle):
+    """Thresholds below zero (the loop never runs), at and above one, iteration caps of 0 and 1, start = end: the plain loop and the exact
+    mode end as the oracle's solve() does, with its outputs; the fast mode must at least return."""
+    occ = maps.random_rect_map(120, 90, 12, 3, 20, 3, 20, seed=4)
+    free = np.argwhere(occ == 1)
+    a, b = free[5], free[-7]
+    start, end = (int(a[1]), int(a[0])), (int(b[1]), int(b[0]))
+    c = _ctx(vhp, occ)
+    for thr in (-1.0, 0.0, 0.3, 1.0, 1.5):
+        for mi in (0, 1, 3, 500):
+            for s, e in ((start, end), (start, start), (end, start)):
+                ref = oracle.solve(occ, s, e, thr, mi)
+                runs = [("plain", c.planner_solve(s, e, thr, mi))] + [("exact k=%d" % k, c.planner_solve_speculative(s, e, thr, mi, k=k, mode=0)) for k in (1, 4)]
+                for what, got in runs:
+                    assert got["status"] == ref["status"], (what, thr, mi, s, e)
+                    if ref["status"] in (0, vhp.VHP_ERR_MAX_ITER):
+                        assert np.array_equal(got["pivots"][: ref["n_pivots"] + 1], ref["pivots"]), (what, thr, mi, s, e)
+                        for key in ("came_from", "vis_global", "vis_local"):
+                            assert np.array_equal(got[key], ref[key]), (what, key, thr, mi, s, e)
+                c.planner_solve_speculative(s, e, thr, mi, k=4, mode=1)
