@@ -173,7 +173,8 @@ int vhp_sweep_batch_offset(vhp_ctx* ctx, const int32_t* src_xy, int n_src, doubl
 
 /* Elapsed milliseconds between the first and last kernel of the most recent
  * vhp_sweep_batch_device / planner call, from hipEvents recorded on the context
- * stream.  Blocks until that work has finished. */
+ * stream.  Blocks until that work has finished.  vhp_probe_stores and vhp_alloc_output time their probes with the same pair of
+ * events: after either of them there is nothing to report (VHP_ERR_ARG, "nothing timed yet") until the next sweep or solve. */
 int vhp_last_elapsed_ms(vhp_ctx* ctx, float* ms);
 
 /* Per-launch kernel timing for benchmarks.  vhp_timing(ctx, 1) makes every following

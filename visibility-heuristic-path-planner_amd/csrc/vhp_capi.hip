@@ -525,9 +525,17 @@ static int set_map_common(vhp_ctx* ctx, const uint8_t* src, int nx, int ny, bool
   const size_t n = (size_t)nx * ny;
   VHP_HIP(hipMalloc(&ctx->d_occ, n));
   VHP_HIP(hipMemcpyAsync(ctx->d_occ, src, n, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-  if (from_device) ctx->h_occ.clear(); else ctx->h_occ.assign(src, src + n);
+  ctx->h_occ.clear();
+  ctx->pl.h_occ = nullptr;
+  const int rc = finish_set_map(ctx, nx, ny);
+  if (rc != VHP_OK) {  // (nothing half-set: neither the old grid's sides with the new grid's arrays nor a host copy of a map that is not there)
+    free_map(ctx);
+    ctx->nx = ctx->ny = 0;
+    return rc;
+  }
+  if (!from_device) ctx->h_occ.assign(src, src + n);
   ctx->pl.h_occ = ctx->h_occ.empty() ? nullptr : ctx->h_occ.data();
-  return finish_set_map(ctx, nx, ny);
+  return VHP_OK;
 }
 
 int vhp_set_map(vhp_ctx* ctx, const uint8_t* occ, int nx, int ny) { return set_map_common(ctx, occ, nx, ny, false); }
@@ -1017,7 +1025,12 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
         ctx->lat_src_index = nb;
         ctx->lat_skip = done;
         ctx->lat_dark_unwritten = dark_unwritten;
+        // (no per-launch event pairs inside a planner loop: vhp_timing times sweep launches, and the loop enqueues a batch of
+        // launches past its end that return at once -- they would fill the pool with pairs that time nothing)
+        const bool timing = ctx->timing;
+        ctx->timing = false;
         const hipError_t e = launch_batch_sweep<double>(ctx, pivots, 1, out, true);
+        ctx->timing = timing;
         ctx->lat_src_index = ctx->lat_skip = nullptr;
         ctx->lat_dark_unwritten = false;
         return e;
@@ -1059,7 +1072,10 @@ int vhp_planner_solve_speculative(vhp_ctx* ctx, int start_x, int start_y, int en
         ctx->lat_dark_unwritten = dark_unwritten;
         const long long stride = ctx->opt_field_stride;
         ctx->opt_field_stride = 0;  // (the cache holds packed fields)
+        const bool timing = ctx->timing;
+        ctx->timing = false;  // (as in vhp_planner_solve's loop)
         const hipError_t e = launch_batch_sweep<double>(ctx, cand, n, cache, true);
+        ctx->timing = timing;
         ctx->opt_field_stride = stride;
         ctx->lat_skip = ctx->lat_slot_base = ctx->lat_run_if = nullptr;
         ctx->lat_dark_unwritten = false;

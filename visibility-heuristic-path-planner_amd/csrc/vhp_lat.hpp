@@ -404,8 +404,10 @@ struct LatX {
     }
     wave_sync();
     vd fa[8], fb[8];
+#ifndef VHP_DIAG_LAT_NOFLUSH  // diagnostic builds only (WRONG results): the sweep without tile read-out and field stores -- the bound of handing both to another wavefront
 #pragma unroll
     for (int u = 0; u < 8; ++u) { fa[u] = lds_load(tile, fl_t + u * (8 * kTStride)); fb[u] = lds_load(tile, fl_t + (u * (8 * kTStride) + 1)); }
+#endif
     vd bv = vd(0.0);
     if (has_consumer) bv = lds_load(tile, (lane & (kLW - 1)) + (kXRows - 1) * kTStride);  // the last row: what the strip above reads
     wave_sync();
@@ -429,7 +431,9 @@ struct LatX {
 #ifdef VHP_DIAG_NODIAGSTORE  // diagnostic builds only (WRONG results): what the stores of a strip that is growing cost its chain
     if (!DIAG)
 #endif
+#ifndef VHP_DIAG_LAT_NOFLUSH
     store_window<DIAG>(ia, xw, lim, fa, fb);
+#endif
     if (DIAG) VHP_WP_ADDP(lk.pp, 11, tw3);
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
     if (DIAG) { VHP_WP_ADDP(lk.pp, 14, tw0); lk.pp[13] += 1; } else { VHP_WP_ADDP(lk.pp, 15, tw0); lk.pp[12] += 1; }
@@ -693,6 +697,9 @@ struct LatY {
         if (DIAG) v = select(ic == ja + k, dg, v);
 #ifdef VHP_DIAG_NODIAGSTORE
         if (!DIAG)
+#endif
+#ifdef VHP_DIAG_LAT_NOFLUSH
+        if (m.nx == 0x7fffffff)
 #endif
         if (PRED) {
           const int j = ja + k;

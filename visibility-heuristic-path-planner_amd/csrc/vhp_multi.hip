@@ -32,20 +32,32 @@ struct Rccl {
   int (*GroupEnd)() = nullptr;
   int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t stream) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  std::string why;  // what load() failed on (dlerror() hands its message out once: taken right after the failing call)
   bool load() {
     if (lib) return true;
+    why.clear();
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
       lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (lib) break;
+      const char* de = dlerror();
+      if (!why.empty()) why += "; ";
+      why += de ? de : "dlopen failed";
     }
     if (!lib) return false;
+    why.clear();
     CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
     AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-    return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather;
+    if (CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather) return true;
+    // a library without one of the entry points is no library at all: the next call must not find `lib` set and call through a null pointer
+    why = "an entry point is missing (ncclCommInitAll / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclAllGather)";
+    CommInitAll = nullptr; CommDestroy = nullptr; GroupStart = nullptr; GroupEnd = nullptr; AllGather = nullptr; GetErrorString = nullptr;
+    dlclose(lib);
+    lib = nullptr;
+    return false;
   }
 };
 constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8;  // ncclDataType_t (rccl.h)
@@ -190,7 +202,7 @@ int vhp_multi_use_rccl(vhp_multi* m, int enable) {
   for (int a = 0; a < nd; ++a)
     for (int b = a + 1; b < nd; ++b)
       if (m->device[a] == m->device[b]) return mfail(m, VHP_ERR_ARG, "vhp_multi_use_rccl: a communicator needs distinct devices (an ordinal is listed twice)");
-  if (!m->rccl.load()) return mfail(m, VHP_ERR_HIP, std::string("vhp_multi_use_rccl: librccl could not be loaded: ") + (dlerror() ? dlerror() : "symbols missing"));
+  if (!m->rccl.load()) return mfail(m, VHP_ERR_HIP, std::string("vhp_multi_use_rccl: librccl could not be loaded: ") + m->rccl.why);
   m->comms.assign((size_t)nd, nullptr);
   const int rc = m->rccl.CommInitAll(m->comms.data(), nd, m->device.data());
   if (rc != 0) {

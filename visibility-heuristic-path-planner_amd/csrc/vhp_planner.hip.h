@@ -399,13 +399,15 @@ inline int planner_poll(PlannerState& s, hipStream_t stream, Enqueue enqueue, Pl
     VHP_PL_HIP(hipEventRecord(s.poll_ev[slot], stream));
     return VHP_OK;
   };
+  // (an error return leaves nothing in flight: kernels of this solve and a copy into h_ctl may be on the stream when a later enqueue fails)
+  auto fail = [&](int rc) -> int { (void)hipStreamSynchronize(stream); return rc; };
   int rc = enqueue();
-  if (rc != VHP_OK) return rc;
-  if ((rc = post(0)) != VHP_OK) return rc;
+  if (rc != VHP_OK) return fail(rc);
+  if ((rc = post(0)) != VHP_OK) return fail(rc);
   for (int q = 0;; ++q) {
-    if ((rc = enqueue()) != VHP_OK) return rc;
-    if ((rc = post((q + 1) & 1)) != VHP_OK) return rc;
-    VHP_PL_HIP(hipEventSynchronize(s.poll_ev[q & 1]));
+    if ((rc = enqueue()) != VHP_OK) return fail(rc);
+    if ((rc = post((q + 1) & 1)) != VHP_OK) return fail(rc);
+    if (hipEventSynchronize(s.poll_ev[q & 1]) != hipSuccess) { *msg = "hipEventSynchronize (planner poll) failed"; return fail(VHP_ERR_HIP); }
     *out = s.h_ctl[q & 1];
     if (out->done) return VHP_OK;
   }
