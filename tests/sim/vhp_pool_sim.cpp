@@ -24,14 +24,14 @@
 #include <memory>
 #include <vector>
 
-#include "../../visibility-heuristic-path-planner_amd/csrc/vhp_lat.hpp"
+#include "../../visibility-heuristic-path-planner_amd/csrc/vhp_band.hpp"
 
 using namespace vhp::pool;
 
 namespace {
 
 struct HostMap {
-  std::vector<uint64_t> rows, cols;
+  std::vector<uint64_t> rows, cols, diag;
   std::vector<double> recip;
   Map m;
 };
@@ -47,6 +47,24 @@ void build_map(const uint8_t* occ, int nx, int ny, HostMap& h) {
         h.rows[(size_t)y * wpr + 1 + (x >> 6)] |= 1ull << (x & 63);
         h.cols[(size_t)x * wpc + 1 + (y >> 6)] |= 1ull << (y & 63);
       }
+  // the grid packed along its diagonals (vhp_band.hpp DiagMaps; vhp_capi.hip vhp_pack_diag)
+  h.diag.assign(DiagMaps::words(nx, ny), 0);
+  {
+    const int wx = DiagMaps::wpdx(nx), wy = DiagMaps::wpdy(ny);
+    uint64_t* mx = h.diag.data() + DiagMaps::offset(nx, ny, 0);
+    uint64_t* ax = h.diag.data() + DiagMaps::offset(nx, ny, 1);
+    uint64_t* my = h.diag.data() + DiagMaps::offset(nx, ny, 2);
+    uint64_t* ay = h.diag.data() + DiagMaps::offset(nx, ny, 3);
+    for (int y = 0; y < ny; ++y)
+      for (int x = 0; x < nx; ++x)
+        if (occ[(size_t)y * nx + x]) {
+          const size_t im = (size_t)(y - x + nx - 1), ia = (size_t)(y + x);
+          mx[im * wx + 1 + (x >> 6)] |= 1ull << (x & 63);
+          ax[ia * wx + 1 + (x >> 6)] |= 1ull << (x & 63);
+          my[im * wy + 1 + (y >> 6)] |= 1ull << (y & 63);
+          ay[ia * wy + 1 + (y >> 6)] |= 1ull << (y & 63);
+        }
+  }
   const int nrec = (nx > ny ? nx : ny) + 1 + 8;
   h.recip.resize(nrec);
   h.recip[0] = 0.0;
@@ -248,15 +266,15 @@ int run_batch(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
 }
 
 // ---- the latency sweep (csrc/vhp_lat.hpp): one workgroup of W wavefronts per unit, strips bound to wavefronts ---------------
-template <typename OutT, bool ODD>
+template <typename WorkerT>
 struct LatCo {
-  LatWorker<OutT, ODD> wk;
+  WorkerT wk;
   int unit;
 };
-template <typename OutT, bool ODD>
-void lat_entry(void* p) { auto* c = static_cast<LatCo<OutT, ODD>*>(p); c->wk.run(c->unit); }
+template <typename WorkerT>
+void lat_entry(void* p) { auto* c = static_cast<LatCo<WorkerT>*>(p); c->wk.run(c->unit); }
 
-template <typename OutT, bool ODD>
+template <typename OutT, bool ODD, typename WorkerT>
 int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int policy, uint32_t seed, long long* stats) {
   HostMap h;
   build_map(occ, nx, ny, h);
@@ -279,18 +297,19 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   a.skip = nullptr;
   a.dead_cells_are_zero = false;
   a.strip_times = nullptr;
+  a.dmap = h.diag.data();
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
-  std::vector<LatCo<OutT, ODD>> workers((size_t)G * W);
+  std::vector<LatCo<WorkerT>> workers((size_t)G * W);
   std::vector<Coro> coros((size_t)G * W);
   for (int gI = 0; gI < G; ++gI) {
-    LatWorker<OutT, ODD>::clear(lds[gI].data(), L, 0, 1);
+    WorkerT::clear(lds[gI].data(), L, 0, 1);
     for (int w = 0; w < W; ++w) {
-      LatCo<OutT, ODD>& wk = workers[(size_t)gI * W + w];
+      LatCo<WorkerT>& wk = workers[(size_t)gI * W + w];
       wk.wk.init(a, lds[gI].data(), L, w);
       wk.unit = gI;
       Coro& c = coros[(size_t)gI * W + w];
       c.stack.reset(new char[kStack]);
-      c.entry = lat_entry<OutT, ODD>;
+      c.entry = lat_entry<WorkerT>;
       c.arg = &wk;
       getcontext(&c.ctx);
       c.ctx.uc_stack.ss_sp = c.stack.get();
@@ -359,9 +378,13 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
 
 // (the ODD build of the kernel where the launch needs it, as launch_lat_t picks it: vhp_lat.hip)
 template <typename OutT>
-int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int policy, uint32_t seed, long long* stats) {
-  return lat_needs_odd<OutT>(nx, (long long)nx * ny, out) ? run_lat_t<OutT, true>(occ, nx, ny, src, n_src, out, W, policy, seed, stats)
-                                                          : run_lat_t<OutT, false>(occ, nx, ny, src, n_src, out, W, policy, seed, stats);
+int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int policy, uint32_t seed, long long* stats, bool bands) {
+  const bool odd = lat_needs_odd<OutT>(nx, (long long)nx * ny, out);
+  if (bands)
+    return odd ? run_lat_t<OutT, true, BandWorker<OutT, true>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats)
+               : run_lat_t<OutT, false, BandWorker<OutT, false>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats);
+  return odd ? run_lat_t<OutT, true, LatWorker<OutT, true>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats)
+             : run_lat_t<OutT, false, LatWorker<OutT, false>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats);
 }
 
 extern "C" {
@@ -370,8 +393,16 @@ extern "C" {
 int vhp_sim_lat_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W, int policy, unsigned seed,
                       long long* stats) {
   if (!occ || !src || !out || nx <= 0 || ny <= 0 || W < 2 || W > 16 || W * kXRows * kTStride < (nx < ny ? nx : ny)) return 1;
-  if (dtype == 0) return run_lat<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), W, policy, seed, stats);
-  return run_lat<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), W, policy, seed, stats);
+  if (dtype == 0) return run_lat<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), W, policy, seed, stats, false);
+  return run_lat<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), W, policy, seed, stats, false);
+}
+
+// The latency sweep in bands (csrc/vhp_band.hpp): the same launch shape, arguments and stats.
+int vhp_sim_band_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W, int policy, unsigned seed,
+                       long long* stats) {
+  if (!occ || !src || !out || nx <= 0 || ny <= 0 || W < 1 || W > 16) return 1;
+  if (dtype == 0) return run_lat<double>(occ, nx, ny, src, n_src, static_cast<double*>(out), W, policy, seed, stats, true);
+  return run_lat<float>(occ, nx, ny, src, n_src, static_cast<float*>(out), W, policy, seed, stats, true);
 }
 
 // out: n_src fields of nx*ny elements (dtype 0 = double, 1 = float), pre-filled by the caller (NaN: an unwritten cell shows).

@@ -25,6 +25,7 @@ def load_pool():
                                            C.c_int, C.c_int, C.c_uint, C.c_void_p]
         lib.vhp_sim_lat_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint,
                                           C.c_void_p]
+        lib.vhp_sim_band_sweep.argtypes = lib.vhp_sim_lat_sweep.argtypes
         _pool = lib
     return _pool
 
@@ -55,16 +56,19 @@ def pool_sweep(occ, sources, dtype=np.float64, W=12, C=4, G=1, policy=0, seed=1,
                      overwritten=int(stats[10]), lines_whole=int(stats[11]), lines_part=int(stats[12]), static_round=int(stats[13]))
 
 
-def lat_sweep(occ, sources, dtype=np.float64, W=12, policy=0, seed=1):
-    """Fields [n, ny, nx] of the simulated latency sweep (csrc/vhp_lat.hpp: a workgroup of W wavefronts per unit) and the stats dict."""
+def lat_sweep(occ, sources, dtype=np.float64, W=12, policy=0, seed=1, bands=None):
+    """Fields [n, ny, nx] of the simulated latency sweep (a workgroup of W wavefronts per unit) and the stats dict.
+    bands: the sweep in bands (csrc/vhp_band.hpp, what the library launches) or in strips of rows (csrc/vhp_lat.hpp)."""
     lib = load_pool()
+    if bands is None:
+        bands = os.environ.get("VHP_SIM_LAT", "bands") == "bands"
     occ = np.ascontiguousarray(occ, np.uint8)
     ny, nx = occ.shape
     src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)
     out = np.full((len(src), ny, nx), np.nan, dtype)
     stats = np.zeros(11, np.int64)
-    rc = lib.vhp_sim_lat_sweep(occ.ctypes.data, nx, ny, src.ctypes.data, len(src), 0 if dtype == np.float64 else 1, out.ctypes.data,
-                               W, policy, seed, stats.ctypes.data)
+    rc = (lib.vhp_sim_band_sweep if bands else lib.vhp_sim_lat_sweep)(occ.ctypes.data, nx, ny, src.ctypes.data, len(src), 0 if dtype == np.float64 else 1,
+                                                                      out.ctypes.data, W, policy, seed, stats.ctypes.data)
     assert rc == 0, rc
     return out, dict(switches=int(stats[0]), progress=int(stats[1]), deadlock=int(stats[2]), st16=int(stats[3]), st8=int(stats[4]),
                      err=int(stats[5]), died=int(stats[6]), from_ring=int(stats[7]), from_global=int(stats[8]), too_far=int(stats[9]),

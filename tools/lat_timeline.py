@@ -45,7 +45,10 @@ for u in range(8):
         for v in range(12):
             r = w[u, v]
             nw = r[12] + r[13]
-            if nw > 0:
+            if nw > 0 and r[12] == 0:   # the sweep in bands: one kind of window
+                print("   wave %2d: %3d windows of %5.0f cycles: operands %5.0f compute %5.0f read-out, ring, next request, stores %5.0f | asked the band below again %d times" % (
+                    v, r[13], r[14] / max(r[13], 1), r[8] / max(r[13], 1), r[9] / max(r[13], 1), r[10] / max(r[13], 1), r[7]))
+            elif nw > 0:
                 print("   wave %2d: %3d steady windows of %5.0f cycles, %2d diagonal of %5.0f; diagonal windows: operands %5.0f compute %5.0f tile reads + next request %5.0f stores %5.0f | whole strip %7.0f cycles, outside the windows %6.0f; asked the strip below again %d times" % (
                     v, r[12], r[15] / max(r[12], 1), r[13], r[14] / max(r[13], 1), r[8] / max(r[13], 1), r[9] / max(r[13], 1), r[10] / max(r[13], 1), r[11] / max(r[13], 1), r[2], r[2] - r[15] - r[14], r[7]))
     for p in range(48):

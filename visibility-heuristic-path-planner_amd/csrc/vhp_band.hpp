@@ -1,0 +1,812 @@
+// vhp_band.hpp -- the latency sweep in BANDS: a few sources as fast as their dependency chain allows (round 6).
+//
+// Replaces computeVisibility() (/root/reference/src/visibilityBasedSolver.cpp:570-696) for launches too small to fill the chip,
+// like vhp_lat.hpp before it, whose protocol (Link, Below, words of death, windows of 16 steps) and whose launch shape (one
+// workgroup per octant, a wavefront per strip) it keeps.  What changes is WHICH cells a wavefront owns.
+//
+// The strips of vhp_lat.hpp are 64 ROWS of an octant: lane = row j, step = column i.  Row j exists from column j on, so a strip
+// spends its first 64 steps "growing" along the diagonal, one row switching on per step, with the diagonal rule in
+// every step and ragged stores in every window -- and the strip above cannot start before that is over.  Measured on BASELINE
+// config 2 (profiles/r06_a_lat_timeline_c2.txt): 40 of those growing windows in a row, 4.3 k cycles each against 2.7 k for a
+// steady one, are 72 of the launch's 98 us.
+//
+// A BAND is 64 DIAGONALS of an octant: lane = distance from the diagonal, d = i - j (x-major) or j - i (y-major), step t = the
+// marching coordinate (column i / row j).  Cell (d, t) reads (d - 1, t - 1) -- the lane below, one step ago: a DPP shift -- and
+// (d, t - 1) -- its own previous value --, with the ratio (t - d) / t in both kinds of octant:
+//     v = a - c (a - b),  a = lane d - 1 at step t - 1,  b = lane d at step t - 1,  c = (t - d) / t        (solver.cpp:592-600)
+// Every lane runs this from the band's first step: a lane whose cell does not exist yet (t < d) computes with c = 0, i.e. copies
+// its neighbour -- finite garbage that the first real step (c = 0 again: the axis cell, a copy; solver.cpp:586-590) does not look
+// at -- and a lane whose cell lies past the octant's last row computes zeros (the packed map holds no cell there).  So a band has
+// NO growing phase: all its windows are the steady window, and the diagonal rule is two fixed lanes of band 0 (diag(t) = the new
+// sub-diagonal cell of the same step times its occupancy), which both octants of a quadrant run for themselves -- the y-major
+// octants need no seeds from anybody, the diagonal's wavefront and its LDS line are gone.
+//
+// Price: a lane's cells run along a diagonal of the grid, so their occupancy bits are contiguous in neither the row-packed nor
+// the column-packed map.  vhp_set_map packs the grid along its diagonals as well (DiagMaps: both directions, indexed by x and by
+// y: 4 maps of (nx + ny - 1) runs), one 64-bit word per lane per block of 64 steps as before.  And the cells a window produces
+// form a parallelogram: an x-major window's tile is read out along its diagonals (79 rows of up to 16 cells: 10 store
+// instructions, 6 of them whole); a y-major step stores 64 adjacent cells of its row, one column further every step.
+//
+// Written against vhp_lanes.hpp: compiled for gfx950 (vhp_lat.hip) and for the CPU simulator (tests/sim), bit-exact against the
+// oracle in both (tests/test_lat_sim.py, tests/test_gpu_lat.py).
+#pragma once
+#include "vhp_lat.hpp"
+
+namespace vhp {
+namespace pool {
+
+// The occupancy packed along diagonals.  A "main" run holds the cells with y - x constant (id = y - x + nx - 1), an "anti" run
+// those with y + x constant (id = y + x); nx + ny - 1 runs of either kind.  Packed by x: bit x & 63 of word 1 + (x >> 6) of the
+// run; packed by y likewise (a run has one cell per x and one per y).  Cells outside the grid read as 0.
+// Layout in one allocation: [main by x][anti by x][main by y][anti by y].
+struct DiagMaps {
+  static VHP_HD int runs(int nx, int ny) { return nx + ny - 1; }
+  static VHP_HD int wpdx(int nx) { return (nx + 63) / 64 + 2; }
+  static VHP_HD int wpdy(int ny) { return (ny + 63) / 64 + 2; }
+  static VHP_HD size_t words(int nx, int ny) { return (size_t)2 * runs(nx, ny) * (size_t)(wpdx(nx) + wpdy(ny)); }
+  // kind: 0 main by x, 1 anti by x, 2 main by y, 3 anti by y
+  static VHP_HD size_t offset(int nx, int ny, int kind) {
+    const size_t n = (size_t)runs(nx, ny);
+    return kind < 2 ? (size_t)kind * n * wpdx(nx) : 2 * n * wpdx(nx) + (size_t)(kind - 2) * n * wpdy(ny);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// x-major band b of a unit: lanes d = 64 b + lane (distance from the diagonal), steps t = column index i; the lane's cell of
+// step t is (i, j) = (t, t - d).  Cells exist for 0 <= j < rows_total, t < ni.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY, typename OutT, bool ODD = false>
+struct BandX {
+  static constexpr int CB = sizeof(OutT);
+  static constexpr bool kMain = DX * DY > 0;  // the lanes' runs: y - x constant (main) or y + x constant (anti)
+  static constexpr bool odd_pitch = ODD;
+  Map m;
+  const uint64_t* dm;  // the packed runs of this quadrant's kind, by x
+  int wpd;
+  Quad<DX, DY> g;
+  OutT* out;
+  double* tile;   // 64 lanes x 16 columns (pitch kTStride): column c = x - (lowest x of the window)
+  double* slab;   // reciprocals of the step indices of two blocks of 64 coordinates, indexed by x & 127
+  double* bin;
+  Link<DX> lk;
+  int b, D0, t_last, t_end, i_last, rows_total;
+  bool below, has_consumer, retires;
+  int blk, pf_blk, staged_blk;
+  bool pf_wait;
+  int* dead_mine;
+  const int* dead_below;
+  bool skip_fill;
+  vi lane, tile_l, fl_a, fl_l, fl_rj, fl_c;
+  vu32 fl_off;
+  vi dgw;      // word 0 of the lane's run in dm (clamped into the map)
+  vb dg_ok;    // ... which exists
+  vd prev, jd; // jd = t - d of the next step
+  vu64 ow, ow_nx;
+  vd rv_nx;
+  Below<DX, kLW> nx;
+  vd nx_rr[kLW];
+
+  static VHP_FN int n_bands(const Quad<DX, DY>& q) { return (q.ni > 0 && q.nj > 0) ? (q.ni + kBlock - 1) / kBlock : 0; }
+  // the lowest step of the band's first window (windows are aligned to 16 cells of x)
+  static VHP_FN int first_window(const Quad<DX, DY>& q, int b_) {
+    const int xw = q.X(kBlock * b_) & ~(kLW - 1);
+    return DX > 0 ? xw - q.sx : q.sx - (xw + kLW - 1);
+  }
+
+  // (the caller has initialised lk)
+  VHP_FN void init(const Map& m_, const uint64_t* dmap, int sx, int sy, OutT* out_, const Shared& sh, int w, int b_) {
+    m = m_; out = out_;
+    g.init(m.nx, m.ny, sx, sy);
+    dm = dmap + DiagMaps::offset(m.nx, m.ny, kMain ? 0 : 1);
+    wpd = DiagMaps::wpdx(m.nx);
+    tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
+    slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
+    bin = lk.bin;
+    lane = lane_id();
+    tile_l = lane * kTStride;
+    b = b_;
+    D0 = kBlock * b;
+    rows_total = g.rows_total;
+    i_last = g.ni - 1;
+    t_last = imin(i_last, D0 + kBlock - 2 + rows_total);  // lane 63's cell of the octant's last row
+    below = b > 0;
+    has_consumer = b + 1 < n_bands(g);
+    // A band whose lanes leave the octant at its last row before the march ends (a quadrant wider than high) RETIRES: the band above
+    // still needs one value of its last lane's last cell, and zeros after that -- it marches one step further (all zeros) and then
+    // says it is dead (the reader's zeros: Below::accept).
+    retires = has_consumer && t_last < i_last;
+    t_end = retires ? t_last + 1 : t_last;
+    {
+      // read-out geometry: lane -> (memory row slot rs = lane >> 3, pair pc = lane & 7: the cells at columns 2 pc, 2 pc + 1 of the
+      // window).  Group u of a window holds the rows j = jA + 8 u + rj, jA = ta - D0 - 63 (the row of lane 63 at the window's first
+      // step), rj = the slot counted in j.  The lane that computed cell (column c, row j) is t - D0 - j.
+      const vi rs = lane >> 3, pc = lane & 7;
+      fl_rj = DY > 0 ? rs : (-rs) + 7;
+      fl_c = pc * 2;
+      fl_l = DX > 0 ? (fl_c - fl_rj) + 63 : (-fl_c - fl_rj) + 78;  // the lane of the pair's first cell in group 0; - 8 per group
+      fl_a = (fl_l - 56) * kTStride + fl_c + (DX > 0 ? 0 : 1 - kTStride);
+      fl_off = to_u32((rs * m.nx + pc * 2) * CB);
+    }
+    {
+      // the lane's run: y - s x = sy - s sx - DY d
+      const vi d = lane + D0;
+      const vi id = kMain ? (-d) * DY + (sy - sx + m.nx - 1) : (-d) * DY + (sy + sx);
+      dg_ok = (id >= 0) && (id < DiagMaps::runs(m.nx, m.ny));
+      dgw = vmin(vmax(id, 0), DiagMaps::runs(m.nx, m.ny) - 1) * wpd;
+    }
+    dead_mine = sh.owner(0) + b;
+    dead_below = sh.owner(0) + (b > 0 ? b - 1 : b);
+    skip_fill = false;
+    nx.hd = 0;
+    prev = vd(0.0);
+    pf_blk = -1;
+    pf_wait = false;
+    staged_blk = -0x7fffffff;
+    blk = -0x7fffffff;
+  }
+
+  // the occupancy word of every lane's run and the reciprocals of the step indices of the 64 coordinates of block blk_ (x >> 6)
+  VHP_FN void load_ops(int blk_, vu64& o, vd& rv) {
+    o = select(dg_ok, g_load_u64(dm, dgw + (1 + blk_)), vu64(0));
+    const vi it = (lane + (blk_ * 64 - g.sx)) * DX;
+    const vb ok = (it >= 0) && (it < g.ni);
+    rv = select(ok, g_load_f64(m.recip, select(ok, it, vi(0))), vd(0.0));
+  }
+  VHP_FN bool block_in_march(int b_) const { const int xe = g.X(t_end); return DX > 0 ? 64 * b_ <= xe : 64 * b_ + 63 >= xe; }
+  VHP_FN void prefetch_ops(int b_) { pf_blk = b_; pf_wait = true; load_ops(b_, ow_nx, rv_nx); }
+  VHP_FN void stage(int b_, vd rv) {
+    wave_sync();
+    lds_store(slab, lane + kBlock * (b_ & 1), rv);
+    wave_sync();
+    staged_blk = b_;
+  }
+  VHP_FN void settle() {
+    if (pf_wait) { pin(ow_nx); pin(rv_nx); pf_wait = false; }
+  }
+  VHP_FN void stage_next() {
+    if (pf_blk != -1 && staged_blk != pf_blk) { settle(); stage(pf_blk, rv_nx); }
+  }
+  VHP_FN void enter_block(int b_) {
+    if (pf_blk == b_) { stage_next(); ow = ow_nx; }
+    else { vd rv; load_ops(b_, ow, rv); pin(ow); pin(rv); stage(b_, rv); }
+    blk = b_;
+    if (block_in_march(b_ + DX)) prefetch_ops(b_ + DX); else pf_blk = -1;
+  }
+
+  // requests the operands of the window whose lowest x is xw (lowest step ta) in block nb; nothing is waited for
+  VHP_FN void request(int ta, int xw, int nb) {
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (xw & (2 * kBlock - 1)) + (DX > 0 ? k : kLW - 1 - k));
+    if (below) {
+      if (VHP_DIAG_WAITS) nx.request(lk, dead_below, bin, xw, DX > 0 ? xw : xw + kLW - 1, nb); else nx.ring = false;
+    }
+  }
+
+  // One group of 8 rows of a window: the lane's pair (cells ok0, ok1).  On an odd pitch the pairs of every other row lie 8 bytes
+  // off the 16-byte grid: there every cell leaves by itself.
+  VHP_FN void store_group(OutT* base, const vb& ok0, const vb& ok1, const vd& a, const vd& c) {
+    if (!odd_pitch) { g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, a, c); return; }
+    g_store2_if(vb(false), ok0, vb(false), base, fl_off, a, c);
+    g_store2_if(vb(false), vb(false), ok1, base, fl_off, a, c);
+  }
+  // The cells of the window at xw (lowest step ta) leave: fa[u], fb[u] = the lane's pair of the rows of group u.  INTERIOR: every
+  // row of the window is a row of the octant and every step a step of the march -- only the two ends of the parallelogram (the
+  // groups 0, 1, 8, 9) need a lane mask, and that one is the same in every window.
+  template <bool INTERIOR>
+  VHP_FN void store_half(int u0, int ta, int xw, const vd (&fa)[5], const vd (&fb)[5]) {
+    const int jA = ta - D0 - (kBlock - 1);
+    const long base_step = (long)(8 * DY) * m.nx;
+    OutT* base = out + (long)(DY > 0 ? g.Y(jA) : g.Y(jA + 7)) * (long)m.nx + xw + u0 * base_step;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int u = u0 + q;
+      if (INTERIOR && !odd_pitch && u >= 2 && u <= 7) {
+        g_store2(base, fl_off, fa[q], fb[q]);
+      } else if (INTERIOR || (jA + 8 * u + 7 >= 0 && jA + 8 * u < rows_total)) {
+        const vi la = fl_l - 8 * u, lb = DX > 0 ? la + 1 : la - 1;
+        vb ok0 = (la >= 0) && (la < kBlock), ok1 = (lb >= 0) && (lb < kBlock);
+        if (!INTERIOR) {
+          const vi j = fl_rj + (jA + 8 * u);
+          const vi t0 = DX > 0 ? fl_c + ta : (-fl_c) + (ta + kLW - 1), t1 = t0 + DX;
+          const vb row_ok = (j >= 0) && (j < rows_total);
+          ok0 = ok0 && row_ok && (t0 <= i_last);
+          ok1 = ok1 && row_ok && (t1 <= i_last);
+        }
+        store_group(base, ok0, ok1, fa[q], fb[q]);
+      }
+      base += base_step;
+    }
+  }
+  // the tile's cells in read-out order: the pairs of every lane for the groups u0 .. u0 + 4 (the lanes of the two ends of the
+  // parallelogram that have no cell read the nearest row of the tile instead of what lies beside it)
+  VHP_FN void read_out(int u0, vd (&fa)[5], vd (&fb)[5]) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int u = u0 + q;
+      if (u >= 2 && u <= 7) {
+        // (fl_a = the lower of the pair's two addresses in group 7, the last whole group: every other whole group at a positive
+        // immediate offset from it -- a DS instruction encodes no negative one, the compiler would keep a register per group)
+        fa[q] = lds_load(tile, fl_a + ((DX > 0 ? 0 : kTStride - 1) + (7 - u) * (8 * kTStride)));
+        fb[q] = lds_load(tile, fl_a + ((DX > 0 ? kTStride + 1 : 0) + (7 - u) * (8 * kTStride)));
+      } else {
+        const vi la = vmin(vmax(fl_l - 8 * u, 0), kBlock - 1), lb = vmin(vmax(fl_l + ((DX > 0 ? 1 : -1) - 8 * u), 0), kBlock - 1);
+        fa[q] = lds_load(tile, la * kTStride + fl_c);
+        fb[q] = lds_load(tile, lb * kTStride + (fl_c + 1));
+      }
+    }
+  }
+
+  // One window: steps ta + k, k = 0 .. 15, at x = xw + (k marching up, 15 - k marching down).  B0: band 0, whose lane 0 is the
+  // diagonal -- diag(t) = the sub-diagonal cell of the same step (lane 1's new value) times its own occupancy.  A lane
+  // whose cell does not exist yet has a negative numerator: clamped to 0, it copies its neighbour.  A window that sticks out of the
+  // march (before step 0, past the last) is swept like any other: the reciprocal of a step that does not exist is 0.  The source
+  // itself needs no step of its own either (origin_bits).  more: the next window belongs to the march.
+  // (ONE loop of windows per march, whatever the window's kind: a loop per kind, as the strips had, keeps a copy of the 32 operand
+  // registers per loop and spills them where the loops meet.)
+  template <bool B0>
+  VHP_FN void window(int ta, int xw, int nb, bool more) {
+    const int k_hi = imin(kLW - 1, t_end - ta);
+    VHP_WP_T0(tw0);
+    // (the window's operands have been requested: by run() for the band's first window, by the window before for every other --
+    // unconditionally, so that the compiler sees that none of the 32 registers outlives its band)
+    if (below) nx.accept(lk, dead_below, bin, xw, DX > 0 ? xw : xw + kLW - 1, ta, ta + k_hi - 1, nb);
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+    pin(nx_rr[kLW - 1]);
+#endif
+    VHP_WP_ADDP(lk.pp, 8, tw0);
+    VHP_WP_T0(tw1);
+    const vu32 hs = half_shifted(ow, xw & 63, xw & 31);  // the window's 16 occupancy bits: bit c = the lane's cell at x = xw + c
+    vd di = vd((double)ta);
+    vd cc = ratio(vmaxd(jd, 0.0), di, nx_rr[0]);
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) {
+      const int c = DX > 0 ? k : kLW - 1 - k;
+      const vd a = shift_up(prev, below ? nx.v[k] : vd(0.0));
+      const vi mk = sbfe1(hs, c);
+      vd v = and_mask(stencil(a, prev, cc), mk);
+      if (B0) {
+        const vd up = shift_down(v, v);
+        v = select(lane == 0, and_mask(up, mk), v);
+      }
+      prev = v;
+      lds_store(tile, tile_l + c, v);
+      di = di + 1.0;
+      jd = jd + 1.0;
+      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), di, nx_rr[k + 1]);  // the next step's ratio beside this step's chain, and no further ahead
+      sched_fence();
+    }
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+    pin(prev);
+#endif
+    VHP_WP_ADDP(lk.pp, 9, tw1);
+    VHP_WP_T0(tw2);
+    // ---- the window's cells leave (two halves of five groups of rows); the last lane's values go to the ring ----
+    const bool inside = interior(ta);
+    wave_sync();
+    vd fa[5], fb[5];
+#ifndef VHP_DIAG_LAT_NOFLUSH
+    read_out(0, fa, fb);
+#endif
+    vd bv = vd(0.0);
+    if (has_consumer) bv = lds_load(tile, (lane & (kLW - 1)) + (kBlock - 1) * kTStride);  // lane 63: what the band above reads
+    if (has_consumer) {
+      lds_store(lk.ring, (lane & (kLW - 1)) + (xw & (kRing - 1)), bv);
+      lk.publish(retires ? ta + kLW : ta + k_hi + 1);  // (a band that retires: its reader's window reaches past its own last step)
+    }
+#ifndef VHP_DIAG_LAT_NOFLUSH
+    if (inside) store_half<true>(0, ta, xw, fa, fb); else store_half<false>(0, ta, xw, fa, fb);
+    read_out(5, fa, fb);
+#endif
+    wave_sync();
+    if (more) {
+      const int xn = xw + kLW * DX;
+      const bool other = (xn >> 6) != (xw >> 6);  // the next window opens the next block
+      if (other) stage_next();
+      request(ta + kLW, xn, other ? nb + 1 : nb);
+    }
+#ifndef VHP_DIAG_LAT_NOFLUSH
+    if (inside) store_half<true>(5, ta, xw, fa, fb); else store_half<false>(5, ta, xw, fa, fb);
+#endif
+    VHP_WP_ADDP(lk.pp, 10, tw2);
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+    VHP_WP_ADDP(lk.pp, 14, tw0); lk.pp[13] += 1;
+#endif
+  }
+
+  VHP_FN void open_block(int xw, int ta) {
+    const int b_ = xw >> 6;
+    if (b_ == blk) return;
+    if (has_consumer) lk.store_block(g.nbx(ta - 1), blk);
+    enter_block(b_);
+  }
+  // every row and step of the window at ta exists
+  VHP_FN bool interior(int ta) const { return ta - D0 - (kBlock - 1) >= 0 && ta + kLW - 1 - D0 <= rows_total - 1 && ta + kLW - 1 <= i_last; }
+
+  template <bool B0>
+  VHP_FN void march(int& ta, int& xw, bool& dead) {
+    while (ta <= t_end) {
+      if (dies_at(ta - 1)) { dead = true; break; }
+      open_block(xw, ta);
+      window<B0>(ta, xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk, ta + kLW <= t_end);
+      ta += kLW; xw += kLW * DX;
+      sim_progress();
+      sim_point();
+    }
+  }
+  // Band 0 starts at the source, whose value is 1.0 times its occupancy (solver.cpp:583-585) -- by data, not by a step of its own:
+  // the diagonal lane starts from 1.0, and in the steps of the first window that lie before the source (they do not exist: every
+  // lane copies) the diagonal's and the sub-diagonal's cells read as free, so that the 1.0 comes through to step 0, where the
+  // diagonal cell takes it times its own occupancy.  (The sub-diagonal's cell of step 0 does not exist either: free as well.)
+  VHP_FN void origin_bits(int xw) {
+    const int s0 = g.sx & 63, w0 = xw & 63;
+    // bits of the coordinates of the steps before step 0 in the window (marching up: below the source; marching down: above it)
+    const uint64_t before = DX > 0 ? ((1ull << s0) - 1) & ~((1ull << w0) - 1) : ((w0 + kLW == 64 ? 0ull : 1ull << (w0 + kLW)) - 1) & ~((2ull << s0) - 1);
+    ow = ow | select(lane == 0, vu64(before), select(lane == 1, vu64(before | (1ull << s0)), vu64(0)));
+    prev = select(lane == 0, vd(1.0), vd(0.0));
+  }
+
+  VHP_FN void run() {
+    int xw = g.X(D0) & ~(kLW - 1);
+    int ta = DX > 0 ? xw - g.sx : g.sx - (xw + kLW - 1);
+    jd = to_f64((-lane) + (ta - D0));
+    if (below) nx.hd = lds_poll(dead_below);  // (a band that starts above a dead band need not sweep a window to find out)
+    enter_block(xw >> 6);
+    bool dead = below && lds_poll(dead_mine) != 0;  // (a band below died before this one could start, and said so for it)
+    if (!dead) {
+      if (!below) {  // (band 0 reads no band: its lane 0 -- the diagonal -- takes nothing from below; defined, so that no register of the band before lives on)
+#pragma unroll
+        for (int k = 0; k < kLW; ++k) nx.v[k] = vd(0.0);
+      }
+      request(ta, xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk);
+      if (b == 0) { origin_bits(xw); march<true>(ta, xw, dead); } else march<false>(ta, xw, dead);
+    }
+    if (has_consumer) lk.store_block(imax(g.nbx(imin(imax(ta - 1, 0), i_last)), 0), blk);
+    if (dead || retires) {
+      // Everything from step ta - 1 on is +0.0, in this band and below it (or: the band has left the octant): the word of death
+      // first, then the progress word that lets the band above past its gate.
+      lds_publish(dead_mine, ta);
+      lds_publish(lk.prog, 0x3fff);
+      if (dead) {
+        announce_death(ta - 1);
+        sim_count(4);
+      }
+      sim_progress();
+      if (!dead || skip_fill) return;
+      // the zeros of what is left of the march, window by window
+      vd z[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) z[u] = vd(0.0);
+      for (; ta <= t_last; ta += kLW, xw += kLW * DX) {
+        store_half<false>(0, ta, xw, z, z);
+        store_half<false>(5, ta, xw, z, z);
+        sim_point();
+      }
+    }
+  }
+  // If the band above cannot have started yet (its first step lies past s + 1), neither has any band above that one, and all of
+  // them are dead from their first step on (a band's light comes from the band below it and from nowhere else): they are told at
+  // once, instead of one waking the next.  (A band above that HAS started may still hold light of its own.)
+  VHP_FN void announce_death(int s) {
+    if ((b + 1) * kBlock <= s + 1) return;
+    const int n = n_bands(g);
+    int* dead_base = dead_mine - b;
+    int* prog_base = lk.prog - b;
+    for (int q0 = b + 1; q0 < n; q0 += kLanes) {
+      const vi q = lane + q0;
+      const vb up = q < n;
+      lds_store_i_if(up, dead_base, q, s + 1);
+      lds_acquire();
+      lds_store_i_if(up, prog_base, q, 0x3fff);
+    }
+    lds_acquire();
+  }
+  // Is the band dead from step te on?  (Asked between windows, te = the last step swept.)  Every lane holds +0.0 -- lanes whose cells
+  // do not exist yet hold copies of the lanes below them -- and the band below has been dead since te or before (band 0: the diagonal
+  // and the sub-diagonal are lanes of its own): then all this band will ever compute is the stencil of zeros.
+  VHP_FN bool dies_at(int te) {
+#ifdef VHP_DIAG_NODEATH
+    return false;
+#endif
+    if (te < 0) return false;
+    if (below && nx.dead_from() > te) return false;
+    return wave_all(is_pos_zero(prev));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// y-major band b of a unit: lanes d' = 64 b - 1 + lane (distance j - i from the diagonal), steps t = row index j; the lane's cell of
+// step t is (i, j) = (t - d', t): the 64 cells of a step are adjacent cells of one row.  Band 0's lane 0 (d' = -1) is the
+// sub-diagonal cell (t, t - 1) of the x-major octant and its lane 1 the diagonal: the octant runs the two-term recurrence for
+// itself.  Cells exist for max(d', 0) <= t <= min(nj - 1, d' + ni - 1); the sub-diagonal lane stores nothing.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DX, int DY, typename OutT>
+struct BandY {
+  static constexpr int CB = sizeof(OutT);
+  static constexpr bool kMain = DX * DY > 0;
+  static constexpr int kNever = 0x7fffffff;
+  Map m;
+  const uint64_t* dm;  // the packed runs of this quadrant's kind, by y
+  int wpd;
+  Quad<DX, DY> g;
+  OutT* out;
+  double* slab;
+  double* bin;
+  double* dummy;
+  Link<DY> lk;
+  int b, D0, t_last, t_end, j_last;
+  bool below, has_consumer, retires;
+  int blk, pf_blk, staged_blk;
+  bool pf_wait;
+  int* dead_mine;
+  const int* dead_below;
+  bool skip_fill;
+  vi lane, t_lo, t_hi;  // the steps at which the lane's cell exists (t_lo > t_hi: never)
+  vu32 xoff;
+  vi dgw;
+  vb dg_ok;
+  vd prev, jd;
+  vu64 ow, ow_nx;
+  vd rv_nx;
+  Below<DY, kLW> nx;
+  vd nx_rr[kLW];
+
+  static VHP_FN int n_bands(const Quad<DX, DY>& q) { return (q.ni > 0 && q.nj > 1) ? (q.nj + kBlock) / kBlock : 0; }
+  static VHP_FN int first_window(const Quad<DX, DY>& q, int b_) {
+    const int yw = q.Y(imax(kBlock * b_ - 1, 0)) & ~(kLW - 1);
+    return DY > 0 ? yw - q.sy : q.sy - (yw + kLW - 1);
+  }
+
+  VHP_FN void init(const Map& m_, const uint64_t* dmap, int sx, int sy, OutT* out_, const Shared& sh, int w, int b_) {
+    m = m_; out = out_;
+    g.init(m.nx, m.ny, sx, sy);
+    dm = dmap + DiagMaps::offset(m.nx, m.ny, kMain ? 2 : 3);
+    wpd = DiagMaps::wpdy(m.ny);
+    slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
+    bin = lk.bin;
+    dummy = sh.lds + sh.L.dummies + w * kLatDummy;
+    lane = lane_id();
+    b = b_;
+    D0 = kBlock * b - 1;
+    j_last = g.nj - 1;
+    t_last = imin(j_last, D0 + kBlock - 1 + g.ni - 1);  // lane 63's cell of the octant's last column
+    below = b > 0;
+    has_consumer = b + 1 < n_bands(g);
+    retires = has_consumer && t_last < j_last;   // (see BandX::init)
+    t_end = retires ? t_last + 1 : t_last;
+    const vi d = lane + D0;
+    t_lo = select(d >= 0, d, vi(kNever));
+    t_hi = vmin(d + (g.ni - 1), j_last);
+    {
+      // the lane's run: y - s x = sy - s sx + DY d'
+      const vi id = kMain ? d * DY + (sy - sx + m.nx - 1) : d * DY + (sy + sx);
+      dg_ok = (id >= 0) && (id < DiagMaps::runs(m.nx, m.ny));
+      dgw = vmin(vmax(id, 0), DiagMaps::runs(m.nx, m.ny) - 1) * wpd;
+    }
+    // the lane's cell of step t is at x = X(t) - DX d': byte offsets from the row's lowest x of the band, never negative
+    xoff = to_u32((DX > 0 ? (-lane) + (kLanes - 1) : lane) * CB);
+    dead_mine = sh.owner(0) + b;
+    dead_below = sh.owner(0) + (b > 0 ? b - 1 : b);
+    skip_fill = false;
+    nx.hd = 0;
+    prev = vd(0.0);
+    pf_blk = -1;
+    pf_wait = false;
+    staged_blk = -0x7fffffff;
+    blk = -0x7fffffff;
+  }
+  // where lane 0's (DX < 0) or lane 63's (DX > 0) cell of step t is stored: xoff counts from there
+  VHP_FN OutT* row_base(int t) const {
+    const long x0 = DX > 0 ? (long)g.X(t) - (D0 + kLanes - 1) : (long)g.X(t) + D0;
+    return out + (long)g.Y(t) * (long)m.nx + x0;
+  }
+
+  VHP_FN void load_ops(int blk_, vu64& o, vd& rv) {
+    o = select(dg_ok, g_load_u64(dm, dgw + (1 + blk_)), vu64(0));
+    if (b == 0) {
+      // band 0's sub-diagonal lane: its cell of step t lies in the row of step t - 1 -- one bit behind in its run, where every
+      // other lane's cell is at the step's own y
+      const vu64 o2 = select(dg_ok, g_load_u64(dm, dgw + (1 + blk_ - DY)), vu64(0));
+      const vu64 sh = DY > 0 ? (o << uint64_t(1)) | (o2 >> uint64_t(63)) : (o >> uint64_t(1)) | (o2 << uint64_t(63));
+      o = select(lane == 0, sh, o);
+    }
+    const vi jt = (lane + (blk_ * 64 - g.sy)) * DY;
+    const vb ok = (jt >= 0) && (jt < g.nj);
+    rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
+  }
+  VHP_FN bool block_in_march(int b_) const { const int ye = g.Y(t_end); return DY > 0 ? 64 * b_ <= ye : 64 * b_ + 63 >= ye; }
+  VHP_FN void prefetch_ops(int b_) { pf_blk = b_; pf_wait = true; load_ops(b_, ow_nx, rv_nx); }
+  VHP_FN void stage(int b_, vd rv) {
+    wave_sync();
+    lds_store(slab, lane + kBlock * (b_ & 1), rv);
+    wave_sync();
+    staged_blk = b_;
+  }
+  VHP_FN void settle() {
+    if (pf_wait) { pin(ow_nx); pin(rv_nx); pf_wait = false; }
+  }
+  VHP_FN void stage_next() {
+    if (pf_blk != -1 && staged_blk != pf_blk) { settle(); stage(pf_blk, rv_nx); }
+  }
+  VHP_FN void enter_block(int b_) {
+    if (pf_blk == b_) { stage_next(); ow = ow_nx; }
+    else { vd rv; load_ops(b_, ow, rv); pin(ow); pin(rv); stage(b_, rv); }
+    blk = b_;
+    if (block_in_march(b_ + DY)) prefetch_ops(b_ + DY); else pf_blk = -1;
+  }
+  VHP_FN void request(int ta, int yw, int nb) {
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (yw & (2 * kBlock - 1)) + (DY > 0 ? k : kLW - 1 - k));
+    if (below) {
+      if (VHP_DIAG_WAITS) nx.request(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, nb); else nx.ring = false;
+    }
+  }
+
+  // One window: steps ta + k, k = 0 .. 15, at y = yw + (k marching up, 15 - k marching down).  B0: see BandX::window (here band 0's
+  // lane 0 is the sub-diagonal -- its neighbour the diagonal sits one lane UP -- and lane 1 the diagonal).  PRED: some lane has no
+  // cell in some step of the window.
+  template <bool B0, bool PRED>
+  VHP_FN void steps(int ta, const vu32& hs, double* wbase, const vi& widx) {
+    vd dj = vd((double)ta);
+    vd cc = ratio(vmaxd(jd, 0.0), dj, nx_rr[0]);
+    const long rowstep = (long)DY * m.nx + DX;
+    OutT* row = row_base(ta);
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) {
+      const int c = DY > 0 ? k : kLW - 1 - k;
+      vd a = shift_up(prev, below ? nx.v[k] : vd(0.0));
+      if (B0) a = select(lane == 0, shift_down(prev, prev), a);
+      const vi mk = sbfe1(hs, c);
+      vd v = and_mask(stencil(a, prev, cc), mk);
+      if (B0) {
+        const vd up = shift_up(v, v);
+        v = select(lane == 1, and_mask(up, mk), v);
+      }
+#ifdef VHP_DIAG_LAT_NOFLUSH
+      if (m.nx == 0x7fffffff)
+#endif
+      {
+        if (PRED) {
+          const int t = ta + k;
+          g_store1_if((t_lo <= t) && (t_hi >= t), row, xoff, v);
+        } else if (B0) {
+          g_store1_if(lane != 0, row, xoff, v);
+        } else {
+          g_store1_if(vb(true), row, xoff, v);
+        }
+      }
+      prev = v;
+      lds_store(wbase, widx + c, v);
+      dj = dj + 1.0;
+      jd = jd + 1.0;
+      row += rowstep;
+      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), dj, nx_rr[k + 1]);
+      sched_fence();
+    }
+  }
+  template <bool B0>
+  VHP_FN void window(int ta, int yw, int nb, bool more) {
+    const int k_hi = imin(kLW - 1, t_end - ta);
+    if (below) nx.accept(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, ta, ta + k_hi - 1, nb);  // (requested: see BandX::window)
+    const vu32 hs = half_shifted(ow, yw & 63, yw & 31);
+    double* wbase = has_consumer ? lk.ring + (yw & (kRing - 1)) : dummy;
+    const vi widx = select(lane == kLanes - 1, vi(0), vi((int)(dummy - wbase)));
+    if (interior(ta)) steps<B0, false>(ta, hs, wbase, widx); else steps<B0, true>(ta, hs, wbase, widx);
+    if (more) {
+      const int yn = yw + kLW * DY;
+      const bool other = (yn >> 6) != (yw >> 6);
+      if (other) stage_next();
+      request(ta + kLW, yn, other ? nb + 1 : nb);
+    }
+    if (has_consumer) lk.publish(retires ? ta + kLW : ta + k_hi + 1);
+  }
+
+  VHP_FN void open_block(int yw, int ta) {
+    const int b_ = yw >> 6;
+    if (b_ == blk) return;
+    if (has_consumer) lk.store_block(g.nby(ta - 1), blk);
+    enter_block(b_);
+  }
+  // every lane (band 0: but the sub-diagonal's) has a cell in every step of the window at ta
+  VHP_FN bool interior(int ta) const { return ta >= D0 + kLanes - 1 && ta + kLW - 1 <= imin(j_last, imax(D0, 0) + g.ni - 1); }
+
+  template <bool B0>
+  VHP_FN void march(int& ta, int& yw, bool& dead) {
+    while (ta <= t_end) {
+      if (dies_at(ta - 1)) { dead = true; break; }
+      open_block(yw, ta);
+      window<B0>(ta, yw, DY > 0 ? blk - g.by0 : g.by0 - blk, ta + kLW <= t_end);
+      ta += kLW; yw += kLW * DY;
+      sim_progress();
+      sim_point();
+    }
+  }
+  // (see BandX::origin_bits; here lane 1 is the diagonal and lane 0 the sub-diagonal, whose word is one bit behind: load_ops)
+  VHP_FN void origin_bits(int yw) {
+    const int s0 = g.sy & 63, w0 = yw & 63;
+    const uint64_t before = DY > 0 ? ((1ull << s0) - 1) & ~((1ull << w0) - 1) : ((w0 + kLW == 64 ? 0ull : 1ull << (w0 + kLW)) - 1) & ~((2ull << s0) - 1);
+    ow = ow | select(lane == 1, vu64(before), select(lane == 0, vu64(before | (1ull << s0)), vu64(0)));
+    prev = select(lane == 1, vd(1.0), vd(0.0));
+  }
+
+  VHP_FN void run() {
+    int yw = g.Y(imax(D0, 0)) & ~(kLW - 1);
+    int ta = DY > 0 ? yw - g.sy : g.sy - (yw + kLW - 1);
+    {
+      // the ratio's numerator: t - d' (band 0's sub-diagonal lane: t - 1, the cell (t, t - 1) of the x-major octant)
+      const vi d = lane + D0;
+      jd = to_f64((-select(d >= 0, d, vi(1))) + ta);
+    }
+    if (below) nx.hd = lds_poll(dead_below);
+    enter_block(yw >> 6);
+    bool dead = below && lds_poll(dead_mine) != 0;
+    if (!dead) {
+      if (!below) {
+#pragma unroll
+        for (int k = 0; k < kLW; ++k) nx.v[k] = vd(0.0);
+      }
+      request(ta, yw, DY > 0 ? blk - g.by0 : g.by0 - blk);
+      if (b == 0) { origin_bits(yw); march<true>(ta, yw, dead); } else march<false>(ta, yw, dead);
+    }
+    if (has_consumer) lk.store_block(imax(g.nby(imin(imax(ta - 1, 0), j_last)), 0), blk);
+    if (dead || retires) {  // (see BandX::run)
+      lds_publish(dead_mine, ta);
+      lds_publish(lk.prog, 0x3fff);
+      if (dead) {
+        announce_death(ta - 1);
+        sim_count(4);
+      }
+      sim_progress();
+      if (!dead || skip_fill) return;
+      const long rowstep = (long)DY * m.nx + DX;
+      OutT* row = row_base(ta);
+      for (int t = ta; t <= t_last; ++t) {
+        g_store1_if((t_lo <= t) && (t_hi >= t), row, xoff, vd(0.0));
+        row += rowstep;
+        if (((t - ta) & (kLW - 1)) == kLW - 1) sim_point();
+      }
+    }
+  }
+  VHP_FN void announce_death(int s) {
+    if ((b + 1) * kBlock - 1 <= s + 1) return;
+    const int n = n_bands(g);
+    int* dead_base = dead_mine - b;
+    int* prog_base = lk.prog - b;
+    for (int q0 = b + 1; q0 < n; q0 += kLanes) {
+      const vi q = lane + q0;
+      const vb up = q < n;
+      lds_store_i_if(up, dead_base, q, s + 1);
+      lds_acquire();
+      lds_store_i_if(up, prog_base, q, 0x3fff);
+    }
+    lds_acquire();
+  }
+  VHP_FN bool dies_at(int te) {
+#ifdef VHP_DIAG_NODEATH
+    return false;
+#endif
+    if (te < 0) return false;
+    if (below && nx.dead_from() > te) return false;
+    return wave_all(is_pos_zero(prev));
+  }
+};
+
+template <typename OutT, bool ODD = false>
+struct BandWorker {
+  LatArgs<OutT> a;
+  Shared sh;
+  int w, W;
+  vi lane;
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
+  unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+  VHP_FN void init(const LatArgs<OutT>& a_, double* lds, const Layout& L, int w_) {
+    a = a_;
+    sh.lds = lds;
+    sh.L = L;
+    w = w_;
+    W = L.W;
+    lane = lane_id();
+  }
+  static VHP_FN void clear(double* lds, const Layout& L, int tid, int nthreads) { Worker<OutT>::clear(lds, L, tid, nthreads); }
+
+  VHP_FN Tagged* line_of(int unit, int p, int nb) const { return a.lines + (size_t)64 * ((size_t)unit * (size_t)a.unit_blocks + (size_t)p * nb); }
+  static VHP_FN int tag_of(int p) { return (1 << 8) | p; }  // (never 0: a cleared header belongs to no band)
+
+  // a coarse gate ahead of a band's first window (which then checks exactly what it reads): one word per poll
+  VHP_FN void wait_for(const int* word, int at_least) {
+    while (lds_poll(word) < at_least) { ready_backoff(); sim_point(); }
+    lds_acquire();
+  }
+
+  template <int DX, int DY>
+  VHP_FN void run_x(int unit, int sx, int sy, OutT* field) {
+    Quad<DX, DY> g;
+    g.init(a.m.nx, a.m.ny, sx, sy);
+    int* prog = sh.prog(0);
+    const int n = BandX<DX, DY, OutT, ODD>::n_bands(g);
+    for (int p = w; p < n; p += W) {
+      BandX<DX, DY, OutT, ODD> xs;
+      xs.lk.init(sh, w, sx, imax(BandX<DX, DY, OutT, ODD>::first_window(g, p), 0), tag_of(p), prog + p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr,
+                 p + 1 < n ? line_of(unit, p, g.Nbx) : nullptr, a.epoch, p > 0 ? (p - 1) % W : -1, p > 0 ? tag_of(p - 1) : 0);
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
+      xs.lk.pp = prof;
+#endif
+      xs.init(a.m, a.dmap, sx, sy, field, sh, w, p);
+      xs.skip_fill = a.dead_cells_are_zero;
+      xs.prefetch_ops(g.X(kBlock * p) >> 6);
+      VHP_LAT_STAMP(unit, p, 0);
+      if (VHP_DIAG_WAITS && p > 0) wait_for(prog + (p - 1), imin(kBlock * p + 2, g.ni));  // the band below has got to my first step
+      VHP_LAT_STAMP(unit, p, 1);
+      xs.run();
+      VHP_LAT_STAMP(unit, p, 3);
+      lds_publish(prog + p, 0x3fff);  // finished
+      sim_progress();
+    }
+  }
+
+  template <int DX, int DY>
+  VHP_FN void run_y(int unit, int sx, int sy, OutT* field) {
+    Quad<DX, DY> g;
+    g.init(a.m.nx, a.m.ny, sx, sy);
+    int* prog = sh.prog(0);
+    const int n = BandY<DX, DY, OutT>::n_bands(g);
+    const int Nby = g.Nby;
+    for (int q = w; q < n; q += W) {
+      BandY<DX, DY, OutT> ys;
+      ys.lk.init(sh, w, sy, imax(BandY<DX, DY, OutT>::first_window(g, q), 0), tag_of(q), prog + q, q > 0 ? line_of(unit, q - 1, Nby) : nullptr,
+                 q + 1 < n ? line_of(unit, q, Nby) : nullptr, a.epoch, q > 0 ? (q - 1) % W : -1, q > 0 ? tag_of(q - 1) : 0);
+#if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
+      ys.lk.pp = prof;
+#endif
+      VHP_LAT_STAMP(unit, q, 0);
+      ys.init(a.m, a.dmap, sx, sy, field, sh, w, q);
+      ys.skip_fill = a.dead_cells_are_zero;
+      ys.prefetch_ops(g.Y(imax(kBlock * q - 1, 0)) >> 6);
+      if (VHP_DIAG_WAITS && q > 0) wait_for(prog + (q - 1), imin(kBlock * q + 1, g.nj));
+      VHP_LAT_STAMP(unit, q, 1);
+      ys.run();
+      VHP_LAT_STAMP(unit, q, 3);
+      lds_publish(prog + q, 0x3fff);
+      sim_progress();
+    }
+  }
+
+  // the whole life of this wavefront: its bands of unit `unit` (8 * source + 2 * quadrant + {0: x-major, 1: y-major})
+  VHP_FN void run(int unit) {
+    const int s = unit / kUnits, qo = unit - s * kUnits;
+    // (the planners' control words together, before any of them is looked at: one trip to memory, then the source's)
+    const int skip = a.skip ? *a.skip : 0, run = a.run_if ? *a.run_if : 1, si0 = a.src_index ? *a.src_index : s;
+    const int slot0 = a.slot_base ? *a.slot_base : 0;
+    if (uniform(skip) != 0 || uniform(run) == 0) return;
+    const int si = uniform(si0);
+    const int sx = uniform(a.src_xy[2 * si]), sy = uniform(a.src_xy[2 * si + 1]);
+    if (a.slot_base && sx < 0) return;
+    if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
+      if (qo == 0 && w == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
+      return;
+    }
+    OutT* field = a.out + (size_t)(s + uniform(slot0)) * a.field_stride;
+    // Row 0 and column 0 are swept only from a source that lies on them and read as zero otherwise.  (A field that is
+    // known to hold +0.0 wherever the launch does not write -- the planner's loop -- holds it there as well.)
+    if (!a.dead_cells_are_zero && w == W - 1) {
+      if (qo == 0 && sy > 0)
+        for (int x0 = 0; x0 < a.m.nx; x0 += kLanes) g_store_scalar_if(lane + x0 < a.m.nx, field, lane + x0, OutT(0));
+      if (qo == 1 && sx > 0)
+        for (int y0 = 0; y0 < a.m.ny; y0 += kLanes) g_store_scalar_if(lane + y0 < a.m.ny, field, (lane + y0) * a.m.nx, OutT(0));
+    }
+    switch (qo) {
+      case 0: run_x<+1, +1>(unit, sx, sy, field); break;
+      case 1: run_y<+1, +1>(unit, sx, sy, field); break;
+      case 2: run_x<-1, +1>(unit, sx, sy, field); break;
+      case 3: run_y<-1, +1>(unit, sx, sy, field); break;
+      case 4: run_x<-1, -1>(unit, sx, sy, field); break;
+      case 5: run_y<-1, -1>(unit, sx, sy, field); break;
+      case 6: run_x<+1, -1>(unit, sx, sy, field); break;
+      default: run_y<+1, -1>(unit, sx, sy, field); break;
+    }
+  }
+};
+
+}  // namespace pool
+}  // namespace vhp

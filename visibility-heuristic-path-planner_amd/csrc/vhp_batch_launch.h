@@ -12,6 +12,7 @@ struct BatchArgs {
   const uint64_t* rows;   // packed maps and reciprocal table of the context (vhp_set_map)
   const uint64_t* cols;
   const double* recip;
+  const uint64_t* dmap = nullptr;  // the occupancy packed along diagonals (lat_pack_diag_maps): what the latency sweep reads
   int wpr, wpc, nx, ny;
   const int32_t* d_src;   // n_src (x, y) pairs, device
   int n_src;
@@ -55,5 +56,9 @@ size_t pool_scratch_bytes(int n_src, int nx, int ny);
 bool lat_supported(int nx, int ny);
 hipError_t launch_lat(const BatchArgs& a);
 size_t lat_scratch_bytes(int n_src, int nx, int ny);
+// The latency sweep's lanes run along diagonals of the grid: it reads the occupancy packed along them (vhp_band.hpp DiagMaps),
+// built once per map from the byte map: lat_diag_map_bytes of device memory, zero-filled and packed by lat_pack_diag_maps.
+size_t lat_diag_map_bytes(int nx, int ny);
+hipError_t lat_pack_diag_maps(const uint8_t* d_occ, int nx, int ny, uint64_t* d_dmap, hipStream_t stream);
 
 }  // namespace vhp

@@ -43,6 +43,7 @@ struct vhp_ctx {
   uint64_t* d_rows = nullptr;  // packed along x
   uint64_t* d_cols = nullptr;  // packed along y
   double* d_recip = nullptr;
+  uint64_t* d_dmap = nullptr;  // packed along both diagonals, by x and by y (the latency sweep's maps: vhp_batch_launch.h lat_pack_diag_maps)
   int wpr = 0, wpc = 0;
   int* d_err = nullptr;
 
@@ -182,7 +183,8 @@ void free_map(vhp_ctx* c) {
   if (c->d_rows) hipFree(c->d_rows);
   if (c->d_cols) hipFree(c->d_cols);
   if (c->d_recip) hipFree(c->d_recip);
-  c->d_occ = nullptr; c->d_rows = nullptr; c->d_cols = nullptr; c->d_recip = nullptr;
+  if (c->d_dmap) hipFree(c->d_dmap);
+  c->d_occ = nullptr; c->d_rows = nullptr; c->d_cols = nullptr; c->d_recip = nullptr; c->d_dmap = nullptr;
   c->h_occ.clear();
   c->pl.h_occ = nullptr;
   vhp::planner_free(c->pl);
@@ -342,7 +344,7 @@ hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT*
     if (eo != hipSuccess) return eo;
   }
   vhp::BatchArgs a;
-  a.rows = c->d_rows; a.cols = c->d_cols; a.recip = c->d_recip;
+  a.rows = c->d_rows; a.cols = c->d_cols; a.recip = c->d_recip; a.dmap = c->d_dmap;
   a.wpr = c->wpr; a.wpc = c->wpc; a.nx = c->nx; a.ny = c->ny;
   a.d_src = d_src; a.n_src = n_src; a.d_out = d_out;
   a.dtype = sizeof(OutT) == 8 ? VHP_F64 : VHP_F32;
@@ -446,6 +448,12 @@ int finish_set_map(vhp_ctx* ctx, int nx, int ny) {
   for (int k = 1; k < nrec; ++k) {
     volatile double d = (double)k;
     recip[k] = 1.0 / d;  // correctly rounded IEEE division on the host
+  }
+  if (vhp::lat_supported(nx, ny)) {
+    const size_t bytes = vhp::lat_diag_map_bytes(nx, ny);
+    VHP_HIP(hipMalloc(&ctx->d_dmap, bytes));
+    VHP_HIP(hipMemsetAsync(ctx->d_dmap, 0, bytes, ctx->stream));
+    VHP_HIP(vhp::lat_pack_diag_maps(ctx->d_occ, nx, ny, ctx->d_dmap, ctx->stream));
   }
   VHP_HIP(hipMalloc(&ctx->d_recip, nrec * sizeof(double)));
   VHP_HIP(hipMemcpyAsync(ctx->d_recip, recip.data(), nrec * sizeof(double), hipMemcpyHostToDevice, ctx->stream));

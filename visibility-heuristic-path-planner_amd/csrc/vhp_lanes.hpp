@@ -81,6 +81,8 @@ template <typename T> inline V<T> select(const vb& c, const V<T>& a, const V<T>&
 inline vi vmin(const vi& a, int b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] < b ? a.v[l] : b; return r; }
 inline vi vmax(const vi& a, int b) { vi r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] > b ? a.v[l] : b; return r; }
 inline vd vfma(const vd& a, const vd& b, const vd& c) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = std::fma(a.v[l], b.v[l], c.v[l]); return r; }
+// max(a, b) of a lane vector and a uniform double (neither is ever NaN where this is used)
+inline vd vmaxd(const vd& a, double b) { vd r; for (int l = 0; l < kLanes; ++l) r.v[l] = a.v[l] > b ? a.v[l] : b; return r; }
 
 // lane l <- lane l-1; lane 0 <- fill's lane 0
 inline vd shift_up(const vd& v, const vd& fill) { vd r; r.v[0] = fill.v[0]; for (int l = 1; l < kLanes; ++l) r.v[l] = v.v[l - 1]; return r; }
@@ -190,6 +192,7 @@ template <typename OutT> inline void g_store1_if(const vb& p1, OutT* base, const
   store_stats().end_instruction();
 }
 inline void wave_sync() {}
+inline void sched_fence() {}
 template <typename T> inline void pin(T&) {}
 inline int uniform(int x) { return x; }
 // release: everything this wavefront has written to LDS becomes visible, then the progress word
@@ -261,6 +264,7 @@ template <typename T> VHP_LANE_FN T select(bool c, T a, T b) { return c ? a : b;
 VHP_LANE_FN vi vmin(vi a, int b) { return a < b ? a : b; }
 VHP_LANE_FN vi vmax(vi a, int b) { return a > b ? a : b; }
 VHP_LANE_FN vd vfma(vd a, vd b, vd c) { return __builtin_fma(a, b, c); }
+VHP_LANE_FN vd vmaxd(vd a, double b) { return __builtin_fmax(a, b); }
 
 // lane l <- lane l-1, lane 0 keeps `fill`'s lane 0.  DPP wave_shr:1 (gfx9 encoding 0x138); with bound_ctrl off the
 // lane without a source keeps `old`.
@@ -381,6 +385,10 @@ template <typename OutT> VHP_LANE_FN void g_store1_if(bool p1, OutT* base, vu32 
 VHP_LANE_FN void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
+// The instruction scheduler moves nothing across this point (no code is emitted).  Between the steps of an unrolled window it keeps
+// the compiler from computing all sixteen steps' ratios and masks ahead of the dependent chain -- sixty-odd registers that a lone
+// wavefront gains nothing from.
+VHP_LANE_FN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Makes a just-loaded value count as "used here": the compiler then waits for the load at this point instead of at
 // the first real use (where the s_waitcnt vmcnt would also drain every store issued in between).
 VHP_LANE_FN void pin(double& v) { asm volatile("" : "+v"(v)); }

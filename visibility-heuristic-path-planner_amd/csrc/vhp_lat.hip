@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "vhp.h"
-#include "vhp_lat.hpp"
+#include "vhp_band.hpp"
 
 namespace vhp {
 namespace pool {
@@ -31,9 +31,14 @@ __global__ void __launch_bounds__(64 * kLatWaves, 1) vhp_lat_sweep(LatArgs<OutT>
 #ifdef VHP_DIAG_POOLPROF
   const unsigned long long t_begin = wall_clock64();
 #endif
-  LatWorker<OutT, ODD>::clear(lds, L, (int)threadIdx.x, 64 * kLatWaves);
+#ifdef VHP_LAT_STRIPS  // A/B builds only: the sweep in strips of rows (vhp_lat.hpp), what the kernel was until round 6
+  using WorkerT = LatWorker<OutT, ODD>;
+#else
+  using WorkerT = BandWorker<OutT, ODD>;
+#endif
+  WorkerT::clear(lds, L, (int)threadIdx.x, 64 * kLatWaves);
   __syncthreads();
-  LatWorker<OutT, ODD> wk;
+  WorkerT wk;
   wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
   wk.run((int)blockIdx.x);
 #ifdef VHP_DIAG_POOLPROF
@@ -46,6 +51,30 @@ __global__ void __launch_bounds__(64 * kLatWaves, 1) vhp_lat_sweep(LatArgs<OutT>
 #endif
 }
 
+// One thread per word of the four diagonal-packed maps (DiagMaps): its 64 cells of the byte map.  Once per vhp_set_map.
+__global__ void vhp_pack_diag(const uint8_t* __restrict__ occ, uint64_t* __restrict__ dmap, int nx, int ny) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= DiagMaps::words(nx, ny)) return;
+  const size_t by_y0 = DiagMaps::offset(nx, ny, 2);
+  const bool by_y = k >= by_y0;
+  const int wpd = by_y ? DiagMaps::wpdy(ny) : DiagMaps::wpdx(nx);
+  const size_t r = by_y ? k - by_y0 : k;
+  const size_t run_all = r / (size_t)wpd;
+  const int word = (int)(r - run_all * (size_t)wpd), n_runs = DiagMaps::runs(nx, ny);
+  const bool anti = run_all >= (size_t)n_runs;
+  const int id = (int)(anti ? run_all - (size_t)n_runs : run_all);
+  if (word == 0 || word == wpd - 1) return;  // (the pad words at either end of a run stay zero)
+  uint64_t bits = 0;
+  for (int t = 0; t < 64; ++t) {
+    const int c = (word - 1) * 64 + t;  // x (by x) or y (by y)
+    // main: y - x = id - (nx - 1); anti: y + x = id
+    const int x = by_y ? (anti ? id - c : c - (id - (nx - 1))) : c;
+    const int y = by_y ? c : (anti ? id - c : c + (id - (nx - 1)));
+    if (x >= 0 && x < nx && y >= 0 && y < ny && occ[(size_t)y * nx + x]) bits |= 1ull << t;
+  }
+  dmap[k] = bits;
+}
+
 }  // namespace pool
 
 namespace {
@@ -56,18 +85,31 @@ template <typename OutT>
 hipError_t launch_lat_t(const BatchArgs& a) {
   using namespace pool;
   const bool odd = lat_needs_odd<OutT>(a.nx, a.field_stride, static_cast<const OutT*>(a.d_out));
+#ifdef VHP_EXP_ONE_KERNEL  // compile-time experiments only: one instantiation instead of four
+  auto k = vhp_lat_sweep<double, false>;
+  if (odd || sizeof(OutT) != 8) return hipErrorInvalidValue;
+#else
   auto k = odd ? vhp_lat_sweep<OutT, true> : vhp_lat_sweep<OutT, false>;
+#endif
   const size_t lds = lat_lds_bytes(a.nx, a.ny);
   if (lds > kLdsLimit || a.pool_epoch == 0) return hipErrorInvalidValue;
   if (a.raise_lds) {
     hipError_t e = a.raise_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return e;
   }
+#ifdef VHP_EXP_ONE_KERNEL
+  LatArgs<double> g;
+#else
   LatArgs<OutT> g;
+#endif
   g.m.rows = a.rows; g.m.cols = a.cols; g.m.recip = a.recip;
   g.m.wpr = a.wpr; g.m.wpc = a.wpc; g.m.nx = a.nx; g.m.ny = a.ny;
   g.src_xy = a.d_src;
+#ifdef VHP_EXP_ONE_KERNEL
+  g.out = static_cast<double*>(a.d_out);
+#else
   g.out = static_cast<OutT*>(a.d_out);
+#endif
   g.field_stride = a.field_stride;
   g.err_flag = a.d_err;
   g.lines = reinterpret_cast<vhp::lanes::Tagged*>(a.d_queue);
@@ -79,6 +121,8 @@ hipError_t launch_lat_t(const BatchArgs& a) {
   g.run_if = a.d_run_if;
   g.dead_cells_are_zero = a.lat_dead_cells_are_zero;
   g.strip_times = nullptr;
+  g.dmap = a.dmap;
+  if (!g.dmap) return hipErrorInvalidValue;
 #ifdef VHP_DIAG_POOLPROF
   { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_lat_strip_times)) == hipSuccess) g.strip_times = static_cast<unsigned long long*>(p); }
 #endif
@@ -92,6 +136,14 @@ hipError_t launch_lat_t(const BatchArgs& a) {
 
 size_t lat_scratch_bytes(int n_src, int nx, int ny) {
   return (size_t)pool::lat_unit_blocks(nx, ny) * pool::kUnits * (size_t)n_src * 64 * sizeof(vhp::lanes::Tagged);
+}
+
+size_t lat_diag_map_bytes(int nx, int ny) { return pool::DiagMaps::words(nx, ny) * sizeof(uint64_t); }
+
+hipError_t lat_pack_diag_maps(const uint8_t* d_occ, int nx, int ny, uint64_t* d_dmap, hipStream_t stream) {
+  const size_t words = pool::DiagMaps::words(nx, ny);
+  hipLaunchKernelGGL(pool::vhp_pack_diag, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_occ, d_dmap, nx, ny);
+  return hipGetLastError();
 }
 
 bool lat_supported(int nx, int ny) {

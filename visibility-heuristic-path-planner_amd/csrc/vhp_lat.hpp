@@ -60,6 +60,7 @@ struct LatArgs {
   // local fields and clears the one that is not in use while it reads the other: vhp_planner.hip.h)
   bool dead_cells_are_zero;
   unsigned long long* strip_times;  // diagnostic builds (tools/lat_timeline.py): [unit][48][4] wall-clock stamps, or nullptr
+  const uint64_t* dmap = nullptr;   // the occupancy packed along the grid's diagonals (vhp_band.hpp DiagMaps): what the band sweep reads
 };
 
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)  // diagnostic builds only: cycle accounts inside the x-major windows (they cost a few hundred cycles per window themselves)
