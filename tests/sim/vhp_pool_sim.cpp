@@ -299,15 +299,16 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   a.strip_times = nullptr;
   a.dmap = h.diag.data();
   std::vector<std::vector<double>> lds(G, std::vector<double>(L.total, std::numeric_limits<double>::quiet_NaN()));
-  std::vector<LatCo<WorkerT>> workers((size_t)G * W);
-  std::vector<Coro> coros((size_t)G * W);
+  const int WT = W * WorkerT::kRoles;  // wavefronts of a workgroup: the sweepers and, in the band sweep, a storer beside each
+  std::vector<LatCo<WorkerT>> workers((size_t)G * WT);
+  std::vector<Coro> coros((size_t)G * WT);
   for (int gI = 0; gI < G; ++gI) {
     WorkerT::clear(lds[gI].data(), L, 0, 1);
-    for (int w = 0; w < W; ++w) {
-      LatCo<WorkerT>& wk = workers[(size_t)gI * W + w];
+    for (int w = 0; w < WT; ++w) {
+      LatCo<WorkerT>& wk = workers[(size_t)gI * WT + w];
       wk.wk.init(a, lds[gI].data(), L, w);
       wk.unit = gI;
-      Coro& c = coros[(size_t)gI * W + w];
+      Coro& c = coros[(size_t)gI * WT + w];
       c.stack.reset(new char[kStack]);
       c.entry = lat_entry<WorkerT>;
       c.arg = &wk;
@@ -326,7 +327,7 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   g_rng = seed * 2654435761u + 12345u;
   g_point_mode = (policy & 8) ? 1 : (policy & 16) ? 2 : 0;
   g_progress = g_switches = 0;
-  const int n = G * W, mode = policy & 7;
+  const int n = G * WT, mode = policy & 7;
   int cur = mode == 1 ? n - 1 : 0, alive = n, burst = 0;
   long long last_progress = 0, stale = 0, deadlock = 0;
   while (alive > 0) {
@@ -356,7 +357,7 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
       fprintf(stderr, "unit %d (source %d,%d qo %d): strips %d diag ready %d\n   prog:", gI, src[2 * s_], src[2 * s_ + 1], qo, ug.n_strips, sh.ctx(0)[kDiagReady]);
       for (int p = 0; p < ug.n_strips && p < L.S; ++p) fprintf(stderr, " %d", sh.prog(0)[p]);
       fprintf(stderr, "\n   alive:");
-      for (int w = 0; w < W; ++w) fprintf(stderr, " %d", coros[(size_t)gI * W + w].done ? 0 : 1);
+      for (int w = 0; w < WT; ++w) fprintf(stderr, " %d", coros[(size_t)gI * WT + w].done ? 0 : 1);
       fprintf(stderr, "\n");
     }
   }

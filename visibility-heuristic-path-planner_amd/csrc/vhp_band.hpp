@@ -30,6 +30,8 @@
 // Written against vhp_lanes.hpp: compiled for gfx950 (vhp_lat.hip) and for the CPU simulator (tests/sim), bit-exact against the
 // oracle in both (tests/test_lat_sim.py, tests/test_gpu_lat.py).
 #pragma once
+#include <type_traits>
+
 #include "vhp_lat.hpp"
 
 namespace vhp {
@@ -39,6 +41,18 @@ namespace pool {
 // those with y + x constant (id = y + x); nx + ny - 1 runs of either kind.  Packed by x: bit x & 63 of word 1 + (x >> 6) of the
 // run; packed by y likewise (a run has one cell per x and one per y).  Cells outside the grid read as 0.
 // Layout in one allocation: [main by x][anti by x][main by y][anti by y].
+// ---- sweepers and storers --------------------------------------------------------------------------------------------------------
+// A wavefront that runs alone on its SIMD pays 4-6 cycles for every instruction it issues, and a window's cells leaving -- the tile
+// read out along its diagonals, ten store instructions with their addresses and lane masks -- are as many instructions as its
+// sixteen steps (measured: 2.2-2.8 k cycles of a window's 4.1-5.2 k, profiles/r06_b_lat_timeline_c2.txt).  So the workgroup has a
+// second set of wavefronts: SWEEPER w computes, leaves a window's values in its LDS tile and posts a 16-byte record; STORER w (wavefront
+// W + w) reads the tile out and stores.  One tile per sweeper: the storer says when it has read a tile out (its LDS reads are ordered
+// before that word by the LDS itself), and the sweeper looks at the word after the arithmetic of its next window's first step, just
+// before that step's tile write -- by then the storer has long been through.  The zeros of a dead band's cells are the storer's, too.
+constexpr int kPostRec = 4;    // ints into the sweeper's dummy slots (16-byte aligned): {seq, lowest step, lowest coordinate, band | flags << 16}
+constexpr int kPostTaken = 8;  // the storer's word: the last seq whose tile has been read out
+enum { kPostZero = 1, kPostDone = 2 };
+
 struct DiagMaps {
   static VHP_HD int runs(int nx, int ny) { return nx + ny - 1; }
   static VHP_HD int wpdx(int nx) { return (nx + 63) / 64 + 2; }
@@ -51,51 +65,75 @@ struct DiagMaps {
   }
 };
 
+// a sweeper's words for its storer (in the sweeper's dummy slots)
+VHP_FN int* post_of(const Shared& sh, int w) { return reinterpret_cast<int*>(sh.lds + sh.L.dummies + w * kLatDummy); }
+
+// What a sweeper of either kind does with its storer: a record per window (or per run of zeros, or the end), one at a time.
+struct Poster {
+  int* post;
+  int seq;  // the next record's number (the first is 1)
+  VHP_FN void init(const Shared& sh, int w) { post = post_of(sh, w); seq = 1; }
+  // the storer has taken record seq - 1 (read its tile out, or copied the record of a run of zeros)
+  VHP_FN bool taken(int tk) const { return tk >= seq - 1; }
+  VHP_FN void wait_taken() {
+    int tk = lds_poll(post + kPostTaken);
+    while (!taken(tk)) { ready_backoff(); sim_point(); tk = lds_poll(post + kPostTaken); }
+    lds_acquire();
+  }
+  VHP_FN void send(int ta, int cw, int band, int flags) {
+    lds_post4(post + kPostRec, seq, ta, cw, band | (flags << 16));
+    seq += 1;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // x-major band b of a unit: lanes d = 64 b + lane (distance from the diagonal), steps t = column index i; the lane's cell of
-// step t is (i, j) = (t, t - d).  Cells exist for 0 <= j < rows_total, t < ni.
+// step t is (i, j) = (t, t - d).  Cells exist for 0 <= j < rows_total, t < ni.  BandX sweeps; BandXStore stores.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DX, int DY, typename OutT, bool ODD = false>
-struct BandX {
-  static constexpr int CB = sizeof(OutT);
-  static constexpr bool kMain = DX * DY > 0;  // the lanes' runs: y - x constant (main) or y + x constant (anti)
-  static constexpr bool odd_pitch = ODD;
-  Map m;
-  const uint64_t* dm;  // the packed runs of this quadrant's kind, by x
-  int wpd;
-  Quad<DX, DY> g;
-  OutT* out;
-  double* tile;   // 64 lanes x 16 columns (pitch kTStride): column c = x - (lowest x of the window)
-  double* slab;   // reciprocals of the step indices of two blocks of 64 coordinates, indexed by x & 127
-  double* bin;
-  Link<DX> lk;
-  int b, D0, t_last, t_end, i_last, rows_total;
-  bool below, has_consumer, retires;
-  int blk, pf_blk, staged_blk;
-  bool pf_wait;
-  int* dead_mine;
-  const int* dead_below;
-  bool skip_fill;
-  vi lane, tile_l, fl_a, fl_l, fl_rj, fl_c;
-  vu32 fl_off;
-  vi dgw;      // word 0 of the lane's run in dm (clamped into the map)
-  vb dg_ok;    // ... which exists
-  vd prev, jd; // jd = t - d of the next step
-  vu64 ow, ow_nx;
-  vd rv_nx;
-  Below<DX, kLW> nx;
-  vd nx_rr[kLW];
-
+template <int DX, int DY>
+struct BandXGeo {
   static VHP_FN int n_bands(const Quad<DX, DY>& q) { return (q.ni > 0 && q.nj > 0) ? (q.ni + kBlock - 1) / kBlock : 0; }
   // the lowest step of the band's first window (windows are aligned to 16 cells of x)
   static VHP_FN int first_window(const Quad<DX, DY>& q, int b_) {
     const int xw = q.X(kBlock * b_) & ~(kLW - 1);
     return DX > 0 ? xw - q.sx : q.sx - (xw + kLW - 1);
   }
+  // the last step at which a lane of band b_ has a cell: lane 63's cell of the octant's last row
+  static VHP_FN int t_last(const Quad<DX, DY>& q, int b_) { return imin(q.ni - 1, kBlock * b_ + kBlock - 2 + q.rows_total); }
+};
+
+template <int DX, int DY>
+struct BandX {
+  static constexpr bool kMain = DX * DY > 0;  // the lanes' runs: y - x constant (main) or y + x constant (anti)
+  using Geo = BandXGeo<DX, DY>;
+  Map m;
+  const uint64_t* dm;  // the packed runs of this quadrant's kind, by x
+  int wpd;
+  Quad<DX, DY> g;
+  double* tile;   // 64 lanes x 16 columns (pitch kTStride): column c = x - (lowest x of the window)
+  double* slab;   // reciprocals of the step indices of two blocks of 64 coordinates, indexed by x & 127
+  double* bin;
+  Link<DX> lk;
+  Poster* po;
+  int b, D0, t_last, t_end, i_last;
+  bool below, has_consumer, retires;
+  int blk, pf_blk, staged_blk;
+  bool pf_wait;
+  int* dead_mine;
+  const int* dead_below;
+  bool skip_fill;
+  vi lane, tile_l;
+  vi dgw;      // word 0 of the lane's run in dm (clamped into the map)
+  vb dg_ok;    // ... which exists
+  vd prev, jd; // jd = t - d of the next step
+  vu64 ow, ow_nx;
+  vd rv_nx;
+  Below<DX, kLW> nx;
 
   // (the caller has initialised lk)
-  VHP_FN void init(const Map& m_, const uint64_t* dmap, int sx, int sy, OutT* out_, const Shared& sh, int w, int b_) {
-    m = m_; out = out_;
+  VHP_FN void init(const Map& m_, const uint64_t* dmap, int sx, int sy, const Shared& sh, int w, int b_, Poster* po_) {
+    m = m_;
+    po = po_;
     g.init(m.nx, m.ny, sx, sy);
     dm = dmap + DiagMaps::offset(m.nx, m.ny, kMain ? 0 : 1);
     wpd = DiagMaps::wpdx(m.nx);
@@ -106,27 +144,15 @@ struct BandX {
     tile_l = lane * kTStride;
     b = b_;
     D0 = kBlock * b;
-    rows_total = g.rows_total;
     i_last = g.ni - 1;
-    t_last = imin(i_last, D0 + kBlock - 2 + rows_total);  // lane 63's cell of the octant's last row
+    t_last = Geo::t_last(g, b);
     below = b > 0;
-    has_consumer = b + 1 < n_bands(g);
+    has_consumer = b + 1 < Geo::n_bands(g);
     // A band whose lanes leave the octant at its last row before the march ends (a quadrant wider than high) RETIRES: the band above
     // still needs one value of its last lane's last cell, and zeros after that -- it marches one step further (all zeros) and then
     // says it is dead (the reader's zeros: Below::accept).
     retires = has_consumer && t_last < i_last;
     t_end = retires ? t_last + 1 : t_last;
-    {
-      // read-out geometry: lane -> (memory row slot rs = lane >> 3, pair pc = lane & 7: the cells at columns 2 pc, 2 pc + 1 of the
-      // window).  Group u of a window holds the rows j = jA + 8 u + rj, jA = ta - D0 - 63 (the row of lane 63 at the window's first
-      // step), rj = the slot counted in j.  The lane that computed cell (column c, row j) is t - D0 - j.
-      const vi rs = lane >> 3, pc = lane & 7;
-      fl_rj = DY > 0 ? rs : (-rs) + 7;
-      fl_c = pc * 2;
-      fl_l = DX > 0 ? (fl_c - fl_rj) + 63 : (-fl_c - fl_rj) + 78;  // the lane of the pair's first cell in group 0; - 8 per group
-      fl_a = (fl_l - 56) * kTStride + fl_c + (DX > 0 ? 0 : 1 - kTStride);
-      fl_off = to_u32((rs * m.nx + pc * 2) * CB);
-    }
     {
       // the lane's run: y - s x = sy - s sx - DY d
       const vi d = lane + D0;
@@ -138,6 +164,12 @@ struct BandX {
     dead_below = sh.owner(0) + (b > 0 ? b - 1 : b);
     skip_fill = false;
     nx.hd = 0;
+    nx.h1 = nx.h2 = 0;
+    nx.ring = false;
+    // (defined on every path -- band 0 reads no band, a band that is dead when it starts requests nothing --, so that the compiler
+    // sees that no register of the band before lives on into this one)
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) nx.v[k] = vd(0.0);
     prev = vd(0.0);
     pf_blk = -1;
     pf_wait = false;
@@ -173,66 +205,10 @@ struct BandX {
     if (block_in_march(b_ + DX)) prefetch_ops(b_ + DX); else pf_blk = -1;
   }
 
-  // requests the operands of the window whose lowest x is xw (lowest step ta) in block nb; nothing is waited for
-  VHP_FN void request(int ta, int xw, int nb) {
-#pragma unroll
-    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (xw & (2 * kBlock - 1)) + (DX > 0 ? k : kLW - 1 - k));
+  // requests the operands of the window whose lowest x is xw in block nb; nothing is waited for
+  VHP_FN void request(int xw, int nb) {
     if (below) {
       if (VHP_DIAG_WAITS) nx.request(lk, dead_below, bin, xw, DX > 0 ? xw : xw + kLW - 1, nb); else nx.ring = false;
-    }
-  }
-
-  // One group of 8 rows of a window: the lane's pair (cells ok0, ok1).  On an odd pitch the pairs of every other row lie 8 bytes
-  // off the 16-byte grid: there every cell leaves by itself.
-  VHP_FN void store_group(OutT* base, const vb& ok0, const vb& ok1, const vd& a, const vd& c) {
-    if (!odd_pitch) { g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, a, c); return; }
-    g_store2_if(vb(false), ok0, vb(false), base, fl_off, a, c);
-    g_store2_if(vb(false), vb(false), ok1, base, fl_off, a, c);
-  }
-  // The cells of the window at xw (lowest step ta) leave: fa[u], fb[u] = the lane's pair of the rows of group u.  INTERIOR: every
-  // row of the window is a row of the octant and every step a step of the march -- only the two ends of the parallelogram (the
-  // groups 0, 1, 8, 9) need a lane mask, and that one is the same in every window.
-  template <bool INTERIOR>
-  VHP_FN void store_half(int u0, int ta, int xw, const vd (&fa)[5], const vd (&fb)[5]) {
-    const int jA = ta - D0 - (kBlock - 1);
-    const long base_step = (long)(8 * DY) * m.nx;
-    OutT* base = out + (long)(DY > 0 ? g.Y(jA) : g.Y(jA + 7)) * (long)m.nx + xw + u0 * base_step;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int u = u0 + q;
-      if (INTERIOR && !odd_pitch && u >= 2 && u <= 7) {
-        g_store2(base, fl_off, fa[q], fb[q]);
-      } else if (INTERIOR || (jA + 8 * u + 7 >= 0 && jA + 8 * u < rows_total)) {
-        const vi la = fl_l - 8 * u, lb = DX > 0 ? la + 1 : la - 1;
-        vb ok0 = (la >= 0) && (la < kBlock), ok1 = (lb >= 0) && (lb < kBlock);
-        if (!INTERIOR) {
-          const vi j = fl_rj + (jA + 8 * u);
-          const vi t0 = DX > 0 ? fl_c + ta : (-fl_c) + (ta + kLW - 1), t1 = t0 + DX;
-          const vb row_ok = (j >= 0) && (j < rows_total);
-          ok0 = ok0 && row_ok && (t0 <= i_last);
-          ok1 = ok1 && row_ok && (t1 <= i_last);
-        }
-        store_group(base, ok0, ok1, fa[q], fb[q]);
-      }
-      base += base_step;
-    }
-  }
-  // the tile's cells in read-out order: the pairs of every lane for the groups u0 .. u0 + 4 (the lanes of the two ends of the
-  // parallelogram that have no cell read the nearest row of the tile instead of what lies beside it)
-  VHP_FN void read_out(int u0, vd (&fa)[5], vd (&fb)[5]) {
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int u = u0 + q;
-      if (u >= 2 && u <= 7) {
-        // (fl_a = the lower of the pair's two addresses in group 7, the last whole group: every other whole group at a positive
-        // immediate offset from it -- a DS instruction encodes no negative one, the compiler would keep a register per group)
-        fa[q] = lds_load(tile, fl_a + ((DX > 0 ? 0 : kTStride - 1) + (7 - u) * (8 * kTStride)));
-        fb[q] = lds_load(tile, fl_a + ((DX > 0 ? kTStride + 1 : 0) + (7 - u) * (8 * kTStride)));
-      } else {
-        const vi la = vmin(vmax(fl_l - 8 * u, 0), kBlock - 1), lb = vmin(vmax(fl_l + ((DX > 0 ? 1 : -1) - 8 * u), 0), kBlock - 1);
-        fa[q] = lds_load(tile, la * kTStride + fl_c);
-        fb[q] = lds_load(tile, lb * kTStride + (fl_c + 1));
-      }
     }
   }
 
@@ -242,25 +218,29 @@ struct BandX {
   // march (before step 0, past the last) is swept like any other: the reciprocal of a step that does not exist is 0.  The source
   // itself needs no step of its own either (origin_bits).  more: the next window belongs to the march.
   // (ONE loop of windows per march, whatever the window's kind: a loop per kind, as the strips had, keeps a copy of the 32 operand
-  // registers per loop and spills them where the loops meet.)
+  // registers per loop and spills them where the loops meet.  The window's operands have been requested: by run() for the band's
+  // first window, by the window before for every other -- unconditionally, so that none of those registers outlives its band.)
   template <bool B0>
   VHP_FN void window(int ta, int xw, int nb, bool more) {
     const int k_hi = imin(kLW - 1, t_end - ta);
     VHP_WP_T0(tw0);
-    // (the window's operands have been requested: by run() for the band's first window, by the window before for every other --
-    // unconditionally, so that the compiler sees that none of the 32 registers outlives its band)
     if (below) nx.accept(lk, dead_below, bin, xw, DX > 0 ? xw : xw + kLW - 1, ta, ta + k_hi - 1, nb);
-#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
-    pin(nx_rr[kLW - 1]);
-#endif
     VHP_WP_ADDP(lk.pp, 8, tw0);
     VHP_WP_T0(tw1);
     const vu32 hs = half_shifted(ow, xw & 63, xw & 31);  // the window's 16 occupancy bits: bit c = the lane's cell at x = xw + c
+    int tk = lds_peek(po->post + kPostTaken);            // has the storer read the tile of the window before out?  (looked at below)
     vd di = vd((double)ta);
-    vd cc = ratio(vmaxd(jd, 0.0), di, nx_rr[0]);
+    // the reciprocals of the step indices come out of the slab two steps ahead of their use (sixteen of them held in registers from
+    // the request on were 32 registers that the workgroup's sixteen wavefronts do not have)
+    const double* rslab = slab + (xw & (2 * kBlock - 1));
+    vd rr[kLW];
+    rr[0] = lds_bcast(rslab, DX > 0 ? 0 : kLW - 1);
+    rr[1] = lds_bcast(rslab, DX > 0 ? 1 : kLW - 2);
+    vd cc = ratio(vmaxd(jd, 0.0), di, rr[0]);
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DX > 0 ? k : kLW - 1 - k;
+      if (k + 2 < kLW) rr[k + 2] = lds_bcast(rslab, DX > 0 ? k + 2 : kLW - 3 - k);
       const vd a = shift_up(prev, below ? nx.v[k] : vd(0.0));
       const vi mk = sbfe1(hs, c);
       vd v = and_mask(stencil(a, prev, cc), mk);
@@ -269,10 +249,14 @@ struct BandX {
         v = select(lane == 0, and_mask(up, mk), v);
       }
       prev = v;
+      if (k == 0) {  // (the first write to the tile: after the step's arithmetic, which has hidden the look at the storer's word)
+        while (!po->taken(uniform(tk))) { ready_backoff(); sim_point(); tk = lds_peek(po->post + kPostTaken); }
+        lds_acquire();
+      }
       lds_store(tile, tile_l + c, v);
       di = di + 1.0;
       jd = jd + 1.0;
-      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), di, nx_rr[k + 1]);  // the next step's ratio beside this step's chain, and no further ahead
+      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), di, rr[k + 1]);  // the next step's ratio beside this step's chain, and no further ahead
       sched_fence();
     }
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
@@ -280,33 +264,21 @@ struct BandX {
 #endif
     VHP_WP_ADDP(lk.pp, 9, tw1);
     VHP_WP_T0(tw2);
-    // ---- the window's cells leave (two halves of five groups of rows); the last lane's values go to the ring ----
-    const bool inside = interior(ta);
-    wave_sync();
-    vd fa[5], fb[5];
-#ifndef VHP_DIAG_LAT_NOFLUSH
-    read_out(0, fa, fb);
-#endif
-    vd bv = vd(0.0);
-    if (has_consumer) bv = lds_load(tile, (lane & (kLW - 1)) + (kBlock - 1) * kTStride);  // lane 63: what the band above reads
+    // ---- the last lane's values go to the ring, the tile to the storer ----
     if (has_consumer) {
+      wave_sync();
+      const vd bv = lds_load(tile, (lane & (kLW - 1)) + (kBlock - 1) * kTStride);  // lane 63: what the band above reads
       lds_store(lk.ring, (lane & (kLW - 1)) + (xw & (kRing - 1)), bv);
       lk.publish(retires ? ta + kLW : ta + k_hi + 1);  // (a band that retires: its reader's window reaches past its own last step)
     }
-#ifndef VHP_DIAG_LAT_NOFLUSH
-    if (inside) store_half<true>(0, ta, xw, fa, fb); else store_half<false>(0, ta, xw, fa, fb);
-    read_out(5, fa, fb);
-#endif
-    wave_sync();
+    po->send(ta, xw, b, 0);
+    sim_progress();
     if (more) {
       const int xn = xw + kLW * DX;
       const bool other = (xn >> 6) != (xw >> 6);  // the next window opens the next block
       if (other) stage_next();
-      request(ta + kLW, xn, other ? nb + 1 : nb);
+      request(xn, other ? nb + 1 : nb);
     }
-#ifndef VHP_DIAG_LAT_NOFLUSH
-    if (inside) store_half<true>(5, ta, xw, fa, fb); else store_half<false>(5, ta, xw, fa, fb);
-#endif
     VHP_WP_ADDP(lk.pp, 10, tw2);
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
     VHP_WP_ADDP(lk.pp, 14, tw0); lk.pp[13] += 1;
@@ -319,8 +291,6 @@ struct BandX {
     if (has_consumer) lk.store_block(g.nbx(ta - 1), blk);
     enter_block(b_);
   }
-  // every row and step of the window at ta exists
-  VHP_FN bool interior(int ta) const { return ta - D0 - (kBlock - 1) >= 0 && ta + kLW - 1 - D0 <= rows_total - 1 && ta + kLW - 1 <= i_last; }
 
   template <bool B0>
   VHP_FN void march(int& ta, int& xw, bool& dead) {
@@ -353,11 +323,7 @@ struct BandX {
     enter_block(xw >> 6);
     bool dead = below && lds_poll(dead_mine) != 0;  // (a band below died before this one could start, and said so for it)
     if (!dead) {
-      if (!below) {  // (band 0 reads no band: its lane 0 -- the diagonal -- takes nothing from below; defined, so that no register of the band before lives on)
-#pragma unroll
-        for (int k = 0; k < kLW; ++k) nx.v[k] = vd(0.0);
-      }
-      request(ta, xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk);
+      request(xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk);
       if (b == 0) { origin_bits(xw); march<true>(ta, xw, dead); } else march<false>(ta, xw, dead);
     }
     if (has_consumer) lk.store_block(imax(g.nbx(imin(imax(ta - 1, 0), i_last)), 0), blk);
@@ -371,16 +337,11 @@ struct BandX {
         sim_count(4);
       }
       sim_progress();
-      if (!dead || skip_fill) return;
-      // the zeros of what is left of the march, window by window
-      vd z[5];
-#pragma unroll
-      for (int u = 0; u < 5; ++u) z[u] = vd(0.0);
-      for (; ta <= t_last; ta += kLW, xw += kLW * DX) {
-        store_half<false>(0, ta, xw, z, z);
-        store_half<false>(5, ta, xw, z, z);
-        sim_point();
-      }
+      if (!dead || skip_fill || ta > t_last) return;
+      // the zeros of what is left of the march are the storer's
+      po->wait_taken();
+      po->send(ta, xw, b, kPostZero);
+      sim_progress();
     }
   }
   // If the band above cannot have started yet (its first step lies past s + 1), neither has any band above that one, and all of
@@ -388,7 +349,7 @@ struct BandX {
   // once, instead of one waking the next.  (A band above that HAS started may still hold light of its own.)
   VHP_FN void announce_death(int s) {
     if ((b + 1) * kBlock <= s + 1) return;
-    const int n = n_bands(g);
+    const int n = Geo::n_bands(g);
     int* dead_base = dead_mine - b;
     int* prog_base = lk.prog - b;
     for (int q0 = b + 1; q0 < n; q0 += kLanes) {
@@ -413,26 +374,137 @@ struct BandX {
   }
 };
 
+// The storing side of an x-major unit: the tile of a window read out along its diagonals (79 rows of up to 16 cells: 10 groups of 8
+// rows, the lane's pair of cells per group), the six groups in the middle whole.  ODD: pairs of cells are not 16-byte aligned in
+// every row (an odd width, or fields that start off the pair grid): every cell leaves by itself.
+template <int DX, int DY, typename OutT, bool ODD>
+struct BandXStore {
+  static constexpr int CB = sizeof(OutT);
+  using Geo = BandXGeo<DX, DY>;
+  Quad<DX, DY> g;
+  OutT* out;
+  const double* tile;
+  int nxm, rows_total, i_last;
+  vi lane, fl_a, fl_l, fl_rj, fl_c;
+  vu32 fl_off;
+
+  VHP_FN void init(const Map& m, int sx, int sy, OutT* out_, const double* tile_) {
+    g.init(m.nx, m.ny, sx, sy);
+    out = out_;
+    tile = tile_;
+    nxm = m.nx;
+    rows_total = g.rows_total;
+    i_last = g.ni - 1;
+    lane = lane_id();
+    // read-out geometry: lane -> (memory row slot rs = lane >> 3, pair pc = lane & 7: the cells at columns 2 pc, 2 pc + 1 of the
+    // window).  Group u of a window holds the rows j = jA + 8 u + rj, jA = ta - D0 - 63 (the row of lane 63 at the window's first
+    // step), rj = the slot counted in j.  The lane that computed cell (column c, row j) is t - D0 - j.
+    const vi rs = lane >> 3, pc = lane & 7;
+    fl_rj = DY > 0 ? rs : (-rs) + 7;
+    fl_c = pc * 2;
+    fl_l = DX > 0 ? (fl_c - fl_rj) + 63 : (-fl_c - fl_rj) + 78;  // the lane of the pair's first cell in group 0; - 8 per group
+    // (the lower of the pair's two addresses in group 7, the last whole group: every other whole group at a positive immediate
+    // offset from it -- a DS instruction encodes no negative one, the compiler would keep a register per group)
+    fl_a = (fl_l - 56) * kTStride + fl_c + (DX > 0 ? 0 : 1 - kTStride);
+    fl_off = to_u32((rs * nxm + pc * 2) * CB);
+  }
+  VHP_FN void store_group(OutT* base, const vb& ok0, const vb& ok1, const vd& a, const vd& c) {
+    if (!ODD) { g_store2_if(ok0 && ok1, ok0, ok1, base, fl_off, a, c); return; }
+    g_store2_if(vb(false), ok0, vb(false), base, fl_off, a, c);
+    g_store2_if(vb(false), vb(false), ok1, base, fl_off, a, c);
+  }
+  // every row and step of band b's window at ta exists
+  VHP_FN bool interior(int D0, int ta) const { return ta - D0 - (kBlock - 1) >= 0 && ta + kLW - 1 - D0 <= rows_total - 1 && ta + kLW - 1 <= i_last; }
+
+  // INTERIOR: only the two ends of the parallelogram (the groups 0, 1, 8, 9) need a lane mask, and that one is the same in every window
+  template <bool INTERIOR>
+  VHP_FN void store_window(int D0, int ta, int xw, const vd (&fa)[10], const vd (&fb)[10]) {
+    const int jA = ta - D0 - (kBlock - 1);
+    const long base_step = (long)(8 * DY) * nxm;
+    OutT* base = out + (long)(DY > 0 ? g.Y(jA) : g.Y(jA + 7)) * (long)nxm + xw;
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      if (INTERIOR && !ODD && u >= 2 && u <= 7) {
+        g_store2(base, fl_off, fa[u], fb[u]);
+      } else if (INTERIOR || (jA + 8 * u + 7 >= 0 && jA + 8 * u < rows_total)) {
+        const vi la = fl_l - 8 * u, lb = DX > 0 ? la + 1 : la - 1;
+        vb ok0 = (la >= 0) && (la < kBlock), ok1 = (lb >= 0) && (lb < kBlock);
+        if (!INTERIOR) {
+          const vi j = fl_rj + (jA + 8 * u);
+          const vi t0 = DX > 0 ? fl_c + ta : (-fl_c) + (ta + kLW - 1), t1 = t0 + DX;
+          const vb row_ok = (j >= 0) && (j < rows_total);
+          ok0 = ok0 && row_ok && (t0 <= i_last);
+          ok1 = ok1 && row_ok && (t1 <= i_last);
+        }
+        store_group(base, ok0, ok1, fa[u], fb[u]);
+      }
+      base += base_step;
+    }
+  }
+  // a window of band b: the tile read out (the word `taken` tells the sweeper so: an LDS write issued after the reads, which the
+  // LDS executes in that order), then stored
+  VHP_FN void flush(int b, int ta, int xw, int* taken, int seq) {
+    const int D0 = kBlock * b;
+    wave_sync();
+    vd fa[10], fb[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      if (u >= 2 && u <= 7) {
+        fa[u] = lds_load(tile, fl_a + ((DX > 0 ? 0 : kTStride - 1) + (7 - u) * (8 * kTStride)));
+        fb[u] = lds_load(tile, fl_a + ((DX > 0 ? kTStride + 1 : 0) + (7 - u) * (8 * kTStride)));
+      } else {  // (the lanes of the two ends of the parallelogram that have no cell read the nearest row of the tile instead of what lies beside it)
+        const vi la = vmin(vmax(fl_l - 8 * u, 0), kBlock - 1), lb = vmin(vmax(fl_l + ((DX > 0 ? 1 : -1) - 8 * u), 0), kBlock - 1);
+        fa[u] = lds_load(tile, la * kTStride + fl_c);
+        fb[u] = lds_load(tile, lb * kTStride + (fl_c + 1));
+      }
+    }
+    lds_publish(taken, seq);
+    if (interior(D0, ta)) store_window<true>(D0, ta, xw, fa, fb); else store_window<false>(D0, ta, xw, fa, fb);
+  }
+  // the zeros of what is left of band b's march from the window at ta on
+  VHP_FN void zero_fill(int b, int ta, int xw) {
+    const int D0 = kBlock * b, t_last = Geo::t_last(g, b);
+    vd z[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) z[u] = vd(0.0);
+    for (; ta <= t_last; ta += kLW, xw += kLW * DX) {
+      store_window<false>(D0, ta, xw, z, z);
+      sim_point();
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // y-major band b of a unit: lanes d' = 64 b - 1 + lane (distance j - i from the diagonal), steps t = row index j; the lane's cell of
 // step t is (i, j) = (t - d', t): the 64 cells of a step are adjacent cells of one row.  Band 0's lane 0 (d' = -1) is the
 // sub-diagonal cell (t, t - 1) of the x-major octant and its lane 1 the diagonal: the octant runs the two-term recurrence for
 // itself.  Cells exist for max(d', 0) <= t <= min(nj - 1, d' + ni - 1); the sub-diagonal lane stores nothing.
+// The tile of a window: 16 rows (steps, in marching order) of 64 lanes.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DX, int DY, typename OutT>
+template <int DX, int DY>
+struct BandYGeo {
+  static VHP_FN int n_bands(const Quad<DX, DY>& q) { return (q.ni > 0 && q.nj > 1) ? (q.nj + kBlock) / kBlock : 0; }
+  static VHP_FN int first_window(const Quad<DX, DY>& q, int b_) {
+    const int yw = q.Y(imax(kBlock * b_ - 1, 0)) & ~(kLW - 1);
+    return DY > 0 ? yw - q.sy : q.sy - (yw + kLW - 1);
+  }
+  // lane 63's cell of the octant's last column
+  static VHP_FN int t_last(const Quad<DX, DY>& q, int b_) { return imin(q.nj - 1, kBlock * b_ - 1 + kBlock - 1 + q.ni - 1); }
+};
+
+template <int DX, int DY>
 struct BandY {
-  static constexpr int CB = sizeof(OutT);
   static constexpr bool kMain = DX * DY > 0;
-  static constexpr int kNever = 0x7fffffff;
+  using Geo = BandYGeo<DX, DY>;
   Map m;
   const uint64_t* dm;  // the packed runs of this quadrant's kind, by y
   int wpd;
   Quad<DX, DY> g;
-  OutT* out;
+  double* tile;
   double* slab;
   double* bin;
-  double* dummy;
   Link<DY> lk;
+  Poster* po;
   int b, D0, t_last, t_end, j_last;
   bool below, has_consumer, retires;
   int blk, pf_blk, staged_blk;
@@ -440,64 +512,54 @@ struct BandY {
   int* dead_mine;
   const int* dead_below;
   bool skip_fill;
-  vi lane, t_lo, t_hi;  // the steps at which the lane's cell exists (t_lo > t_hi: never)
-  vu32 xoff;
+  vi lane;
   vi dgw;
   vb dg_ok;
   vd prev, jd;
   vu64 ow, ow_nx;
   vd rv_nx;
   Below<DY, kLW> nx;
-  vd nx_rr[kLW];
 
-  static VHP_FN int n_bands(const Quad<DX, DY>& q) { return (q.ni > 0 && q.nj > 1) ? (q.nj + kBlock) / kBlock : 0; }
-  static VHP_FN int first_window(const Quad<DX, DY>& q, int b_) {
-    const int yw = q.Y(imax(kBlock * b_ - 1, 0)) & ~(kLW - 1);
-    return DY > 0 ? yw - q.sy : q.sy - (yw + kLW - 1);
-  }
-
-  VHP_FN void init(const Map& m_, const uint64_t* dmap, int sx, int sy, OutT* out_, const Shared& sh, int w, int b_) {
-    m = m_; out = out_;
+  VHP_FN void init(const Map& m_, const uint64_t* dmap, int sx, int sy, const Shared& sh, int w, int b_, Poster* po_) {
+    m = m_;
+    po = po_;
     g.init(m.nx, m.ny, sx, sy);
     dm = dmap + DiagMaps::offset(m.nx, m.ny, kMain ? 2 : 3);
     wpd = DiagMaps::wpdy(m.ny);
+    tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
     slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
     bin = lk.bin;
-    dummy = sh.lds + sh.L.dummies + w * kLatDummy;
     lane = lane_id();
     b = b_;
     D0 = kBlock * b - 1;
     j_last = g.nj - 1;
-    t_last = imin(j_last, D0 + kBlock - 1 + g.ni - 1);  // lane 63's cell of the octant's last column
+    t_last = Geo::t_last(g, b);
     below = b > 0;
-    has_consumer = b + 1 < n_bands(g);
+    has_consumer = b + 1 < Geo::n_bands(g);
     retires = has_consumer && t_last < j_last;   // (see BandX::init)
     t_end = retires ? t_last + 1 : t_last;
-    const vi d = lane + D0;
-    t_lo = select(d >= 0, d, vi(kNever));
-    t_hi = vmin(d + (g.ni - 1), j_last);
     {
       // the lane's run: y - s x = sy - s sx + DY d'
+      const vi d = lane + D0;
       const vi id = kMain ? d * DY + (sy - sx + m.nx - 1) : d * DY + (sy + sx);
       dg_ok = (id >= 0) && (id < DiagMaps::runs(m.nx, m.ny));
       dgw = vmin(vmax(id, 0), DiagMaps::runs(m.nx, m.ny) - 1) * wpd;
     }
-    // the lane's cell of step t is at x = X(t) - DX d': byte offsets from the row's lowest x of the band, never negative
-    xoff = to_u32((DX > 0 ? (-lane) + (kLanes - 1) : lane) * CB);
     dead_mine = sh.owner(0) + b;
     dead_below = sh.owner(0) + (b > 0 ? b - 1 : b);
     skip_fill = false;
     nx.hd = 0;
+    nx.h1 = nx.h2 = 0;
+    nx.ring = false;
+    // (defined on every path -- band 0 reads no band, a band that is dead when it starts requests nothing --, so that the compiler
+    // sees that no register of the band before lives on into this one)
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) nx.v[k] = vd(0.0);
     prev = vd(0.0);
     pf_blk = -1;
     pf_wait = false;
     staged_blk = -0x7fffffff;
     blk = -0x7fffffff;
-  }
-  // where lane 0's (DX < 0) or lane 63's (DX > 0) cell of step t is stored: xoff counts from there
-  VHP_FN OutT* row_base(int t) const {
-    const long x0 = DX > 0 ? (long)g.X(t) - (D0 + kLanes - 1) : (long)g.X(t) + D0;
-    return out + (long)g.Y(t) * (long)m.nx + x0;
   }
 
   VHP_FN void load_ops(int blk_, vu64& o, vd& rv) {
@@ -533,26 +595,30 @@ struct BandY {
     blk = b_;
     if (block_in_march(b_ + DY)) prefetch_ops(b_ + DY); else pf_blk = -1;
   }
-  VHP_FN void request(int ta, int yw, int nb) {
-#pragma unroll
-    for (int k = 0; k < kLW; ++k) nx_rr[k] = lds_bcast(slab, (yw & (2 * kBlock - 1)) + (DY > 0 ? k : kLW - 1 - k));
+  VHP_FN void request(int yw, int nb) {
     if (below) {
       if (VHP_DIAG_WAITS) nx.request(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, nb); else nx.ring = false;
     }
   }
 
   // One window: steps ta + k, k = 0 .. 15, at y = yw + (k marching up, 15 - k marching down).  B0: see BandX::window (here band 0's
-  // lane 0 is the sub-diagonal -- its neighbour the diagonal sits one lane UP -- and lane 1 the diagonal).  PRED: some lane has no
-  // cell in some step of the window.
-  template <bool B0, bool PRED>
-  VHP_FN void steps(int ta, const vu32& hs, double* wbase, const vi& widx) {
+  // lane 0 is the sub-diagonal -- its neighbour the diagonal sits one lane UP -- and lane 1 the diagonal).
+  template <bool B0>
+  VHP_FN void window(int ta, int yw, int nb, bool more) {
+    const int k_hi = imin(kLW - 1, t_end - ta);
+    if (below) nx.accept(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, ta, ta + k_hi - 1, nb);  // (requested: see BandX::window)
+    const vu32 hs = half_shifted(ow, yw & 63, yw & 31);
+    int tk = lds_peek(po->post + kPostTaken);
     vd dj = vd((double)ta);
-    vd cc = ratio(vmaxd(jd, 0.0), dj, nx_rr[0]);
-    const long rowstep = (long)DY * m.nx + DX;
-    OutT* row = row_base(ta);
+    const double* rslab = slab + (yw & (2 * kBlock - 1));
+    vd rr[kLW];
+    rr[0] = lds_bcast(rslab, DY > 0 ? 0 : kLW - 1);
+    rr[1] = lds_bcast(rslab, DY > 0 ? 1 : kLW - 2);
+    vd cc = ratio(vmaxd(jd, 0.0), dj, rr[0]);
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DY > 0 ? k : kLW - 1 - k;
+      if (k + 2 < kLW) rr[k + 2] = lds_bcast(rslab, DY > 0 ? k + 2 : kLW - 3 - k);
       vd a = shift_up(prev, below ? nx.v[k] : vd(0.0));
       if (B0) a = select(lane == 0, shift_down(prev, prev), a);
       const vi mk = sbfe1(hs, c);
@@ -561,43 +627,33 @@ struct BandY {
         const vd up = shift_up(v, v);
         v = select(lane == 1, and_mask(up, mk), v);
       }
-#ifdef VHP_DIAG_LAT_NOFLUSH
-      if (m.nx == 0x7fffffff)
-#endif
-      {
-        if (PRED) {
-          const int t = ta + k;
-          g_store1_if((t_lo <= t) && (t_hi >= t), row, xoff, v);
-        } else if (B0) {
-          g_store1_if(lane != 0, row, xoff, v);
-        } else {
-          g_store1_if(vb(true), row, xoff, v);
-        }
-      }
       prev = v;
-      lds_store(wbase, widx + c, v);
+      if (k == 0) {
+        while (!po->taken(uniform(tk))) { ready_backoff(); sim_point(); tk = lds_peek(po->post + kPostTaken); }
+        lds_acquire();
+      }
+      lds_store(tile, lane + kLanes * k, v);
       dj = dj + 1.0;
       jd = jd + 1.0;
-      row += rowstep;
-      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), dj, nx_rr[k + 1]);
+      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), dj, rr[k + 1]);
       sched_fence();
     }
-  }
-  template <bool B0>
-  VHP_FN void window(int ta, int yw, int nb, bool more) {
-    const int k_hi = imin(kLW - 1, t_end - ta);
-    if (below) nx.accept(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, ta, ta + k_hi - 1, nb);  // (requested: see BandX::window)
-    const vu32 hs = half_shifted(ow, yw & 63, yw & 31);
-    double* wbase = has_consumer ? lk.ring + (yw & (kRing - 1)) : dummy;
-    const vi widx = select(lane == kLanes - 1, vi(0), vi((int)(dummy - wbase)));
-    if (interior(ta)) steps<B0, false>(ta, hs, wbase, widx); else steps<B0, true>(ta, hs, wbase, widx);
+    if (has_consumer) {
+      wave_sync();
+      // lane 63's values, in the order of the coordinate: what the band above reads
+      const vi kk = DY > 0 ? (lane & (kLW - 1)) : (-(lane & (kLW - 1))) + (kLW - 1);
+      const vd bv = lds_load(tile, kk * kLanes + (kLanes - 1));
+      lds_store(lk.ring, (lane & (kLW - 1)) + (yw & (kRing - 1)), bv);
+      lk.publish(retires ? ta + kLW : ta + k_hi + 1);
+    }
+    po->send(ta, yw, b, 0);
+    sim_progress();
     if (more) {
       const int yn = yw + kLW * DY;
       const bool other = (yn >> 6) != (yw >> 6);
       if (other) stage_next();
-      request(ta + kLW, yn, other ? nb + 1 : nb);
+      request(yn, other ? nb + 1 : nb);
     }
-    if (has_consumer) lk.publish(retires ? ta + kLW : ta + k_hi + 1);
   }
 
   VHP_FN void open_block(int yw, int ta) {
@@ -606,8 +662,6 @@ struct BandY {
     if (has_consumer) lk.store_block(g.nby(ta - 1), blk);
     enter_block(b_);
   }
-  // every lane (band 0: but the sub-diagonal's) has a cell in every step of the window at ta
-  VHP_FN bool interior(int ta) const { return ta >= D0 + kLanes - 1 && ta + kLW - 1 <= imin(j_last, imax(D0, 0) + g.ni - 1); }
 
   template <bool B0>
   VHP_FN void march(int& ta, int& yw, bool& dead) {
@@ -640,11 +694,7 @@ struct BandY {
     enter_block(yw >> 6);
     bool dead = below && lds_poll(dead_mine) != 0;
     if (!dead) {
-      if (!below) {
-#pragma unroll
-        for (int k = 0; k < kLW; ++k) nx.v[k] = vd(0.0);
-      }
-      request(ta, yw, DY > 0 ? blk - g.by0 : g.by0 - blk);
+      request(yw, DY > 0 ? blk - g.by0 : g.by0 - blk);
       if (b == 0) { origin_bits(yw); march<true>(ta, yw, dead); } else march<false>(ta, yw, dead);
     }
     if (has_consumer) lk.store_block(imax(g.nby(imin(imax(ta - 1, 0), j_last)), 0), blk);
@@ -656,19 +706,15 @@ struct BandY {
         sim_count(4);
       }
       sim_progress();
-      if (!dead || skip_fill) return;
-      const long rowstep = (long)DY * m.nx + DX;
-      OutT* row = row_base(ta);
-      for (int t = ta; t <= t_last; ++t) {
-        g_store1_if((t_lo <= t) && (t_hi >= t), row, xoff, vd(0.0));
-        row += rowstep;
-        if (((t - ta) & (kLW - 1)) == kLW - 1) sim_point();
-      }
+      if (!dead || skip_fill || ta > t_last) return;
+      po->wait_taken();
+      po->send(ta, yw, b, kPostZero);
+      sim_progress();
     }
   }
   VHP_FN void announce_death(int s) {
     if ((b + 1) * kBlock - 1 <= s + 1) return;
-    const int n = n_bands(g);
+    const int n = Geo::n_bands(g);
     int* dead_base = dead_mine - b;
     int* prog_base = lk.prog - b;
     for (int q0 = b + 1; q0 < n; q0 += kLanes) {
@@ -690,8 +736,81 @@ struct BandY {
   }
 };
 
+// The storing side of a y-major unit: a step's 64 cells are adjacent cells of its row, one column further every step.
+template <int DX, int DY, typename OutT>
+struct BandYStore {
+  static constexpr int CB = sizeof(OutT);
+  static constexpr int kNever = 0x7fffffff;
+  using Geo = BandYGeo<DX, DY>;
+  Quad<DX, DY> g;
+  OutT* out;
+  const double* tile;
+  int nxm, j_last;
+  vi lane;
+  vu32 xoff;
+
+  VHP_FN void init(const Map& m, int sx, int sy, OutT* out_, const double* tile_) {
+    g.init(m.nx, m.ny, sx, sy);
+    out = out_;
+    tile = tile_;
+    nxm = m.nx;
+    j_last = g.nj - 1;
+    lane = lane_id();
+    // the lane's cell of step t is at x = X(t) - DX d': byte offsets from the row's lowest x of the band, never negative
+    xoff = to_u32((DX > 0 ? (-lane) + (kLanes - 1) : lane) * CB);
+  }
+  // where lane 0's (DX < 0) or lane 63's (DX > 0) cell of step t of the band whose lane 0 is at distance D0 is stored: xoff counts from there
+  VHP_FN OutT* row_base(int D0, int t) const {
+    const long x0 = DX > 0 ? (long)g.X(t) - (D0 + kLanes - 1) : (long)g.X(t) + D0;
+    return out + (long)g.Y(t) * (long)nxm + x0;
+  }
+  // every lane (band 0: but the sub-diagonal's) has a cell in every step of the window at ta
+  VHP_FN bool interior(int D0, int ta) const { return ta >= D0 + kLanes - 1 && ta + kLW - 1 <= imin(j_last, imax(D0, 0) + g.ni - 1); }
+
+  VHP_FN void flush(int b, int ta, int, int* taken, int seq) {
+    const int D0 = kBlock * b - 1;
+    wave_sync();
+    vd fv[kLW];
+#pragma unroll
+    for (int k = 0; k < kLW; ++k) fv[k] = lds_load(tile, lane + kLanes * k);
+    lds_publish(taken, seq);
+    const long rowstep = (long)DY * nxm + DX;
+    OutT* row = row_base(D0, ta);
+    if (interior(D0, ta)) {
+#pragma unroll
+      for (int k = 0; k < kLW; ++k) {
+        if (b == 0) g_store1_if(lane != 0, row, xoff, fv[k]); else g_store1_if(vb(true), row, xoff, fv[k]);
+        row += rowstep;
+      }
+    } else {
+      const vi d = lane + D0;
+      const vi t_lo = select(d >= 0, d, vi(kNever)), t_hi = vmin(d + (g.ni - 1), j_last);  // the steps at which the lane's cell exists
+#pragma unroll
+      for (int k = 0; k < kLW; ++k) {
+        const int t = ta + k;
+        g_store1_if((t_lo <= t) && (t_hi >= t), row, xoff, fv[k]);
+        row += rowstep;
+      }
+    }
+  }
+  VHP_FN void zero_fill(int b, int ta, int) {
+    const int D0 = kBlock * b - 1, t_last = Geo::t_last(g, b);
+    const vi d = lane + D0;
+    const vi t_lo = select(d >= 0, d, vi(kNever)), t_hi = vmin(d + (g.ni - 1), j_last);
+    const long rowstep = (long)DY * nxm + DX;
+    OutT* row = row_base(D0, ta);
+    for (int t = ta; t <= t_last; ++t) {
+      g_store1_if((t_lo <= t) && (t_hi >= t), row, xoff, vd(0.0));
+      row += rowstep;
+      if (((t - ta) & (kLW - 1)) == kLW - 1) sim_point();
+    }
+  }
+};
+
+// One wavefront of a unit's workgroup: sweeper w (w < W) or the storer of sweeper w - W.
 template <typename OutT, bool ODD = false>
 struct BandWorker {
+  static constexpr int kRoles = 2;  // wavefronts per sweeper (the simulator and the launcher size the workgroup by it)
   LatArgs<OutT> a;
   Shared sh;
   int w, W;
@@ -708,7 +827,14 @@ struct BandWorker {
     W = L.W;
     lane = lane_id();
   }
-  static VHP_FN void clear(double* lds, const Layout& L, int tid, int nthreads) { Worker<OutT>::clear(lds, L, tid, nthreads); }
+  // Before any wavefront runs: every thread of the workgroup calls this (tid of nthreads), then a barrier.
+  static VHP_FN void clear(double* lds, const Layout& L, int tid, int nthreads) {
+    Worker<OutT>::clear(lds, L, tid, nthreads);
+    Shared s;
+    s.lds = lds;
+    s.L = L;
+    for (int k = tid; k < L.W * 2; k += nthreads) lds_set_int(post_of(s, k >> 1) + ((k & 1) ? kPostTaken : kPostRec), 0);
+  }
 
   VHP_FN Tagged* line_of(int unit, int p, int nb) const { return a.lines + (size_t)64 * ((size_t)unit * (size_t)a.unit_blocks + (size_t)p * nb); }
   static VHP_FN int tag_of(int p) { return (1 << 8) | p; }  // (never 0: a cleared header belongs to no band)
@@ -720,19 +846,19 @@ struct BandWorker {
   }
 
   template <int DX, int DY>
-  VHP_FN void run_x(int unit, int sx, int sy, OutT* field) {
+  VHP_FN void sweep_x(int unit, int sx, int sy, Poster& po) {
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* prog = sh.prog(0);
-    const int n = BandX<DX, DY, OutT, ODD>::n_bands(g);
+    const int n = BandXGeo<DX, DY>::n_bands(g);
     for (int p = w; p < n; p += W) {
-      BandX<DX, DY, OutT, ODD> xs;
-      xs.lk.init(sh, w, sx, imax(BandX<DX, DY, OutT, ODD>::first_window(g, p), 0), tag_of(p), prog + p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr,
+      BandX<DX, DY> xs;
+      xs.lk.init(sh, w, sx, imax(BandXGeo<DX, DY>::first_window(g, p), 0), tag_of(p), prog + p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr,
                  p + 1 < n ? line_of(unit, p, g.Nbx) : nullptr, a.epoch, p > 0 ? (p - 1) % W : -1, p > 0 ? tag_of(p - 1) : 0);
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
       xs.lk.pp = prof;
 #endif
-      xs.init(a.m, a.dmap, sx, sy, field, sh, w, p);
+      xs.init(a.m, a.dmap, sx, sy, sh, w, p, &po);
       xs.skip_fill = a.dead_cells_are_zero;
       xs.prefetch_ops(g.X(kBlock * p) >> 6);
       VHP_LAT_STAMP(unit, p, 0);
@@ -746,21 +872,21 @@ struct BandWorker {
   }
 
   template <int DX, int DY>
-  VHP_FN void run_y(int unit, int sx, int sy, OutT* field) {
+  VHP_FN void sweep_y(int unit, int sx, int sy, Poster& po) {
     Quad<DX, DY> g;
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* prog = sh.prog(0);
-    const int n = BandY<DX, DY, OutT>::n_bands(g);
+    const int n = BandYGeo<DX, DY>::n_bands(g);
     const int Nby = g.Nby;
     for (int q = w; q < n; q += W) {
-      BandY<DX, DY, OutT> ys;
-      ys.lk.init(sh, w, sy, imax(BandY<DX, DY, OutT>::first_window(g, q), 0), tag_of(q), prog + q, q > 0 ? line_of(unit, q - 1, Nby) : nullptr,
+      BandY<DX, DY> ys;
+      ys.lk.init(sh, w, sy, imax(BandYGeo<DX, DY>::first_window(g, q), 0), tag_of(q), prog + q, q > 0 ? line_of(unit, q - 1, Nby) : nullptr,
                  q + 1 < n ? line_of(unit, q, Nby) : nullptr, a.epoch, q > 0 ? (q - 1) % W : -1, q > 0 ? tag_of(q - 1) : 0);
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
       ys.lk.pp = prof;
 #endif
       VHP_LAT_STAMP(unit, q, 0);
-      ys.init(a.m, a.dmap, sx, sy, field, sh, w, q);
+      ys.init(a.m, a.dmap, sx, sy, sh, w, q, &po);
       ys.skip_fill = a.dead_cells_are_zero;
       ys.prefetch_ops(g.Y(imax(kBlock * q - 1, 0)) >> 6);
       if (VHP_DIAG_WAITS && q > 0) wait_for(prog + (q - 1), imin(kBlock * q + 1, g.nj));
@@ -772,7 +898,31 @@ struct BandWorker {
     }
   }
 
-  // the whole life of this wavefront: its bands of unit `unit` (8 * source + 2 * quadrant + {0: x-major, 1: y-major})
+  // the storer of sweeper ws: record after record until the sweeper says it has swept its last band
+  template <int DX, int DY, bool XM>
+  VHP_FN void store(int ws, int sx, int sy, OutT* field) {
+    int* post = post_of(sh, ws);
+    const double* tile = sh.lds + sh.L.tiles + ws * kXRows * kTStride;
+    typename std::conditional<XM, BandXStore<DX, DY, OutT, ODD>, BandYStore<DX, DY, OutT>>::type st;
+    st.init(a.m, sx, sy, field, tile);
+    for (int n = 1;; ++n) {
+      int seq, ta, cw, bf;
+      lds_read4(post + kPostRec, seq, ta, cw, bf);
+      while (seq < n) { ready_backoff(); sim_point(); lds_read4(post + kPostRec, seq, ta, cw, bf); }
+      lds_acquire();
+      const int band = bf & 0xffff, flags = bf >> 16;
+      if (flags & kPostDone) return;
+      if (flags & kPostZero) {
+        lds_publish(post + kPostTaken, n);  // (the record is in registers: the sweeper may go on)
+        st.zero_fill(band, ta, cw);
+      } else {
+        st.flush(band, ta, cw, post + kPostTaken, n);
+      }
+      sim_progress();
+    }
+  }
+
+  // the whole life of this wavefront in unit `unit` (8 * source + 2 * quadrant + {0: x-major, 1: y-major})
   VHP_FN void run(int unit) {
     const int s = unit / kUnits, qo = unit - s * kUnits;
     // (the planners' control words together, before any of them is looked at: one trip to memory, then the source's)
@@ -787,23 +937,42 @@ struct BandWorker {
       return;
     }
     OutT* field = a.out + (size_t)(s + uniform(slot0)) * a.field_stride;
+    if (w < W) {
+      Poster po;
+      po.init(sh, w);
+      switch (qo) {
+        case 0: sweep_x<+1, +1>(unit, sx, sy, po); break;
+        case 1: sweep_y<+1, +1>(unit, sx, sy, po); break;
+        case 2: sweep_x<-1, +1>(unit, sx, sy, po); break;
+        case 3: sweep_y<-1, +1>(unit, sx, sy, po); break;
+        case 4: sweep_x<-1, -1>(unit, sx, sy, po); break;
+        case 5: sweep_y<-1, -1>(unit, sx, sy, po); break;
+        case 6: sweep_x<+1, -1>(unit, sx, sy, po); break;
+        default: sweep_y<+1, -1>(unit, sx, sy, po); break;
+      }
+      po.wait_taken();
+      po.send(0, 0, 0, kPostDone);
+      sim_progress();
+      return;
+    }
+    const int ws = w - W;
     // Row 0 and column 0 are swept only from a source that lies on them and read as zero otherwise.  (A field that is
     // known to hold +0.0 wherever the launch does not write -- the planner's loop -- holds it there as well.)
-    if (!a.dead_cells_are_zero && w == W - 1) {
+    if (!a.dead_cells_are_zero && ws == W - 1) {
       if (qo == 0 && sy > 0)
         for (int x0 = 0; x0 < a.m.nx; x0 += kLanes) g_store_scalar_if(lane + x0 < a.m.nx, field, lane + x0, OutT(0));
       if (qo == 1 && sx > 0)
         for (int y0 = 0; y0 < a.m.ny; y0 += kLanes) g_store_scalar_if(lane + y0 < a.m.ny, field, (lane + y0) * a.m.nx, OutT(0));
     }
     switch (qo) {
-      case 0: run_x<+1, +1>(unit, sx, sy, field); break;
-      case 1: run_y<+1, +1>(unit, sx, sy, field); break;
-      case 2: run_x<-1, +1>(unit, sx, sy, field); break;
-      case 3: run_y<-1, +1>(unit, sx, sy, field); break;
-      case 4: run_x<-1, -1>(unit, sx, sy, field); break;
-      case 5: run_y<-1, -1>(unit, sx, sy, field); break;
-      case 6: run_x<+1, -1>(unit, sx, sy, field); break;
-      default: run_y<+1, -1>(unit, sx, sy, field); break;
+      case 0: store<+1, +1, true>(ws, sx, sy, field); break;
+      case 1: store<+1, +1, false>(ws, sx, sy, field); break;
+      case 2: store<-1, +1, true>(ws, sx, sy, field); break;
+      case 3: store<-1, +1, false>(ws, sx, sy, field); break;
+      case 4: store<-1, -1, true>(ws, sx, sy, field); break;
+      case 5: store<-1, -1, false>(ws, sx, sy, field); break;
+      case 6: store<+1, -1, true>(ws, sx, sy, field); break;
+      default: store<+1, -1, false>(ws, sx, sy, field); break;
     }
   }
 };

@@ -24,25 +24,29 @@ __device__ unsigned long long g_latprof[256 * 16 * 20];
 __device__ unsigned long long g_lat_strip_times[64 * 48 * 4];
 #endif
 
+#ifdef VHP_LAT_STRIPS  // A/B builds only: the sweep in strips of rows (vhp_lat.hpp), what the kernel was until round 6
+template <typename OutT, bool ODD> using LatWorkerT = LatWorker<OutT, ODD>;
+#else
+template <typename OutT, bool ODD> using LatWorkerT = BandWorker<OutT, ODD>;
+#endif
+// wavefronts of a workgroup: kLatWaves sweepers and, in the band sweep, a storer beside each (16: four per SIMD, 128 vector registers)
+constexpr int kLatThreads = 64 * kLatWaves * LatWorkerT<double, false>::kRoles;
+
 template <typename OutT, bool ODD>
-__global__ void __launch_bounds__(64 * kLatWaves, 1) vhp_lat_sweep(LatArgs<OutT> a) {
+__global__ void __launch_bounds__(kLatThreads, 1) vhp_lat_sweep(LatArgs<OutT> a) {
   extern __shared__ double lds[];
   const Layout L = make_layout(kLatWaves, 1, a.m.nx, a.m.ny);
 #ifdef VHP_DIAG_POOLPROF
   const unsigned long long t_begin = wall_clock64();
 #endif
-#ifdef VHP_LAT_STRIPS  // A/B builds only: the sweep in strips of rows (vhp_lat.hpp), what the kernel was until round 6
-  using WorkerT = LatWorker<OutT, ODD>;
-#else
-  using WorkerT = BandWorker<OutT, ODD>;
-#endif
-  WorkerT::clear(lds, L, (int)threadIdx.x, 64 * kLatWaves);
+  using WorkerT = LatWorkerT<OutT, ODD>;
+  WorkerT::clear(lds, L, (int)threadIdx.x, kLatThreads);
   __syncthreads();
   WorkerT wk;
   wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
   wk.run((int)blockIdx.x);
 #ifdef VHP_DIAG_POOLPROF
-  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && threadIdx.x < 64 * 16) {
     unsigned long long* o = g_latprof + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 20;
     for (int k = 0; k < 16; ++k) o[k] = wk.prof[k];
     o[16] = t_begin;
@@ -127,7 +131,7 @@ hipError_t launch_lat_t(const BatchArgs& a) {
   { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_lat_strip_times)) == hipSuccess) g.strip_times = static_cast<unsigned long long*>(p); }
 #endif
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);
-  hipLaunchKernelGGL(k, dim3((unsigned)(a.n_src * kUnits)), dim3(64 * kLatWaves), lds, a.stream, g);
+  hipLaunchKernelGGL(k, dim3((unsigned)(a.n_src * kUnits)), dim3(kLatThreads), lds, a.stream, g);
   const hipError_t e = hipGetLastError();
   if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
   return e;
