@@ -204,6 +204,19 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value);
  * (vhp_lat_sweep), 0 = none yet.  For benchmarks and profiles. */
 int vhp_last_sweep_kernel(const vhp_ctx* ctx);
 
+/* The max-union of a batch of fields and the source that attains it, on the device: best[c] = max over k of field k at cell c,
+ * arg[c] = first_index + the lowest k that attains it (a sequential max-union that replaces on strict improvement only) -- the
+ * reference's union, src/visibilityBasedSolver.cpp:417-418 (visibility_global_ = max(visibility_, visibility_global_)), over a
+ * whole batch at once, with the label the planner derives from it (:419-423).  What a batch sharded over several devices exchanges
+ * instead of its fields (option 2: one union field and one label field per device).  d_fields: n_fields fields of nx * ny
+ * elements of `dtype` (the map's grid; "field_stride" elements apart as in vhp_sweep_batch_device); d_best: nx * ny elements of
+ * dtype; d_arg: nx * ny int32.  n_fields = 0: best = -1, arg = INT32_MAX everywhere.  One pass over the fields, no temporaries;
+ * asynchronous on the context's stream.
+ * vhp_union_partials_device: the same reduction over n_parts PARTIAL results -- d_bests: n_parts packed union fields, d_args: their
+ * n_parts packed label fields (e.g. the partials of all devices after an all-gather); a tie goes to the lowest label. */
+int vhp_union_fields_device(vhp_ctx* ctx, const void* d_fields, int n_fields, int dtype, int first_index, void* d_best, int32_t* d_arg);
+int vhp_union_partials_device(vhp_ctx* ctx, const void* d_bests, const int32_t* d_args, int n_parts, int dtype, void* d_best, int32_t* d_arg);
+
 /* A measurement aid, not part of the reference's surface (it has no device memory): the rate at which the memory behind a
  * device buffer takes two store patterns of a sweep launch, in TB/s of bytes stored -- 1 KB row pieces in many concurrent
  * streams, (a) every piece on the 128-byte line grid, (b) every other piece half a line off it, so that two lines per piece

@@ -13,7 +13,7 @@ t0 = time.time(); n = 0
 rng = np.random.RandomState(12345)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 900.0
 while time.time() - t0 < budget:
-    nx = int(rng.choice([8, 16, 40, 72, 104, 130, 200, 264, 328, 520, 640])); ny = int(rng.randint(1, 700))
+    nx = int(rng.choice([8, 16, 40, 72, 104, 130, 200, 264, 328, 520, 640, 9, 101, 263])); ny = int(rng.randint(1, 700))
     kind = rng.randint(0, 3)
     if kind == 0:
         occ = maps.random_rect_map(nx, ny, int(rng.randint(1, 40)), 1, max(nx // 6, 2), 1, max(ny // 6, 2), int(rng.randint(1, 1 << 20)))
@@ -25,12 +25,14 @@ while time.time() - t0 < budget:
     ns = int(rng.randint(1, 5))
     src = np.stack([rng.randint(0, nx, ns), rng.randint(0, ny, ns)], 1).astype(np.int32)
     occ[src[:, 1], src[:, 0]] = 1
-    W = int(rng.choice([2, 3, 4, 8, 12])); policy = int(rng.choice([0, 1, 2, 3, 4])) | int(rng.choice([0, 8, 16])); dt = np.float64 if rng.rand() < 0.7 else np.float32
-    got, st = sim_lib.lat_sweep(occ, src, dt, W=W, policy=policy, seed=int(rng.randint(0, 1000)))
+    W = int(rng.choice([1, 2, 3, 4, 8, 12])); policy = int(rng.choice([0, 1, 2, 3, 4])) | int(rng.choice([0, 8, 16])); dt = np.float64 if rng.rand() < 0.7 else np.float32
+    seed = int(rng.randint(0, 1000))
+    got, st = sim_lib.lat_sweep(occ, src, dt, W=W, policy=policy, seed=seed)
     assert st["deadlock"] == 0, (nx, ny, W, policy, st)
     for k, (sx, sy) in enumerate(src):
         want = orc.sweep_full(occ, int(sx), int(sy)).astype(dt)
         if got[k].tobytes() != want.tobytes():
-            print("MISMATCH", nx, ny, W, policy, src, kind); sys.exit(1)
+            print("MISMATCH", nx, ny, W, policy, src, kind)
+            np.savez("/tmp/fuzz_fail.npz", occ=occ, src=src, W=W, policy=policy, seed=seed, f32=(dt == np.float32)); sys.exit(1)
     n += 1
 print("ok: %d random cases, %.0f s" % (n, time.time() - t0))

@@ -50,3 +50,36 @@ def test_no_flat_and_no_scratch_instructions(tmp_path, src, kernel):
     for name in ks:
         m = re.search(r"\.name:\s*%s\n\s*\.private_segment_fixed_size:\s*(\d+)" % re.escape(name), asm)
         assert m and int(m.group(1)) == 0, "%s uses scratch memory" % name
+
+
+def test_latency_sweep_register_budget(tmp_path):
+    """The latency sweep's workgroup is sixteen wavefronts (a sweeper and a storer per band in flight: csrc/vhp_band.hpp): four per
+    SIMD, i.e. 128 vector registers each, with no scratch -- and its spilled scalars stay out of the window loops and few (the sweep
+    in strips of rows, until round 6, spilled 559-677 of them at 256 vector registers and two wavefronts per SIMD)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / "vhp_lat.s")
+    p = subprocess.run([HIPCC, "-std=c++17", "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                        "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "vhp_lat.hip"), "-Rpass-analysis=kernel-resource-usage"],
+                       stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, check=True)
+    blocks = re.split(r"remark: Function Name: ", p.stderr)[1:]
+    seen = 0
+    for blk in blocks:
+        name = blk.split()[0]
+        if "vhp_lat_sweep" not in name:
+            continue
+        seen += 1
+        get = lambda key: int(re.search(key + r":\s*(\d+)", blk).group(1))
+        assert get(r"\bVGPRs") <= 128, (name, get(r"\bVGPRs"))
+        assert get(r"ScratchSize \[bytes/lane\]") == 0, name
+        assert get(r"VGPRs Spill") == 0, name
+        assert get(r"Occupancy \[waves/SIMD\]") >= 4, name
+        assert get(r"SGPRs Spill") <= 240, (name, get(r"SGPRs Spill"))   # (139-209 at the end of round 6)
+    assert seen == 4, seen
+    # ... and none of the spilled scalars is reloaded inside a window's sixteen steps (the blocks that hold the arithmetic)
+    asm = open(out).read()
+    for name, body in _kernels(asm, "vhp_lat_sweep").items():
+        for blk in re.split(r"^\.LBB\d+_\d+:", body, flags=re.M):
+            fp64 = len(re.findall(r"v_(?:fma|mul|add|fmac)_f64", blk))
+            if fp64 >= 90:
+                assert not re.search(r"v_(?:readlane|writelane)_b32", blk), "%s: a spilled scalar inside a window's steps" % name

@@ -112,3 +112,17 @@ def test_lat_sim_maze_6_pivots(oracle):
     st = _check(oracle, occ, src, "maze_6", W=8, policy=POOL_ROUND_ROBIN | POOL_POINTS_ALWAYS, seed=1)
     assert st["died"] > 20 * len(src), st   # (most of the ~60 strips of a source die)
     _check(oracle, occ, src, "maze_6", W=8, policy=POOL_BURSTS | POOL_POINTS_RANDOM, seed=2)
+
+
+@pytest.mark.parametrize("nx,ny", [(16, 375), (8, 571), (375, 16), (9, 300), (40, 333)])
+def test_lat_sim_thin_salted_grids(oracle, nx, ny):
+    """Thin grids with half the cells blocked at random, sources anywhere: light that survives only in the sub-diagonal cell next to a
+    blocked diagonal cell (the stale diagonal, SURVEY Q1: diag(t) = V(t, t - 1) * occ(t, t)) must not be taken for a dead band -- a
+    fuzzing run found exactly that on a 16 x 375 map while band 0 kept the sub-diagonal in a register of its own."""
+    for seed in range(6):
+        rng = np.random.RandomState(1000 * nx + ny + seed)
+        occ = (rng.rand(ny, nx) >= 0.5).astype(np.uint8)
+        src = np.stack([rng.randint(0, nx, 3), rng.randint(0, ny, 3)], 1).astype(np.int32)
+        occ[src[:, 1], src[:, 0]] = 1
+        for W, policy, dtype in SHAPES[:3]:
+            _check(oracle, occ, src, "%dx%d salt seed %d W=%d" % (nx, ny, seed, W), dtype, W=W, policy=policy, seed=seed)

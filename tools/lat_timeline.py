@@ -34,7 +34,8 @@ t = np.array(c.timing_collect(64))
 print("latency sweep: ms min %.4f median %.4f" % (t.min(), np.median(t)))
 buf = np.zeros(256 * 16 * 20, np.uint64)
 assert mod._lib.vhp_debug_read_latprof(C.c_void_p(buf.ctypes.data), buf.size) == 0
-w = buf.reshape(256, 16, 20)[:8, :12].astype(np.float64)
+wall = buf.reshape(256, 16, 20)[:8].astype(np.float64)
+w = wall[:, :12]
 base = w[..., 16][w[..., 16] > 0].min()
 st = np.zeros(64 * 48 * 4, np.uint64)
 assert mod._lib.vhp_debug_read_lat_strip_times(C.c_void_p(st.ctypes.data), st.size) == 0
@@ -46,8 +47,11 @@ for u in range(8):
             r = w[u, v]
             nw = r[12] + r[13]
             if nw > 0 and r[12] == 0:   # the sweep in bands: one kind of window
-                print("   wave %2d: %3d windows of %5.0f cycles: operands %5.0f compute %5.0f read-out, ring, next request, stores %5.0f | asked the band below again %d times" % (
-                    v, r[13], r[14] / max(r[13], 1), r[8] / max(r[13], 1), r[9] / max(r[13], 1), r[10] / max(r[13], 1), r[7]))
+                print("   wave %2d: %3d windows of %5.0f cycles: operands %5.0f compute %5.0f (of it waiting for the storer %5.0f) request, publish, post %5.0f | asked the band below again %d times" % (
+                    v, r[13], r[14] / max(r[13], 1), r[8] / max(r[13], 1), r[9] / max(r[13], 1), r[11] / max(r[13], 1), r[10] / max(r[13], 1), r[7]))
+                rs = wall[u, v + 8]
+                if rs[12] > 0:
+                    print("      its storer: %3d records, %5.0f cycles each from record to last store, %5.0f waiting for the next record" % (rs[12], rs[15] / rs[12], rs[6] / rs[12]))
             elif nw > 0:
                 print("   wave %2d: %3d steady windows of %5.0f cycles, %2d diagonal of %5.0f; diagonal windows: operands %5.0f compute %5.0f tile reads + next request %5.0f stores %5.0f | whole strip %7.0f cycles, outside the windows %6.0f; asked the strip below again %d times" % (
                     v, r[12], r[15] / max(r[12], 1), r[13], r[14] / max(r[13], 1), r[8] / max(r[13], 1), r[9] / max(r[13], 1), r[10] / max(r[13], 1), r[11] / max(r[13], 1), r[2], r[2] - r[15] - r[14], r[7]))

@@ -43,6 +43,7 @@ ABI_SYMBOLS = (
     "vhp_last_elapsed_ms", "vhp_version", "vhp_sweep_batch_offset", "vhp_planner_solve_speculative", "vhp_probe_stores", "vhp_alloc_output", "vhp_alloc_output_cost", "vhp_free_output",
     "vhp_multi_create", "vhp_multi_destroy", "vhp_multi_last_error", "vhp_multi_devices", "vhp_multi_context", "vhp_multi_shard_bounds",
     "vhp_multi_set_map", "vhp_multi_sweep_batch", "vhp_multi_allgather_fields", "vhp_multi_allgather_plan", "vhp_multi_use_rccl",
+    "vhp_union_fields_device", "vhp_union_partials_device", "vhp_multi_union_fields",
 )
 
 
@@ -170,6 +171,15 @@ class Context:
     def sweep_batch_device(self, d_src, n_src, d_out, variant=SWEEP_FULL, dtype=F64):
         """Device-resident, asynchronous on the context stream.  d_src / d_out are raw device pointers."""
         self._check(self.lib.vhp_sweep_batch_device(self.h, C.c_void_p(d_src), n_src, variant, dtype, C.c_void_p(d_out)))
+
+    def union_fields_device(self, d_fields, n_fields, d_best, d_arg, first_index=0, dtype=F64):
+        """Max-union of n_fields device-resident fields and the (lowest) source index that attains it, into d_best / d_arg (int32);
+        raw device pointers, asynchronous on the context stream (include/vhp.h vhp_union_fields_device)."""
+        self._check(self.lib.vhp_union_fields_device(self.h, C.c_void_p(d_fields), n_fields, dtype, first_index, C.c_void_p(d_best), C.c_void_p(d_arg)))
+
+    def union_partials_device(self, d_bests, d_args, n_parts, d_best, d_arg, dtype=F64):
+        """The same reduction over partial unions with their label fields (vhp_union_partials_device)."""
+        self._check(self.lib.vhp_union_partials_device(self.h, C.c_void_p(d_bests), C.c_void_p(d_args), n_parts, dtype, C.c_void_p(d_best), C.c_void_p(d_arg)))
 
     def sync(self):
         self._check(self.lib.vhp_sync(self.h))

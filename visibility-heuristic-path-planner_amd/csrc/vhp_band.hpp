@@ -126,6 +126,11 @@ struct BandX {
   vi dgw;      // word 0 of the lane's run in dm (clamped into the map)
   vb dg_ok;    // ... which exists
   vd prev, jd; // jd = t - d of the next step
+  uint64_t dg_ow;              // band 0: the occupancy word of the DIAGONAL's run for the current block (see window)
+  int dg_w0;                   // ... whose word 0 in dm this is
+  int m_prev;                  // ... and the diagonal cell's occupancy at the step before the next one, as a mask (0 / -1)
+  vb lane0;
+  int ring_rel;                // where lane 63 writes instead of into the tile: the band's ring, as an index from `tile`
   vu64 ow, ow_nx;
   vd rv_nx;
   Below<DX, kLW> nx;
@@ -153,13 +158,16 @@ struct BandX {
     // says it is dead (the reader's zeros: Below::accept).
     retires = has_consumer && t_last < i_last;
     t_end = retires ? t_last + 1 : t_last;
+    lane0 = lane == 0;
     {
-      // the lane's run: y - s x = sy - s sx - DY d
-      const vi d = lane + D0;
+      // the lane's run: y - s x = sy - s sx - DY d.  (Band 0's lane 0 carries the SUB-diagonal cell, distance 1 like lane 1: window)
+      const vi d = b == 0 ? vmax(lane, 1) : lane + D0;
       const vi id = kMain ? (-d) * DY + (sy - sx + m.nx - 1) : (-d) * DY + (sy + sx);
       dg_ok = (id >= 0) && (id < DiagMaps::runs(m.nx, m.ny));
       dgw = vmin(vmax(id, 0), DiagMaps::runs(m.nx, m.ny) - 1) * wpd;
+      dg_w0 = (kMain ? sy - sx + m.nx - 1 : sy + sx) * wpd;   // (the diagonal's run, d = 0: the source lies on it)
     }
+    ring_rel = has_consumer ? (int)(lk.ring - tile) : (kBlock - 1) * kTStride;
     dead_mine = sh.owner(0) + b;
     dead_below = sh.owner(0) + (b > 0 ? b - 1 : b);
     skip_fill = false;
@@ -171,12 +179,16 @@ struct BandX {
 #pragma unroll
     for (int k = 0; k < kLW; ++k) nx.v[k] = vd(0.0);
     prev = vd(0.0);
+    dg_ow = 0;
+    m_prev = -1;
     pf_blk = -1;
     pf_wait = false;
     staged_blk = -0x7fffffff;
     blk = -0x7fffffff;
   }
 
+  // the occupancy word of the diagonal's run for block blk_ (band 0 only; a uniform load, once per 64 steps)
+  VHP_FN uint64_t load_diag(int blk_) const { return b == 0 ? dm[(long)dg_w0 + (1 + blk_)] : 0; }
   // the occupancy word of every lane's run and the reciprocals of the step indices of the 64 coordinates of block blk_ (x >> 6)
   VHP_FN void load_ops(int blk_, vu64& o, vd& rv) {
     o = select(dg_ok, g_load_u64(dm, dgw + (1 + blk_)), vu64(0));
@@ -201,6 +213,7 @@ struct BandX {
   VHP_FN void enter_block(int b_) {
     if (pf_blk == b_) { stage_next(); ow = ow_nx; }
     else { vd rv; load_ops(b_, ow, rv); pin(ow); pin(rv); stage(b_, rv); }
+    dg_ow = load_diag(b_);
     blk = b_;
     if (block_in_march(b_ + DX)) prefetch_ops(b_ + DX); else pf_blk = -1;
   }
@@ -212,12 +225,17 @@ struct BandX {
     }
   }
 
-  // One window: steps ta + k, k = 0 .. 15, at x = xw + (k marching up, 15 - k marching down).  B0: band 0, whose lane 0 is the
-  // diagonal -- diag(t) = the sub-diagonal cell of the same step (lane 1's new value) times its own occupancy.  A lane
-  // whose cell does not exist yet has a negative numerator: clamped to 0, it copies its neighbour.  A window that sticks out of the
-  // march (before step 0, past the last) is swept like any other: the reciprocal of a step that does not exist is 0.  The source
-  // itself needs no step of its own either (origin_bits).  more: the next window belongs to the march.
-  // (ONE loop of windows per march, whatever the window's kind: a loop per kind, as the strips had, keeps a copy of the 32 operand
+  // One window: steps ta + k, k = 0 .. 15, at x = xw + (k marching up, 15 - k marching down).  A lane whose cell does not exist yet
+  // has a negative numerator: clamped to 0, it copies its neighbour.  A window that sticks out of the march (before step 0, past the
+  // last) is swept like any other: the reciprocal of a step that does not exist is 0.  The source itself needs no step of its own
+  // either (origin_bits).  more: the next window belongs to the march.
+  // B0: band 0.  The diagonal cell is the sub-diagonal cell of the same step, S(t) = V(t, t - 1), times its own occupancy (the stale
+  // diagonal), and S(t) = stencil(a = diag(t - 1), b = S(t - 1), c = (t - 1) / t) times ITS occupancy: a two-term recurrence
+  // in S alone, because diag(t - 1) = S(t - 1) times an occupancy bit.  Lane 0 of band 0 therefore carries S, not the diagonal: it is a
+  // lane at distance 1 like lane 1 (same run, same ratio) whose neighbour `a` is its own last value under the diagonal's occupancy bit
+  // of that step (a scalar word) -- and the same masked value is what lane 1 takes from it.  Three more instructions per step, one of
+  // them in the chain.  The diagonal cells themselves are the storer's: lane 0's row of the tile under the diagonal's occupancy bits.
+  // (ONE loop of windows per march, whatever the window's kind: a loop per kind, as the strips had, keeps a copy of the operand
   // registers per loop and spills them where the loops meet.  The window's operands have been requested: by run() for the band's
   // first window, by the window before for every other -- unconditionally, so that none of those registers outlives its band.)
   template <bool B0>
@@ -228,10 +246,14 @@ struct BandX {
     VHP_WP_ADDP(lk.pp, 8, tw0);
     VHP_WP_T0(tw1);
     const vu32 hs = half_shifted(ow, xw & 63, xw & 31);  // the window's 16 occupancy bits: bit c = the lane's cell at x = xw + c
+    const uint32_t hd = (uint32_t)(dg_ow >> (xw & 63));  // ... and the diagonal's (band 0)
     int tk = lds_peek(po->post + kPostTaken);            // has the storer read the tile of the window before out?  (looked at below)
+    // lane 63's values are what the band above reads: that lane writes them into the band's ring instead of into the tile (the storer
+    // looks there for them), so the ring costs the sweeper no read-back of the tile
+    const vi tl = select(lane == kLanes - 1, vi(ring_rel + (has_consumer ? (xw & (kRing - 1)) : 0)), tile_l);
     vd di = vd((double)ta);
-    // the reciprocals of the step indices come out of the slab two steps ahead of their use (sixteen of them held in registers from
-    // the request on were 32 registers that the workgroup's sixteen wavefronts do not have)
+    // the reciprocals of the step indices come out of the slab a pair at a time, two steps ahead of their use (sixteen of them held in
+    // registers from the request on were 32 registers that the workgroup's sixteen wavefronts do not have)
     const double* rslab = slab + (xw & (2 * kBlock - 1));
     vd rr[kLW];
     rr[0] = lds_bcast(rslab, DX > 0 ? 0 : kLW - 1);
@@ -240,20 +262,28 @@ struct BandX {
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DX > 0 ? k : kLW - 1 - k;
-      if (k + 2 < kLW) rr[k + 2] = lds_bcast(rslab, DX > 0 ? k + 2 : kLW - 3 - k);
-      const vd a = shift_up(prev, below ? nx.v[k] : vd(0.0));
-      const vi mk = sbfe1(hs, c);
-      vd v = and_mask(stencil(a, prev, cc), mk);
-      if (B0) {
-        const vd up = shift_down(v, v);
-        v = select(lane == 0, and_mask(up, mk), v);
+      if ((k & 1) == 0 && k + 2 < kLW) {
+        rr[k + 2] = lds_bcast(rslab, DX > 0 ? k + 2 : kLW - 3 - k);
+        rr[k + 3] = lds_bcast(rslab, DX > 0 ? k + 3 : kLW - 4 - k);
       }
+      vd a;
+      if (B0) {
+        const vd gm = and_mask(prev, select(lane0, vi(m_prev), vi(-1)));  // lane 0: S(t - 1) under the diagonal's bit = diag(t - 1)
+        a = shift_up(gm, gm);
+        m_prev = ((hd >> c) & 1u) ? -1 : 0;
+      } else {
+        a = shift_up_into(nx.v[k], prev);  // (the band below's value of this step, in lane 0; read for this step only)
+      }
+      const vi mk = sbfe1(hs, c);
+      const vd v = and_mask(stencil(a, prev, cc), mk);
       prev = v;
       if (k == 0) {  // (the first write to the tile: after the step's arithmetic, which has hidden the look at the storer's word)
+        VHP_WP_T0(tw4);
         while (!po->taken(uniform(tk))) { ready_backoff(); sim_point(); tk = lds_peek(po->post + kPostTaken); }
         lds_acquire();
+        VHP_WP_ADDP(lk.pp, 11, tw4);
       }
-      lds_store(tile, tile_l + c, v);
+      lds_store(tile, tl + c, v);
       di = di + 1.0;
       jd = jd + 1.0;
       if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), di, rr[k + 1]);  // the next step's ratio beside this step's chain, and no further ahead
@@ -264,21 +294,16 @@ struct BandX {
 #endif
     VHP_WP_ADDP(lk.pp, 9, tw1);
     VHP_WP_T0(tw2);
-    // ---- the last lane's values go to the ring, the tile to the storer ----
-    if (has_consumer) {
-      wave_sync();
-      const vd bv = lds_load(tile, (lane & (kLW - 1)) + (kBlock - 1) * kTStride);  // lane 63: what the band above reads
-      lds_store(lk.ring, (lane & (kLW - 1)) + (xw & (kRing - 1)), bv);
-      lk.publish(retires ? ta + kLW : ta + k_hi + 1);  // (a band that retires: its reader's window reaches past its own last step)
-    }
-    po->send(ta, xw, b, 0);
-    sim_progress();
+    // ---- the next window's operands are asked for, the band above is told, the tile goes to the storer ----
     if (more) {
       const int xn = xw + kLW * DX;
       const bool other = (xn >> 6) != (xw >> 6);  // the next window opens the next block
       if (other) stage_next();
       request(xn, other ? nb + 1 : nb);
     }
+    if (has_consumer) lk.publish(retires ? ta + kLW : ta + k_hi + 1);  // (a band that retires: its reader's window reaches past its own last step)
+    po->send(ta, xw, b, 0);
+    sim_progress();
     VHP_WP_ADDP(lk.pp, 10, tw2);
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
     VHP_WP_ADDP(lk.pp, 14, tw0); lk.pp[13] += 1;
@@ -304,21 +329,22 @@ struct BandX {
     }
   }
   // Band 0 starts at the source, whose value is 1.0 times its occupancy (solver.cpp:583-585) -- by data, not by a step of its own:
-  // the diagonal lane starts from 1.0, and in the steps of the first window that lie before the source (they do not exist: every
-  // lane copies) the diagonal's and the sub-diagonal's cells read as free, so that the 1.0 comes through to step 0, where the
-  // diagonal cell takes it times its own occupancy.  (The sub-diagonal's cell of step 0 does not exist either: free as well.)
+  // lane 0 starts from S = 1.0, and in the steps of the first window that lie before the source (they do not exist) the diagonal's
+  // and the sub-diagonal's cells read as free, and so does the sub-diagonal's cell of step 0 (it does not exist either): S is still
+  // 1.0 after step 0, the storer's diagonal cell of step 0 is 1.0 under the source's own occupancy bit, and so is diag(0) in step 1.
   VHP_FN void origin_bits(int xw) {
     const int s0 = g.sx & 63, w0 = xw & 63;
     // bits of the coordinates of the steps before step 0 in the window (marching up: below the source; marching down: above it)
     const uint64_t before = DX > 0 ? ((1ull << s0) - 1) & ~((1ull << w0) - 1) : ((w0 + kLW == 64 ? 0ull : 1ull << (w0 + kLW)) - 1) & ~((2ull << s0) - 1);
-    ow = ow | select(lane == 0, vu64(before), select(lane == 1, vu64(before | (1ull << s0)), vu64(0)));
-    prev = select(lane == 0, vd(1.0), vd(0.0));
+    ow = ow | select(lane0, vu64(before | (1ull << s0)), vu64(0));
+    dg_ow |= before;
+    prev = select(lane0, vd(1.0), vd(0.0));
   }
 
   VHP_FN void run() {
     int xw = g.X(D0) & ~(kLW - 1);
     int ta = DX > 0 ? xw - g.sx : g.sx - (xw + kLW - 1);
-    jd = to_f64((-lane) + (ta - D0));
+    jd = to_f64((-(b == 0 ? vmax(lane, 1) : lane + D0)) + ta);
     if (below) nx.hd = lds_poll(dead_below);  // (a band that starts above a dead band need not sweep a window to find out)
     enter_block(xw >> 6);
     bool dead = below && lds_poll(dead_mine) != 0;  // (a band below died before this one could start, and said so for it)
@@ -384,14 +410,18 @@ struct BandXStore {
   Quad<DX, DY> g;
   OutT* out;
   const double* tile;
-  int nxm, rows_total, i_last;
+  int nxm, rows_total, i_last, ring_rel;
+  const uint64_t* dg_run;   // the diagonal's run in the packed map (by x): band 0's lane 0 carries the sub-diagonal cell, the diagonal
+                            // cell is that value under the diagonal's own occupancy bit (BandX::window)
   vi lane, fl_a, fl_l, fl_rj, fl_c;
   vu32 fl_off;
 
-  VHP_FN void init(const Map& m, int sx, int sy, OutT* out_, const double* tile_) {
+  VHP_FN void init(const Map& m, const uint64_t* dmap, int sx, int sy, OutT* out_, const double* tile_, const double* ring_) {
     g.init(m.nx, m.ny, sx, sy);
     out = out_;
     tile = tile_;
+    ring_rel = (int)(ring_ - tile_);
+    dg_run = dmap + DiagMaps::offset(m.nx, m.ny, DX * DY > 0 ? 0 : 1) + (long)(DX * DY > 0 ? sy - sx + m.nx - 1 : sy + sx) * DiagMaps::wpdx(m.nx);
     nxm = m.nx;
     rows_total = g.rows_total;
     i_last = g.ni - 1;
@@ -445,6 +475,8 @@ struct BandXStore {
   // LDS executes in that order), then stored
   VHP_FN void flush(int b, int ta, int xw, int* taken, int seq) {
     const int D0 = kBlock * b;
+    // (the last lane's row is in the band's ring if a band above reads it: BandX::window)
+    const int row63 = b + 1 < Geo::n_bands(g) ? ring_rel + (xw & (kRing - 1)) : (kBlock - 1) * kTStride;
     wave_sync();
     vd fa[10], fb[10];
 #pragma unroll
@@ -454,11 +486,22 @@ struct BandXStore {
         fb[u] = lds_load(tile, fl_a + ((DX > 0 ? kTStride + 1 : 0) + (7 - u) * (8 * kTStride)));
       } else {  // (the lanes of the two ends of the parallelogram that have no cell read the nearest row of the tile instead of what lies beside it)
         const vi la = vmin(vmax(fl_l - 8 * u, 0), kBlock - 1), lb = vmin(vmax(fl_l + ((DX > 0 ? 1 : -1) - 8 * u), 0), kBlock - 1);
-        fa[u] = lds_load(tile, la * kTStride + fl_c);
-        fb[u] = lds_load(tile, lb * kTStride + (fl_c + 1));
+        fa[u] = lds_load(tile, select(la == kBlock - 1, vi(row63), la * kTStride) + fl_c);
+        fb[u] = lds_load(tile, select(lb == kBlock - 1, vi(row63), lb * kTStride) + (fl_c + 1));
       }
     }
     lds_publish(taken, seq);
+    if (b == 0) {
+      // the diagonal cells: lane 0's values (the groups 7 .. 9 hold them) under the diagonal's occupancy bits of the window
+      const vu64 dbits = vu64(dg_run[1 + (xw >> 6)] >> (xw & 63));
+      const vi bm0 = bit_mask_lane(dbits, fl_c), bm1 = bit_mask_lane(dbits, fl_c + 1);
+#pragma unroll
+      for (int u = 7; u < 10; ++u) {
+        const vi la = fl_l - 8 * u, lb = DX > 0 ? la + 1 : la - 1;
+        fa[u] = and_mask(fa[u], select(la == 0, bm0, vi(-1)));
+        fb[u] = and_mask(fb[u], select(lb == 0, bm1, vi(-1)));
+      }
+    }
     if (interior(D0, ta)) store_window<true>(D0, ta, xw, fa, fb); else store_window<false>(D0, ta, xw, fa, fb);
   }
   // the zeros of what is left of band b's march from the window at ta on
@@ -475,21 +518,20 @@ struct BandXStore {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// y-major band b of a unit: lanes d' = 64 b - 1 + lane (distance j - i from the diagonal), steps t = row index j; the lane's cell of
-// step t is (i, j) = (t - d', t): the 64 cells of a step are adjacent cells of one row.  Band 0's lane 0 (d' = -1) is the
-// sub-diagonal cell (t, t - 1) of the x-major octant and its lane 1 the diagonal: the octant runs the two-term recurrence for
-// itself.  Cells exist for max(d', 0) <= t <= min(nj - 1, d' + ni - 1); the sub-diagonal lane stores nothing.
-// The tile of a window: 16 rows (steps, in marching order) of 64 lanes.
+// y-major band b of a unit: lanes d' = 64 b + lane (distance j - i from the diagonal), steps t = row index j; the lane's cell of
+// step t is (i, j) = (t - d', t): the 64 cells of a step are adjacent cells of one row.  Band 0's lane 0 is the diagonal (stored
+// again here), run by the same private two-term recurrence as in BandX: both octants of a quadrant compute their diagonal for
+// themselves, nobody seeds anybody.  Cells exist for d' <= t <= min(nj - 1, d' + ni - 1).
 // ---------------------------------------------------------------------------------------------------------------
 template <int DX, int DY>
 struct BandYGeo {
-  static VHP_FN int n_bands(const Quad<DX, DY>& q) { return (q.ni > 0 && q.nj > 1) ? (q.nj + kBlock) / kBlock : 0; }
+  static VHP_FN int n_bands(const Quad<DX, DY>& q) { return (q.ni > 0 && q.nj > 1) ? (q.nj + kBlock - 1) / kBlock : 0; }
   static VHP_FN int first_window(const Quad<DX, DY>& q, int b_) {
-    const int yw = q.Y(imax(kBlock * b_ - 1, 0)) & ~(kLW - 1);
+    const int yw = q.Y(kBlock * b_) & ~(kLW - 1);
     return DY > 0 ? yw - q.sy : q.sy - (yw + kLW - 1);
   }
   // lane 63's cell of the octant's last column
-  static VHP_FN int t_last(const Quad<DX, DY>& q, int b_) { return imin(q.nj - 1, kBlock * b_ - 1 + kBlock - 1 + q.ni - 1); }
+  static VHP_FN int t_last(const Quad<DX, DY>& q, int b_) { return imin(q.nj - 1, kBlock * b_ + kBlock - 1 + q.ni - 1); }
 };
 
 template <int DX, int DY>
@@ -500,7 +542,7 @@ struct BandY {
   const uint64_t* dm;  // the packed runs of this quadrant's kind, by y
   int wpd;
   Quad<DX, DY> g;
-  double* tile;
+  double* tile;   // 64 lanes x 16 rows (pitch kTStride): column c = y - (lowest y of the window)
   double* slab;
   double* bin;
   Link<DY> lk;
@@ -512,10 +554,15 @@ struct BandY {
   int* dead_mine;
   const int* dead_below;
   bool skip_fill;
-  vi lane;
+  vi lane, tile_l;
   vi dgw;
   vb dg_ok;
   vd prev, jd;
+  uint64_t dg_ow;              // band 0: the occupancy word of the diagonal's run (see BandX)
+  int sub_w0, dg_w0;           // ... and where lane 0's run (the sub-diagonal's: load_sub) and the diagonal's start in dm
+  int m_prev;
+  vb lane0;
+  int ring_rel;
   vu64 ow, ow_nx;
   vd rv_nx;
   Below<DY, kLW> nx;
@@ -530,8 +577,9 @@ struct BandY {
     slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
     bin = lk.bin;
     lane = lane_id();
+    tile_l = lane * kTStride;
     b = b_;
-    D0 = kBlock * b - 1;
+    D0 = kBlock * b;
     j_last = g.nj - 1;
     t_last = Geo::t_last(g, b);
     below = b > 0;
@@ -544,7 +592,14 @@ struct BandY {
       const vi id = kMain ? d * DY + (sy - sx + m.nx - 1) : d * DY + (sy + sx);
       dg_ok = (id >= 0) && (id < DiagMaps::runs(m.nx, m.ny));
       dgw = vmin(vmax(id, 0), DiagMaps::runs(m.nx, m.ny) - 1) * wpd;
+      // (the sub-diagonal's run, d' = -1: the cells (t, t - 1) of the x-major octant -- what band 0's lane 0 carries, BandX::window)
+      const int id1 = kMain ? -DY + (sy - sx + m.nx - 1) : -DY + (sy + sx);
+      sub_w0 = imin(imax(id1, 0), DiagMaps::runs(m.nx, m.ny) - 1) * wpd;
+      if (id1 < 0 || id1 >= DiagMaps::runs(m.nx, m.ny)) sub_w0 = -1;
+      dg_w0 = (kMain ? sy - sx + m.nx - 1 : sy + sx) * wpd;
     }
+    lane0 = lane == 0;
+    ring_rel = has_consumer ? (int)(lk.ring - tile) : (kBlock - 1) * kTStride;
     dead_mine = sh.owner(0) + b;
     dead_below = sh.owner(0) + (b > 0 ? b - 1 : b);
     skip_fill = false;
@@ -556,21 +611,24 @@ struct BandY {
 #pragma unroll
     for (int k = 0; k < kLW; ++k) nx.v[k] = vd(0.0);
     prev = vd(0.0);
+    dg_ow = 0;
+    m_prev = -1;
     pf_blk = -1;
     pf_wait = false;
     staged_blk = -0x7fffffff;
     blk = -0x7fffffff;
   }
 
+  // The occupancy word of the sub-diagonal's run for block blk_ (band 0 only; uniform loads).  The sub-diagonal's cell of step t lies
+  // in the row of step t - 1 -- one bit behind in its run, where every lane's cell is at the step's own y: the word is shifted by it.
+  VHP_FN uint64_t load_sub(int blk_) const {
+    if (b != 0 || sub_w0 < 0) return 0;
+    const uint64_t o = dm[(long)sub_w0 + (1 + blk_)], o2 = dm[(long)sub_w0 + (1 + blk_ - DY)];
+    return DY > 0 ? (o << 1) | (o2 >> 63) : (o >> 1) | (o2 << 63);
+  }
+  VHP_FN uint64_t load_diag(int blk_) const { return b == 0 ? dm[(long)dg_w0 + (1 + blk_)] : 0; }
   VHP_FN void load_ops(int blk_, vu64& o, vd& rv) {
     o = select(dg_ok, g_load_u64(dm, dgw + (1 + blk_)), vu64(0));
-    if (b == 0) {
-      // band 0's sub-diagonal lane: its cell of step t lies in the row of step t - 1 -- one bit behind in its run, where every
-      // other lane's cell is at the step's own y
-      const vu64 o2 = select(dg_ok, g_load_u64(dm, dgw + (1 + blk_ - DY)), vu64(0));
-      const vu64 sh = DY > 0 ? (o << uint64_t(1)) | (o2 >> uint64_t(63)) : (o >> uint64_t(1)) | (o2 << uint64_t(63));
-      o = select(lane == 0, sh, o);
-    }
     const vi jt = (lane + (blk_ * 64 - g.sy)) * DY;
     const vb ok = (jt >= 0) && (jt < g.nj);
     rv = select(ok, g_load_f64(m.recip, select(ok, jt, vi(0))), vd(0.0));
@@ -592,6 +650,10 @@ struct BandY {
   VHP_FN void enter_block(int b_) {
     if (pf_blk == b_) { stage_next(); ow = ow_nx; }
     else { vd rv; load_ops(b_, ow, rv); pin(ow); pin(rv); stage(b_, rv); }
+    if (b == 0) {  // (lane 0 carries the sub-diagonal cell; uniform loads, once per 64 steps)
+      ow = select(lane0, vu64(load_sub(b_)), ow);
+      dg_ow = load_diag(b_);
+    }
     blk = b_;
     if (block_in_march(b_ + DY)) prefetch_ops(b_ + DY); else pf_blk = -1;
   }
@@ -601,14 +663,15 @@ struct BandY {
     }
   }
 
-  // One window: steps ta + k, k = 0 .. 15, at y = yw + (k marching up, 15 - k marching down).  B0: see BandX::window (here band 0's
-  // lane 0 is the sub-diagonal -- its neighbour the diagonal sits one lane UP -- and lane 1 the diagonal).
+  // One window: steps ta + k, k = 0 .. 15, at y = yw + (k marching up, 15 - k marching down): BandX::window with x and y exchanged.
   template <bool B0>
   VHP_FN void window(int ta, int yw, int nb, bool more) {
     const int k_hi = imin(kLW - 1, t_end - ta);
-    if (below) nx.accept(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, ta, ta + k_hi - 1, nb);  // (requested: see BandX::window)
+    if (below) nx.accept(lk, dead_below, bin, yw, DY > 0 ? yw : yw + kLW - 1, ta, ta + k_hi - 1, nb);
     const vu32 hs = half_shifted(ow, yw & 63, yw & 31);
+    const uint32_t hd = (uint32_t)(dg_ow >> (yw & 63));
     int tk = lds_peek(po->post + kPostTaken);
+    const vi tl = select(lane == kLanes - 1, vi(ring_rel + (has_consumer ? (yw & (kRing - 1)) : 0)), tile_l);
     vd dj = vd((double)ta);
     const double* rslab = slab + (yw & (2 * kBlock - 1));
     vd rr[kLW];
@@ -618,42 +681,40 @@ struct BandY {
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DY > 0 ? k : kLW - 1 - k;
-      if (k + 2 < kLW) rr[k + 2] = lds_bcast(rslab, DY > 0 ? k + 2 : kLW - 3 - k);
-      vd a = shift_up(prev, below ? nx.v[k] : vd(0.0));
-      if (B0) a = select(lane == 0, shift_down(prev, prev), a);
-      const vi mk = sbfe1(hs, c);
-      vd v = and_mask(stencil(a, prev, cc), mk);
-      if (B0) {
-        const vd up = shift_up(v, v);
-        v = select(lane == 1, and_mask(up, mk), v);
+      if ((k & 1) == 0 && k + 2 < kLW) {
+        rr[k + 2] = lds_bcast(rslab, DY > 0 ? k + 2 : kLW - 3 - k);
+        rr[k + 3] = lds_bcast(rslab, DY > 0 ? k + 3 : kLW - 4 - k);
       }
+      vd a;
+      if (B0) {
+        const vd gm = and_mask(prev, select(lane0, vi(m_prev), vi(-1)));
+        a = shift_up(gm, gm);
+        m_prev = ((hd >> c) & 1u) ? -1 : 0;
+      } else {
+        a = shift_up_into(nx.v[k], prev);
+      }
+      const vi mk = sbfe1(hs, c);
+      const vd v = and_mask(stencil(a, prev, cc), mk);
       prev = v;
       if (k == 0) {
         while (!po->taken(uniform(tk))) { ready_backoff(); sim_point(); tk = lds_peek(po->post + kPostTaken); }
         lds_acquire();
       }
-      lds_store(tile, lane + kLanes * k, v);
+      lds_store(tile, tl + c, v);
       dj = dj + 1.0;
       jd = jd + 1.0;
       if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), dj, rr[k + 1]);
       sched_fence();
     }
-    if (has_consumer) {
-      wave_sync();
-      // lane 63's values, in the order of the coordinate: what the band above reads
-      const vi kk = DY > 0 ? (lane & (kLW - 1)) : (-(lane & (kLW - 1))) + (kLW - 1);
-      const vd bv = lds_load(tile, kk * kLanes + (kLanes - 1));
-      lds_store(lk.ring, (lane & (kLW - 1)) + (yw & (kRing - 1)), bv);
-      lk.publish(retires ? ta + kLW : ta + k_hi + 1);
-    }
-    po->send(ta, yw, b, 0);
-    sim_progress();
     if (more) {
       const int yn = yw + kLW * DY;
       const bool other = (yn >> 6) != (yw >> 6);
       if (other) stage_next();
       request(yn, other ? nb + 1 : nb);
     }
+    if (has_consumer) lk.publish(retires ? ta + kLW : ta + k_hi + 1);
+    po->send(ta, yw, b, 0);
+    sim_progress();
   }
 
   VHP_FN void open_block(int yw, int ta) {
@@ -674,22 +735,19 @@ struct BandY {
       sim_point();
     }
   }
-  // (see BandX::origin_bits; here lane 1 is the diagonal and lane 0 the sub-diagonal, whose word is one bit behind: load_ops)
+  // (see BandX::origin_bits)
   VHP_FN void origin_bits(int yw) {
     const int s0 = g.sy & 63, w0 = yw & 63;
     const uint64_t before = DY > 0 ? ((1ull << s0) - 1) & ~((1ull << w0) - 1) : ((w0 + kLW == 64 ? 0ull : 1ull << (w0 + kLW)) - 1) & ~((2ull << s0) - 1);
-    ow = ow | select(lane == 1, vu64(before), select(lane == 0, vu64(before | (1ull << s0)), vu64(0)));
-    prev = select(lane == 1, vd(1.0), vd(0.0));
+    ow = ow | select(lane0, vu64(before | (1ull << s0)), vu64(0));
+    dg_ow |= before;
+    prev = select(lane0, vd(1.0), vd(0.0));
   }
 
   VHP_FN void run() {
-    int yw = g.Y(imax(D0, 0)) & ~(kLW - 1);
+    int yw = g.Y(D0) & ~(kLW - 1);
     int ta = DY > 0 ? yw - g.sy : g.sy - (yw + kLW - 1);
-    {
-      // the ratio's numerator: t - d' (band 0's sub-diagonal lane: t - 1, the cell (t, t - 1) of the x-major octant)
-      const vi d = lane + D0;
-      jd = to_f64((-select(d >= 0, d, vi(1))) + ta);
-    }
+    jd = to_f64((-(b == 0 ? vmax(lane, 1) : lane + D0)) + ta);
     if (below) nx.hd = lds_poll(dead_below);
     enter_block(yw >> 6);
     bool dead = below && lds_poll(dead_mine) != 0;
@@ -713,7 +771,7 @@ struct BandY {
     }
   }
   VHP_FN void announce_death(int s) {
-    if ((b + 1) * kBlock - 1 <= s + 1) return;
+    if ((b + 1) * kBlock <= s + 1) return;
     const int n = Geo::n_bands(g);
     int* dead_base = dead_mine - b;
     int* prog_base = lk.prog - b;
@@ -740,19 +798,21 @@ struct BandY {
 template <int DX, int DY, typename OutT>
 struct BandYStore {
   static constexpr int CB = sizeof(OutT);
-  static constexpr int kNever = 0x7fffffff;
   using Geo = BandYGeo<DX, DY>;
   Quad<DX, DY> g;
   OutT* out;
   const double* tile;
-  int nxm, j_last;
+  int nxm, j_last, ring_rel;
+  const uint64_t* dg_run;   // the diagonal's run in the packed map (by y): see BandXStore
   vi lane;
   vu32 xoff;
 
-  VHP_FN void init(const Map& m, int sx, int sy, OutT* out_, const double* tile_) {
+  VHP_FN void init(const Map& m, const uint64_t* dmap, int sx, int sy, OutT* out_, const double* tile_, const double* ring_) {
     g.init(m.nx, m.ny, sx, sy);
     out = out_;
     tile = tile_;
+    ring_rel = (int)(ring_ - tile_);
+    dg_run = dmap + DiagMaps::offset(m.nx, m.ny, DX * DY > 0 ? 2 : 3) + (long)(DX * DY > 0 ? sy - sx + m.nx - 1 : sy + sx) * DiagMaps::wpdy(m.ny);
     nxm = m.nx;
     j_last = g.nj - 1;
     lane = lane_id();
@@ -764,43 +824,51 @@ struct BandYStore {
     const long x0 = DX > 0 ? (long)g.X(t) - (D0 + kLanes - 1) : (long)g.X(t) + D0;
     return out + (long)g.Y(t) * (long)nxm + x0;
   }
-  // every lane (band 0: but the sub-diagonal's) has a cell in every step of the window at ta
-  VHP_FN bool interior(int D0, int ta) const { return ta >= D0 + kLanes - 1 && ta + kLW - 1 <= imin(j_last, imax(D0, 0) + g.ni - 1); }
+  // every lane has a cell in every step of the window at ta
+  VHP_FN bool interior(int D0, int ta) const { return ta >= D0 + kLanes - 1 && ta + kLW - 1 <= imin(j_last, D0 + g.ni - 1); }
 
-  VHP_FN void flush(int b, int ta, int, int* taken, int seq) {
-    const int D0 = kBlock * b - 1;
+  VHP_FN void flush(int b, int ta, int yw, int* taken, int seq) {
+    const int D0 = kBlock * b;
+    const int row63 = b + 1 < Geo::n_bands(g) ? ring_rel + (yw & (kRing - 1)) : (kBlock - 1) * kTStride;
+    const vi tl = select(lane == kLanes - 1, vi(row63), lane * kTStride);
     wave_sync();
     vd fv[kLW];
 #pragma unroll
-    for (int k = 0; k < kLW; ++k) fv[k] = lds_load(tile, lane + kLanes * k);
+    for (int k = 0; k < kLW; ++k) fv[k] = lds_load(tile, tl + (DY > 0 ? k : kLW - 1 - k));
     lds_publish(taken, seq);
+    if (b == 0) {  // the diagonal cells: lane 0's values under the diagonal's occupancy bits of the window
+      const uint32_t dbits = (uint32_t)(dg_run[1 + (yw >> 6)] >> (yw & 63));
+      const vb lane0 = lane == 0;
+#pragma unroll
+      for (int k = 0; k < kLW; ++k) fv[k] = and_mask(fv[k], select(lane0, vi(((dbits >> (DY > 0 ? k : kLW - 1 - k)) & 1u) ? -1 : 0), vi(-1)));
+    }
     const long rowstep = (long)DY * nxm + DX;
     OutT* row = row_base(D0, ta);
     if (interior(D0, ta)) {
 #pragma unroll
       for (int k = 0; k < kLW; ++k) {
-        if (b == 0) g_store1_if(lane != 0, row, xoff, fv[k]); else g_store1_if(vb(true), row, xoff, fv[k]);
+        g_store1_if(vb(true), row, xoff, fv[k]);
         row += rowstep;
       }
     } else {
       const vi d = lane + D0;
-      const vi t_lo = select(d >= 0, d, vi(kNever)), t_hi = vmin(d + (g.ni - 1), j_last);  // the steps at which the lane's cell exists
+      const vi t_hi = vmin(d + (g.ni - 1), j_last);  // the lane's cell exists at the steps d' .. t_hi
 #pragma unroll
       for (int k = 0; k < kLW; ++k) {
         const int t = ta + k;
-        g_store1_if((t_lo <= t) && (t_hi >= t), row, xoff, fv[k]);
+        g_store1_if((d <= t) && (t_hi >= t), row, xoff, fv[k]);
         row += rowstep;
       }
     }
   }
   VHP_FN void zero_fill(int b, int ta, int) {
-    const int D0 = kBlock * b - 1, t_last = Geo::t_last(g, b);
+    const int D0 = kBlock * b, t_last = Geo::t_last(g, b);
     const vi d = lane + D0;
-    const vi t_lo = select(d >= 0, d, vi(kNever)), t_hi = vmin(d + (g.ni - 1), j_last);
+    const vi t_hi = vmin(d + (g.ni - 1), j_last);
     const long rowstep = (long)DY * nxm + DX;
     OutT* row = row_base(D0, ta);
     for (int t = ta; t <= t_last; ++t) {
-      g_store1_if((t_lo <= t) && (t_hi >= t), row, xoff, vd(0.0));
+      g_store1_if((d <= t) && (t_hi >= t), row, xoff, vd(0.0));
       row += rowstep;
       if (((t - ta) & (kLW - 1)) == kLW - 1) sim_point();
     }
@@ -888,8 +956,8 @@ struct BandWorker {
       VHP_LAT_STAMP(unit, q, 0);
       ys.init(a.m, a.dmap, sx, sy, sh, w, q, &po);
       ys.skip_fill = a.dead_cells_are_zero;
-      ys.prefetch_ops(g.Y(imax(kBlock * q - 1, 0)) >> 6);
-      if (VHP_DIAG_WAITS && q > 0) wait_for(prog + (q - 1), imin(kBlock * q + 1, g.nj));
+      ys.prefetch_ops(g.Y(kBlock * q) >> 6);
+      if (VHP_DIAG_WAITS && q > 0) wait_for(prog + (q - 1), imin(kBlock * q + 2, g.nj));
       VHP_LAT_STAMP(unit, q, 1);
       ys.run();
       VHP_LAT_STAMP(unit, q, 3);
@@ -904,12 +972,17 @@ struct BandWorker {
     int* post = post_of(sh, ws);
     const double* tile = sh.lds + sh.L.tiles + ws * kXRows * kTStride;
     typename std::conditional<XM, BandXStore<DX, DY, OutT, ODD>, BandYStore<DX, DY, OutT>>::type st;
-    st.init(a.m, sx, sy, field, tile);
+    st.init(a.m, a.dmap, sx, sy, field, tile, sh.ring(ws));
     for (int n = 1;; ++n) {
       int seq, ta, cw, bf;
+      VHP_WP_T0(ts0);
       lds_read4(post + kPostRec, seq, ta, cw, bf);
-      while (seq < n) { ready_backoff(); sim_point(); lds_read4(post + kPostRec, seq, ta, cw, bf); }
+      while (seq < n) { short_backoff(); sim_point(); lds_read4(post + kPostRec, seq, ta, cw, bf); }
       lds_acquire();
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+      VHP_WP_ADDP(prof, 6, ts0);
+#endif
+      VHP_WP_T0(ts1);
       const int band = bf & 0xffff, flags = bf >> 16;
       if (flags & kPostDone) return;
       if (flags & kPostZero) {
@@ -918,6 +991,9 @@ struct BandWorker {
       } else {
         st.flush(band, ta, cw, post + kPostTaken, n);
       }
+#if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
+      VHP_WP_ADDP(prof, 15, ts1); prof[12] += 1;
+#endif
       sim_progress();
     }
   }

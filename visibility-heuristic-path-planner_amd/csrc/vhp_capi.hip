@@ -22,6 +22,7 @@
 #include "vhp_planner.hip.h"
 #include "vhp_queue.hip.h"
 #include "vhp_variant.hip.h"
+#include "vhp_union.hip.h"
 
 struct vhp_ctx {
   int device = 0;
@@ -653,6 +654,37 @@ int vhp_raycast_all(vhp_ctx* ctx, int src_x, int src_y, double* out_host) {
   VHP_HIP(hipMemcpyAsync(out_host, d, cells * 8, hipMemcpyDeviceToHost, ctx->stream));
   VHP_HIP(hipStreamSynchronize(ctx->stream));
   return VHP_OK;
+}
+
+// ---- max-union + arg-source of a batch of fields (vhp_union.hip.h) ---------------------------------------------------
+static int union_common(vhp_ctx* ctx, const char* who, const void* d_fields, int n, int dtype, long long stride, const int32_t* d_labels, int first_index,
+                        void* d_best, int32_t* d_arg) {
+  if (!ctx || !d_best || !d_arg || n < 0 || (n > 0 && !d_fields)) return fail(ctx, VHP_ERR_ARG, std::string(who) + ": bad argument");
+  if (dtype != VHP_F64 && dtype != VHP_F32) return fail(ctx, VHP_ERR_ARG, std::string(who) + ": bad dtype");
+  if (ctx->nx <= 0) return fail(ctx, VHP_ERR_NO_MAP, std::string(who) + ": no map set (the grid's size is the map's)");
+  const long long cells = (long long)ctx->nx * ctx->ny;
+  if (stride == 0) stride = cells;
+  if (stride < cells) return fail(ctx, VHP_ERR_ARG, std::string(who) + ": field_stride is smaller than a field");
+  const size_t el = dtype == VHP_F64 ? 8 : 4;
+  if (reinterpret_cast<uintptr_t>(d_fields) % el || reinterpret_cast<uintptr_t>(d_best) % el || reinterpret_cast<uintptr_t>(d_arg) % 4)
+    return fail(ctx, VHP_ERR_ARG, std::string(who) + ": a pointer is not aligned to its element type");
+  VHP_ON_DEVICE(ctx);
+  VHP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  const hipError_t e = dtype == VHP_F64 ? vhp::launch_union<double>(d_fields, n, stride, d_labels, first_index, cells, d_best, d_arg, ctx->n_cus, ctx->stream)
+                                        : vhp::launch_union<float>(d_fields, n, stride, d_labels, first_index, cells, d_best, d_arg, ctx->n_cus, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, VHP_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
+  VHP_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->timed = true;
+  return VHP_OK;
+}
+
+int vhp_union_fields_device(vhp_ctx* ctx, const void* d_fields, int n_fields, int dtype, int first_index, void* d_best, int32_t* d_arg) {
+  return union_common(ctx, "vhp_union_fields_device", d_fields, n_fields, dtype, ctx ? ctx->opt_field_stride : 0, nullptr, first_index, d_best, d_arg);
+}
+
+int vhp_union_partials_device(vhp_ctx* ctx, const void* d_bests, const int32_t* d_args, int n_parts, int dtype, void* d_best, int32_t* d_arg) {
+  if (n_parts > 0 && !d_args) return fail(ctx, VHP_ERR_ARG, "vhp_union_partials_device: bad argument");
+  return union_common(ctx, "vhp_union_partials_device", d_bests, n_parts, dtype, 0, d_args, 0, d_best, d_arg);
 }
 
 // ---- MATLAB-flavoured variants (vhp_variant.hip.h) -------------------------------------------------------------------

@@ -86,6 +86,8 @@ inline vd vmaxd(const vd& a, double b) { vd r; for (int l = 0; l < kLanes; ++l) 
 
 // lane l <- lane l-1; lane 0 <- fill's lane 0
 inline vd shift_up(const vd& v, const vd& fill) { vd r; r.v[0] = fill.v[0]; for (int l = 1; l < kLanes; ++l) r.v[l] = v.v[l - 1]; return r; }
+// the same, written over `fill` (whose other lanes are dead after it): the device build shifts into fill's own registers
+inline vd shift_up_into(vd& fill, const vd& v) { fill = shift_up(v, fill); return fill; }
 // the value is +0.0, bit for bit
 inline vb is_pos_zero(const vd& v) { vb r; for (int l = 0; l < kLanes; ++l) { uint64_t u; std::memcpy(&u, &v.v[l], 8); r.v[l] = u == 0; } return r; }
 // lane l <- lane l+1; lane 63 <- fill's lane 63
@@ -212,6 +214,7 @@ struct SimHooks { void (*yield)() = nullptr; void (*progress)() = nullptr; void 
 inline SimHooks& sim_hooks() { static SimHooks h; return h; }
 inline void backoff() { if (sim_hooks().yield) sim_hooks().yield(); }
 inline void ready_backoff() { backoff(); }
+inline void short_backoff() { backoff(); }
 inline void wave_priority(int) {}
 // event counters of the simulator (which path a hand-off took); the device build counts nothing
 struct SimCounts { long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
@@ -274,6 +277,19 @@ VHP_LANE_FN vd shift_up(vd v, vd fill) {
   lo = __builtin_amdgcn_update_dpp(flo, lo, 0x138, 0xf, 0xf, false);
   hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
+}
+// The same, written over `fill` -- a value whose other lanes are dead after this (a boundary value read for this one step): the DPP
+// move goes into fill's own registers.  (update_dpp makes the compiler copy `old` first -- two v_mov per step of every window --
+// even where the copy's source dies right there; the asm's tied operand leaves it no choice.)
+VHP_LANE_FN vd shift_up_into(vd& fill, vd v) {
+  int flo = __double2loint(fill), fhi = __double2hiint(fill);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  // (s_nop 1: a DPP read needs two wait states after the vector instruction that wrote its source, and the compiler's hazard
+  // recognizer does not look inside an asm; the two sources were written by adjacent instructions, so one s_nop covers both)
+  asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(flo) : "v"(lo));
+  asm("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(fhi) : "v"(hi), "v"(flo));
+  fill = __hiloint2double(fhi, flo);
+  return fill;
 }
 // the value is +0.0, bit for bit
 VHP_LANE_FN vb is_pos_zero(vd v) { return __double_as_longlong(v) == 0; }
@@ -525,6 +541,7 @@ VHP_LANE_FN bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0u
 VHP_LANE_FN void lds_store_i_if(bool p, int* base, vi idx, int v) { if (p) ((lds_int*)base)[idx] = v; }
 VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(VHP_BACKOFF_SLEEP); }
 VHP_LANE_FN void ready_backoff() { __builtin_amdgcn_s_sleep(VHP_READY_SLEEP); }
+VHP_LANE_FN void short_backoff() { __builtin_amdgcn_s_sleep(1); }   // (64 cycles: a wavefront whose answer another one is waiting for)
 // waits until every global store (and load) this wavefront has issued has completed
 VHP_LANE_FN void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // acquire: the poll's value has arrived (the branch on it waited for lgkmcnt); later LDS reads are issued after it, in order
