@@ -556,7 +556,7 @@ def main():
 
             def step_union():
                 ctx.sweep_batch_device(d_src.data_ptr(), n_src, d_first.data_ptr(), dtype=vdt)
-                vdist.union_fields(d_first, first, world * n_src)
+                vdist.union_fields(d_first, first, world * n_src, ctx=ctx)   # (one pass of the HIP max-union kernel per rank, the partials all-gathered)
 
             for name, fn in (("allgather_f32", step_gather), ("union_fields", step_union)):
                 fn()

@@ -277,6 +277,16 @@ int vhp_multi_sweep_batch(vhp_multi* m, const int32_t* src_xy, int n_src, int va
 int vhp_multi_allgather_fields(vhp_multi* m, int n_src, int dtype, void* const* d_shard_per_device, void* const* d_all_per_device);
 int vhp_multi_allgather_plan(int n_src, int n_devices, int* to, int* from, int* lane, int* lo, int* hi, int cap);
 int vhp_multi_use_rccl(vhp_multi* m, int enable);
+/* The max-union of ALL n_src fields of a sharded batch and the source that attains it (vhp_union_fields_device), on every device:
+ * each device reduces its own shard (one pass over its fields), the N partial results -- one union field and one label field per
+ * device, whatever the batch -- are exchanged (peer copies on the lanes of vhp_multi_allgather_plan, or ncclAllGather after
+ * vhp_multi_use_rccl), and every device merges them (vhp_union_partials_device; a tie goes to the lowest source index).  SURVEY 8e,
+ * option 2: what the planner needs of a batch is this, not the fields (at BASELINE config 5: 0.2 GB per device instead of 137).
+ * d_shard_per_device[d]: device d's fields as vhp_multi_sweep_batch left them; d_best_per_device[d]: nx * ny elements of dtype on
+ * device d; d_arg_per_device[d]: nx * ny int32 there.  Blocks.  Like the rest of vhp_multi_*: NEVER RUN ACROSS DEVICES in this
+ * repository's test environment (one GPU; the tests list its ordinal twice). */
+int vhp_multi_union_fields(vhp_multi* m, int n_src, int dtype, void* const* d_shard_per_device, void* const* d_best_per_device,
+                           int32_t* const* d_arg_per_device);
 
 /* Library / build identification: "vhp-hip <version> gfx950". */
 const char* vhp_version(void);

@@ -117,6 +117,9 @@ def load_library():
     lib.vhp_multi_allgather_fields.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(vp)]
     lib.vhp_multi_allgather_plan.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32]
     lib.vhp_multi_use_rccl.argtypes = [vp, i32]
+    lib.vhp_union_fields_device.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.vhp_union_partials_device.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.vhp_multi_union_fields.argtypes = [vp, i32, i32, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -60,7 +60,7 @@ struct Rccl {
     return false;
   }
 };
-constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8;  // ncclDataType_t (rccl.h)
+constexpr int kNcclInt32 = 2, kNcclFloat32 = 7, kNcclFloat64 = 8;  // ncclDataType_t (rccl.h)
 }  // namespace
 
 struct vhp_multi {
@@ -75,6 +75,10 @@ struct vhp_multi {
   std::string err;
   Rccl rccl;
   std::vector<void*> comms;  // one communicator per device when the RCCL path is on
+  // vhp_multi_union_fields: every device's N partial unions and their label fields (its own partial in slot d)
+  std::vector<void*> parts_best;
+  std::vector<int32_t*> parts_arg;
+  std::vector<size_t> parts_cap;   // bytes of parts_best[d] (parts_arg[d] holds the matching N * cells int32)
 };
 
 namespace {
@@ -177,6 +181,8 @@ int vhp_multi_destroy(vhp_multi* m) {
   for (size_t d = 0; d < m->ctx.size(); ++d) {
     DevGuard g(m->device[d]);
     if (m->d_src[d]) (void)hipFree(m->d_src[d]);
+    if (d < m->parts_best.size() && m->parts_best[d]) (void)hipFree(m->parts_best[d]);
+    if (d < m->parts_arg.size() && m->parts_arg[d]) (void)hipFree(m->parts_arg[d]);
     if (m->done[d]) (void)hipEventDestroy(m->done[d]);
     vhp_destroy(m->ctx[d]);
     for (hipStream_t l : m->lane[d]) if (l) (void)hipStreamDestroy(l);
@@ -307,6 +313,88 @@ int vhp_multi_allgather_fields(vhp_multi* m, int n_src, int dtype, void* const* 
       if (hipStreamSynchronize(s) != hipSuccess) { drain(m, nd); return mfail(m, VHP_ERR_HIP, "vhp_multi_allgather_fields: a copy failed"); }
   }
   return VHP_OK;
+}
+
+int vhp_multi_union_fields(vhp_multi* m, int n_src, int dtype, void* const* d_shard_per_device, void* const* d_best_per_device,
+                           int32_t* const* d_arg_per_device) {
+  if (!m || !d_shard_per_device || !d_best_per_device || !d_arg_per_device || n_src < 0) return VHP_ERR_ARG;
+  if (m->nx == 0) return mfail(m, VHP_ERR_NO_MAP, "vhp_multi_union_fields: no map set");
+  if (bad_dtype(dtype)) return mfail(m, VHP_ERR_ARG, "vhp_multi_union_fields: bad dtype");
+  const int nd = (int)m->ctx.size();
+  const size_t cells = (size_t)m->nx * m->ny, el = dtype == VHP_F64 ? 8 : 4;
+  for (int d = 0; d < nd; ++d) {
+    int lo, hi;
+    vhp_multi_shard_bounds(n_src, nd, d, &lo, &hi);
+    if ((hi > lo && !d_shard_per_device[d]) || !d_best_per_device[d] || !d_arg_per_device[d]) return mfail(m, VHP_ERR_ARG, "vhp_multi_union_fields: missing buffer");
+  }
+  m->parts_best.resize((size_t)nd, nullptr);
+  m->parts_arg.resize((size_t)nd, nullptr);
+  m->parts_cap.resize((size_t)nd, 0);
+  // 1. every device reduces its own shard into slot d of its table of partials (an empty shard: the neutral partial)
+  for (int d = 0; d < nd; ++d) {
+    DevGuard g(m->device[d]);
+    if (m->parts_cap[d] < (size_t)nd * cells * el) {
+      if (m->parts_best[d]) (void)hipFree(m->parts_best[d]);
+      if (m->parts_arg[d]) (void)hipFree(m->parts_arg[d]);
+      m->parts_best[d] = nullptr; m->parts_arg[d] = nullptr; m->parts_cap[d] = 0;
+      if (hipMalloc(&m->parts_best[d], (size_t)nd * cells * el) != hipSuccess || hipMalloc(&m->parts_arg[d], (size_t)nd * cells * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        drain(m, d);
+        return mfail(m, VHP_ERR_HIP, "vhp_multi_union_fields: out of device memory for the partial unions");
+      }
+      m->parts_cap[d] = (size_t)nd * cells * el;
+    }
+    int lo, hi;
+    vhp_multi_shard_bounds(n_src, nd, d, &lo, &hi);
+    const int rc = vhp_union_fields_device(m->ctx[d], d_shard_per_device[d], hi - lo, dtype, lo, static_cast<char*>(m->parts_best[d]) + (size_t)d * cells * el,
+                                           m->parts_arg[d] + (size_t)d * cells);
+    if (rc != VHP_OK) { drain(m, d + 1); return mfail(m, rc, std::string("device ") + std::to_string(m->device[d]) + ": " + vhp_last_error(m->ctx[d])); }
+  }
+  for (int d = 0; d < nd; ++d) {
+    const int rc = vhp_sync(m->ctx[d]);
+    if (rc != VHP_OK) { drain(m, nd); return mfail(m, rc, std::string("device ") + std::to_string(m->device[d]) + ": " + vhp_last_error(m->ctx[d])); }
+  }
+  // 2. the partials travel: one union field and one label field per device, whatever the batch (option 2)
+  if (!m->comms.empty()) {
+    int rc = m->rccl.GroupStart();
+    for (int d = 0; rc == 0 && d < nd; ++d) {
+      DevGuard g(m->device[d]);
+      rc = m->rccl.AllGather(static_cast<char*>(m->parts_best[d]) + (size_t)d * cells * el, m->parts_best[d], cells, dtype == VHP_F64 ? kNcclFloat64 : kNcclFloat32,
+                             m->comms[d], m->stream[d]);
+      if (rc == 0) rc = m->rccl.AllGather(m->parts_arg[d] + (size_t)d * cells, m->parts_arg[d], cells, kNcclInt32, m->comms[d], m->stream[d]);
+    }
+    const int rc_end = m->rccl.GroupEnd();
+    if (rc == 0) rc = rc_end;
+    drain(m, nd);
+    if (rc != 0) return mfail(m, VHP_ERR_HIP, std::string("ncclAllGather (partial unions): ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(rc) : std::to_string(rc)));
+  } else {
+    for (int k = 1; k < nd; ++k)       // round k: device `to` pulls slot (to + k) mod N from its owner, on its lane k (see vhp_multi_allgather_plan)
+      for (int to = 0; to < nd; ++to) {
+        const int from = (to + k) % nd;
+        DevGuard g(m->device[to]);
+        hipError_t e = hipMemcpyPeerAsync(static_cast<char*>(m->parts_best[to]) + (size_t)from * cells * el, m->device[to],
+                                          static_cast<char*>(m->parts_best[from]) + (size_t)from * cells * el, m->device[from], cells * el, m->lane[to][k]);
+        if (e == hipSuccess)
+          e = hipMemcpyPeerAsync(m->parts_arg[to] + (size_t)from * cells, m->device[to], m->parts_arg[from] + (size_t)from * cells, m->device[from], cells * 4, m->lane[to][k]);
+        if (e != hipSuccess) { drain(m, nd); return mfail(m, VHP_ERR_HIP, std::string("peer copy of a partial union: ") + hipGetErrorString(e)); }
+      }
+    for (int d = 0; d < nd; ++d) {
+      DevGuard g(m->device[d]);
+      for (hipStream_t s : m->lane[d])
+        if (hipStreamSynchronize(s) != hipSuccess) { drain(m, nd); return mfail(m, VHP_ERR_HIP, "vhp_multi_union_fields: a copy failed"); }
+    }
+  }
+  // 3. every device merges the N partials (a tie goes to the lowest label: the lowest source index)
+  for (int d = 0; d < nd; ++d) {
+    const int rc = vhp_union_partials_device(m->ctx[d], m->parts_best[d], m->parts_arg[d], nd, dtype, d_best_per_device[d], d_arg_per_device[d]);
+    if (rc != VHP_OK) { drain(m, d + 1); return mfail(m, rc, std::string("device ") + std::to_string(m->device[d]) + ": " + vhp_last_error(m->ctx[d])); }
+  }
+  int worst = VHP_OK;
+  for (int d = 0; d < nd; ++d) {
+    const int rc = vhp_sync(m->ctx[d]);
+    if (rc != VHP_OK && worst == VHP_OK) { worst = rc; m->err = std::string("device ") + std::to_string(m->device[d]) + ": " + vhp_last_error(m->ctx[d]); }
+  }
+  return worst;
 }
 
 }  // extern "C"

@@ -66,31 +66,60 @@ def gather_fields(local_fields, n_sources, out=None):
     return torch.cat(pieces, 0)
 
 
-def union_fields(local_fields, first_index, n_sources):
+def _union_shim(fields, labels, first_index):
+    """The reduction of vhp_union_fields_device / vhp_union_partials_device (csrc/vhp_union.hip.h) in torch ops, for tensors that are
+    not on a GPU (the gloo tests): one pass, field after field, replace on strict improvement -- or, with label fields, on a tie
+    with a lower label --, no temporaries beyond one mask.  Returns (best, arg int32); no field at all: (-1, INT32_MAX)."""
+    shape = tuple(fields.shape[1:])
+    best = fields.new_full(shape, -1.0)
+    arg = torch.full(shape, 0x7fffffff, dtype=torch.int32, device=fields.device)
+    for k in range(fields.shape[0]):
+        f = fields[k]
+        lab = labels[k] if labels is not None else None
+        better = f > best
+        if lab is not None:
+            better |= (f == best) & (lab < arg)
+        best = torch.where(better, f, best)
+        arg = torch.where(better, lab if lab is not None else torch.full_like(arg, first_index + k), arg)
+    return best, arg
+
+
+def union_fields(local_fields, first_index, n_sources, ctx=None):
     """Max-union over ALL sources and the index of the (first) source attaining it.
 
-    Returns (best [ny, nx], arg_source int64 [ny, nx]); ties resolve to the lowest source index,
-    like a sequential max-union that only replaces on strict improvement."""
+    Returns (best [ny, nx], arg_source int64 [ny, nx]); ties resolve to the lowest source index, like a sequential max-union
+    that only replaces on strict improvement (reference src/visibilityBasedSolver.cpp:417-418).  Every rank reduces its own
+    shard in ONE pass over its fields (ctx given and the fields on its GPU: the HIP kernel behind vhp_union_fields_device --
+    no temporaries; at BASELINE config 5 the torch expression this replaces made a 17 GB int64 temporary and read the 17 GB of
+    fields four times), the partials -- one union field and one label field per rank -- are all-gathered (RCCL over xGMI, or
+    gloo), and every rank merges them (vhp_union_partials_device: a tie goes to the lowest label)."""
     world = dist.get_world_size()
-    if local_fields.shape[0]:
-        best, arg = local_fields.max(dim=0)
-        # torch.max returns an arbitrary index among ties: recompute the first index explicitly
-        eq = local_fields == best.unsqueeze(0)
-        arg = eq.to(torch.int64).argmax(dim=0) + first_index
+    on_gpu = ctx is not None and local_fields.is_cuda
+    shape = tuple(local_fields.shape[1:])
+    if on_gpu:
+        import vhp_amd
+        vdt = vhp_amd.F64 if local_fields.dtype == torch.float64 else vhp_amd.F32
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        local_fields = local_fields.contiguous()
+        best = local_fields.new_empty(shape)
+        arg = torch.empty(shape, dtype=torch.int32, device=local_fields.device)
+        ctx.union_fields_device(local_fields.data_ptr() if local_fields.shape[0] else best.data_ptr(), local_fields.shape[0], best.data_ptr(), arg.data_ptr(),
+                                first_index=first_index, dtype=vdt)
     else:
-        shape = tuple(local_fields.shape[1:])
-        best = local_fields.new_full(shape, -1.0)
-        arg = torch.full(shape, n_sources, dtype=torch.int64, device=local_fields.device)
+        best, arg = _union_shim(local_fields, None, first_index)
     # concatenated-along-dim-0 form: accepted by both RCCL and gloo
-    all_best = best.new_empty((world * best.shape[0],) + tuple(best.shape[1:]))
-    all_arg = arg.new_empty((world * arg.shape[0],) + tuple(arg.shape[1:]))
-    dist.all_gather_into_tensor(all_best, best.contiguous())
-    dist.all_gather_into_tensor(all_arg, arg.contiguous())
-    all_best = all_best.view((world,) + tuple(best.shape))
-    all_arg = all_arg.view((world,) + tuple(arg.shape))
-    gbest, _ = all_best.max(dim=0)
-    cand = torch.where(all_best == gbest.unsqueeze(0), all_arg, torch.full_like(all_arg, n_sources))
-    return gbest, cand.min(dim=0).values
+    all_best = best.new_empty((world,) + shape)
+    all_arg = arg.new_empty((world,) + shape)
+    dist.all_gather_into_tensor(all_best.view((world * shape[0],) + shape[1:]), best.contiguous())
+    dist.all_gather_into_tensor(all_arg.view((world * shape[0],) + shape[1:]), arg.contiguous())
+    if on_gpu:
+        gbest = best.new_empty(shape)
+        garg = arg.new_empty(shape)
+        ctx.union_partials_device(all_best.data_ptr(), all_arg.data_ptr(), world, gbest.data_ptr(), garg.data_ptr(), dtype=vdt)
+    else:
+        gbest, garg = _union_shim(all_best, all_arg, 0)
+    # (a cell that no field covers -- no sources at all -- is labelled n_sources, as before)
+    return gbest, torch.clamp(garg.to(torch.int64), max=n_sources)
 
 
 def sweep_gather_overlapped(launch, sources, out, chunks=4):
@@ -140,10 +169,11 @@ def gathered_index(source_index, n_sources, world, chunks):
     return k * world * m + r * m + j
 
 
-def sweep_sharded(compute, sources, mode="none"):
+def sweep_sharded(compute, sources, mode="none", ctx=None):
     """compute(shard [n,2] int32) -> fields [n, ny, nx] tensor on this rank's device.
 
-    mode: "none" -> (local fields, first index); "gather" -> all fields; "union" -> (best, arg_source)."""
+    mode: "none" -> (local fields, first index); "gather" -> all fields; "union" -> (best, arg_source) (ctx: the vhp context of this
+    rank's device -- the reduction then runs as the HIP kernel of vhp_union_fields_device, see union_fields)."""
     shard, lo = shard_sources(sources)
     local = compute(shard)
     if mode == "none":
@@ -151,5 +181,5 @@ def sweep_sharded(compute, sources, mode="none"):
     if mode == "gather":
         return gather_fields(local, len(sources))
     if mode == "union":
-        return union_fields(local, lo, len(sources))
+        return union_fields(local, lo, len(sources), ctx=ctx)
     raise ValueError(mode)
