@@ -504,15 +504,18 @@ struct BandXStore {
     }
     if (interior(D0, ta)) store_window<true>(D0, ta, xw, fa, fb); else store_window<false>(D0, ta, xw, fa, fb);
   }
-  // the zeros of what is left of band b's march from the window at ta on
-  VHP_FN void zero_fill(int b, int ta, int xw) {
+  // The zeros of what is left of band b's march from step ta on: row by row -- a row of the band is at most 64 adjacent cells, the
+  // steps max(ta, j + D0) .. min(t_last, j + D0 + 63) of row j --, one store instruction per row (window by window, through the
+  // read-out's predicates, it was forty-odd instructions per group of eight rows: 18 us for a band of the maze).
+  VHP_FN void zero_fill(int b, int ta, int) {
     const int D0 = kBlock * b, t_last = Geo::t_last(g, b);
-    vd z[10];
-#pragma unroll
-    for (int u = 0; u < 10; ++u) z[u] = vd(0.0);
-    for (; ta <= t_last; ta += kLW, xw += kLW * DX) {
-      store_window<false>(D0, ta, xw, z, z);
-      sim_point();
+    const int j_lo = imax(0, ta - D0 - (kBlock - 1)), j_hi = imin(rows_total - 1, t_last - D0);
+    for (int j = j_lo; j <= j_hi; ++j) {
+      const int t_lo = imax(ta, j + D0), t_hi = imin(t_last, j + D0 + kBlock - 1);
+      // lane l: the cell l columns above the row piece's lowest x
+      const int x_lo = DX > 0 ? g.X(t_lo) : g.X(t_hi);
+      g_store_scalar_if(lane <= t_hi - t_lo, out, lane + (g.Y(j) * nxm + x_lo), OutT(0));
+      if (((j - j_lo) & 15) == 15) sim_point();
     }
   }
 };
@@ -1002,11 +1005,19 @@ struct BandWorker {
   VHP_FN void run(int unit) {
     const int s = unit / kUnits, qo = unit - s * kUnits;
     // (the planners' control words together, before any of them is looked at: one trip to memory, then the source's)
-    const int skip = a.skip ? *a.skip : 0, run = a.run_if ? *a.run_if : 1, si0 = a.src_index ? *a.src_index : s;
+    int sx, sy;
     const int slot0 = a.slot_base ? *a.slot_base : 0;
-    if (uniform(skip) != 0 || uniform(run) == 0) return;
-    const int si = uniform(si0);
-    const int sx = uniform(a.src_xy[2 * si]), sy = uniform(a.src_xy[2 * si + 1]);
+    if (a.pivot_rec) {  // the planner's loop: {done, nb, x, y} in one load
+      int done, nb;
+      g_load_rec4(a.pivot_rec, 0, done, nb, sx, sy);
+      if (done != 0) return;
+    } else {
+      const int skip = a.skip ? *a.skip : 0, run = a.run_if ? *a.run_if : 1, si0 = a.src_index ? *a.src_index : s;
+      if (uniform(skip) != 0 || uniform(run) == 0) return;
+      const int si = uniform(si0);
+      sx = uniform(a.src_xy[2 * si]);
+      sy = uniform(a.src_xy[2 * si + 1]);
+    }
     if (a.slot_base && sx < 0) return;
     if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
       if (qo == 0 && w == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);

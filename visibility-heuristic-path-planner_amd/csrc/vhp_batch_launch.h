@@ -8,6 +8,8 @@
 
 namespace vhp {
 
+struct PlannerDev;  // (vhp_planner_dev.hip.h)
+
 struct BatchArgs {
   const uint64_t* rows;   // packed maps and reciprocal table of the context (vhp_set_map)
   const uint64_t* cols;
@@ -37,6 +39,7 @@ struct BatchArgs {
   int pool_static_round = 2;  // pool sweep: every context's first unit by workgroup index, no pull (vhp_pool.hpp Args::static_round; 2: odd head contexts count down, Args::static_snake); 0: every unit pulled
   const int* d_src_index = nullptr;  // latency sweep in the planner's loop: sweep source number *d_src_index of d_src (n_src = 1) ...
   const int* d_skip = nullptr;       // ... and nothing at all if *d_skip is set
+  const int* d_pivot_rec = nullptr;  // ... or, instead of both: the 16-byte record {done, nb, x, y} of the planner's loop (LatArgs::pivot_rec)
   const int* d_slot_base = nullptr;  // the speculative planner's launches (LatArgs::slot_base, run_if)
   const int* d_run_if = nullptr;
   bool lat_dead_cells_are_zero = false;  // ... and dead strips store nothing: the field holds +0.0 wherever the launch does not write
@@ -55,6 +58,9 @@ size_t pool_scratch_bytes(int n_src, int nx, int ny);
 // share the epoch counter, so either may follow the other on one allocation).
 bool lat_supported(int nx, int ny);
 hipError_t launch_lat(const BatchArgs& a);
+// A planner iteration as one launch: the latency sweep of the pivot named by a.d_pivot_rec (fp64, into a.d_out) and, in the same
+// grid, the epilogue over d (union, labels, heuristic, next pivot: vhp_planner_dev.hip.h).  d.ticket[1] counts the sweep's workgroups.
+hipError_t launch_lat_planner(const BatchArgs& a, const PlannerDev& d);
 size_t lat_scratch_bytes(int n_src, int nx, int ny);
 // The latency sweep's lanes run along diagonals of the grid: it reads the occupancy packed along them (vhp_band.hpp DiagMaps),
 // built once per map from the byte map: lat_diag_map_bytes of device memory, zero-filled and packed by lat_pack_diag_maps.

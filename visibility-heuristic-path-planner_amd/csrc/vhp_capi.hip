@@ -72,6 +72,8 @@ struct vhp_ctx {
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
   const int* lat_src_index = nullptr;  // set around a latency-sweep launch of the planner's loop (vhp_planner_solve)
   const int* lat_skip = nullptr;
+  const int* lat_pivot_rec = nullptr;  // ... or both and the pivot in one 16-byte record (vhp_planner.hip.h PlannerDev::rec)
+  const vhp::PlannerDev* planner_dev = nullptr;  // ... and the launch is a whole planner iteration (vhp_batch_launch.h launch_lat_planner)
   const int* lat_slot_base = nullptr;  // ... of the speculative planner's (vhp_planner_solve_speculative)
   const int* lat_run_if = nullptr;
   bool lat_dark_unwritten = false;
@@ -355,6 +357,7 @@ hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT*
   a.pool_epoch = ++c->pool_epoch;
   a.d_src_index = lat ? c->lat_src_index : nullptr;
   a.d_skip = lat ? c->lat_skip : nullptr;
+  a.d_pivot_rec = lat ? c->lat_pivot_rec : nullptr;
   a.d_slot_base = lat ? c->lat_slot_base : nullptr;
   a.d_run_if = lat ? c->lat_run_if : nullptr;
   a.lat_dead_cells_are_zero = lat && c->lat_dark_unwritten;
@@ -380,7 +383,7 @@ hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT*
       if (hipEventCreate(&a.ev_end) != hipSuccess) { (void)hipEventDestroy(a.ev_begin); return hipErrorOutOfMemory; }
     }
   }
-  const hipError_t e = lat ? vhp::launch_lat(a) : vhp::launch_pool(a);
+  const hipError_t e = lat ? (c->planner_dev ? vhp::launch_lat_planner(a, *c->planner_dev) : vhp::launch_lat(a)) : vhp::launch_pool(a);
   if (c->timing) {
     // (a launch that failed before its events were recorded must not leave a pair that can never be waited for)
     if (e == hipSuccess) c->timed_launches.push_back({a.ev_begin, a.ev_end});
@@ -1061,9 +1064,10 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
     ctx->pl.lat_sweep = nullptr;
     ctx->last_kernel = use_lat_kernel(ctx, 1) ? 4 : 1;  // (vhp_last_sweep_kernel after a solve: what swept its iterations)
     if (use_lat_kernel(ctx, 1))
-      ctx->pl.lat_sweep = [ctx](const int32_t* pivots, const int* nb, const int* done, double* out, bool dark_unwritten) {
+      ctx->pl.lat_sweep = [ctx](const int32_t* pivots, const int* nb, const int* done, const int* rec, double* out, bool dark_unwritten) {
         ctx->lat_src_index = nb;
         ctx->lat_skip = done;
+        ctx->lat_pivot_rec = rec;
         ctx->lat_dark_unwritten = dark_unwritten;
         // (no per-launch event pairs inside a planner loop: vhp_timing times sweep launches, and the loop enqueues a batch of
         // launches past its end that return at once -- they would fill the pool with pairs that time nothing)
@@ -1071,7 +1075,27 @@ int vhp_planner_solve(vhp_ctx* ctx, int start_x, int start_y, int end_x, int end
         ctx->timing = false;
         const hipError_t e = launch_batch_sweep<double>(ctx, pivots, 1, out, true);
         ctx->timing = timing;
-        ctx->lat_src_index = ctx->lat_skip = nullptr;
+        ctx->lat_src_index = ctx->lat_skip = ctx->lat_pivot_rec = nullptr;
+        ctx->lat_dark_unwritten = false;
+        return e;
+      };
+    // ... or the iteration as ONE launch (vhp_lat.hip vhp_planner_iteration) -- built in round 6, bit-exact, and SLOWER on this part: the
+    // epilogue's workgroups sit behind other L2s than the sweep's, so the hand-off inside a launch costs an L2 write-back and an
+    // invalidate (39.6 us per pivot on maze_6 against 22.8 with two launches; 32.6 with the local fields in uncached memory and no
+    // fences, VHP_PLANNER_UNCACHED: profiles/r06_planner_one_kernel_ab.txt).  Only with VHP_PLANNER_ONE_KERNEL set in the environment.
+    ctx->pl.lat_iteration = nullptr;
+    static const bool one_kernel = std::getenv("VHP_PLANNER_ONE_KERNEL") != nullptr;
+    if (ctx->pl.lat_sweep && one_kernel)
+      ctx->pl.lat_iteration = [ctx](const vhp::PlannerDev& d) {
+        ctx->lat_pivot_rec = d.rec;
+        ctx->lat_dark_unwritten = true;
+        ctx->planner_dev = &d;
+        const bool timing = ctx->timing;
+        ctx->timing = false;
+        const hipError_t e = launch_batch_sweep<double>(ctx, d.pivots, 1, d.vis_local, true);
+        ctx->timing = timing;
+        ctx->planner_dev = nullptr;
+        ctx->lat_pivot_rec = nullptr;
         ctx->lat_dark_unwritten = false;
         return e;
       };

@@ -8,6 +8,7 @@
 
 #include "vhp.h"
 #include "vhp_band.hpp"
+#include "vhp_planner_dev.hip.h"
 
 namespace vhp {
 namespace pool {
@@ -55,6 +56,37 @@ __global__ void __launch_bounds__(kLatThreads, 1) vhp_lat_sweep(LatArgs<OutT> a)
 #endif
 }
 
+// A whole planner iteration as ONE launch (the reference's loop body, src/visibilityBasedSolver.cpp:127-141 with updateVisibility()
+// :379-565: sweep, union, labels, heuristic, next pivot): the first eight workgroups are the eight octants of the pivot's sweep, the
+// others run the epilogue (vhp_planner_dev.hip.h) behind them -- the loads that do not depend on the sweep on their way while it runs,
+// the local field read once the eight have counted themselves in.  (Until round 6: two launches per iteration, 1.7 us between them.)
+constexpr int kPlanEpiBlocks = kEpilogueBlocks;   // epilogue workgroups: the epilogue kernel's shape, 128 x 512 (the upper half of such a workgroup returns at once: 64 x 1024 measured 8 us slower per iteration, as in round 5)
+template <bool ODD>
+__global__ void __launch_bounds__(kLatThreads, 1) vhp_planner_iteration(LatArgs<double> a, PlannerDev d) {
+  extern __shared__ double lds[];
+  if (blockIdx.x >= (unsigned)kUnits) {
+    if (threadIdx.x < (unsigned)kEpilogueThreads)
+      planner_epilogue_body<kEpilogueThreads>(a.m.nx, a.m.ny, d, (int)blockIdx.x - kUnits, (int)gridDim.x - kUnits, d.ticket + 1, (unsigned)kUnits);
+    return;
+  }
+  const Layout L = make_layout(kLatWaves, 1, a.m.nx, a.m.ny);
+  using WorkerT = LatWorkerT<double, ODD>;
+  WorkerT::clear(lds, L, (int)threadIdx.x, kLatThreads);
+  __syncthreads();
+  WorkerT wk;
+  wk.init(a, lds, L, uniform((int)(threadIdx.x >> 6)));
+  wk.run((int)blockIdx.x);
+  // this octant's stores are out: counted for the epilogue's workgroups (every wavefront drains its stores, the barrier, then one
+  // lane releases at agent scope -- the readers sit behind other L2s -- and counts)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (!d.local_uncached) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    (void)__hip_atomic_fetch_add(d.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // One thread per word of the four diagonal-packed maps (DiagMaps): its 64 cells of the byte map.  Once per vhp_set_map.
 __global__ void vhp_pack_diag(const uint8_t* __restrict__ occ, uint64_t* __restrict__ dmap, int nx, int ny) {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,7 +118,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 size_t lat_lds_bytes(int nx, int ny) { return (size_t)pool::make_layout(pool::kLatWaves, 1, nx, ny).total * 8; }
 
 template <typename OutT>
-hipError_t launch_lat_t(const BatchArgs& a) {
+hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {
   using namespace pool;
   const bool odd = lat_needs_odd<OutT>(a.nx, a.field_stride, static_cast<const OutT*>(a.d_out));
 #ifdef VHP_EXP_ONE_KERNEL  // compile-time experiments only: one instantiation instead of four
@@ -121,6 +153,7 @@ hipError_t launch_lat_t(const BatchArgs& a) {
   g.epoch = a.pool_epoch;
   g.src_index = a.d_src_index;
   g.skip = a.d_skip;
+  g.pivot_rec = a.d_pivot_rec;
   g.slot_base = a.d_slot_base;
   g.run_if = a.d_run_if;
   g.dead_cells_are_zero = a.lat_dead_cells_are_zero;
@@ -131,6 +164,21 @@ hipError_t launch_lat_t(const BatchArgs& a) {
   { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_lat_strip_times)) == hipSuccess) g.strip_times = static_cast<unsigned long long*>(p); }
 #endif
   if (a.ev_begin) (void)hipEventRecord(a.ev_begin, a.stream);
+#ifndef VHP_EXP_ONE_KERNEL
+  if constexpr (sizeof(OutT) == 8) {
+    if (pd) {  // the planner's iteration: the sweep's eight workgroups and the epilogue's in one launch
+      auto kp = odd ? vhp_planner_iteration<true> : vhp_planner_iteration<false>;
+      if (a.raise_lds) {
+        hipError_t e2 = a.raise_lds(reinterpret_cast<const void*>(kp), lds);
+        if (e2 != hipSuccess) return e2;
+      }
+      hipLaunchKernelGGL(kp, dim3((unsigned)(kUnits + kPlanEpiBlocks)), dim3(kLatThreads), lds, a.stream, g, *pd);
+      const hipError_t e3 = hipGetLastError();
+      if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
+      return e3;
+    }
+  }
+#endif
   hipLaunchKernelGGL(k, dim3((unsigned)(a.n_src * kUnits)), dim3(kLatThreads), lds, a.stream, g);
   const hipError_t e = hipGetLastError();
   if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
@@ -168,6 +216,11 @@ extern "C" int vhp_debug_read_lat_strip_times(unsigned long long* dst, int n_wor
 hipError_t launch_lat(const BatchArgs& a) {
   if (!lat_supported(a.nx, a.ny)) return hipErrorInvalidValue;
   return a.dtype == VHP_F64 ? launch_lat_t<double>(a) : launch_lat_t<float>(a);
+}
+
+hipError_t launch_lat_planner(const BatchArgs& a, const PlannerDev& d) {
+  if (!lat_supported(a.nx, a.ny) || a.dtype != VHP_F64 || a.n_src != 1 || !a.d_pivot_rec) return hipErrorInvalidValue;
+  return launch_lat_t<double>(a, &d);
 }
 
 }  // namespace vhp

@@ -52,6 +52,9 @@ struct LatArgs {
   // or nothing at all if *skip is set (the loop has ended: launches are enqueued ahead of the host's polls); both may be null
   const int* src_index;
   const int* skip;
+  // ... or both and the pivot itself as one 16-byte record {done, nb, x, y} that the loop's epilogue keeps beside its control block: one
+  // trip to memory before the sweep can start instead of two (the band sweep; null: the two words above)
+  const int* pivot_rec = nullptr;
   // the speculative planner's launches: field s of the launch is field *slot_base + s of `out`, a source with a negative x is no
   // source (its units do nothing, no error), and the launch sweeps nothing unless *run_if is set; both may be null
   const int* slot_base = nullptr;

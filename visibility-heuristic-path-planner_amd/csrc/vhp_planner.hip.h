@@ -31,89 +31,9 @@
 
 #include "vhp.h"
 #include "vhp_sweep.hip.h"
+#include "vhp_planner_dev.hip.h"
 
 namespace vhp {
-
-constexpr uint32_t kUnlabelled32 = 0xffffffffu;
-
-struct PlannerCtl {
-  int nb;        // nb_of_sources_
-  int done;      // loop finished (any reason)
-  int status;    // vhp_status of the solve
-  int iters;     // planner steps executed
-};
-
-struct PlannerKey {
-  unsigned long long h;     // bits of the heuristic (h >= 0, so the bit pattern orders like the value)
-  unsigned long long rank;  // push order, lower = earlier
-  int x, y;
-};
-
-struct PlannerDev {
-  double* vis_global;
-  double* vis_local;
-  double* vis_other;    // the local field that is NOT in use this iteration (two take turns when the sweep leaves dark cells
-                        // unwritten): the epilogue clears it for the next sweep; nullptr: one local field, fully written by every sweep
-  uint32_t* label;
-  int32_t* pivots;      // (x, y) pairs, lightSources_
-  PlannerCtl* ctl;
-  PlannerKey* partial;  // one per epilogue workgroup
-  unsigned int* ticket; // epilogue workgroups that have delivered their partial (the last one picks the pivot)
-  double threshold, scale;
-  int end_x, end_y;
-  unsigned long long max_iter;
-};
-
-__device__ __forceinline__ bool key_less(const PlannerKey& a, const PlannerKey& b) {
-  return a.h < b.h || (a.h == b.h && a.rank < b.rank);
-}
-
-// eval_d, visibilityBasedSolver.h:112-115: first product in double, second in int
-__device__ __forceinline__ double eval_d_dev(int ax, int ay, int bx, int by) {
-  const int dx = ax - bx, dy = ay - by;
-  return __builtin_sqrt((double)dx * dx + (double)(dy * dy));
-}
-
-// push-order rank of cell (x, y) for the pivot (sx, sy): quadrants in the order Q1..Q4,
-// inside a quadrant the x offset is the outer loop and the y offset the inner one
-// (solver.cpp:392-395 etc.); a cell several quadrants visit counts where it is first pushed.
-__device__ __forceinline__ unsigned long long push_rank(int nx, int ny, int sx, int sy, int x, int y) {
-  const long long dx = x - sx, dy = y - sy;
-  long long q, r;
-  if (dx >= 0 && dy >= 0) { q = 0; r = dx * (ny - sy) + dy; }
-  else if (dx < 0 && dy >= 0) { q = 1; r = (-dx) * (ny - sy) + dy; }
-  else if (dy < 0 && (dx < 0 || (dx == 0 && sx >= 1))) { q = 2; r = (-dx) * (long long)sy + (-dy); }
-  else { q = 3; r = dx * (long long)sy + (-dy); }
-  (void)nx;
-  return ((unsigned long long)q << 40) | (unsigned long long)r;
-}
-
-// The minimum over a whole wavefront (every lane active), in every lane: four DPP steps inside the rows of 16 (pairs, quads, the
-// half-row and the row mirrored), the four rows' results through scalar registers.  (A butterfly of ds_bpermute takes 12 trips through
-// the LDS crossbar per 64-bit value: 0.9 us per round of the speculative epilogue's pick.)
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
-  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));  // row_mirror
-  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), e = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-  return min(min(a, b), min(c, e));
-}
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-  const unsigned hi = wave_min_u32((unsigned)(v >> 32));
-  const unsigned lo = wave_min_u32((unsigned)(v >> 32) == hi ? (unsigned)v : 0xffffffffu);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-// Is this lane the one that holds the wavefront's minimum of (h, rank)?  (The lowest such lane: ranks of lit cells are distinct, keys
-// of lanes that found nothing are all alike.)  Every lane of the wavefront calls it.
-__device__ __forceinline__ bool wave_holds_min(const PlannerKey& k) {
-  const unsigned long long hmin = wave_min_u64(k.h);
-  const unsigned long long rmin = wave_min_u64(k.h == hmin ? k.rank : ~0ull);
-  const unsigned long long holders = __ballot(k.h == hmin && k.rank == rmin);
-  return (int)(threadIdx.x & 63) == __ffsll((long long)holders) - 1;
-}
 
 // Step 1 of a planner iteration: the plain front sweep (vhp_sweep.hip.h, fast path) from the
 // current pivot into vis_local -- the reference's visibility_ (solver.cpp:386-416).
@@ -127,171 +47,9 @@ __global__ void __launch_bounds__((R == 2 && MULTI) ? 512 : 1024, R >= 4 ? 4 : (
   sweep_quadrant<R>(m, emit, sx, sy, blockIdx.x, lds, whole_workgroup());
 }
 
-// Step 2: the per-cell body of updateVisibility() that follows the store (solver.cpp:417-430)
-// over every cell the sweep visited: max-union into vis_global, first-lit labelling, heuristic
-// of every lit cell, arg-min of (h, push rank).  Embarrassingly parallel and coalesced.
-// The epilogue's launch shape: kEpilogueBlocks workgroups of kEpilogueThreads (blocks <= threads: the last workgroup merges one partial
-// per thread).  Measured on maze_6 (bench.py --workload c4, us per pivot of the device loop, one box): 256 x 256 31.3, 128 x 512 30.3,
-// 64 x 1024 38.6 (profiles/r05_planner_epilogue_shapes.txt); later in round 5, with the polls overlapped: 96 x 512 27.2, 128 x 512 26.5,
-// 192 x 512 27.3, 256 x 512 28.8.
-#ifndef VHP_EPI_BLOCKS
-#define VHP_EPI_BLOCKS 128
-#endif
-#ifndef VHP_EPI_THREADS
-#define VHP_EPI_THREADS 512
-#endif
-constexpr int kEpilogueBlocks = VHP_EPI_BLOCKS;
-constexpr int kEpilogueThreads = VHP_EPI_THREADS;
-constexpr int kEpilogueWaves = kEpilogueThreads / 64;
-// cells of a thread per batch of loads in vhp_planner_epilogue (measured on maze_6 -- 277 380 cells, 65 536 threads: 4.2 cells each --,
-// us per pivot: 4: 26.4-26.6, 5 -- one batch instead of a full one and a quarter of a second --: 26.9, 6: 27.0)
-#ifndef VHP_EPI_CELLS
-#define VHP_EPI_CELLS 4
-#endif
-constexpr int kEpiCells = VHP_EPI_CELLS;
-constexpr int kSpecPartials = kEpilogueBlocks * kEpilogueWaves;  // the speculative solve's epilogue (same launch shape) leaves one partial per wavefront
+// Step 2 (vhp_planner_dev.hip.h): the per-cell body of updateVisibility() that follows the store, and the pick of the next pivot.
 __global__ void __launch_bounds__(kEpilogueThreads) vhp_planner_epilogue(DevMap m, PlannerDev d) {
-  __shared__ PlannerKey slots[kEpilogueWaves];
-  const int nx = m.nx, ny = m.ny;
-  const size_t cells = (size_t)nx * ny;
-  // kEpiCells cells of a thread at a time, their loads issued together -- the label's too, whether or not the cell turns out lit: the
-  // kernel is a chain of memory latencies, not of bytes.  The first batch is asked for with the control block, before anybody knows
-  // what that says (the loads are harmless if the loop has ended; the stores wait): one trip to memory less per iteration.
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  double vv[kEpiCells], oo[kEpiCells], ot[kEpiCells];
-  uint32_t ll[kEpiCells];
-  auto load_batch = [&](size_t k0) {
-#pragma unroll
-    for (int u = 0; u < kEpiCells; ++u) {
-      const size_t k = k0 + u * stride;
-      const bool in = k < cells;
-      vv[u] = in ? d.vis_local[k] : 0.0;
-      oo[u] = in ? d.vis_global[k] : 0.0;
-      ll[u] = in ? d.label[k] : 0u;
-      ot[u] = (d.vis_other && in) ? d.vis_other[k] : 0.0;
-    }
-  };
-  size_t k0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int done = d.ctl->done, nb = d.ctl->nb;
-  load_batch(k0);
-  if (done) return;
-  const int sx = d.pivots[2 * nb], sy = d.pivots[2 * nb + 1];
-  PlannerKey best;
-  best.h = ~0ull;
-  best.rank = ~0ull;
-  best.x = best.y = -1;
-  // The pivots a label can name (lightSources_[0 .. nb]) into LDS, beside the first batch of loads: a lit cell's parent then
-  // costs no round trip to memory of its own (beyond kPivLds entries: from global memory as before).
-  constexpr int kPivLds = 1024;
-  __shared__ int piv_lds[2 * kPivLds];
-  const int n_piv = nb + 1 < kPivLds ? nb + 1 : kPivLds;
-  for (int t = threadIdx.x; t < 2 * n_piv; t += blockDim.x) piv_lds[t] = d.pivots[t];
-  __syncthreads();
-  for (;;) {
-#pragma unroll
-    for (int u = 0; u < kEpiCells; ++u) {
-      const size_t k = k0 + u * stride;
-      if (k >= cells) continue;
-      if (ot[u] != 0.0) d.vis_other[k] = 0.0;   // (what iteration n - 1 left in the field the next sweep writes)
-      const int y = (int)((unsigned)k / (unsigned)nx), x = (int)((unsigned)k - (unsigned)y * (unsigned)nx);  // (cells < 2^31: VHP_MAX_SIDE^2)
-      // column 0 / row 0 are swept only when the pivot lies on them: unvisited cells are
-      // neither united, labelled nor pushed
-      if ((x == 0 && sx > 0) || (y == 0 && sy > 0)) continue;
-      const double v = vv[u];
-      const double old = oo[u];
-      const double g = fmax(v, old);  // :417-418
-      if (g != old) d.vis_global[k] = g;  // (most cells of most iterations are dark: nothing to write)
-      if (g >= d.threshold) {  // :424-430 (v >= threshold implies g >= threshold)
-        uint32_t lab = ll[u];
-        if (v >= d.threshold && lab == kUnlabelled32) {  // :419-423
-          lab = (uint32_t)nb;
-          d.label[k] = lab;
-        }
-        const int px = lab < (uint32_t)kPivLds ? piv_lds[2 * lab] : d.pivots[2 * lab];
-        const int py = lab < (uint32_t)kPivLds ? piv_lds[2 * lab + 1] : d.pivots[2 * lab + 1];
-        const double h = (d.scale * g) + (eval_d_dev(x, y, d.end_x, d.end_y) + eval_d_dev(x, y, px, py));
-        PlannerKey c;
-        c.h = (unsigned long long)__double_as_longlong(h);
-        c.rank = push_rank(nx, ny, sx, sy, x, y);
-        c.x = x;
-        c.y = y;
-        if (key_less(c, best)) best = c;
-      }
-    }
-    k0 += kEpiCells * stride;
-    if (k0 >= cells) break;
-    load_batch(k0);
-  }
-  const int wave = threadIdx.x >> 6;
-  if (wave_holds_min(best)) slots[wave] = best;   // (the one lane that holds the wavefront's minimum of (h, rank))
-  // The workgroup whose partial arrives last merges them all and picks the next pivot: no third kernel, no single-thread
-  // walk over the partials.  Cross-CU hand-off (MI355X_MICROARCH "Valid forms"): every storing wavefront drains its
-  // stores, the workgroup's barrier, then one lane: partial, agent-scope release, drained again, ticket.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  __shared__ int is_last;
-  if (threadIdx.x == 0) {
-    PlannerKey b = slots[0];
-    for (int w = 1; w < kEpilogueWaves; ++w)
-      if (key_less(slots[w], b)) b = slots[w];
-    d.partial[blockIdx.x] = b;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    is_last = __hip_atomic_fetch_add(d.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
-    if (is_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  if (!is_last) return;
-  // Wavefront 0 alone, on registers: the partials (agent-scope loads: other CUs wrote them), the loop condition's cell (written by
-  // some workgroup of this kernel) and the iteration count are asked for together; the minimum of (h, rank) by DPP; lane 0 stores
-  // the pick -- ls_ = top(); ++nb_of_sources_; lightSources_[nb] = ls_; the loop condition (solver.cpp:127-141).
-  // (Until round 5: a partial per thread, a butterfly of ds_bpermute per wavefront, a barrier, one thread over the wavefronts'
-  // minima and then the pick's trips to memory one after the other.)
-  if (wave != 0) return;
-  const int lane = (int)threadIdx.x;
-  const double ge = __longlong_as_double((long long)__hip_atomic_load(
-      reinterpret_cast<const unsigned long long*>(d.vis_global + (size_t)d.end_y * m.nx + d.end_x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  const int iters = d.ctl->iters;
-  constexpr int kPerLane = (kEpilogueBlocks + 63) / 64;
-  PlannerKey k;
-  k.h = ~0ull; k.rank = ~0ull; k.x = k.y = -1;
-#pragma unroll
-  for (int t = 0; t < kPerLane; ++t) {
-    const int i = lane + 64 * t;
-    const bool in = i < (int)gridDim.x;
-    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(d.partial + (in ? i : 0));
-    PlannerKey o;
-    o.h = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    o.rank = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long xy = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    o.x = (int)(unsigned)xy;
-    o.y = (int)(unsigned)(xy >> 32);
-    if (in && key_less(o, k)) k = o;
-  }
-  const unsigned long long hmin = wave_min_u64(k.h);
-  const unsigned long long rmin = wave_min_u64(k.h == hmin ? k.rank : ~0ull);
-  const unsigned long long holders = __ballot(k.h == hmin && k.rank == rmin);
-  const int wl = holders ? __ffsll((long long)holders) - 1 : 0;
-  const int wx = __builtin_amdgcn_readlane(k.x, wl), wy = __builtin_amdgcn_readlane(k.y, wl);  // (-1: nothing reached the threshold)
-  if (lane != 0) return;
-  *d.ticket = 0;  // for the next iteration (kernels of one stream run in order)
-  d.ctl->iters = iters + 1;
-  if (wx < 0) {  // the reference would call top() on an empty heap
-    d.ctl->status = VHP_ERR_NOTHING_LIT;
-    d.ctl->done = 1;
-    return;
-  }
-  const int nbn = nb + 1;
-  int px = wx, py = wy, status = -1;
-  if ((unsigned long long)nbn > d.max_iter) status = VHP_ERR_MAX_ITER;  // :134-139
-  else if (ge > d.threshold) { px = d.end_x; py = d.end_y; status = VHP_OK; }  // :127, :141
-  d.ctl->nb = nbn;
-  d.pivots[2 * nbn] = px;
-  d.pivots[2 * nbn + 1] = py;
-  if (status >= 0) { d.ctl->status = status; d.ctl->done = 1; }
+  planner_epilogue_body<kEpilogueThreads>(m.nx, m.ny, d, (int)blockIdx.x, (int)gridDim.x, nullptr, 0u);
 }
 
 __global__ void vhp_planner_init(PlannerDev d, int nx, int start_x, int start_y) {
@@ -310,6 +68,7 @@ __global__ void vhp_planner_init(PlannerDev d, int nx, int start_x, int start_y)
       d.pivots[1] = d.end_y;
       d.ctl->done = 1;
     }
+    *reinterpret_cast<int4*>(d.rec) = make_int4(d.ctl->done, 0, d.pivots[0], d.pivots[1]);
   }
 }
 
@@ -325,6 +84,7 @@ struct PlannerState {
   double* vis_global = nullptr;
   double* vis_local = nullptr;
   double* vis_local2 = nullptr;      // the second local field of the plain solve (see PlannerDev::vis_other)
+  bool local_uncached = false;       // the local fields are uncached device memory (PlannerDev::local_uncached)
   double* vis_local_out = nullptr;   // where the last solve left its local field (one of the two)
   uint32_t* label = nullptr;
   unsigned long long* came64 = nullptr;
@@ -344,7 +104,9 @@ struct PlannerState {
   // set by the caller when the latency sweep (vhp_lat.hpp) can sweep this grid: launches it for source number *nb of pivots into
   // out unless *done is set (the same contract as vhp_planner_sweep: everything read on the device when the launch runs)
   // (dark_unwritten: the field holds +0.0 wherever the sweep does not write, dead strips store nothing)
-  std::function<hipError_t(const int32_t* pivots, const int* nb, const int* done, double* out, bool dark_unwritten)> lat_sweep;
+  std::function<hipError_t(const int32_t* pivots, const int* nb, const int* done, const int* rec, double* out, bool dark_unwritten)> lat_sweep;
+  // ... or the whole iteration -- that sweep and the epilogue over d -- as ONE launch (vhp_lat.hip vhp_planner_iteration)
+  std::function<hipError_t(const PlannerDev& d)> lat_iteration;
   // ... of the speculative loop: the n candidates of `cand` into fields *slot_base .. of `cache`, if *run_if and not *done
   std::function<hipError_t(const int32_t* cand, int n, const int* slot_base, const int* run_if, const int* done, double* cache, bool dark_unwritten)> lat_sweep_k;
 };
@@ -453,12 +215,14 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   if (s.cells != cells) {
     planner_free(s);
     VHP_PL_HIP(hipMalloc(&s.vis_global, cells * 8));
-    VHP_PL_HIP(hipMalloc(&s.vis_local, cells * 8));
+    s.local_uncached = std::getenv("VHP_PLANNER_UNCACHED") != nullptr;   // (an experiment of the one-kernel iteration: vhp_capi.hip)
+    if (s.local_uncached) VHP_PL_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&s.vis_local), cells * 8, hipDeviceMallocUncached));
+    else VHP_PL_HIP(hipMalloc(&s.vis_local, cells * 8));
     VHP_PL_HIP(hipMalloc(&s.label, cells * 4));
     VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
-    VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
+    VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl) + 16));   // (+ the 16-byte pivot record: PlannerDev::rec)
     VHP_PL_HIP(hipMalloc(&s.partial, kSpecPartials * sizeof(PlannerKey)));
-    VHP_PL_HIP(hipMalloc(&s.ticket, sizeof(unsigned int)));
+    VHP_PL_HIP(hipMalloc(&s.ticket, 2 * sizeof(unsigned int)));   // ([1]: the sweep workgroups of a one-kernel iteration that have finished)
     s.cells = cells;
   }
   if (s.pivot_cap < pcap) {
@@ -468,14 +232,17 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
     s.pivot_cap = pcap;
   }
   // (the second local field only where the latency sweep runs the loop; the speculative solve, which shares this state, has one)
-  if (s.lat_sweep && !s.vis_local2) VHP_PL_HIP(hipMalloc(&s.vis_local2, cells * 8));
+  if (s.lat_sweep && !s.vis_local2) {
+    if (s.local_uncached) VHP_PL_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&s.vis_local2), cells * 8, hipDeviceMallocUncached));
+    else VHP_PL_HIP(hipMalloc(&s.vis_local2, cells * 8));
+  }
   // reset(): visibility_global_ = 0, visibility_ = 0, cameFrom_ = 1e15   (solver.cpp:42-47)
   VHP_PL_HIP(hipMemsetAsync(s.vis_global, 0, cells * 8, stream));
   VHP_PL_HIP(hipMemsetAsync(s.vis_local, 0, cells * 8, stream));
   if (s.vis_local2) VHP_PL_HIP(hipMemsetAsync(s.vis_local2, 0, cells * 8, stream));
   VHP_PL_HIP(hipMemsetAsync(s.label, 0xff, cells * 4, stream));
   VHP_PL_HIP(hipMemsetAsync(s.pivots, 0, pcap * sizeof(int32_t), stream));
-  VHP_PL_HIP(hipMemsetAsync(s.ticket, 0, sizeof(unsigned int), stream));
+  VHP_PL_HIP(hipMemsetAsync(s.ticket, 0, 2 * sizeof(unsigned int), stream));
 
   PlannerDev d;
   d.vis_global = s.vis_global;
@@ -488,6 +255,8 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
   d.label = s.label;
   d.pivots = s.pivots;
   d.ctl = s.ctl;
+  d.rec = reinterpret_cast<int*>(s.ctl + 1);
+  d.local_uncached = s.local_uncached ? 1 : 0;
   d.partial = s.partial;
   d.ticket = s.ticket;
   d.threshold = threshold;
@@ -516,7 +285,12 @@ inline int planner_solve(PlannerState& s, const DevMap& m, const uint8_t* d_occ,
           d.vis_local = (launches & 1) ? s.vis_local2 : s.vis_local;
           d.vis_other = (launches & 1) ? s.vis_local : s.vis_local2;
         }
-        hipError_t e = s.lat_sweep ? s.lat_sweep(d.pivots, &s.ctl->nb, &s.ctl->done, d.vis_local, true)
+        if (s.lat_iteration) {
+          const hipError_t ei = s.lat_iteration(d);
+          if (ei != hipSuccess) { *msg = std::string("planner launch: ") + hipGetErrorString(ei); return VHP_ERR_HIP; }
+          continue;
+        }
+        hipError_t e = s.lat_sweep ? s.lat_sweep(d.pivots, &s.ctl->nb, &s.ctl->done, d.rec, d.vis_local, true)
                      : R == 1 ? (multi ? launch_planner_fronts<1, true>(s, m, d, W, stream) : launch_planner_fronts<1, false>(s, m, d, W, stream))
                      : R == 2 ? (multi ? launch_planner_fronts<2, true>(s, m, d, W, stream) : launch_planner_fronts<2, false>(s, m, d, W, stream))
                               : (multi ? launch_planner_fronts<4, true>(s, m, d, W, stream) : launch_planner_fronts<4, false>(s, m, d, W, stream));
@@ -1003,9 +777,9 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
     VHP_PL_HIP(hipMalloc(&s.vis_local, cells * 8));
     VHP_PL_HIP(hipMalloc(&s.label, cells * 4));
     VHP_PL_HIP(hipMalloc(&s.came64, cells * 8));
-    VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl)));
+    VHP_PL_HIP(hipMalloc(&s.ctl, sizeof(PlannerCtl) + 16));   // (+ the 16-byte pivot record: PlannerDev::rec)
     VHP_PL_HIP(hipMalloc(&s.partial, kSpecPartials * sizeof(PlannerKey)));
-    VHP_PL_HIP(hipMalloc(&s.ticket, sizeof(unsigned int)));
+    VHP_PL_HIP(hipMalloc(&s.ticket, 2 * sizeof(unsigned int)));   // ([1]: the sweep workgroups of a one-kernel iteration that have finished)
     s.cells = cells;
   }
   if (s.pivot_cap < pcap) {
@@ -1023,7 +797,7 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
   VHP_PL_HIP(hipMemsetAsync(s.vis_global, 0, cells * 8, stream));
   VHP_PL_HIP(hipMemsetAsync(s.label, 0xff, cells * 4, stream));
   VHP_PL_HIP(hipMemsetAsync(s.pivots, 0, s.pivot_cap * sizeof(int32_t), stream));
-  VHP_PL_HIP(hipMemsetAsync(s.ticket, 0, sizeof(unsigned int), stream));
+  VHP_PL_HIP(hipMemsetAsync(s.ticket, 0, 2 * sizeof(unsigned int), stream));
   if (mode == 1) VHP_PL_HIP(hipMemsetAsync(ss.cache, 0, (size_t)2 * K * cells * 8, stream));  // (the two groups of k slots that take turns: vhp_spec_epilogue)
 
   PlannerDev d;
@@ -1034,6 +808,8 @@ inline int planner_solve_speculative(PlannerState& s, SpecState& ss, const DevMa
   d.label = s.label;
   d.pivots = s.pivots;
   d.ctl = s.ctl;
+  d.rec = reinterpret_cast<int*>(s.ctl + 1);
+  d.local_uncached = s.local_uncached ? 1 : 0;
   d.partial = s.partial;
   d.ticket = s.ticket;
   d.threshold = threshold;
