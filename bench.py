@@ -51,10 +51,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "c1-batch", "c-250", "c1k-empty", "c3-1024", "c3-1016", "c3-512"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "c1-batch", "c-250", "c3-8", "c3-32", "c3-64", "c3-96", "c1k-empty", "c3-1024", "c3-1016", "c3-512"],
                     help="c3 (default): BASELINE config 3, the configuration the metric is quoted on; c2 / c4 / c5: configs 2, 4, 5 (per-GPU share); "
                          "c1-batch: the reference's own headline size -- config 1's 101x101 rnd_1 mask -- as a batch of 4096 sources; c-250: a 250x250 "
-                         "random grid, 256 sources (small-grid batches); the others are diagnostics")
+                         "random grid, 256 sources (small-grid batches); c3-8 / c3-32 / c3-64 / c3-96: config 3's map with that many sources -- the batches a planner "
+                         "makes of start, goal and frontier pivots; the others are diagnostics")
     ap.add_argument("--sources", type=int, default=0, help="sources per GPU (default: workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--gather", action="store_true", help="all-gather the fields over RCCL inside the timed region")
@@ -95,6 +96,9 @@ def make_workload(name, rank, n_src):
     import vhp_amd
     from importlib import import_module
     synth = import_module("visibility-heuristic-path-planner_amd.synth")
+    if name in ("c3-8", "c3-32", "c3-64", "c3-96"):   # config 3's map, the first n of its seeded sources
+        n_src = n_src or int(name.split("-")[1])
+        name = "c3"
     if name == "c3":
         n = n_src or 256
         # (rank 0's launch IS synth.config_c3(n): the launch tests/test_gpu_sweep.py::test_config3_all_256_fields... checks field by
@@ -522,11 +526,11 @@ def main():
     # the timed launches left in the first allocation, byte for byte against ANOTHER kernel's -- the front sweep's -- on the same
     # sources.  Behind both timed regions, before anything else writes the buffer.
     self_check = None
+    timed_kernel = ctx.last_sweep_kernel()   # what the timed launches ran (the self-check below launches another kernel)
     if rank == 0 and not overlapped:
         try:
             n_chk = min(8, n_src)
             ref = torch.empty((n_chk, ny, nx), dtype=tdt, device=dev)
-            timed_kernel = ctx.last_sweep_kernel()
             ctx.set_option("kernel", 1)
             ctx.sweep_batch_device(d_src.data_ptr(), n_chk, ref.data_ptr(), dtype=vdt)
             ctx.sync()
@@ -632,7 +636,8 @@ def main():
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of this
         # command): collected by tools/collect_profiles.sh into profiles/, not measured inside this run
         traffic, traffic_src = None, None
-        kname = {1: "vhp_sweep_fronts", 3: "vhp_pool_sweep", 4: "vhp_lat_sweep"}.get(ctx.last_sweep_kernel(), "unknown")  # what the library launched
+        # what the library launched IN THE TIMED REGION (recorded there: the self-check behind it launches the front sweep)
+        kname = {1: "vhp_sweep_fronts", 3: "vhp_pool_sweep", 4: "vhp_lat_sweep"}.get(timed_kernel, "unknown")
         tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s_%s.json" % (args.workload, args.dtype, kname))
         if os.path.exists(tpath):
             try:
@@ -663,6 +668,7 @@ def main():
                        "collective": ("rccl all_gather of fields (%s%s)" % (args.gather_mode if gathered is not None else "", ", %d chunks per shard" % args.chunks if overlapped else "")
                                       if gathered is not None else "none (independent sources)"),
                        "map": "rccl broadcast from rank 0" if world > 1 else "uploaded by the only rank",
+                       **({"multi_gpu": "the builder has never run this path across devices (one-GPU boxes only): first run on a node is the driver's"} if world > 1 else {}),
                        **({"share_device": "TEST MODE: every rank on cuda:0, gloo collectives -- not a result"} if args.share_device else {})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,

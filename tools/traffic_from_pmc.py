@@ -19,7 +19,7 @@ def per_kernel(path, counter):
 
 fetch_csv, write_csv, workload, dtype, out_dir = sys.argv[1:6]
 fetch, write = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
-KERNELS = ("vhp_sweep_fronts", "vhp_pool_sweep")   # the batch-sweep kernels (bench.py names them the same way)
+KERNELS = ("vhp_sweep_fronts", "vhp_pool_sweep", "vhp_lat_sweep")   # the batch-sweep kernels (bench.py names them the same way)
 names = [k for k in write if any(n in k for n in KERNELS)]
 name = max(names, key=lambda k: sum(write[k]))
 short = next(n for n in KERNELS if n in name)

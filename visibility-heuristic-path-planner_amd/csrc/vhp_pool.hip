@@ -111,15 +111,17 @@ __device__ __forceinline__ void order_units(const int32_t* __restrict__ src_xy, 
   for (int u = threadIdx.x; u < n_units; u += 1024) blocks[u] &= (1 << 20) - 1;
   __syncthreads();
   const int total = block_exclusive_scan_1024(blocks, n_units, wave_tot);
-  // the records, in launch order (order[] was written by this workgroup before the barriers above)
+  const bool fits = (long long)total <= capacity_blocks;
+  // the records, in launch order (order[] was written by this workgroup before the barriers above).  If the boundary lines do not fit
+  // the scratch, NOTHING is swept: the queue starts exhausted, and every record says so as well (-2) -- the first unit of a context is
+  // handed out by workgroup index without a look at the queue (Args::static_round), and its lines would lie beyond the scratch.
   for (int k = threadIdx.x; k < n_units; k += 1024) {
     const int u = order[k], s = u / kUnits;
     const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
     const bool inside = !(sx < 0 || sy < 0 || sx >= nx || sy >= ny);
-    reinterpret_cast<int4*>(recs)[k] = make_int4(u, inside ? (sx | (sy << 16)) : -1, blocks[u], 0);
+    reinterpret_cast<int4*>(recs)[k] = make_int4(u, !fits ? -2 : inside ? (sx | (sy << 16)) : -1, blocks[u], 0);
   }
   if (threadIdx.x == 0) {
-    const bool fits = (long long)total <= capacity_blocks;
     *queue = fits ? queue0 : (unsigned long long)n_units;
     if (!fits) atomicOr(err_flag, 4);
   }

@@ -1628,8 +1628,8 @@ struct Worker {
     int unit, sxsy, lbase, rsvd;
     g_load_rec4(a.recs, idx, unit, sxsy, lbase, rsvd);
     const int s = unit / kUnits, qo = unit - s * kUnits;
-    if (sxsy < 0) {  // units of a rejected source do nothing
-      if (qo == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
+    if (sxsy < 0) {  // units of a rejected source do nothing (-2: the launch's boundary lines do not fit its scratch -- vhp_pool_order has said so in the error flag -- and no unit is swept)
+      if (qo == 0 && sxsy == -1) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
       lds_publish(cx + kState, 0);
       return;
     }
