@@ -510,13 +510,30 @@ struct BandXStore {
   VHP_FN void zero_fill(int b, int ta, int) {
     const int D0 = kBlock * b, t_last = Geo::t_last(g, b);
     const int j_lo = imax(0, ta - D0 - (kBlock - 1)), j_hi = imin(rows_total - 1, t_last - D0);
-    for (int j = j_lo; j <= j_hi; ++j) {
-      const int t_lo = imax(ta, j + D0), t_hi = imin(t_last, j + D0 + kBlock - 1);
-      // lane l: the cell l columns above the row piece's lowest x
-      const int x_lo = DX > 0 ? g.X(t_lo) : g.X(t_hi);
-      g_store_scalar_if(lane <= t_hi - t_lo, out, lane + (g.Y(j) * nxm + x_lo), OutT(0));
-      if (((j - j_lo) & 15) == 15) sim_point();
+    // the rows whose piece is whole (64 cells: the steps j + D0 .. j + D0 + 63 all lie in [ta, t_last]): one store and one pointer
+    // increment per row -- the piece slides by one column from row to row
+    const int jf_lo = imax(j_lo, ta - D0), jf_hi = imin(j_hi, t_last - D0 - (kBlock - 1));
+    auto ragged = [&](int ja, int jb) {
+      for (int j = ja; j <= jb; ++j) {
+        const int t_lo = imax(ta, j + D0), t_hi = imin(t_last, j + D0 + kBlock - 1);
+        const int x_lo = DX > 0 ? g.X(t_lo) : g.X(t_hi);   // lane l: the cell l columns above the row piece's lowest x
+        g_store_scalar_if(lane <= t_hi - t_lo, out, lane + (g.Y(j) * nxm + x_lo), OutT(0));
+        if (((j - ja) & 15) == 15) sim_point();
+      }
+    };
+    if (jf_lo > jf_hi) { ragged(j_lo, j_hi); return; }
+    ragged(j_lo, jf_lo - 1);
+    {
+      const vu32 off = to_u32(lane * CB);
+      OutT* row = out + ((long)g.Y(jf_lo) * nxm + (DX > 0 ? g.X(jf_lo + D0) : g.X(jf_lo + D0 + kBlock - 1)));
+      const long step = (long)DY * nxm + DX;
+      for (int j = jf_lo; j <= jf_hi; ++j) {
+        g_store1_if(vb(true), row, off, vd(0.0));
+        row += step;
+        if (((j - jf_lo) & 15) == 15) sim_point();
+      }
     }
+    ragged(jf_hi + 1, j_hi);
   }
 };
 
@@ -870,8 +887,10 @@ struct BandYStore {
     const vi t_hi = vmin(d + (g.ni - 1), j_last);
     const long rowstep = (long)DY * nxm + DX;
     OutT* row = row_base(D0, ta);
+    // (the rows in which every lane has a cell: no predicate)
+    const int tf_lo = imax(ta, D0 + kLanes - 1), tf_hi = imin(t_last, imin(j_last, D0 + g.ni - 1));
     for (int t = ta; t <= t_last; ++t) {
-      g_store1_if((d <= t) && (t_hi >= t), row, xoff, vd(0.0));
+      if (t >= tf_lo && t <= tf_hi) g_store1_if(vb(true), row, xoff, vd(0.0)); else g_store1_if((d <= t) && (t_hi >= t), row, xoff, vd(0.0));
       row += rowstep;
       if (((t - ta) & (kLW - 1)) == kLW - 1) sim_point();
     }
