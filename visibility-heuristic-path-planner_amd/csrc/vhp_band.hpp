@@ -446,26 +446,40 @@ struct BandXStore {
   // every row and step of band b's window at ta exists
   VHP_FN bool interior(int D0, int ta) const { return ta - D0 - (kBlock - 1) >= 0 && ta + kLW - 1 - D0 <= rows_total - 1 && ta + kLW - 1 <= i_last; }
 
-  // INTERIOR: only the two ends of the parallelogram (the groups 0, 1, 8, 9) need a lane mask, and that one is the same in every window
+  // Which groups of a window hold a cell of the lane's pair?  A RANGE of groups: cell (column c, group u, row slot rj) was computed by
+  // lane l = fl_l - 8 u of the band (0 .. 63 for u in [(fl_l - 56) >> 3, fl_l >> 3]: the parallelogram's two ends) and lies in row
+  // jA + 8 u + rj (0 .. rows_total - 1 for another range of u: the rows the octant has); its step must be a step of the march.  The
+  // ranges are intersected once per window, and a group's predicate is one subtraction and one unsigned compare per cell -- per
+  // group, the same conditions spelt out were fourteen vector and two dozen scalar instructions, in the windows of a band's first 64
+  // steps, the ones the band above waits for.
+  VHP_FN void group_range(const vi& l0, const vb& step_ok, int jA, bool interior_, vi& lo, vi& w) const {
+    vi a = (l0 - (kBlock - 8)) >> 3, b = l0 >> 3;      // 0 <= l0 - 8 u <= 63
+    if (!interior_) {
+      a = select((-fl_rj - jA + 7) >> 3 > a, (-fl_rj - jA + 7) >> 3, a);                           // jA + 8 u + rj >= 0
+      b = select((-fl_rj + (rows_total - 1 - jA)) >> 3 < b, (-fl_rj + (rows_total - 1 - jA)) >> 3, b);  // ... <= rows_total - 1
+    }
+    const vb none = (b < a) || !step_ok;
+    lo = select(none, vi(100), a);
+    w = select(none, vi(0), b - a);
+  }
+  // INTERIOR: only the two ends of the parallelogram (the groups 0, 1, 8, 9) need a lane mask
   template <bool INTERIOR>
   VHP_FN void store_window(int D0, int ta, int xw, const vd (&fa)[10], const vd (&fb)[10]) {
     const int jA = ta - D0 - (kBlock - 1);
     const long base_step = (long)(8 * DY) * nxm;
     OutT* base = out + (long)(DY > 0 ? g.Y(jA) : g.Y(jA + 7)) * (long)nxm + xw;
+    vi lo0, w0, lo1, w1;
+    {
+      const vi t0 = DX > 0 ? fl_c + ta : (-fl_c) + (ta + kLW - 1), t1 = t0 + DX;   // the steps of the pair's two cells
+      group_range(fl_l, INTERIOR ? vb(true) : (t0 <= i_last), jA, INTERIOR, lo0, w0);
+      group_range(DX > 0 ? fl_l + 1 : fl_l - 1, INTERIOR ? vb(true) : (t1 <= i_last), jA, INTERIOR, lo1, w1);
+    }
 #pragma unroll
     for (int u = 0; u < 10; ++u) {
       if (INTERIOR && !ODD && u >= 2 && u <= 7) {
         g_store2(base, fl_off, fa[u], fb[u]);
       } else if (INTERIOR || (jA + 8 * u + 7 >= 0 && jA + 8 * u < rows_total)) {
-        const vi la = fl_l - 8 * u, lb = DX > 0 ? la + 1 : la - 1;
-        vb ok0 = (la >= 0) && (la < kBlock), ok1 = (lb >= 0) && (lb < kBlock);
-        if (!INTERIOR) {
-          const vi j = fl_rj + (jA + 8 * u);
-          const vi t0 = DX > 0 ? fl_c + ta : (-fl_c) + (ta + kLW - 1), t1 = t0 + DX;
-          const vb row_ok = (j >= 0) && (j < rows_total);
-          ok0 = ok0 && row_ok && (t0 <= i_last);
-          ok1 = ok1 && row_ok && (t1 <= i_last);
-        }
+        const vb ok0 = to_u32((-lo0) + u) <= to_u32(w0), ok1 = to_u32((-lo1) + u) <= to_u32(w1);
         store_group(base, ok0, ok1, fa[u], fb[u]);
       }
       base += base_step;

@@ -140,7 +140,7 @@ __device__ __forceinline__ void planner_epilogue_body(int nx, int ny, const Plan
       const bool in = k < cells;
       oo[u] = in ? d.vis_global[k] : 0.0;
       ll[u] = in ? d.label[k] : 0u;
-      ot[u] = (d.vis_other && in) ? d.vis_other[k] : 0.0;
+      ot[u] = (d.vis_other && in) ? d.vis_other[k] : 0.0;   // (cleared without looking -- a store per cell instead of this load -- measured: 23.0 -> 23.4 us per pivot)
     }
   };
   auto load_local = [&](size_t k0) {
