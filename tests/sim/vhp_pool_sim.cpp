@@ -278,7 +278,7 @@ template <typename OutT, bool ODD, typename WorkerT>
 int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int policy, uint32_t seed, long long* stats) {
   HostMap h;
   build_map(occ, nx, ny, h);
-  const Layout L = make_layout(W, 1, nx, ny);
+  const Layout L = make_layout(W, 1, nx, ny, WorkerT::kTilePitch);
   const int G = n_src * kUnits;
   int err = 0;
   LatArgs<OutT> a;

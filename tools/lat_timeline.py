@@ -42,7 +42,7 @@ assert mod._lib.vhp_debug_read_lat_strip_times(C.c_void_p(st.ctypes.data), st.si
 st = st.reshape(64, 48, 4).astype(np.float64)
 for u in range(8):
     print("unit %d (%s-major): workgroup start %.1f us, last wavefront out %.1f us" % (u, "xy"[u % 2], (w[u, :, 16].min() - base) / 100, (w[u, :, 17].max() - base) / 100))
-    if u % 2 == 0:
+    if True:
         for v in range(12):
             r = w[u, v]
             nw = r[12] + r[13]

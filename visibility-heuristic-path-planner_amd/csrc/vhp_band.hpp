@@ -49,6 +49,22 @@ namespace pool {
 // W + w) reads the tile out and stores.  One tile per sweeper: the storer says when it has read a tile out (its LDS reads are ordered
 // before that word by the LDS itself), and the sweeper looks at the word after the arithmetic of its next window's first step, just
 // before that step's tile write -- by then the storer has long been through.  The zeros of a dead band's cells are the storer's, too.
+// instruction-arbitration priorities (s_setprio): the sweeper of a band in its first 64 steps / of a band in its steady state; storers run at 0.
+// Measured (profiles/r06_exp_band_priorities.txt): 3 / 0 takes 2 µs off C2 and 1 µs off one source at 512²; resetting the priority after a
+// march costs 512² 3 µs (the end of a launch is the last bands' zeros and set-ups); all sweepers at 3 is the same as all at 0.
+#ifndef VHP_BAND_PRIO_CHAIN
+#define VHP_BAND_PRIO_CHAIN 3
+#endif
+#ifndef VHP_BAND_PRIO_STEADY
+#define VHP_BAND_PRIO_STEADY 0
+#endif
+// The tile's pitch.  The storer of an x-major band reads the tile out along the grid's rows, i.e. along the tile's DIAGONALS: the cell at
+// column c of row j sits in lane c - j (marching up) or -c - j (marching down) + const, at pitch P word (P + 1) c - P j or -(P - 1) c - P j.
+// At the pool sweep's pitch of 17 the second form is -16 c - 17 j: the eight pairs of a row in ONE bank, an eight-way conflict in every
+// read-out of the two x-major units that march down (their windows 3.4-4.7 k cycles against 2.6-3.5 k, profiles/r06_b_lat_timeline_c2.txt).
+// 19 is conflict-free for them (and two-way marching up, where 17 is conflict-free): the pitch goes by direction, the space by the larger.
+constexpr int kBandTStrideDown = 19;
+constexpr int kBandTileDoubles = kXRows * kBandTStrideDown;   // a sweeper's tile
 constexpr int kPostRec = 4;    // ints into the sweeper's dummy slots (16-byte aligned): {seq, lowest step, lowest coordinate, band | flags << 16}
 constexpr int kPostTaken = 8;  // the storer's word: the last seq whose tile has been read out
 enum { kPostZero = 1, kPostDone = 2 };
@@ -104,13 +120,14 @@ struct BandXGeo {
 
 template <int DX, int DY>
 struct BandX {
+  static constexpr int kTS = DX > 0 ? kTStride : kBandTStrideDown;   // the tile's pitch (see kBandTStrideDown)
   static constexpr bool kMain = DX * DY > 0;  // the lanes' runs: y - x constant (main) or y + x constant (anti)
   using Geo = BandXGeo<DX, DY>;
   Map m;
   const uint64_t* dm;  // the packed runs of this quadrant's kind, by x
   int wpd;
   Quad<DX, DY> g;
-  double* tile;   // 64 lanes x 16 columns (pitch kTStride): column c = x - (lowest x of the window)
+  double* tile;   // 64 lanes x 16 columns (pitch kTS): column c = x - (lowest x of the window)
   double* slab;   // reciprocals of the step indices of two blocks of 64 coordinates, indexed by x & 127
   double* bin;
   Link<DX> lk;
@@ -142,11 +159,11 @@ struct BandX {
     g.init(m.nx, m.ny, sx, sy);
     dm = dmap + DiagMaps::offset(m.nx, m.ny, kMain ? 0 : 1);
     wpd = DiagMaps::wpdx(m.nx);
-    tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
+    tile = sh.lds + sh.L.tiles + w * kBandTileDoubles;
     slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
     bin = lk.bin;
     lane = lane_id();
-    tile_l = lane * kTStride;
+    tile_l = lane * kTS;
     b = b_;
     D0 = kBlock * b;
     i_last = g.ni - 1;
@@ -167,7 +184,7 @@ struct BandX {
       dgw = vmin(vmax(id, 0), DiagMaps::runs(m.nx, m.ny) - 1) * wpd;
       dg_w0 = (kMain ? sy - sx + m.nx - 1 : sy + sx) * wpd;   // (the diagonal's run, d = 0: the source lies on it)
     }
-    ring_rel = has_consumer ? (int)(lk.ring - tile) : (kBlock - 1) * kTStride;
+    ring_rel = has_consumer ? (int)(lk.ring - tile) : (kBlock - 1) * kTS;
     dead_mine = sh.owner(0) + b;
     dead_below = sh.owner(0) + (b > 0 ? b - 1 : b);
     skip_fill = false;
@@ -258,7 +275,11 @@ struct BandX {
     vd rr[kLW];
     rr[0] = lds_bcast(rslab, DX > 0 ? 0 : kLW - 1);
     rr[1] = lds_bcast(rslab, DX > 0 ? 1 : kLW - 2);
+#ifdef VHP_EXP_NORATIO
+    vd cc = rr[0];
+#else
     vd cc = ratio(vmaxd(jd, 0.0), di, rr[0]);
+#endif
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DX > 0 ? k : kLW - 1 - k;
@@ -286,7 +307,11 @@ struct BandX {
       lds_store(tile, tl + c, v);
       di = di + 1.0;
       jd = jd + 1.0;
-      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), di, rr[k + 1]);  // the next step's ratio beside this step's chain, and no further ahead
+#ifdef VHP_EXP_NORATIO
+      if (k + 1 < kLW) cc = rr[k + 1];
+#else
+      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), di, rr[k + 1]);
+#endif  // the next step's ratio beside this step's chain, and no further ahead
       sched_fence();
     }
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
@@ -322,6 +347,9 @@ struct BandX {
     while (ta <= t_end) {
       if (dies_at(ta - 1)) { dead = true; break; }
       open_block(xw, ta);
+      // (a band's first 64 steps and the window that hands over are what the band above waits for: the chain of the unit issues ahead of
+      // the bands in their steady state and of the storers that share its SIMD)
+      wave_priority(ta < D0 + kBlock + kLW ? VHP_BAND_PRIO_CHAIN : VHP_BAND_PRIO_STEADY);
       window<B0>(ta, xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk, ta + kLW <= t_end);
       ta += kLW; xw += kLW * DX;
       sim_progress();
@@ -405,6 +433,7 @@ struct BandX {
 // every row (an odd width, or fields that start off the pair grid): every cell leaves by itself.
 template <int DX, int DY, typename OutT, bool ODD>
 struct BandXStore {
+  static constexpr int kTS = DX > 0 ? kTStride : kBandTStrideDown;
   static constexpr int CB = sizeof(OutT);
   using Geo = BandXGeo<DX, DY>;
   Quad<DX, DY> g;
@@ -435,7 +464,7 @@ struct BandXStore {
     fl_l = DX > 0 ? (fl_c - fl_rj) + 63 : (-fl_c - fl_rj) + 78;  // the lane of the pair's first cell in group 0; - 8 per group
     // (the lower of the pair's two addresses in group 7, the last whole group: every other whole group at a positive immediate
     // offset from it -- a DS instruction encodes no negative one, the compiler would keep a register per group)
-    fl_a = (fl_l - 56) * kTStride + fl_c + (DX > 0 ? 0 : 1 - kTStride);
+    fl_a = (fl_l - 56) * kTS + fl_c + (DX > 0 ? 0 : 1 - kTS);
     fl_off = to_u32((rs * nxm + pc * 2) * CB);
   }
   VHP_FN void store_group(OutT* base, const vb& ok0, const vb& ok1, const vd& a, const vd& c) {
@@ -490,18 +519,18 @@ struct BandXStore {
   VHP_FN void flush(int b, int ta, int xw, int* taken, int seq) {
     const int D0 = kBlock * b;
     // (the last lane's row is in the band's ring if a band above reads it: BandX::window)
-    const int row63 = b + 1 < Geo::n_bands(g) ? ring_rel + (xw & (kRing - 1)) : (kBlock - 1) * kTStride;
+    const int row63 = b + 1 < Geo::n_bands(g) ? ring_rel + (xw & (kRing - 1)) : (kBlock - 1) * kTS;
     wave_sync();
     vd fa[10], fb[10];
 #pragma unroll
     for (int u = 0; u < 10; ++u) {
       if (u >= 2 && u <= 7) {
-        fa[u] = lds_load(tile, fl_a + ((DX > 0 ? 0 : kTStride - 1) + (7 - u) * (8 * kTStride)));
-        fb[u] = lds_load(tile, fl_a + ((DX > 0 ? kTStride + 1 : 0) + (7 - u) * (8 * kTStride)));
+        fa[u] = lds_load(tile, fl_a + ((DX > 0 ? 0 : kTS - 1) + (7 - u) * (8 * kTS)));
+        fb[u] = lds_load(tile, fl_a + ((DX > 0 ? kTS + 1 : 0) + (7 - u) * (8 * kTS)));
       } else {  // (the lanes of the two ends of the parallelogram that have no cell read the nearest row of the tile instead of what lies beside it)
         const vi la = vmin(vmax(fl_l - 8 * u, 0), kBlock - 1), lb = vmin(vmax(fl_l + ((DX > 0 ? 1 : -1) - 8 * u), 0), kBlock - 1);
-        fa[u] = lds_load(tile, select(la == kBlock - 1, vi(row63), la * kTStride) + fl_c);
-        fb[u] = lds_load(tile, select(lb == kBlock - 1, vi(row63), lb * kTStride) + (fl_c + 1));
+        fa[u] = lds_load(tile, select(la == kBlock - 1, vi(row63), la * kTS) + fl_c);
+        fb[u] = lds_load(tile, select(lb == kBlock - 1, vi(row63), lb * kTS) + (fl_c + 1));
       }
     }
     lds_publish(taken, seq);
@@ -607,7 +636,7 @@ struct BandY {
     g.init(m.nx, m.ny, sx, sy);
     dm = dmap + DiagMaps::offset(m.nx, m.ny, kMain ? 2 : 3);
     wpd = DiagMaps::wpdy(m.ny);
-    tile = sh.lds + sh.L.tiles + w * kXRows * kTStride;
+    tile = sh.lds + sh.L.tiles + w * kBandTileDoubles;
     slab = sh.lds + sh.L.slabs + w * (2 * kBlock);
     bin = lk.bin;
     lane = lane_id();
@@ -711,7 +740,11 @@ struct BandY {
     vd rr[kLW];
     rr[0] = lds_bcast(rslab, DY > 0 ? 0 : kLW - 1);
     rr[1] = lds_bcast(rslab, DY > 0 ? 1 : kLW - 2);
+#ifdef VHP_EXP_NORATIO
+    vd cc = rr[0];
+#else
     vd cc = ratio(vmaxd(jd, 0.0), dj, rr[0]);
+#endif
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DY > 0 ? k : kLW - 1 - k;
@@ -737,7 +770,11 @@ struct BandY {
       lds_store(tile, tl + c, v);
       dj = dj + 1.0;
       jd = jd + 1.0;
+#ifdef VHP_EXP_NORATIO
+      if (k + 1 < kLW) cc = rr[k + 1];
+#else
       if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), dj, rr[k + 1]);
+#endif
       sched_fence();
     }
     if (more) {
@@ -763,6 +800,7 @@ struct BandY {
     while (ta <= t_end) {
       if (dies_at(ta - 1)) { dead = true; break; }
       open_block(yw, ta);
+      wave_priority(ta < D0 + kBlock + kLW ? VHP_BAND_PRIO_CHAIN : VHP_BAND_PRIO_STEADY);   // (see BandX::march)
       window<B0>(ta, yw, DY > 0 ? blk - g.by0 : g.by0 - blk, ta + kLW <= t_end);
       ta += kLW; yw += kLW * DY;
       sim_progress();
@@ -915,6 +953,7 @@ struct BandYStore {
 template <typename OutT, bool ODD = false>
 struct BandWorker {
   static constexpr int kRoles = 2;  // wavefronts per sweeper (the simulator and the launcher size the workgroup by it)
+  static constexpr int kTilePitch = kBandTStrideDown;  // ... and the LDS layout's tiles by this
   LatArgs<OutT> a;
   Shared sh;
   int w, W;
@@ -1006,7 +1045,7 @@ struct BandWorker {
   template <int DX, int DY, bool XM>
   VHP_FN void store(int ws, int sx, int sy, OutT* field) {
     int* post = post_of(sh, ws);
-    const double* tile = sh.lds + sh.L.tiles + ws * kXRows * kTStride;
+    const double* tile = sh.lds + sh.L.tiles + ws * kBandTileDoubles;
     typename std::conditional<XM, BandXStore<DX, DY, OutT, ODD>, BandYStore<DX, DY, OutT>>::type st;
     st.init(a.m, a.dmap, sx, sy, field, tile, sh.ring(ws));
     for (int n = 1;; ++n) {

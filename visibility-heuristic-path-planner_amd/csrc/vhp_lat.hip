@@ -32,11 +32,12 @@ template <typename OutT, bool ODD> using LatWorkerT = BandWorker<OutT, ODD>;
 #endif
 // wavefronts of a workgroup: kLatWaves sweepers and, in the band sweep, a storer beside each (16: four per SIMD, 128 vector registers)
 constexpr int kLatThreads = 64 * kLatWaves * LatWorkerT<double, false>::kRoles;
+constexpr int kLatTilePitch = LatWorkerT<double, false>::kTilePitch;
 
 template <typename OutT, bool ODD>
 __global__ void __launch_bounds__(kLatThreads, 1) vhp_lat_sweep(LatArgs<OutT> a) {
   extern __shared__ double lds[];
-  const Layout L = make_layout(kLatWaves, 1, a.m.nx, a.m.ny);
+  const Layout L = make_layout(kLatWaves, 1, a.m.nx, a.m.ny, kLatTilePitch);
 #ifdef VHP_DIAG_POOLPROF
   const unsigned long long t_begin = wall_clock64();
 #endif
@@ -69,7 +70,7 @@ __global__ void __launch_bounds__(kLatThreads, 1) vhp_planner_iteration(LatArgs<
       planner_epilogue_body<kEpilogueThreads>(a.m.nx, a.m.ny, d, (int)blockIdx.x - kUnits, (int)gridDim.x - kUnits, d.ticket + 1, (unsigned)kUnits);
     return;
   }
-  const Layout L = make_layout(kLatWaves, 1, a.m.nx, a.m.ny);
+  const Layout L = make_layout(kLatWaves, 1, a.m.nx, a.m.ny, kLatTilePitch);
   using WorkerT = LatWorkerT<double, ODD>;
   WorkerT::clear(lds, L, (int)threadIdx.x, kLatThreads);
   __syncthreads();
@@ -115,7 +116,7 @@ __global__ void vhp_pack_diag(const uint8_t* __restrict__ occ, uint64_t* __restr
 
 namespace {
 constexpr size_t kLdsLimit = 160 * 1024;
-size_t lat_lds_bytes(int nx, int ny) { return (size_t)pool::make_layout(pool::kLatWaves, 1, nx, ny).total * 8; }
+size_t lat_lds_bytes(int nx, int ny) { return (size_t)pool::make_layout(pool::kLatWaves, 1, nx, ny, pool::kLatTilePitch).total * 8; }
 
 template <typename OutT>
 hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {

@@ -917,6 +917,7 @@ VHP_HD bool lat_needs_odd(int nx, long long field_stride, const OutT* out) {
 template <typename OutT, bool ODD = false>
 struct LatWorker {
   static constexpr int kRoles = 1;  // wavefronts per strip wavefront (the band sweep, vhp_band.hpp, has a storer beside every sweeper)
+  static constexpr int kTilePitch = kTStride;
   LatArgs<OutT> a;
   Shared sh;
   int w, W;
