@@ -300,7 +300,7 @@ struct BandX {
       prev = v;
       if (k == 0) {  // (the first write to the tile: after the step's arithmetic, which has hidden the look at the storer's word)
         VHP_WP_T0(tw4);
-        while (!po->taken(uniform(tk))) { ready_backoff(); sim_point(); tk = lds_peek(po->post + kPostTaken); }
+        while (!po->taken(uniform(tk))) { taken_backoff(); sim_point(); tk = lds_peek(po->post + kPostTaken); }
         lds_acquire();
         VHP_WP_ADDP(lk.pp, 11, tw4);
       }
@@ -764,7 +764,7 @@ struct BandY {
       const vd v = and_mask(stencil(a, prev, cc), mk);
       prev = v;
       if (k == 0) {
-        while (!po->taken(uniform(tk))) { ready_backoff(); sim_point(); tk = lds_peek(po->post + kPostTaken); }
+        while (!po->taken(uniform(tk))) { taken_backoff(); sim_point(); tk = lds_peek(po->post + kPostTaken); }
         lds_acquire();
       }
       lds_store(tile, tl + c, v);

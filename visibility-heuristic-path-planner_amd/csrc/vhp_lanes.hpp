@@ -215,6 +215,7 @@ inline SimHooks& sim_hooks() { static SimHooks h; return h; }
 inline void backoff() { if (sim_hooks().yield) sim_hooks().yield(); }
 inline void ready_backoff() { backoff(); }
 inline void short_backoff() { backoff(); }
+inline void taken_backoff() { backoff(); }
 inline void wave_priority(int) {}
 // event counters of the simulator (which path a hand-off took); the device build counts nothing
 struct SimCounts { long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
@@ -541,6 +542,10 @@ VHP_LANE_FN bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0u
 VHP_LANE_FN void lds_store_i_if(bool p, int* base, vi idx, int v) { if (p) ((lds_int*)base)[idx] = v; }
 VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(VHP_BACKOFF_SLEEP); }
 VHP_LANE_FN void ready_backoff() { __builtin_amdgcn_s_sleep(VHP_READY_SLEEP); }
+#ifndef VHP_TAKEN_SLEEP
+#define VHP_TAKEN_SLEEP 1
+#endif
+VHP_LANE_FN void taken_backoff() { __builtin_amdgcn_s_sleep(VHP_TAKEN_SLEEP); }   // (a sweeper in the middle of its window's first step, waiting for its storer's word)
 VHP_LANE_FN void short_backoff() { __builtin_amdgcn_s_sleep(1); }   // (64 cycles: a wavefront whose answer another one is waiting for)
 // waits until every global store (and load) this wavefront has issued has completed
 VHP_LANE_FN void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

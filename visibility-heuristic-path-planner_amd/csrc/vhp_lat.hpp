@@ -123,34 +123,45 @@ struct Below {
   // Makes sure the values are those of steps ia - 1 .. last_needed of the strip below: waits for the writer (asking again), or
   // takes the block from global memory if the writer is gone or too far ahead for its ring.
   VHP_FN void accept(Link<D>& lk, const int* dead_below, const double* bin, int cw, int c_first, int ia, int last_needed, int nb) {
-    for (;;) {
-      // (a strip dies at the end of a window, and all strips cut their windows alike: a window is before the death of the strip
-      // below or after it, never across)
-      if (dead_from() <= ia - 1) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) v[k] = vd(0.0);
-        ring = false;
-        return;
-      }
-      if (!ring) return;
-      const int ha = uniform(h1), hb = uniform(h2);
-      if ((ha >> 14) != lk.rd_tag) break;                                                            // the writer has finished that strip: its line is (being) stored
-      if ((ha & 0x3fff) <= last_needed) {  // not swept yet
+    // (a strip dies at the end of a window, and all strips cut their windows alike: a window is before the death of the strip
+    // below or after it, never across)
+    if (dead_from() <= ia - 1) { zeros(); return; }
+    if (!ring) return;
+    int ha = uniform(h1);
+    if ((ha >> 14) == lk.rd_tag && (ha & 0x3fff) <= last_needed) {
+      // Not swept yet.  The wait looks at the writer's header and at its word of death only, and the values are read ONCE after it:
+      // a loop that re-read them carried the sixteen values around its back edge, and the compiler paid for that with two sets of
+      // sixteen register copies in EVERY window, the ones that never wait included.
+      for (;;) {
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
         lk.pp[7] += 1;
 #endif
         ready_backoff();
-        from_ring(lk, dead_below, cw, c_first);
-        continue;
+        sim_point();
+        const int d = lds_poll(dead_below);
+        if (d != 0 && d - 1 <= ia - 1) { hd = d; zeros(); return; }
+        ha = lds_poll(lk.rd_hdr);
+        if ((ha >> 14) != lk.rd_tag || (ha & 0x3fff) > last_needed) break;
       }
-      // (a writer is at most one window past what it has published: an entry of step s is safe while published - s <= kRingSafe)
-      if ((hb >> 14) != lk.rd_tag || (hb & 0x3fff) - (ia - 1) > kRingSafe) { sim_count(3); break; }
+      from_ring(lk, dead_below, cw, c_first);
+      ha = uniform(h1);
+    }
+    const int hb = uniform(h2);
+    // (the writer has finished that strip -- its line is (being) stored --, or it is too far ahead for its ring: a writer is at most
+    // one window past what it has published, an entry of step s is safe while published - s <= kRingSafe)
+    if ((ha >> 14) == lk.rd_tag && (hb >> 14) == lk.rd_tag && (hb & 0x3fff) - (ia - 1) <= kRingSafe) {
       sim_count(0);
       ring = false;
       return;
     }
+    sim_count(3);
     lk.fetch(ia, last_needed, nb);
     from_slab(bin, cw, c_first);
+  }
+  VHP_FN void zeros() {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) v[k] = vd(0.0);
+    ring = false;
   }
 };
 
