@@ -275,11 +275,7 @@ struct BandX {
     vd rr[kLW];
     rr[0] = lds_bcast(rslab, DX > 0 ? 0 : kLW - 1);
     rr[1] = lds_bcast(rslab, DX > 0 ? 1 : kLW - 2);
-#ifdef VHP_EXP_NORATIO
-    vd cc = rr[0];
-#else
     vd cc = ratio(vmaxd(jd, 0.0), di, rr[0]);
-#endif
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DX > 0 ? k : kLW - 1 - k;
@@ -307,11 +303,7 @@ struct BandX {
       lds_store(tile, tl + c, v);
       di = di + 1.0;
       jd = jd + 1.0;
-#ifdef VHP_EXP_NORATIO
-      if (k + 1 < kLW) cc = rr[k + 1];
-#else
-      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), di, rr[k + 1]);
-#endif  // the next step's ratio beside this step's chain, and no further ahead
+      if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), di, rr[k + 1]);  // the next step's ratio beside this step's chain, and no further ahead
       sched_fence();
     }
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)
@@ -740,11 +732,7 @@ struct BandY {
     vd rr[kLW];
     rr[0] = lds_bcast(rslab, DY > 0 ? 0 : kLW - 1);
     rr[1] = lds_bcast(rslab, DY > 0 ? 1 : kLW - 2);
-#ifdef VHP_EXP_NORATIO
-    vd cc = rr[0];
-#else
     vd cc = ratio(vmaxd(jd, 0.0), dj, rr[0]);
-#endif
 #pragma unroll
     for (int k = 0; k < kLW; ++k) {
       const int c = DY > 0 ? k : kLW - 1 - k;
@@ -770,11 +758,7 @@ struct BandY {
       lds_store(tile, tl + c, v);
       dj = dj + 1.0;
       jd = jd + 1.0;
-#ifdef VHP_EXP_NORATIO
-      if (k + 1 < kLW) cc = rr[k + 1];
-#else
       if (k + 1 < kLW) cc = ratio(vmaxd(jd, 0.0), dj, rr[k + 1]);
-#endif
       sched_fence();
     }
     if (more) {
