@@ -27,12 +27,13 @@ while time.time() - t0 < budget:
     occ[src[:, 1], src[:, 0]] = 1
     W = int(rng.choice([1, 2, 3, 4, 8, 12])); policy = int(rng.choice([0, 1, 2, 3, 4])) | int(rng.choice([0, 8, 16])); dt = np.float64 if rng.rand() < 0.7 else np.float32
     seed = int(rng.randint(0, 1000))
-    got, st = sim_lib.lat_sweep(occ, src, dt, W=W, policy=policy, seed=seed)
-    assert st["deadlock"] == 0, (nx, ny, W, policy, st)
+    halves = int(rng.choice([1, 2, 2]))   # (two workgroups per unit: the bands of an octant dealt out to both, LatArgs::halves)
+    got, st = sim_lib.lat_sweep(occ, src, dt, W=W, policy=policy, seed=seed, halves=halves)
+    assert st["deadlock"] == 0, (nx, ny, W, policy, halves, st)
     for k, (sx, sy) in enumerate(src):
         want = orc.sweep_full(occ, int(sx), int(sy)).astype(dt)
         if got[k].tobytes() != want.tobytes():
-            print("MISMATCH", nx, ny, W, policy, src, kind)
-            np.savez("/tmp/fuzz_fail.npz", occ=occ, src=src, W=W, policy=policy, seed=seed, f32=(dt == np.float32)); sys.exit(1)
+            print("MISMATCH", nx, ny, W, policy, halves, src, kind)
+            np.savez("/tmp/fuzz_fail.npz", occ=occ, src=src, W=W, policy=policy, seed=seed, halves=halves, f32=(dt == np.float32)); sys.exit(1)
     n += 1
 print("ok: %d random cases, %.0f s" % (n, time.time() - t0))

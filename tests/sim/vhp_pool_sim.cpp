@@ -274,14 +274,20 @@ struct LatCo {
 template <typename WorkerT>
 void lat_entry(void* p) { auto* c = static_cast<LatCo<WorkerT>*>(p); c->wk.run(c->unit); }
 
+int g_lat_halves = 1;   // workgroups per unit of the band sweep (vhp_sim_set_lat_halves)
+
 template <typename OutT, bool ODD, typename WorkerT>
 int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int policy, uint32_t seed, long long* stats) {
   HostMap h;
   build_map(occ, nx, ny, h);
   const Layout L = make_layout(W, 1, nx, ny, WorkerT::kTilePitch);
-  const int G = n_src * kUnits;
+  const int H = (WorkerT::kRoles == 2 && g_lat_halves > 1) ? g_lat_halves : 1;   // (the sweep in strips knows no halves)
+  const int n_units = n_src * kUnits;
+  const int G = n_units * H;   // workgroups
   int err = 0;
   LatArgs<OutT> a;
+  a.halves = H;
+  a.n_units = n_units;
   a.m = h.m;
   a.src_xy = src;
   a.out = out;
@@ -289,7 +295,7 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
   a.err_flag = &err;
   const uint64_t epoch = 0x5A17000000000000ull + 7 + seed;
   a.unit_blocks = lat_unit_blocks(nx, ny);
-  std::vector<vhp::lanes::Tagged> lines((size_t)a.unit_blocks * G * 64 + 64);
+  std::vector<vhp::lanes::Tagged> lines((size_t)a.unit_blocks * n_units * 64 + 64);
   for (size_t k = 0; k < lines.size(); ++k) { lines[k].v = std::numeric_limits<double>::quiet_NaN(); lines[k].tag = (k % 5 == 0) ? 0 : epoch - 1 - (k % 3); }
   a.lines = lines.data();
   a.epoch = epoch;
@@ -351,7 +357,7 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
       Shared sh;
       sh.lds = lds[gI].data();
       sh.L = L;
-      const int s_ = gI / kUnits, qo = gI % kUnits;
+      const int s_ = (gI % n_units) / kUnits, qo = gI % kUnits;
       UnitGeo ug;
       ug.init(nx, ny, qo, src[2 * s_], src[2 * s_ + 1]);
       fprintf(stderr, "unit %d (source %d,%d qo %d): strips %d diag ready %d\n   prog:", gI, src[2 * s_], src[2 * s_ + 1], qo, ug.n_strips, sh.ctx(0)[kDiagReady]);
@@ -389,6 +395,9 @@ int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, O
 }
 
 extern "C" {
+
+// workgroups per unit of the band sweep's next runs (1 or 2: LatArgs::halves)
+void vhp_sim_set_lat_halves(int h) { g_lat_halves = h; }
 
 // The latency sweep: n_src * 8 workgroups of W wavefronts, one per unit.  Arguments and stats as vhp_sim_pool_sweep.
 int vhp_sim_lat_sweep(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, int dtype, void* out, int W, int policy, unsigned seed,

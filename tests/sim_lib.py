@@ -56,12 +56,17 @@ def pool_sweep(occ, sources, dtype=np.float64, W=12, C=4, G=1, policy=0, seed=1,
                      overwritten=int(stats[10]), lines_whole=int(stats[11]), lines_part=int(stats[12]), static_round=int(stats[13]))
 
 
-def lat_sweep(occ, sources, dtype=np.float64, W=12, policy=0, seed=1, bands=None):
+def lat_sweep(occ, sources, dtype=np.float64, W=12, policy=0, seed=1, bands=None, halves=None):
     """Fields [n, ny, nx] of the simulated latency sweep (a workgroup of W wavefronts per unit) and the stats dict.
-    bands: the sweep in bands (csrc/vhp_band.hpp, what the library launches) or in strips of rows (csrc/vhp_lat.hpp)."""
+    bands: the sweep in bands (csrc/vhp_band.hpp, what the library launches) or in strips of rows (csrc/vhp_lat.hpp).
+    halves: workgroups per unit of the band sweep (1, or 2: the bands of an octant dealt out to two workgroups, LatArgs::halves;
+    default: the environment's VHP_SIM_HALVES, else 1)."""
     lib = load_pool()
     if bands is None:
         bands = os.environ.get("VHP_SIM_LAT", "bands") == "bands"
+    if halves is None:
+        halves = int(os.environ.get("VHP_SIM_HALVES", "1"))
+    lib.vhp_sim_set_lat_halves(int(halves))
     occ = np.ascontiguousarray(occ, np.uint8)
     ny, nx = occ.shape
     src = np.ascontiguousarray(sources, np.int32).reshape(-1, 2)

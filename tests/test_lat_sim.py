@@ -126,3 +126,18 @@ def test_lat_sim_thin_salted_grids(oracle, nx, ny):
         occ[src[:, 1], src[:, 0]] = 1
         for W, policy, dtype in SHAPES[:3]:
             _check(oracle, occ, src, "%dx%d salt seed %d W=%d" % (nx, ny, seed, W), dtype, W=W, policy=policy, seed=seed)
+
+
+@pytest.mark.parametrize("nx,ny,density", [(328, 300, 0.0), (200, 520, 0.02), (640, 603, 0.08), (1104, 72, 0.3), (72, 1100, 0.3), (329, 301, 0.2)])
+def test_lat_sim_two_workgroups_per_unit(oracle, nx, ny, density):
+    """The long octants' launch shape (LatArgs::halves = 2, 4 or 8): the bands of an octant dealt out to that many workgroups, band p to workgroup
+    (p / W) % halves -- a band whose band below lives in the other workgroup reads that band's line in global memory, block by block, and its
+    death out of a record beside the lines.  With one sweeper per workgroup EVERY band reads across; with two or three, every second or
+    third; bands that die before, while and after their reader starts (walls of every density), every order of the wavefronts."""
+    occ = _walled(nx, ny, nx + 2 * ny, density) if density > 0 else np.ones((ny, nx), np.uint8)
+    src = _sources(occ, 3, nx + ny)
+    for W, policy, halves in [(1, POOL_ROUND_ROBIN, 2), (1, POOL_BACKWARD | POOL_POINTS_ALWAYS, 2), (2, POOL_RANDOM | POOL_POINTS_RANDOM, 2), (3, POOL_BURSTS, 2),
+                              (8, POOL_GREEDY | POOL_POINTS_RANDOM, 2), (1, POOL_RANDOM | POOL_POINTS_ALWAYS, 4), (2, POOL_BURSTS | POOL_POINTS_RANDOM, 4), (1, POOL_GREEDY, 8)]:
+        dtype = np.float32 if (W == 3) else np.float64
+        _check(oracle, occ, src, "%dx%d density %.2f W=%d policy=%d, %d workgroups per unit" % (nx, ny, density, W, policy, halves), dtype, W=W, policy=policy, seed=nx + W,
+               halves=halves)

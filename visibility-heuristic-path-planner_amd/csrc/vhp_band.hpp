@@ -150,6 +150,7 @@ struct BandX {
   int ring_rel;                // where lane 63 writes instead of into the tile: the band's ring, as an index from `tile`
   vu64 ow, ow_nx;
   vd rv_nx;
+  Tagged* death_out;           // this band's record of death beside the lines, if the band above is swept by another workgroup (else null)
   Below<DX, kLW> nx;
 
   // (the caller has initialised lk)
@@ -188,6 +189,7 @@ struct BandX {
     dead_mine = sh.owner(0) + b;
     dead_below = sh.owner(0) + (b > 0 ? b - 1 : b);
     skip_fill = false;
+    death_out = nullptr;
     nx.hd = 0;
     nx.h1 = nx.h2 = 0;
     nx.ring = false;
@@ -365,13 +367,18 @@ struct BandX {
     int xw = g.X(D0) & ~(kLW - 1);
     int ta = DX > 0 ? xw - g.sx : g.sx - (xw + kLW - 1);
     jd = to_f64((-(b == 0 ? vmax(lane, 1) : lane + D0)) + ta);
-    if (below) nx.hd = lds_poll(dead_below);  // (a band that starts above a dead band need not sweep a window to find out)
+    if (below) nx.hd = lk.remote ? (lk.remote_died_by(0), lk.remote_dead) : lds_poll(dead_below);  // (a band that starts above a dead band need not sweep a window to find out)
     enter_block(xw >> 6);
     bool dead = below && lds_poll(dead_mine) != 0;  // (a band below died before this one could start, and said so for it)
+    // (a band below in another workgroup says it for nobody: this band's first step lies past that band's death, as in announce_death)
+    if (lk.remote && lk.remote_dead != 0 && D0 > lk.remote_dead) dead = true;
     if (!dead) {
       request(xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk);
       if (b == 0) { origin_bits(xw); march<true>(ta, xw, dead); } else march<false>(ta, xw, dead);
     }
+    // (a reader in another workgroup sees this band's death in a record beside the lines -- stored, and through, BEFORE the band's last
+    // block: whoever holds that block knows how much of it was swept)
+    if ((dead || retires) && death_out) { g_store_tagged(death_out, vi(0), vd((double)ta), lk.epoch); stores_done(); }
     if (has_consumer) lk.store_block(imax(g.nbx(imin(imax(ta - 1, 0), i_last)), 0), blk);
     if (dead || retires) {
       // Everything from step ta - 1 on is +0.0, in this band and below it (or: the band has left the octant): the word of death
@@ -620,6 +627,7 @@ struct BandY {
   int ring_rel;
   vu64 ow, ow_nx;
   vd rv_nx;
+  Tagged* death_out;           // this band's record of death beside the lines, if the band above is swept by another workgroup (else null)
   Below<DY, kLW> nx;
 
   VHP_FN void init(const Map& m_, const uint64_t* dmap, int sx, int sy, const Shared& sh, int w, int b_, Poster* po_) {
@@ -658,6 +666,7 @@ struct BandY {
     dead_mine = sh.owner(0) + b;
     dead_below = sh.owner(0) + (b > 0 ? b - 1 : b);
     skip_fill = false;
+    death_out = nullptr;
     nx.hd = 0;
     nx.h1 = nx.h2 = 0;
     nx.ring = false;
@@ -804,13 +813,15 @@ struct BandY {
     int yw = g.Y(D0) & ~(kLW - 1);
     int ta = DY > 0 ? yw - g.sy : g.sy - (yw + kLW - 1);
     jd = to_f64((-(b == 0 ? vmax(lane, 1) : lane + D0)) + ta);
-    if (below) nx.hd = lds_poll(dead_below);
+    if (below) nx.hd = lk.remote ? (lk.remote_died_by(0), lk.remote_dead) : lds_poll(dead_below);
     enter_block(yw >> 6);
     bool dead = below && lds_poll(dead_mine) != 0;
+    if (lk.remote && lk.remote_dead != 0 && D0 > lk.remote_dead) dead = true;   // (see BandX::run)
     if (!dead) {
       request(yw, DY > 0 ? blk - g.by0 : g.by0 - blk);
       if (b == 0) { origin_bits(yw); march<true>(ta, yw, dead); } else march<false>(ta, yw, dead);
     }
+    if ((dead || retires) && death_out) { g_store_tagged(death_out, vi(0), vd((double)ta), lk.epoch); stores_done(); }   // (see BandX::run)
     if (has_consumer) lk.store_block(imax(g.nby(imin(imax(ta - 1, 0), j_last)), 0), blk);
     if (dead || retires) {  // (see BandX::run)
       lds_publish(dead_mine, ta);
@@ -941,6 +952,7 @@ struct BandWorker {
   LatArgs<OutT> a;
   Shared sh;
   int w, W;
+  int H, half;   // workgroups per unit, and which of them this is (run)
   vi lane;
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
   unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -952,6 +964,8 @@ struct BandWorker {
     sh.L = L;
     w = w_;
     W = L.W;
+    H = a.halves > 1 ? a.halves : 1;
+    half = 0;
     lane = lane_id();
   }
   // Before any wavefront runs: every thread of the workgroup calls this (tid of nthreads), then a barrier.
@@ -965,6 +979,14 @@ struct BandWorker {
 
   VHP_FN Tagged* line_of(int unit, int p, int nb) const { return a.lines + (size_t)64 * ((size_t)unit * (size_t)a.unit_blocks + (size_t)p * nb); }
   static VHP_FN int tag_of(int p) { return (1 << 8) | p; }  // (never 0: a cleared header belongs to no band)
+  // More than one workgroup per unit (LatArgs::halves): band p is swept by workgroup (p / W) % H of its unit, sweeper p % W -- band W's
+  // sweeper no longer waits for band 0's, and an octant of 16 bands has them all in flight.  Where a band and the band below it live in
+  // different workgroups (p % W == 0) the reader takes the writer's LINE in global memory, block by block (Link::remote; the lines are
+  // the durable copy that every band with a reader writes anyway), and the writer's death out of a record beside the lines: entry p of
+  // the unit's last two blocks of scratch (the lines of at most 128 bands leave them free: lat_unit_blocks).
+  VHP_FN Tagged* death_rec(int unit, int p) const { return a.lines + ((size_t)64 * ((size_t)unit * (size_t)a.unit_blocks + (size_t)(a.unit_blocks - 2)) + (size_t)p); }
+  VHP_FN bool remote_below(int p) const { return H > 1 && p > 0 && p % W == 0; }
+  VHP_FN bool remote_above(int p, int n) const { return H > 1 && p + 1 < n && (p + 1) % W == 0; }
 
   // a coarse gate ahead of a band's first window (which then checks exactly what it reads): one word per poll
   VHP_FN void wait_for(const int* word, int at_least) {
@@ -978,18 +1000,20 @@ struct BandWorker {
     g.init(a.m.nx, a.m.ny, sx, sy);
     int* prog = sh.prog(0);
     const int n = BandXGeo<DX, DY>::n_bands(g);
-    for (int p = w; p < n; p += W) {
+    for (int p = half * W + w; p < n; p += H * W) {
       BandX<DX, DY> xs;
       xs.lk.init(sh, w, sx, imax(BandXGeo<DX, DY>::first_window(g, p), 0), tag_of(p), prog + p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr,
                  p + 1 < n ? line_of(unit, p, g.Nbx) : nullptr, a.epoch, p > 0 ? (p - 1) % W : -1, p > 0 ? tag_of(p - 1) : 0);
+      if (remote_below(p)) { xs.lk.remote = true; xs.lk.death_in = death_rec(unit, p - 1); }
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
       xs.lk.pp = prof;
 #endif
       xs.init(a.m, a.dmap, sx, sy, sh, w, p, &po);
+      if (remote_above(p, n)) xs.death_out = death_rec(unit, p);
       xs.skip_fill = a.dead_cells_are_zero;
       xs.prefetch_ops(g.X(kBlock * p) >> 6);
       VHP_LAT_STAMP(unit, p, 0);
-      if (VHP_DIAG_WAITS && p > 0) wait_for(prog + (p - 1), imin(kBlock * p + 2, g.ni));  // the band below has got to my first step
+      if (VHP_DIAG_WAITS && p > 0 && !remote_below(p)) wait_for(prog + (p - 1), imin(kBlock * p + 2, g.ni));  // the band below has got to my first step
       VHP_LAT_STAMP(unit, p, 1);
       xs.run();
       VHP_LAT_STAMP(unit, p, 3);
@@ -1005,18 +1029,20 @@ struct BandWorker {
     int* prog = sh.prog(0);
     const int n = BandYGeo<DX, DY>::n_bands(g);
     const int Nby = g.Nby;
-    for (int q = w; q < n; q += W) {
+    for (int q = half * W + w; q < n; q += H * W) {
       BandY<DX, DY> ys;
       ys.lk.init(sh, w, sy, imax(BandYGeo<DX, DY>::first_window(g, q), 0), tag_of(q), prog + q, q > 0 ? line_of(unit, q - 1, Nby) : nullptr,
                  q + 1 < n ? line_of(unit, q, Nby) : nullptr, a.epoch, q > 0 ? (q - 1) % W : -1, q > 0 ? tag_of(q - 1) : 0);
+      if (remote_below(q)) { ys.lk.remote = true; ys.lk.death_in = death_rec(unit, q - 1); }
 #if defined(VHP_DIAG_POOLPROF) && !defined(VHP_SIM)
       ys.lk.pp = prof;
 #endif
       VHP_LAT_STAMP(unit, q, 0);
       ys.init(a.m, a.dmap, sx, sy, sh, w, q, &po);
+      if (remote_above(q, n)) ys.death_out = death_rec(unit, q);
       ys.skip_fill = a.dead_cells_are_zero;
       ys.prefetch_ops(g.Y(kBlock * q) >> 6);
-      if (VHP_DIAG_WAITS && q > 0) wait_for(prog + (q - 1), imin(kBlock * q + 2, g.nj));
+      if (VHP_DIAG_WAITS && q > 0 && !remote_below(q)) wait_for(prog + (q - 1), imin(kBlock * q + 2, g.nj));
       VHP_LAT_STAMP(unit, q, 1);
       ys.run();
       VHP_LAT_STAMP(unit, q, 3);
@@ -1058,7 +1084,11 @@ struct BandWorker {
   }
 
   // the whole life of this wavefront in unit `unit` (8 * source + 2 * quadrant + {0: x-major, 1: y-major})
-  VHP_FN void run(int unit) {
+  // (with two workgroups per unit: workgroup g is half g / n_units of unit g % n_units -- the halves of a unit eight workgroups x the
+  // sources apart, i.e. behind the same L2 where workgroups go round the XCDs by their number)
+  VHP_FN void run(int wg) {
+    half = H > 1 ? wg / a.n_units : 0;
+    const int unit = H > 1 ? wg - half * a.n_units : wg;
     const int s = unit / kUnits, qo = unit - s * kUnits;
     // (the planners' control words together, before any of them is looked at: one trip to memory, then the source's)
     int sx, sy;
@@ -1076,7 +1106,7 @@ struct BandWorker {
     }
     if (a.slot_base && sx < 0) return;
     if (sx < 0 || sy < 0 || sx >= a.m.nx || sy >= a.m.ny) {  // units of a rejected source do nothing
-      if (qo == 0 && w == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
+      if (qo == 0 && w == 0 && half == 0) g_store_scalar_if(lane == 0, a.err_flag, vi(0), 1);
       return;
     }
     OutT* field = a.out + (size_t)(s + uniform(slot0)) * a.field_stride;
@@ -1101,7 +1131,7 @@ struct BandWorker {
     const int ws = w - W;
     // Row 0 and column 0 are swept only from a source that lies on them and read as zero otherwise.  (A field that is
     // known to hold +0.0 wherever the launch does not write -- the planner's loop -- holds it there as well.)
-    if (!a.dead_cells_are_zero && ws == W - 1) {
+    if (!a.dead_cells_are_zero && ws == W - 1 && half == 0) {
       if (qo == 0 && sy > 0)
         for (int x0 = 0; x0 < a.m.nx; x0 += kLanes) g_store_scalar_if(lane + x0 < a.m.nx, field, lane + x0, OutT(0));
       if (qo == 1 && sx > 0)

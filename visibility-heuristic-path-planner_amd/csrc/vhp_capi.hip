@@ -275,6 +275,16 @@ bool use_lat_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel == 4) return n_src <= 64;
   // (a caller that sets a launch shape of the front sweep is asking for the front sweep)
   if (c->opt_rows_per_lane || c->opt_strips || c->opt_multi || c->opt_slide >= 0 || c->opt_pack) return false;
+  // Round 6, late: a long octant's bands go to two, four or eight workgroups (vhp_lat.hip lat_halves) -- while 16 x sources <= CUs.  With
+  // 17-32 sources on a large grid the octants are back to one workgroup each, rounds of eight bands, and the pool sweep is ahead
+  // (latency / pool sweep, us, profiles/r06_exp_workgroups_per_unit.txt): 2048^2: 16 sources 349 / 478, 24: 440 / 497, 32: 535 / 489;
+  // 3072^2: 16: 664 / 904, 24: 1094 / 927, 32: 1377 / 1010; 4096^2: 16: 1226 / 1575, 24: 2053 / 1646, 32: 2414 / 1660; 1536^2: 24: 227 / 332,
+  // 32: 280 / 332.  (Widths that are a multiple of 8: the pool sweep's other build was not measured against it.)
+  const int maxdim = std::max(c->nx, c->ny);
+  if ((c->nx & 7) == 0 && c->opt_kernel == 0 && vhp::pool_supported(c->nx, c->ny)) {
+    if (n_src > 16 && maxdim > 2560) return false;
+    if (n_src >= 28 && maxdim > 1792) return false;
+  }
   // (the boundary lines of a launch -- 16 bytes per strip and step -- stay below two gigabytes: 32 sources at 8192^2 would take four)
   return 8 * n_src <= c->n_cus && vhp::lat_scratch_bytes(n_src, c->nx, c->ny) <= ((size_t)2 << 30);
 }
@@ -323,6 +333,7 @@ bool use_pool_kernel(const vhp_ctx* c, int n_src) {
   if (maxdim < 576) return n_src >= 96;
   if (maxdim < 768) return n_src >= 48;
   if (maxdim <= 1024) return n_src >= 33;
+  if (maxdim > 2560) return n_src >= 17;   // (where the latency sweep has left the launch to this: use_lat_kernel)
   return n_src >= 24;
 }
 

@@ -197,6 +197,7 @@ inline void wave_sync() {}
 inline void sched_fence() {}
 template <typename T> inline void pin(T&) {}
 inline int uniform(int x) { return x; }
+inline int lane0_int(const vd& a) { return (int)a.v[0]; }   // a value that is the same in every lane, as an integer
 // release: everything this wavefront has written to LDS becomes visible, then the progress word
 inline void lds_publish(volatile int* word, int value) { *word = value; }
 inline int lds_poll(const volatile int* word) { return *word; }
@@ -412,6 +413,7 @@ VHP_LANE_FN void pin(double& v) { asm volatile("" : "+v"(v)); }
 VHP_LANE_FN void pin(uint64_t& v) { asm volatile("" : "+v"(v)); }
 VHP_LANE_FN void pin(int& v) { asm volatile("" : "+v"(v)); }  // (... and nothing derived from it is computed ahead of this point and kept)
 VHP_LANE_FN int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+VHP_LANE_FN int lane0_int(vd a) { return __builtin_amdgcn_readfirstlane((int)a); }
 typedef __attribute__((address_space(3))) int lds_int;
 // Release of LDS data to the other wavefronts of the workgroup: the progress word is an LDS write issued after the data's
 // LDS writes by the same wavefront, and the LDS executes one wavefront's instructions in order -- nothing to wait for.

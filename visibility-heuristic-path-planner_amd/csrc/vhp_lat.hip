@@ -6,6 +6,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "vhp.h"
 #include "vhp_band.hpp"
 #include "vhp_planner_dev.hip.h"
@@ -116,6 +119,24 @@ __global__ void vhp_pack_diag(const uint8_t* __restrict__ occ, uint64_t* __restr
 
 namespace {
 constexpr size_t kLdsLimit = 160 * 1024;
+#ifndef VHP_LAT_HALVES_MIN_SIDE
+#define VHP_LAT_HALVES_MIN_SIDE 1024
+#endif
+// Workgroups per unit of a latency-sweep launch (LatArgs::halves; vhp_band.hpp BandWorker).  One up to 1024 cells a side: an octant
+// has at most 16 bands there, and what bands 8-15 gain by not waiting for the sweepers of bands 0-7 the hand-over through global
+// memory takes back (measured at 1000^2: 117.8 / 118.4 us over eight source positions).  Above: two up to 2048, four up to 4096, eight
+// beyond -- an octant of P bands is swept in rounds of 8 x that number, and every round waits for the one before (8192^2, one source:
+// 3.47 ms with one workgroup per unit, 1.92 with two, 1.18 with four).  All workgroups of a unit must be resident at once -- the
+// others spin on the first one's lines --: halved until workgroups <= CUs.  (VHP_LAT_HALVES in the environment: 1 / 2 / 4 / 8, for
+// measurements.)
+int lat_halves(int n_src, int nx, int ny, int n_cus) {
+  static const char* env = std::getenv("VHP_LAT_HALVES");
+  const int cus = n_cus > 0 ? n_cus : 256, side = std::max(nx, ny);
+  int want = env ? std::atoi(env) : side > 4 * VHP_LAT_HALVES_MIN_SIDE ? 8 : side > 2 * VHP_LAT_HALVES_MIN_SIDE ? 4 : side > VHP_LAT_HALVES_MIN_SIDE ? 2 : 1;
+  int h = 1;
+  while (2 * h <= want && 2 * h <= 8 && 2 * h * pool::kUnits * n_src <= cus) h *= 2;
+  return h;
+}
 size_t lat_lds_bytes(int nx, int ny) { return (size_t)pool::make_layout(pool::kLatWaves, 1, nx, ny, pool::kLatTilePitch).total * 8; }
 
 template <typename OutT>
@@ -161,6 +182,13 @@ hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {
   g.strip_times = nullptr;
   g.dmap = a.dmap;
   if (!g.dmap) return hipErrorInvalidValue;
+  // Two workgroups per unit where an octant can have more bands than a workgroup has sweepers and the launch leaves the CUs for it
+  // (vhp_band.hpp BandWorker: bands 8-15, 24-31, ... of an octant on the second one).
+  g.n_units = a.n_src * kUnits;
+  g.halves = lat_halves(a.n_src, a.nx, a.ny, a.n_cus);
+#if defined(VHP_LAT_STRIPS)
+  g.halves = 1;
+#endif
 #ifdef VHP_DIAG_POOLPROF
   { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_lat_strip_times)) == hipSuccess) g.strip_times = static_cast<unsigned long long*>(p); }
 #endif
@@ -173,6 +201,7 @@ hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {
         hipError_t e2 = a.raise_lds(reinterpret_cast<const void*>(kp), lds);
         if (e2 != hipSuccess) return e2;
       }
+      g.halves = 1;
       hipLaunchKernelGGL(kp, dim3((unsigned)(kUnits + kPlanEpiBlocks)), dim3(kLatThreads), lds, a.stream, g, *pd);
       const hipError_t e3 = hipGetLastError();
       if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
@@ -180,7 +209,7 @@ hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {
     }
   }
 #endif
-  hipLaunchKernelGGL(k, dim3((unsigned)(a.n_src * kUnits)), dim3(kLatThreads), lds, a.stream, g);
+  hipLaunchKernelGGL(k, dim3((unsigned)(a.n_src * kUnits * g.halves)), dim3(kLatThreads), lds, a.stream, g);
   const hipError_t e = hipGetLastError();
   if (a.ev_end) (void)hipEventRecord(a.ev_end, a.stream);
   return e;

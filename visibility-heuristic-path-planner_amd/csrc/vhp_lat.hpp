@@ -64,6 +64,10 @@ struct LatArgs {
   bool dead_cells_are_zero;
   unsigned long long* strip_times;  // diagnostic builds (tools/lat_timeline.py): [unit][48][4] wall-clock stamps, or nullptr
   const uint64_t* dmap = nullptr;   // the occupancy packed along the grid's diagonals (vhp_band.hpp DiagMaps): what the band sweep reads
+  // The band sweep's long octants: `halves` workgroups per unit (1 or 2), workgroup g = half (g / n_units) of unit g % n_units; half h
+  // sweeps the bands p with (p / sweepers) % halves == h, so that 16 bands of an octant are in flight instead of 8 (vhp_band.hpp BandWorker)
+  int halves = 1;
+  int n_units = 0;
 };
 
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)  // diagnostic builds only: cycle accounts inside the x-major windows (they cost a few hundred cycles per window themselves)
@@ -116,6 +120,14 @@ struct Below {
     ring = false;
   }
   VHP_FN void request(const Link<D>& lk, const int* dead_below, const double* bin, int cw, int c_first, int nb) {
+    if (lk.remote) {
+      // the writer is in another workgroup: its word of death as the link last saw it beside the lines, its values out of the slab if
+      // the block is there -- and otherwise out of its line in global memory, when the window is about to start (accept: a header that
+      // belongs to nobody sends it there)
+      hd = lk.remote_dead;
+      if (lk.bin_block == nb) from_slab(bin, cw, c_first); else { h1 = h2 = 0; ring = true; }
+      return;
+    }
     if (lk.bin_block == nb) { from_slab(bin, cw, c_first); hd = lds_peek(dead_below); } else from_ring(lk, dead_below, cw, c_first);
   }
   // the step from which the strip below is dead, as of the last request (0x7fffffff: alive)
@@ -155,7 +167,12 @@ struct Below {
       return;
     }
     sim_count(3);
-    lk.fetch(ia, last_needed, nb);
+    if (!lk.fetch(ia, last_needed, nb)) { hd = lk.remote_dead; zeros(); return; }   // (a remote writer that died before this window)
+    if (lk.remote) {
+      // (the block may be the writer's last, stored when it died: what lies past its death in it was never swept)
+      hd = lk.remote_dead;
+      if (dead_from() <= ia - 1) { zeros(); return; }
+    }
     from_slab(bin, cw, c_first);
   }
   VHP_FN void zeros() {

@@ -185,6 +185,12 @@ struct Link {
   const Tagged* line_in;   // the strip below's line in global memory: entry of x in block n at 64 n + (x & 63)
   int bin_block;           // the block that is in `bin` as a whole (from global memory), or -1
   int first_step;
+  // The strip below is swept by ANOTHER workgroup (the latency sweep's long octants, vhp_band.hpp BandWorker: halves): no ring, no
+  // header, no word of death in this workgroup's LDS -- its line in global memory is all there is, a block of 64 steps at a time, and
+  // beside the lines a record of its death {step + 1, epoch}, which the waits for a block look at (a dead writer stores no further block).
+  bool remote;
+  const Tagged* death_in;  // the writer's record (one entry)
+  int remote_dead;         // ... as last seen: 0 alive, else 1 + the step from which all its values are +0.0
   // writing side
   double* ring;            // mine: entry of x at x & 255
   int* hdr;
@@ -213,6 +219,9 @@ struct Link {
     rd_ring = below_w >= 0 ? sh.ring(below_w) : nullptr;
     rd_hdr = below_w >= 0 ? sh.hdr(below_w) : nullptr;
     rd_tag = below_tag;
+    remote = false;
+    death_in = nullptr;
+    remote_dead = 0;
     lds_publish(hdr, my_tag << 14);  // the ring is this strip's from here on (before its first entry is written)
   }
   // steps 0 .. steps-1 of this strip are swept: their boundary values are in the ring
@@ -228,27 +237,45 @@ struct Link {
   // block nb of the strip below from global memory into the slab (it has been stored, or is about to be; the tag tells)
   // step index of the first coordinate of block nb >= 1
   VHP_FN int block_first_step(int nb) const { return D > 0 ? 64 * ((c0 >> 6) + nb) - c0 : c0 - (64 * ((c0 >> 6) - nb) + 63); }
-  VHP_FN void load_block(int nb) {
+  // the remote writer's record, read afresh: has it died, and at or before step `need`?
+  VHP_FN bool remote_died_by(int need) {
+    vd r;
+    if (wave_all(g_load_tagged(death_in, vi(0), epoch, r))) remote_dead = lane0_int(r);
+    return remote_dead != 0 && remote_dead - 1 <= need;
+  }
+  // need: the first step whose value the caller wants out of the block (a remote writer that died at or before it stores no such
+  // block: false, and nothing is loaded)
+  VHP_FN bool load_block(int nb, int need = 0) {
     // the neighbour of the block's first step is the last entry of the line's previous block -- wanted (and written by the strip
     // below) if that step is one of mine.  (Out of memory, not out of what the slab held before: the latency sweep's windows
     // read the writer's ring directly and leave the slab alone.)
     vd carry = vd(0.0);
     if (nb >= 1 && block_first_step(nb) >= imax(first_step, 1))
-      while (!wave_all(g_load_tagged(line_in, vi(64 * (nb - 1) + (D > 0 ? 63 : 0)), epoch, carry))) backoff();
+      while (!wave_all(g_load_tagged(line_in, vi(64 * (nb - 1) + (D > 0 ? 63 : 0)), epoch, carry))) {
+        if (remote && remote_died_by(need)) return false;
+        backoff();
+      }
     vd v;
-    while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) backoff();
+    while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) {
+      if (remote && remote_died_by(need)) return false;
+      backoff();
+    }
     wave_sync();
     lds_store(bin, lane + 1, v);
     lds_store(bin, vi(D > 0 ? 0 : 65), carry);
     wave_sync();
     bin_block = nb;
+    // (a writer that dies stores its record BEFORE its last block: whoever has that block sees the record)
+    if (remote) (void)remote_died_by(need);
+    return true;
   }
   // Makes the boundary values of steps ia-1 .. ib of the strip below (all of block nb but possibly the first) readable in
   // the slab.  Fast: out of the writer's ring, with its header read before and after the copy.  Otherwise the whole
   // block from global memory.
-  VHP_FN void fetch(int ia, int ib, int nb) {
-    if (bin_block == nb) return;
+  VHP_FN bool fetch(int ia, int ib, int nb) {
+    if (bin_block == nb) return true;
     VHP_DIAG_NOWAIT_RETURN  // (vhp_diag.h: diagnostic builds in which no strip waits for another)
+    if (remote) return load_block(nb, ia - 1);
     for (;;) {
       const int h = lds_poll(rd_hdr);
       if ((h >> 14) != rd_tag) break;                 // the writer has finished that strip: its line is (being) stored
@@ -267,10 +294,10 @@ struct Link {
       lds_store(bin, slot, v);
       wave_sync();
       sim_count(0);
-      return;
+      return true;
     }
     sim_count(1);
-    load_block(nb);
+    return load_block(nb, ia - 1);
   }
 };
 
