@@ -188,7 +188,9 @@ int vhp_timing_collect(vhp_ctx* ctx, float* ms_out, int cap, int* n);
 /* Launch-shape overrides for tuning and for parity tests that must reach every compiled shape
  * (0 / -1 = automatic, the default).  Keys: "rows_per_lane" (1, 2, 4), "strips" (1..8 wavefront
  * strips per octant), "multi_round" (1 = force the multi-round build), "slide" (0 / 1: y-major
- * column grid slid onto 128-byte lines), "pack" (1 = pack short quadrants), "kernel" (1 = front
+ * column grid slid onto 128-byte lines), "pack" (1 = pack short quadrants), "lat_workgroups" (1, 2, 4, 8:
+ * workgroups per octant of a latency-sweep launch; 0: one up to 1024 cells a side, two up to 2048, four up to 4096, eight beyond,
+ * halved until the launch is resident at once), "kernel" (1 = front
  * sweep, 3 = pool sweep, 4 = latency sweep; 2 was the streaming sweep, retired in round 4 and refused),
  * "pool_contexts" (1..16: units a workgroup of the pool sweep holds
  * at once), "pool_static_round" (0: every unit of a pool-sweep launch is pulled from its queue; 1: the first unit of

@@ -388,8 +388,10 @@ template <typename OutT>
 int run_lat(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src, OutT* out, int W, int policy, uint32_t seed, long long* stats, bool bands) {
   const bool odd = lat_needs_odd<OutT>(nx, (long long)nx * ny, out);
   if (bands)
-    return odd ? run_lat_t<OutT, true, BandWorker<OutT, true>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats)
-               : run_lat_t<OutT, false, BandWorker<OutT, false>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats);
+    return g_lat_halves > 1 ? (odd ? run_lat_t<OutT, true, BandWorker<OutT, true, true>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats)
+                                   : run_lat_t<OutT, false, BandWorker<OutT, false, true>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats))
+                            : (odd ? run_lat_t<OutT, true, BandWorker<OutT, true, false>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats)
+                                   : run_lat_t<OutT, false, BandWorker<OutT, false, false>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats));
   return odd ? run_lat_t<OutT, true, LatWorker<OutT, true>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats)
              : run_lat_t<OutT, false, LatWorker<OutT, false>>(occ, nx, ny, src, n_src, out, W, policy, seed, stats);
 }

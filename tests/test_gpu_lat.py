@@ -129,6 +129,52 @@ def test_lat_kernel_strips_that_die(vhp, oracle, nx, ny, density, dtype):
         _assert_same(got[k], want if dtype == "f64" else want.astype(np.float32), "%dx%d density %.2f %s, source (%d,%d)" % (nx, ny, density, dtype, sx, sy))
 
 
+@pytest.mark.parametrize("nx,ny,density", [(1104, 1030, 0.0), (1104, 1030, 0.03), (2600, 1100, 0.01), (1100, 4200, 0.01), (4200, 1100, 0.0), (1031, 1101, 0.02)])
+def test_lat_kernel_several_workgroups_per_unit(vhp, oracle, nx, ny, density):
+    """Sides above 1024: the bands of an octant are dealt out to two, four or eight workgroups (csrc/vhp_lat.hip lat_halves; LatArgs::halves), a
+    band above a band of another workgroup reads that band's line in global memory and its death from a record beside the lines.  Sources in
+    the corners and in the middle (octants of one band and of sixty), walls (bands that die early, late, never), NaN-filled output, an odd
+    width, both dtypes, every cell against the oracle -- and the same launch again (the records of the first one are stale tags by then)."""
+    import torch
+    occ = _walled(nx, ny, nx + ny, density) if density > 0 else np.ones((ny, nx), np.uint8)
+    src = _sources(occ, 2, nx + ny)[:6]
+    c = _ctx(vhp, occ)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
+    want = [oracle.sweep_full(occ, int(sx), int(sy)) for sx, sy in src]
+    for dtype in ("f64", "f32"):
+        tdt = torch.float64 if dtype == "f64" else torch.float32
+        for rep in range(2):
+            out = torch.full((len(src), ny, nx), float("nan"), dtype=tdt, device="cuda")
+            c.sweep_batch_device(d_src.data_ptr(), len(src), out.data_ptr(), dtype=vhp.F64 if dtype == "f64" else vhp.F32)
+            torch.cuda.synchronize()
+            assert c.last_sweep_kernel() == 4
+            got = out.cpu().numpy()
+            for k, (sx, sy) in enumerate(src):
+                _assert_same(got[k], want[k] if dtype == "f64" else want[k].astype(np.float32), "%dx%d density %.2f %s launch %d, source (%d,%d)" % (nx, ny, density, dtype, rep, sx, sy))
+
+
+@pytest.mark.parametrize("workgroups", [2, 4, 8])
+def test_lat_kernel_workgroups_per_unit_option(vhp, oracle, workgroups):
+    """vhp_set_option("lat_workgroups", n): the launch shape of the large grids asked for on a small one (1000 x 1000 with walls, 690 x 402),
+    where most bands of a second or fourth workgroup die before, while or after their readers start; the results do not depend on it."""
+    import torch
+    for nx, ny, density in [(1000, 1000, 0.03), (690, 402, 0.0), (1000, 1000, 0.0)]:
+        occ = _walled(nx, ny, nx + ny + workgroups, density) if density > 0 else np.ones((ny, nx), np.uint8)
+        src = _sources(occ, 2, nx + ny)[:4]
+        c = _ctx(vhp, occ)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.set_option("lat_workgroups", workgroups)
+        d_src = torch.from_numpy(np.ascontiguousarray(src, np.int32)).cuda()
+        out = torch.full((len(src), ny, nx), float("nan"), dtype=torch.float64, device="cuda")
+        c.sweep_batch_device(d_src.data_ptr(), len(src), out.data_ptr())
+        torch.cuda.synchronize()
+        assert c.last_sweep_kernel() == 4
+        got = out.cpu().numpy()
+        for k, (sx, sy) in enumerate(src):
+            _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d, %d workgroups per unit, source (%d,%d)" % (nx, ny, workgroups, sx, sy))
+
+
 def test_lat_kernel_maze_6_pivots(vhp, oracle):
     occ = maps.maze_6()
     res = oracle.solve(occ, (345, 391), (341, 10), 0.1, 1000)

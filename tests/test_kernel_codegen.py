@@ -39,7 +39,9 @@ def _kernels(asm, name):
 def test_no_flat_and_no_scratch_instructions(tmp_path, src, kernel):
     asm = _asm(src, tmp_path)
     ks = _kernels(asm, kernel)
-    want = 4   # fp64 and fp32, each also in its build for the other widths (pool sweep: not a multiple of 8; latency sweep: odd)
+    # fp64 and fp32, each also in its build for the other widths (pool sweep: not a multiple of 8; latency sweep: odd); the latency sweep
+    # all of that twice: for launches with one workgroup per unit and for those whose bands read across workgroups
+    want = 8 if kernel == "vhp_lat_sweep" else 4
     assert len(ks) == want, "%d instantiations of %s expected, found %r" % (want, kernel, list(ks))
     for name, body in ks.items():
         flat = re.findall(r"^\s+flat_\w+", body, re.M)
@@ -74,8 +76,11 @@ def test_latency_sweep_register_budget(tmp_path):
         assert get(r"ScratchSize \[bytes/lane\]") == 0, name
         assert get(r"VGPRs Spill") == 0, name
         assert get(r"Occupancy \[waves/SIMD\]") >= 4, name
-        assert get(r"SGPRs Spill") <= 240, (name, get(r"SGPRs Spill"))   # (139-209 at the end of round 6)
-    assert seen == 4, seen
+        # the build for launches with one workgroup per unit (C2, C4, the small batches: <..., false>): 170-202 at the end of round 6;
+        # the build whose bands read across workgroups (sides above 1024: <..., true>) holds that protocol on top: 420-462
+        multi = "Lb1EEEvNS0_7LatArgs" in name
+        assert get(r"SGPRs Spill") <= (520 if multi else 240), (name, get(r"SGPRs Spill"))
+    assert seen == 8, seen
     # ... and (next to) none of the spilled scalars is reloaded inside a window's sixteen steps (the blocks that hold the arithmetic)
     asm = open(out).read()
     for name, body in _kernels(asm, "vhp_lat_sweep").items():

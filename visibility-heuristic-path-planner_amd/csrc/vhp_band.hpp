@@ -118,7 +118,7 @@ struct BandXGeo {
   static VHP_FN int t_last(const Quad<DX, DY>& q, int b_) { return imin(q.ni - 1, kBlock * b_ + kBlock - 2 + q.rows_total); }
 };
 
-template <int DX, int DY>
+template <int DX, int DY, bool MULTI>
 struct BandX {
   static constexpr int kTS = DX > 0 ? kTStride : kBandTStrideDown;   // the tile's pitch (see kBandTStrideDown)
   static constexpr bool kMain = DX * DY > 0;  // the lanes' runs: y - x constant (main) or y + x constant (anti)
@@ -151,7 +151,7 @@ struct BandX {
   vu64 ow, ow_nx;
   vd rv_nx;
   Tagged* death_out;           // this band's record of death beside the lines, if the band above is swept by another workgroup (else null)
-  Below<DX, kLW> nx;
+  Below<DX, kLW, MULTI> nx;
 
   // (the caller has initialised lk)
   VHP_FN void init(const Map& m_, const uint64_t* dmap, int sx, int sy, const Shared& sh, int w, int b_, Poster* po_) {
@@ -321,6 +321,7 @@ struct BandX {
       request(xn, other ? nb + 1 : nb);
     }
     if (has_consumer) lk.publish(retires ? ta + kLW : ta + k_hi + 1);  // (a band that retires: its reader's window reaches past its own last step)
+    if (MULTI && death_out) lk.store_window(nb, xw);  // (the band above is swept by another workgroup: it reads this band's line, window by window)
     po->send(ta, xw, b, 0);
     sim_progress();
     VHP_WP_ADDP(lk.pp, 10, tw2);
@@ -332,7 +333,7 @@ struct BandX {
   VHP_FN void open_block(int xw, int ta) {
     const int b_ = xw >> 6;
     if (b_ == blk) return;
-    if (has_consumer) lk.store_block(g.nbx(ta - 1), blk);
+    if (has_consumer && !(MULTI && death_out)) lk.store_block(g.nbx(ta - 1), blk);
     enter_block(b_);
   }
 
@@ -367,19 +368,19 @@ struct BandX {
     int xw = g.X(D0) & ~(kLW - 1);
     int ta = DX > 0 ? xw - g.sx : g.sx - (xw + kLW - 1);
     jd = to_f64((-(b == 0 ? vmax(lane, 1) : lane + D0)) + ta);
-    if (below) nx.hd = lk.remote ? (lk.remote_died_by(0), lk.remote_dead) : lds_poll(dead_below);  // (a band that starts above a dead band need not sweep a window to find out)
+    if (below) nx.hd = (MULTI && lk.remote) ? (lk.remote_died_by(0), lk.remote_dead) : lds_poll(dead_below);  // (a band that starts above a dead band need not sweep a window to find out)
     enter_block(xw >> 6);
     bool dead = below && lds_poll(dead_mine) != 0;  // (a band below died before this one could start, and said so for it)
     // (a band below in another workgroup says it for nobody: this band's first step lies past that band's death, as in announce_death)
-    if (lk.remote && lk.remote_dead != 0 && D0 > lk.remote_dead) dead = true;
+    if (MULTI && lk.remote && lk.remote_dead != 0 && D0 > lk.remote_dead) dead = true;
     if (!dead) {
       request(xw, DX > 0 ? blk - g.bx0 : g.bx0 - blk);
       if (b == 0) { origin_bits(xw); march<true>(ta, xw, dead); } else march<false>(ta, xw, dead);
     }
-    // (a reader in another workgroup sees this band's death in a record beside the lines -- stored, and through, BEFORE the band's last
-    // block: whoever holds that block knows how much of it was swept)
-    if ((dead || retires) && death_out) { g_store_tagged(death_out, vi(0), vd((double)ta), lk.epoch); stores_done(); }
-    if (has_consumer) lk.store_block(imax(g.nbx(imin(imax(ta - 1, 0), i_last)), 0), blk);
+    // (a reader in another workgroup sees this band's death in a record beside the lines; the line itself it has window by window,
+    // Link::store_window, and never as whole blocks -- the entries of a block past a band's death were never swept)
+    if (MULTI && (dead || retires) && death_out) g_store_tagged(death_out, vi(0), vd((double)ta), lk.epoch);
+    if (has_consumer && !(MULTI && death_out)) lk.store_block(imax(g.nbx(imin(imax(ta - 1, 0), i_last)), 0), blk);
     if (dead || retires) {
       // Everything from step ta - 1 on is +0.0, in this band and below it (or: the band has left the octant): the word of death
       // first, then the progress word that lets the band above past its gate.
@@ -596,7 +597,7 @@ struct BandYGeo {
   static VHP_FN int t_last(const Quad<DX, DY>& q, int b_) { return imin(q.nj - 1, kBlock * b_ + kBlock - 1 + q.ni - 1); }
 };
 
-template <int DX, int DY>
+template <int DX, int DY, bool MULTI>
 struct BandY {
   static constexpr bool kMain = DX * DY > 0;
   using Geo = BandYGeo<DX, DY>;
@@ -628,7 +629,7 @@ struct BandY {
   vu64 ow, ow_nx;
   vd rv_nx;
   Tagged* death_out;           // this band's record of death beside the lines, if the band above is swept by another workgroup (else null)
-  Below<DY, kLW> nx;
+  Below<DY, kLW, MULTI> nx;
 
   VHP_FN void init(const Map& m_, const uint64_t* dmap, int sx, int sy, const Shared& sh, int w, int b_, Poster* po_) {
     m = m_;
@@ -777,6 +778,7 @@ struct BandY {
       request(yn, other ? nb + 1 : nb);
     }
     if (has_consumer) lk.publish(retires ? ta + kLW : ta + k_hi + 1);
+    if (MULTI && death_out) lk.store_window(nb, yw);  // (see BandX::window)
     po->send(ta, yw, b, 0);
     sim_progress();
   }
@@ -784,7 +786,7 @@ struct BandY {
   VHP_FN void open_block(int yw, int ta) {
     const int b_ = yw >> 6;
     if (b_ == blk) return;
-    if (has_consumer) lk.store_block(g.nby(ta - 1), blk);
+    if (has_consumer && !(MULTI && death_out)) lk.store_block(g.nby(ta - 1), blk);
     enter_block(b_);
   }
 
@@ -813,16 +815,16 @@ struct BandY {
     int yw = g.Y(D0) & ~(kLW - 1);
     int ta = DY > 0 ? yw - g.sy : g.sy - (yw + kLW - 1);
     jd = to_f64((-(b == 0 ? vmax(lane, 1) : lane + D0)) + ta);
-    if (below) nx.hd = lk.remote ? (lk.remote_died_by(0), lk.remote_dead) : lds_poll(dead_below);
+    if (below) nx.hd = (MULTI && lk.remote) ? (lk.remote_died_by(0), lk.remote_dead) : lds_poll(dead_below);
     enter_block(yw >> 6);
     bool dead = below && lds_poll(dead_mine) != 0;
-    if (lk.remote && lk.remote_dead != 0 && D0 > lk.remote_dead) dead = true;   // (see BandX::run)
+    if (MULTI && lk.remote && lk.remote_dead != 0 && D0 > lk.remote_dead) dead = true;   // (see BandX::run)
     if (!dead) {
       request(yw, DY > 0 ? blk - g.by0 : g.by0 - blk);
       if (b == 0) { origin_bits(yw); march<true>(ta, yw, dead); } else march<false>(ta, yw, dead);
     }
-    if ((dead || retires) && death_out) { g_store_tagged(death_out, vi(0), vd((double)ta), lk.epoch); stores_done(); }   // (see BandX::run)
-    if (has_consumer) lk.store_block(imax(g.nby(imin(imax(ta - 1, 0), j_last)), 0), blk);
+    if (MULTI && (dead || retires) && death_out) g_store_tagged(death_out, vi(0), vd((double)ta), lk.epoch);   // (see BandX::run)
+    if (has_consumer && !(MULTI && death_out)) lk.store_block(imax(g.nby(imin(imax(ta - 1, 0), j_last)), 0), blk);
     if (dead || retires) {  // (see BandX::run)
       lds_publish(dead_mine, ta);
       lds_publish(lk.prog, 0x3fff);
@@ -945,7 +947,8 @@ struct BandYStore {
 };
 
 // One wavefront of a unit's workgroup: sweeper w (w < W) or the storer of sweeper w - W.
-template <typename OutT, bool ODD = false>
+// MULTI: the build for launches with more than one workgroup per unit (LatArgs::halves > 1); the build for one holds none of that code
+template <typename OutT, bool ODD = false, bool MULTI = false>
 struct BandWorker {
   static constexpr int kRoles = 2;  // wavefronts per sweeper (the simulator and the launcher size the workgroup by it)
   static constexpr int kTilePitch = kBandTStrideDown;  // ... and the LDS layout's tiles by this
@@ -964,7 +967,7 @@ struct BandWorker {
     sh.L = L;
     w = w_;
     W = L.W;
-    H = a.halves > 1 ? a.halves : 1;
+    H = (MULTI && a.halves > 1) ? a.halves : 1;
     half = 0;
     lane = lane_id();
   }
@@ -985,8 +988,8 @@ struct BandWorker {
   // the durable copy that every band with a reader writes anyway), and the writer's death out of a record beside the lines: entry p of
   // the unit's last two blocks of scratch (the lines of at most 128 bands leave them free: lat_unit_blocks).
   VHP_FN Tagged* death_rec(int unit, int p) const { return a.lines + ((size_t)64 * ((size_t)unit * (size_t)a.unit_blocks + (size_t)(a.unit_blocks - 2)) + (size_t)p); }
-  VHP_FN bool remote_below(int p) const { return H > 1 && p > 0 && p % W == 0; }
-  VHP_FN bool remote_above(int p, int n) const { return H > 1 && p + 1 < n && (p + 1) % W == 0; }
+  VHP_FN bool remote_below(int p) const { return MULTI && H > 1 && p > 0 && p % W == 0; }
+  VHP_FN bool remote_above(int p, int n) const { return MULTI && H > 1 && p + 1 < n && (p + 1) % W == 0; }
 
   // a coarse gate ahead of a band's first window (which then checks exactly what it reads): one word per poll
   VHP_FN void wait_for(const int* word, int at_least) {
@@ -1001,7 +1004,7 @@ struct BandWorker {
     int* prog = sh.prog(0);
     const int n = BandXGeo<DX, DY>::n_bands(g);
     for (int p = half * W + w; p < n; p += H * W) {
-      BandX<DX, DY> xs;
+      BandX<DX, DY, MULTI> xs;
       xs.lk.init(sh, w, sx, imax(BandXGeo<DX, DY>::first_window(g, p), 0), tag_of(p), prog + p, p > 0 ? line_of(unit, p - 1, g.Nbx) : nullptr,
                  p + 1 < n ? line_of(unit, p, g.Nbx) : nullptr, a.epoch, p > 0 ? (p - 1) % W : -1, p > 0 ? tag_of(p - 1) : 0);
       if (remote_below(p)) { xs.lk.remote = true; xs.lk.death_in = death_rec(unit, p - 1); }
@@ -1030,7 +1033,7 @@ struct BandWorker {
     const int n = BandYGeo<DX, DY>::n_bands(g);
     const int Nby = g.Nby;
     for (int q = half * W + w; q < n; q += H * W) {
-      BandY<DX, DY> ys;
+      BandY<DX, DY, MULTI> ys;
       ys.lk.init(sh, w, sy, imax(BandYGeo<DX, DY>::first_window(g, q), 0), tag_of(q), prog + q, q > 0 ? line_of(unit, q - 1, Nby) : nullptr,
                  q + 1 < n ? line_of(unit, q, Nby) : nullptr, a.epoch, q > 0 ? (q - 1) % W : -1, q > 0 ? tag_of(q - 1) : 0);
       if (remote_below(q)) { ys.lk.remote = true; ys.lk.death_in = death_rec(unit, q - 1); }

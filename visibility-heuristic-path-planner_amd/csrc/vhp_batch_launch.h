@@ -24,6 +24,7 @@ struct BatchArgs {
   int* d_err;             // device flag: a source outside the grid
   int* d_queue;           // the launch's scratch (pool_scratch_bytes / lat_scratch_bytes)
   int n_cus;              // compute units of the device (the persistent grid is sized to what the chip holds at once)
+  int lat_workgroups = 0; // latency sweep: workgroups per octant asked for (0: by the grid's size, lat_halves)
   hipStream_t stream;
   // called with (kernel, bytes) before a launch that needs more than the default dynamic LDS: the per-device
   // bookkeeping lives with the context

@@ -70,6 +70,7 @@ struct vhp_ctx {
   int opt_multi = 0;          // 1: force the multi-round build
   int opt_slide = -1;         // 0 / 1: y-major column grid slid onto 128-byte lines
   int opt_pack = 0;           // 1: pack short quadrants into one workgroup
+  int opt_lat_workgroups = 0; // latency sweep: workgroups per octant (0 automatic, 1 / 2 / 4 / 8: vhp_lat.hip lat_halves)
   const int* lat_src_index = nullptr;  // set around a latency-sweep launch of the planner's loop (vhp_planner_solve)
   const int* lat_skip = nullptr;
   const int* lat_pivot_rec = nullptr;  // ... or both and the pivot in one 16-byte record (vhp_planner.hip.h PlannerDev::rec)
@@ -372,6 +373,7 @@ hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT*
   a.d_slot_base = lat ? c->lat_slot_base : nullptr;
   a.d_run_if = lat ? c->lat_run_if : nullptr;
   a.lat_dead_cells_are_zero = lat && c->lat_dark_unwritten;
+  a.lat_workgroups = c->opt_lat_workgroups;
   a.n_cus = c->n_cus;
   a.stream = c->stream;
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
@@ -883,6 +885,7 @@ int vhp_set_option(vhp_ctx* ctx, const char* key, long long value) {
   else if (k == "multi_round") { ctx->opt_multi = v != 0; }
   else if (k == "slide") { if (v < -1 || v > 1) return fail(ctx, VHP_ERR_ARG, "slide: -1, 0 or 1"); ctx->opt_slide = v; }
   else if (k == "pack") { ctx->opt_pack = v != 0; }
+  else if (k == "lat_workgroups") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) return fail(ctx, VHP_ERR_ARG, "lat_workgroups: 0 (automatic), 1, 2, 4 or 8"); ctx->opt_lat_workgroups = v; }
   else if (k == "kernel") { if (v < 0 || v > 4 || v == 2) return fail(ctx, VHP_ERR_ARG, "kernel: 0 auto, 1 fronts, 3 pool, 4 latency (2, the streaming sweep, was retired)"); ctx->opt_kernel = v; }
   else if (k == "field_stride") { if (value < 0) return fail(ctx, VHP_ERR_ARG, "field_stride: 0 (packed) or elements per field"); ctx->opt_field_stride = value; }
   else if (k == "pool_claim_ahead") { if (v < -1 || v > 64) return fail(ctx, VHP_ERR_ARG, "pool_claim_ahead: -1 (automatic) .. 64"); ctx->opt_pool_claim_ahead = v; }

@@ -62,7 +62,7 @@
 
 // no strip waits for another (wrong results): fetch() returns at once, find_work() claims whatever is unclaimed
 #ifdef VHP_DIAG_NOWAIT
-#define VHP_DIAG_NOWAIT_RETURN return true;
+#define VHP_DIAG_NOWAIT_RETURN return;
 #define VHP_DIAG_WAITS false
 #else
 #define VHP_DIAG_NOWAIT_RETURN

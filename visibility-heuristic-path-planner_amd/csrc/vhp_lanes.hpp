@@ -251,6 +251,10 @@ inline vb g_load_tagged(const Tagged* base, const vi& idx, uint64_t tag, vd& v) 
   vb ok; for (int l = 0; l < kLanes; ++l) { v.v[l] = base[idx.v[l]].v; ok.v[l] = base[idx.v[l]].tag == tag; } return ok; }
 inline bool wave_all(const vb& p) { for (int l = 0; l < kLanes; ++l) if (!p.v[l]) return false; return true; }
 inline void lds_store_i_if(const vb& p, int* base, const vi& idx, int v) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) base[idx.v[l]] = v; }
+// a tagged entry per lane as it is in memory, tag and value -- what g_load_tagged compares at once, for a caller that looks later
+inline void g_load_tagged_raw(const Tagged* base, const vi& idx, vu64& tag, vd& v) { for (int l = 0; l < kLanes; ++l) { v.v[l] = base[idx.v[l]].v; tag.v[l] = base[idx.v[l]].tag; } }
+inline vb tags_are(const vu64& tag, uint64_t want) { vb ok; for (int l = 0; l < kLanes; ++l) ok.v[l] = tag.v[l] == want; return ok; }
+inline void g_store_tagged_if(const vb& p, Tagged* base, const vi& idx, const vd& v, uint64_t tag) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) { base[idx.v[l]].v = v.v[l]; base[idx.v[l]].tag = tag; } }
 
 #else
 // ------------------------------------------------------------------------------------------------------------
@@ -540,6 +544,14 @@ VHP_LANE_FN bool g_load_tagged(const Tagged* base, vi idx, uint64_t tag, vd& v) 
   v = __hip_atomic_load(&base[idx].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return t == tag;
 }
+// (the loads are issued and nothing waits for them: the tag is compared where the caller needs the value)
+VHP_LANE_FN void g_load_tagged_raw(const Tagged* base, vi idx, vu64& tag, vd& v) {
+  tag = __hip_atomic_load(&base[idx].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::: "memory");
+  v = __hip_atomic_load(&base[idx].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+VHP_LANE_FN bool tags_are(vu64 tag, uint64_t want) { return tag == want; }
+VHP_LANE_FN void g_store_tagged_if(bool p, Tagged* base, vi idx, vd v, uint64_t tag) { if (p) base[idx] = Tagged{v, tag}; }
 VHP_LANE_FN bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0ull; }
 VHP_LANE_FN void lds_store_i_if(bool p, int* base, vi idx, int v) { if (p) ((lds_int*)base)[idx] = v; }
 VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(VHP_BACKOFF_SLEEP); }

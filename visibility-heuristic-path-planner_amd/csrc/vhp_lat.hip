@@ -7,7 +7,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 
 #include "vhp.h"
 #include "vhp_band.hpp"
@@ -29,22 +28,23 @@ __device__ unsigned long long g_lat_strip_times[64 * 48 * 4];
 #endif
 
 #ifdef VHP_LAT_STRIPS  // A/B builds only: the sweep in strips of rows (vhp_lat.hpp), what the kernel was until round 6
-template <typename OutT, bool ODD> using LatWorkerT = LatWorker<OutT, ODD>;
+template <typename OutT, bool ODD, bool MULTI = false> using LatWorkerT = LatWorker<OutT, ODD>;
 #else
-template <typename OutT, bool ODD> using LatWorkerT = BandWorker<OutT, ODD>;
+template <typename OutT, bool ODD, bool MULTI = false> using LatWorkerT = BandWorker<OutT, ODD, MULTI>;
 #endif
 // wavefronts of a workgroup: kLatWaves sweepers and, in the band sweep, a storer beside each (16: four per SIMD, 128 vector registers)
 constexpr int kLatThreads = 64 * kLatWaves * LatWorkerT<double, false>::kRoles;
 constexpr int kLatTilePitch = LatWorkerT<double, false>::kTilePitch;
 
-template <typename OutT, bool ODD>
+// MULTI: the build for launches with more than one workgroup per unit (lat_halves below): its bands can read across workgroups
+template <typename OutT, bool ODD, bool MULTI>
 __global__ void __launch_bounds__(kLatThreads, 1) vhp_lat_sweep(LatArgs<OutT> a) {
   extern __shared__ double lds[];
   const Layout L = make_layout(kLatWaves, 1, a.m.nx, a.m.ny, kLatTilePitch);
 #ifdef VHP_DIAG_POOLPROF
   const unsigned long long t_begin = wall_clock64();
 #endif
-  using WorkerT = LatWorkerT<OutT, ODD>;
+  using WorkerT = LatWorkerT<OutT, ODD, MULTI>;
   WorkerT::clear(lds, L, (int)threadIdx.x, kLatThreads);
   __syncthreads();
   WorkerT wk;
@@ -127,12 +127,11 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // memory takes back (measured at 1000^2: 117.8 / 118.4 us over eight source positions).  Above: two up to 2048, four up to 4096, eight
 // beyond -- an octant of P bands is swept in rounds of 8 x that number, and every round waits for the one before (8192^2, one source:
 // 3.47 ms with one workgroup per unit, 1.92 with two, 1.18 with four).  All workgroups of a unit must be resident at once -- the
-// others spin on the first one's lines --: halved until workgroups <= CUs.  (VHP_LAT_HALVES in the environment: 1 / 2 / 4 / 8, for
-// measurements.)
-int lat_halves(int n_src, int nx, int ny, int n_cus) {
-  static const char* env = std::getenv("VHP_LAT_HALVES");
+// others spin on the first one's lines --: halved until workgroups <= CUs.  (asked: vhp_set_option "lat_workgroups", 1 / 2 / 4 / 8, for
+// measurements and tests; 0: by the size.)
+int lat_halves(int n_src, int nx, int ny, int n_cus, int asked) {
   const int cus = n_cus > 0 ? n_cus : 256, side = std::max(nx, ny);
-  int want = env ? std::atoi(env) : side > 4 * VHP_LAT_HALVES_MIN_SIDE ? 8 : side > 2 * VHP_LAT_HALVES_MIN_SIDE ? 4 : side > VHP_LAT_HALVES_MIN_SIDE ? 2 : 1;
+  const int want = asked > 0 ? asked : side > 4 * VHP_LAT_HALVES_MIN_SIDE ? 8 : side > 2 * VHP_LAT_HALVES_MIN_SIDE ? 4 : side > VHP_LAT_HALVES_MIN_SIDE ? 2 : 1;
   int h = 1;
   while (2 * h <= want && 2 * h <= 8 && 2 * h * pool::kUnits * n_src <= cus) h *= 2;
   return h;
@@ -143,11 +142,17 @@ template <typename OutT>
 hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {
   using namespace pool;
   const bool odd = lat_needs_odd<OutT>(a.nx, a.field_stride, static_cast<const OutT*>(a.d_out));
-#ifdef VHP_EXP_ONE_KERNEL  // compile-time experiments only: one instantiation instead of four
-  auto k = vhp_lat_sweep<double, false>;
+  int halves = lat_halves(a.n_src, a.nx, a.ny, a.n_cus, a.lat_workgroups);
+#if defined(VHP_LAT_STRIPS)
+  halves = 1;
+#endif
+#ifdef VHP_EXP_ONE_KERNEL  // compile-time experiments only: one instantiation instead of eight
+  auto k = vhp_lat_sweep<double, false, false>;
+  halves = 1;
   if (odd || sizeof(OutT) != 8) return hipErrorInvalidValue;
 #else
-  auto k = odd ? vhp_lat_sweep<OutT, true> : vhp_lat_sweep<OutT, false>;
+  auto k = halves > 1 ? (odd ? vhp_lat_sweep<OutT, true, true> : vhp_lat_sweep<OutT, false, true>)
+                      : (odd ? vhp_lat_sweep<OutT, true, false> : vhp_lat_sweep<OutT, false, false>);
 #endif
   const size_t lds = lat_lds_bytes(a.nx, a.ny);
   if (lds > kLdsLimit || a.pool_epoch == 0) return hipErrorInvalidValue;
@@ -185,10 +190,7 @@ hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {
   // Two workgroups per unit where an octant can have more bands than a workgroup has sweepers and the launch leaves the CUs for it
   // (vhp_band.hpp BandWorker: bands 8-15, 24-31, ... of an octant on the second one).
   g.n_units = a.n_src * kUnits;
-  g.halves = lat_halves(a.n_src, a.nx, a.ny, a.n_cus);
-#if defined(VHP_LAT_STRIPS)
-  g.halves = 1;
-#endif
+  g.halves = halves;
 #ifdef VHP_DIAG_POOLPROF
   { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(pool::g_lat_strip_times)) == hipSuccess) g.strip_times = static_cast<unsigned long long*>(p); }
 #endif

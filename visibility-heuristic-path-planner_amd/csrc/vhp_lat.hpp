@@ -92,10 +92,17 @@ VHP_HD long long lat_unit_blocks(int nx, int ny) {
 // What the strips of both kinds read from the strip below for one window.  D = direction of the marching coordinate;
 // v[0] = the strip below at the coordinate one step BEFORE the window's first-marched cell, v[k] (k >= 1) at the cell of
 // step k - 1 of the window.
-template <int D, int NB>
+// MULTI: the build whose writer may live in another workgroup (Link::remote; the band sweep's launches with more than one workgroup
+// per unit) -- the other build holds none of that code
+template <int D, int NB, bool MULTI = false>
 struct Below {
   bool ring;   // the values came out of the writer's ring and are still to be checked against h1 / h2
   int h1, h2;
+  // a writer in another workgroup (Link::remote): the window's entries of its line in global memory as loaded when the window was
+  // asked for -- lane l: step ia - 1 + l, l = 0 .. NB - 1 --, tags not looked at yet (accept), and the window's first step
+  vu64 gtag;
+  vd gval;
+  int g_ia;
   int hd;      // the strip below's word of death, read with the values: 0 alive, else 1 + the step from which all its values are +0.0
   vd v[NB];
 
@@ -120,15 +127,20 @@ struct Below {
     ring = false;
   }
   VHP_FN void request(const Link<D>& lk, const int* dead_below, const double* bin, int cw, int c_first, int nb) {
-    if (lk.remote) {
-      // the writer is in another workgroup: its word of death as the link last saw it beside the lines, its values out of the slab if
-      // the block is there -- and otherwise out of its line in global memory, when the window is about to start (accept: a header that
-      // belongs to nobody sends it there)
+    if (MULTI && lk.remote) {
+      // the writer is in another workgroup: its word of death as the link last saw it beside the lines, its values out of its line in
+      // global memory -- the loads go out now, a window ahead like the reads of a ring, and accept looks at the tags
       hd = lk.remote_dead;
-      if (lk.bin_block == nb) from_slab(bin, cw, c_first); else { h1 = h2 = 0; ring = true; }
+      g_ia = (c_first - lk.c0) * D;
+      remote_load(lk);
+      ring = true;
       return;
     }
     if (lk.bin_block == nb) { from_slab(bin, cw, c_first); hd = lds_peek(dead_below); } else from_ring(lk, dead_below, cw, c_first);
+  }
+  VHP_FN void remote_load(const Link<D>& lk) {
+    const vi st = vmin(lane_id(), NB - 1) + (g_ia - 1);
+    g_load_tagged_raw(lk.line_in, lk.line_index(st), gtag, gval);
   }
   // the step from which the strip below is dead, as of the last request (0x7fffffff: alive)
   VHP_FN int dead_from() const { const int d = uniform(hd); return d != 0 ? d - 1 : 0x7fffffff; }
@@ -139,6 +151,24 @@ struct Below {
     // below or after it, never across)
     if (dead_from() <= ia - 1) { zeros(); return; }
     if (!ring) return;
+    if (MULTI && lk.remote) {
+      // every entry of the window carries this launch's tag, or the writer has died at or before the window (its record beside the
+      // lines: it stores no further entry) -- asked again until one of the two
+      while (!wave_all(tags_are(gtag, lk.epoch))) {
+        if (lk.remote_died_by(ia - 1)) { hd = lk.remote_dead; zeros(); return; }
+        backoff();
+        sim_point();
+        remote_load(lk);
+      }
+      // (the writer stores its record BEFORE the entries of its last window: whoever holds those knows whether it died behind them;
+      // this window lies before that death or the loop above has caught it)
+      const vi ln = lane_id();
+      const vi x = (vmin(ln, NB - 1) + (ia - 1)) * D + lk.c0;
+      lds_store_if(ln < NB, lk.bin, select(ln == 0, vi(1 + (c_first & 63) - D), (x & 63) + 1), gval);
+      wave_sync();
+      from_slab(bin, cw, c_first);
+      return;
+    }
     int ha = uniform(h1);
     if ((ha >> 14) == lk.rd_tag && (ha & 0x3fff) <= last_needed) {
       // Not swept yet.  The wait looks at the writer's header and at its word of death only, and the values are read ONCE after it:
@@ -167,12 +197,7 @@ struct Below {
       return;
     }
     sim_count(3);
-    if (!lk.fetch(ia, last_needed, nb)) { hd = lk.remote_dead; zeros(); return; }   // (a remote writer that died before this window)
-    if (lk.remote) {
-      // (the block may be the writer's last, stored when it died: what lies past its death in it was never swept)
-      hd = lk.remote_dead;
-      if (dead_from() <= ia - 1) { zeros(); return; }
-    }
+    lk.fetch(ia, last_needed, nb);
     from_slab(bin, cw, c_first);
   }
   VHP_FN void zeros() {

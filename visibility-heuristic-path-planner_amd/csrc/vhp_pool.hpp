@@ -52,6 +52,7 @@ using geom::Quad;
 constexpr int kBlock = geom::kBlock;
 constexpr int kXRows = geom::kXRows;
 constexpr int kYCols = geom::kYCols;
+constexpr int kLW16 = 16;     // steps of a window of the latency sweep (vhp_lat.hpp kLW), for the hand-over across workgroups (Link::store_window)
 constexpr int kTStride = 17;  // doubles per tile row: two windows of 8 columns + 1 (spreads the column writes over the banks)
 constexpr int kTStrideAny = 25;  // ... of the build for widths that are not a multiple of 8: three windows + 1 (XStrip::flush_rows)
 constexpr int kUnits = 8;     // units per source: 4 quadrants x {x-major, y-major}
@@ -186,8 +187,9 @@ struct Link {
   int bin_block;           // the block that is in `bin` as a whole (from global memory), or -1
   int first_step;
   // The strip below is swept by ANOTHER workgroup (the latency sweep's long octants, vhp_band.hpp BandWorker: halves): no ring, no
-  // header, no word of death in this workgroup's LDS -- its line in global memory is all there is, a block of 64 steps at a time, and
-  // beside the lines a record of its death {step + 1, epoch}, which the waits for a block look at (a dead writer stores no further block).
+  // header, no word of death in this workgroup's LDS -- its line in global memory is all there is, written window by window
+  // (store_window) and read the same way (vhp_lat.hpp Below, remote), and beside the lines a record of its death {the step from
+  // which its values are +0.0, epoch}, which the reader's wait for a window looks at (a dead writer stores no further entry).
   bool remote;
   const Tagged* death_in;  // the writer's record (one entry)
   int remote_dead;         // ... as last seen: 0 alive, else 1 + the step from which all its values are +0.0
@@ -229,6 +231,19 @@ struct Link {
     lds_publish(hdr, (my_tag << 14) | steps);
     lds_publish(prog, steps);
   }
+  // The sixteen entries of the window whose lowest coordinate is cw (march block nb) go to my line in global memory, out of the ring: what
+  // a reader in another workgroup waits for, window by window (Below, remote) -- a block at a time it would start 64 steps late.
+  VHP_FN void store_window(int nb, int cw) {
+    wave_sync();
+    const vi l = lane & (kLW16 - 1);
+    g_store_tagged_if(lane < kLW16, line_out, l + (64 * nb + (cw & 63)), lds_load(ring, l + (cw & (kRing - 1))), epoch);
+  }
+  // the entry of step s in a line: its march block and its coordinate in the block (lane vector of steps)
+  VHP_FN vi line_index(const vi& s) const {
+    const vi x = s * D + c0;
+    const vi nbv = D > 0 ? (x >> 6) - (c0 >> 6) : (-(x >> 6)) + (c0 >> 6);
+    return nbv * 64 + (x & 63);
+  }
   // the whole block nb (coordinate block blk = x >> 6) goes to my line in global memory, out of the ring
   VHP_FN void store_block(int nb, int blk) {
     wave_sync();
@@ -243,39 +258,27 @@ struct Link {
     if (wave_all(g_load_tagged(death_in, vi(0), epoch, r))) remote_dead = lane0_int(r);
     return remote_dead != 0 && remote_dead - 1 <= need;
   }
-  // need: the first step whose value the caller wants out of the block (a remote writer that died at or before it stores no such
-  // block: false, and nothing is loaded)
-  VHP_FN bool load_block(int nb, int need = 0) {
+  VHP_FN void load_block(int nb) {
     // the neighbour of the block's first step is the last entry of the line's previous block -- wanted (and written by the strip
     // below) if that step is one of mine.  (Out of memory, not out of what the slab held before: the latency sweep's windows
     // read the writer's ring directly and leave the slab alone.)
     vd carry = vd(0.0);
     if (nb >= 1 && block_first_step(nb) >= imax(first_step, 1))
-      while (!wave_all(g_load_tagged(line_in, vi(64 * (nb - 1) + (D > 0 ? 63 : 0)), epoch, carry))) {
-        if (remote && remote_died_by(need)) return false;
-        backoff();
-      }
+      while (!wave_all(g_load_tagged(line_in, vi(64 * (nb - 1) + (D > 0 ? 63 : 0)), epoch, carry))) backoff();
     vd v;
-    while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) {
-      if (remote && remote_died_by(need)) return false;
-      backoff();
-    }
+    while (!wave_all(g_load_tagged(line_in, lane + 64 * nb, epoch, v))) backoff();
     wave_sync();
     lds_store(bin, lane + 1, v);
     lds_store(bin, vi(D > 0 ? 0 : 65), carry);
     wave_sync();
     bin_block = nb;
-    // (a writer that dies stores its record BEFORE its last block: whoever has that block sees the record)
-    if (remote) (void)remote_died_by(need);
-    return true;
   }
   // Makes the boundary values of steps ia-1 .. ib of the strip below (all of block nb but possibly the first) readable in
   // the slab.  Fast: out of the writer's ring, with its header read before and after the copy.  Otherwise the whole
   // block from global memory.
-  VHP_FN bool fetch(int ia, int ib, int nb) {
-    if (bin_block == nb) return true;
+  VHP_FN void fetch(int ia, int ib, int nb) {
+    if (bin_block == nb) return;
     VHP_DIAG_NOWAIT_RETURN  // (vhp_diag.h: diagnostic builds in which no strip waits for another)
-    if (remote) return load_block(nb, ia - 1);
     for (;;) {
       const int h = lds_poll(rd_hdr);
       if ((h >> 14) != rd_tag) break;                 // the writer has finished that strip: its line is (being) stored
@@ -294,10 +297,10 @@ struct Link {
       lds_store(bin, slot, v);
       wave_sync();
       sim_count(0);
-      return true;
+      return;
     }
     sim_count(1);
-    return load_block(nb, ia - 1);
+    load_block(nb);
   }
 };
 
