@@ -32,6 +32,7 @@ pmc driver_cmd --gpus 1 --steps 20 --warmup 5
 python3 $R/tools/traffic_from_pmc.py $O/${tag}_pmc_fetch_size_driver_cmd.csv $O/${tag}_pmc_write_size_driver_cmd.csv c3 f64 $O > $O/traffic_c3.log 2>&1
 stats c5 --gpus 1 --workload c5 --steps 10 --warmup 3
 stats c2 --workload c2 --steps 300 --warmup 10
+stats c5_8_sources --workload c5 --sources 8 --steps 50 --warmup 5   # (4096^2 with 8 sources: the latency sweep with four workgroups per octant)
 stats c4 --workload c4 --steps 20 --warmup 2
 for n in 8 32 64 96; do
   stats c3_$n --workload c3-$n --steps 100 --warmup 10
