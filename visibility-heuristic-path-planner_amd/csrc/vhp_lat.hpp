@@ -156,12 +156,12 @@ struct Below {
       // lines: it stores no further entry) -- asked again until one of the two
       while (!wave_all(tags_are(gtag, lk.epoch))) {
         if (lk.remote_died_by(ia - 1)) { hd = lk.remote_dead; zeros(); return; }
-        backoff();
+        short_backoff();   // (every look is a trip to memory already)
         sim_point();
         remote_load(lk);
       }
-      // (the writer stores its record BEFORE the entries of its last window: whoever holds those knows whether it died behind them;
-      // this window lies before that death or the loop above has caught it)
+      // (a window's entries are stored when the window has been swept and the record after the last of them: a window whose entries
+      // are all there lies before the writer's death)
       const vi ln = lane_id();
       const vi x = (vmin(ln, NB - 1) + (ia - 1)) * D + lk.c0;
       lds_store_if(ln < NB, lk.bin, select(ln == 0, vi(1 + (c_first & 63) - D), (x & 63) + 1), gval);
