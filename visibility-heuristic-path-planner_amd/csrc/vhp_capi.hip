@@ -160,7 +160,7 @@ vhp::DevMap dev_map(const vhp_ctx* c) {
 // with VHP_R / VHP_W / VHP_MULTI.
 void pick_shape(const vhp_ctx* c, int maxdim, int* R, int* W, bool* multi, int n_src = 1, bool f64 = true, bool pitch64 = false) {
   if (maxdim <= 64) { *R = 1; *W = 1; }
-  else if (maxdim <= 128) { *R = 1; *W = 2; }
+  else if (maxdim <= 128) { *R = 2; *W = 1; }   // (one strip of two rows per lane per octant, no hand-over: 101^2 x 4096 sources 0.203 -> 0.191 ms, tools/small_grid_shapes.py)
   else if (maxdim <= 256) { *R = 1; *W = 4; }
   else if (maxdim <= 512) { *R = 2; *W = 4; }
   else if (maxdim <= 1024) { *R = 2; *W = 8; }
