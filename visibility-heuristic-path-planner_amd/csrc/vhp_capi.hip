@@ -286,8 +286,17 @@ bool use_lat_kernel(const vhp_ctx* c, int n_src) {
     if (n_src > 16 && maxdim > 2560) return false;
     if (n_src >= 28 && maxdim > 1792) return false;
   }
+  // Round 6, last: MORE sources than octants fit the chip at once, up to 1024 cells a side.  The launch is as long as its longest octant
+  // while most octants are short, so the workgroups beyond the first 256 find CUs long before the long ones are through (latency /
+  // pool / front sweep, us, profiles/r06_exp_lat_beyond_one_octant_per_cu.txt): 320^2: 48 sources 51 / 92 / 87, 64: 62 / 96 / 87;
+  // 512^2: 48: 84 / 131 / 128, 64: 107 / 134 / 128; 640^2: 64: 132 / 159 / 165; 768^2: 48: 157 / 192 / 221, 64: 190 / 193 / 220; 896^2: 48: 166 /
+  // 207 / 250, 64: 214 / 210 / 252; 1000^2: 36: 155 / 234, 44: 201 / 234, 52: 220 / 234, 56: 269 / 237, 64: 273 / 242; from 96 sources the others
+  // are ahead everywhere (512^2: 96: 128 / 127 / 138, 128: 156 / 132 / 145).  Other widths (the pool sweep's slower build): 64 sources at
+  // 1001 x 971 273 against the front sweep's 295 and the pool sweep's ~ 340; at 101^2 28 / 34, at 255^2 60 / 71 (front).
+  const int one_round = c->n_cus / 8;   // sources whose octants have a CU each
+  const int cap = maxdim <= 832 ? 2 * one_round : maxdim <= 1024 ? ((c->nx & 7) == 0 ? one_round * 13 / 8 : 2 * one_round) : one_round;
   // (the boundary lines of a launch -- 16 bytes per strip and step -- stay below two gigabytes: 32 sources at 8192^2 would take four)
-  return 8 * n_src <= c->n_cus && vhp::lat_scratch_bytes(n_src, c->nx, c->ny) <= ((size_t)2 << 30);
+  return n_src <= std::min(cap, 64) && vhp::lat_scratch_bytes(n_src, c->nx, c->ny) <= ((size_t)2 << 30);
 }
 
 bool use_pool_kernel(const vhp_ctx* c, int n_src) {
