@@ -185,27 +185,29 @@ def test_lat_kernel_maze_6_pivots(vhp, oracle):
         _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "maze_6 pivot %d (%d,%d)" % (k, sx, sy))
 
 
-def test_lat_kernel_sixty_four_sources_by_default(vhp, oracle):
-    # the largest launch the library gives to the latency sweep by itself up to 832 cells a side: 64 sources = 512 workgroups on 256 CUs
-    # (most octants are short: the second 256 find their CUs long before the longest of the first are through)
+def test_lat_kernel_more_units_than_cus_by_default(vhp, oracle):
+    # the largest launches the library gives to the latency sweep by itself: 96 sources up to 640 cells a side = 768 workgroups on 256 CUs,
+    # launched by falling length of their march (vhp_lat_order: most octants are short, and find their CUs long before the longest are through)
     occ = maps.random_rect_map(328, 300, 30, 3, 40, 3, 40, 77)
-    src = maps.free_sources(occ, 64, 5)
+    src = maps.free_sources(occ, 96, 5)
+    src[5] = (0, 0); src[17] = (327, 299); src[40] = (327, 0)
+    occ[src[:, 1], src[:, 0]] = 1
     c = vhp.Context(0)
     c.set_map(occ)
     got = c.sweep_batch(src)
     assert c.last_sweep_kernel() == 4
     for k, (sx, sy) in enumerate(src):
-        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "64 sources, source %d (%d,%d)" % (k, sx, sy))
-    got = c.sweep_batch(np.concatenate([src, src[:1]]))   # 65: the front sweep again
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "96 sources, source %d (%d,%d)" % (k, sx, sy))
+    got = c.sweep_batch(np.concatenate([src, src[:1]]))   # 97: the front sweep again
     assert c.last_sweep_kernel() == 1
-    # ... and 52 at 1000 x 1000 (53: the pool sweep), every field of the launch against the oracle
-    occ, src = maps.config_c3(53)
+    # ... and 64 at 1000 x 1000 (65: the pool sweep), every field of the launch against the oracle
+    occ, src = maps.config_c3(65)
     c = vhp.Context(0)
     c.set_map(occ)
-    got = c.sweep_batch(src[:52])
+    got = c.sweep_batch(src[:64])
     assert c.last_sweep_kernel() == 4
-    for k, (sx, sy) in enumerate(src[:52]):
-        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "52 sources at 1000^2, source %d (%d,%d)" % (k, sx, sy))
+    for k, (sx, sy) in enumerate(src[:64]):
+        _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "64 sources at 1000^2, source %d (%d,%d)" % (k, sx, sy))
     c.sweep_batch(src)
     assert c.last_sweep_kernel() == 3
 

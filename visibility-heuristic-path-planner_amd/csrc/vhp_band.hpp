@@ -1091,7 +1091,7 @@ struct BandWorker {
   // sources apart, i.e. behind the same L2 where workgroups go round the XCDs by their number)
   VHP_FN void run(int wg) {
     half = H > 1 ? wg / a.n_units : 0;
-    const int unit = H > 1 ? wg - half * a.n_units : wg;
+    const int unit = H > 1 ? wg - half * a.n_units : (a.order ? uniform(a.order[wg]) : wg);
     const int s = unit / kUnits, qo = unit - s * kUnits;
     // (the planners' control words together, before any of them is looked at: one trip to memory, then the source's)
     int sx, sy;

@@ -273,7 +273,7 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
 bool use_lat_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel != 0 && c->opt_kernel != 4) return false;
   if (!vhp::lat_supported(c->nx, c->ny)) return false;
-  if (c->opt_kernel == 4) return n_src <= 64;
+  if (c->opt_kernel == 4) return n_src <= 128;
   // (a caller that sets a launch shape of the front sweep is asking for the front sweep)
   if (c->opt_rows_per_lane || c->opt_strips || c->opt_multi || c->opt_slide >= 0 || c->opt_pack) return false;
   // Round 6, late: a long octant's bands go to two, four or eight workgroups (vhp_lat.hip lat_halves) -- while 16 x sources <= CUs.  With
@@ -293,10 +293,18 @@ bool use_lat_kernel(const vhp_ctx* c, int n_src) {
   // 207 / 250, 64: 214 / 210 / 252; 1000^2: 36: 155 / 234, 44: 201 / 234, 52: 220 / 234, 56: 269 / 237, 64: 273 / 242; from 96 sources the others
   // are ahead everywhere (512^2: 96: 128 / 127 / 138, 128: 156 / 132 / 145).  Other widths (the pool sweep's slower build): 64 sources at
   // 1001 x 971 273 against the front sweep's 295 and the pool sweep's ~ 340; at 101^2 28 / 34, at 255^2 60 / 71 (front).
+  // ... and with the units launched by falling length of their march (vhp_lat.hip vhp_lat_order: the long octants start first, the short
+  // ones fill the CUs they leave; unordered / ordered / pool sweep): 1000^2: 40 sources 171 / 157 / 233, 48: 212 / 171 / 234, 64: 273 / 216 / 239,
+  // 96: 361 / 311 / 237; 768^2: 64: 190 / 125 / 197, 96: 234 / 187 / 181; 512^2: 64: 107 / 72 / 131, 96: 139 / 99 / 126, 128: 145 / 126 / 132.
+  // 896^2: 80: 177 / 213 (ordered / pool); 640^2: 96: 133 / 154, 128: 177 / 157; 256^2: 96: 54 / 71, 128: 67 / 71 (front); 128^2: 96: 36 / 46, 128: 44 / 46
+  // (front); 1280^2: 40: 229 / 291, 64: 342 / 287; 1536^2: 40: 365 / 335.
+  // So, in rounds of octants (32 sources on 256 CUs): four up to 256 cells a side, three up to 640, two and a half up to 896, two up to
+  // 1024, one and a quarter up to 1280, one above.
   const int one_round = c->n_cus / 8;   // sources whose octants have a CU each
-  const int cap = maxdim <= 832 ? 2 * one_round : maxdim <= 1024 ? ((c->nx & 7) == 0 ? one_round * 13 / 8 : 2 * one_round) : one_round;
+  const int cap = maxdim <= 256 ? 4 * one_round : maxdim <= 640 ? 3 * one_round : maxdim <= 896 ? one_round * 5 / 2 : maxdim <= 1024 ? 2 * one_round
+                : maxdim <= 1280 ? one_round * 5 / 4 : one_round;
   // (the boundary lines of a launch -- 16 bytes per strip and step -- stay below two gigabytes: 32 sources at 8192^2 would take four)
-  return n_src <= std::min(cap, 64) && vhp::lat_scratch_bytes(n_src, c->nx, c->ny) <= ((size_t)2 << 30);
+  return n_src <= std::min(cap, 128) && vhp::lat_scratch_bytes(n_src, c->nx, c->ny) <= ((size_t)2 << 30);
 }
 
 bool use_pool_kernel(const vhp_ctx* c, int n_src) {

@@ -68,6 +68,9 @@ struct LatArgs {
   // sweeps the bands p with (p / sweepers) % halves == h, so that 16 bands of an octant are in flight instead of 8 (vhp_band.hpp BandWorker)
   int halves = 1;
   int n_units = 0;
+  // Launches with more units than the chip holds workgroups at once: workgroup g sweeps unit order[g] -- the units by falling length of
+  // their march (vhp_lat.hip vhp_lat_order), so that the long ones start first and the short ones fill the CUs they leave; null: unit g
+  const int* order = nullptr;
 };
 
 #if defined(VHP_DIAG_WINPROF) && !defined(VHP_SIM)  // diagnostic builds only: cycle accounts inside the x-major windows (they cost a few hundred cycles per window themselves)
