@@ -155,7 +155,7 @@ def test_field_stride_pads_between_fields(vhp, oracle, kernel, nx, ny, pad):
             _assert_same(got[k, :nx * ny].reshape(ny, nx), want, "%dx%d stride +%d kernel %d, source (%d,%d)" % (nx, ny, pad, kernel, sx, sy))
 
 
-@pytest.mark.parametrize("nx,ny,n", [(1002, 700, 96), (1001, 971, 96), (690, 402, 128), (500, 500, 256)])
+@pytest.mark.parametrize("nx,ny,n", [(1002, 700, 160), (1001, 971, 136), (690, 402, 192), (500, 500, 256)])
 def test_pool_is_the_default_for_batches_on_other_widths(vhp, oracle, nx, ny, n):
     # the library's own choice (vhp_capi.hip use_pool_kernel) on widths that are not a multiple of 8: the pool sweep's ANYW build from
     # these batch sizes up; every 8th field against the oracle, all of them written

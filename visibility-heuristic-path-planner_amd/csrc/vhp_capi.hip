@@ -301,8 +301,13 @@ bool use_lat_kernel(const vhp_ctx* c, int n_src) {
   // So, in rounds of octants (32 sources on 256 CUs): four up to 256 cells a side, three up to 640, two and a half up to 896, two up to
   // 1024, one and a quarter up to 1280, one above.
   const int one_round = c->n_cus / 8;   // sources whose octants have a CU each
-  const int cap = maxdim <= 256 ? 4 * one_round : maxdim <= 640 ? 3 * one_round : maxdim <= 896 ? one_round * 5 / 2 : maxdim <= 1024 ? 2 * one_round
-                : maxdim <= 1280 ? one_round * 5 / 4 : one_round;
+  int cap = maxdim <= 256 ? 4 * one_round : maxdim <= 640 ? 3 * one_round : maxdim <= 896 ? one_round * 5 / 2 : maxdim <= 1024 ? 2 * one_round
+          : maxdim <= 1280 ? one_round * 5 / 4 : one_round;
+  // Widths that are not a multiple of 8, where the other two kernels store 8-byte cells or run their slower build (tools/kernel_choice_other_widths.py,
+  // latency / pool / front, us): 1001 x 971: 64 sources 234 / 360 / 287, 128: 335 / 375 / 433; 1002 x 1000: 96: 281 / 327 / 378; 689^2: 80: 137 / 254 /
+  // 191, 128: 230 / 262 / 278; 690 x 402: 128: 160 / 182 / 171; 500^2: 128: 146 / 170 / 147; 1101 x 1100: 64: 274 / 380 / 392; 1201 x 1200: 40: 241 / 416 /
+  // 435; but 255^2: 128: 78 / 112 / 72, 101^2: 128: 44 / 57 / 39.  Four rounds up to 1280 cells a side, three up to 256.
+  if ((c->nx & 7) != 0) cap = maxdim <= 256 ? 3 * one_round : maxdim <= 1280 ? 4 * one_round : one_round;
   // (the boundary lines of a launch -- 16 bytes per strip and step -- stay below two gigabytes: 32 sources at 8192^2 would take four)
   return n_src <= std::min(cap, 128) && vhp::lat_scratch_bytes(n_src, c->nx, c->ny) <= ((size_t)2 << 30);
 }
