@@ -273,7 +273,7 @@ hipError_t launch_sweep_t(vhp_ctx* c, const int32_t* d_src, int n_src, OutT* d_o
 bool use_lat_kernel(const vhp_ctx* c, int n_src) {
   if (c->opt_kernel != 0 && c->opt_kernel != 4) return false;
   if (!vhp::lat_supported(c->nx, c->ny)) return false;
-  if (c->opt_kernel == 4) return n_src <= 128;
+  if (c->opt_kernel == 4) return n_src <= 256 && vhp::lat_scratch_bytes(n_src, c->nx, c->ny) <= ((size_t)2 << 30);
   // (a caller that sets a launch shape of the front sweep is asking for the front sweep)
   if (c->opt_rows_per_lane || c->opt_strips || c->opt_multi || c->opt_slide >= 0 || c->opt_pack) return false;
   // Round 6, late: a long octant's bands go to two, four or eight workgroups (vhp_lat.hip lat_halves) -- while 16 x sources <= CUs.  With

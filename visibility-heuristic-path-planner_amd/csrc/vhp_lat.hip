@@ -116,25 +116,32 @@ __global__ void vhp_pack_diag(const uint8_t* __restrict__ occ, uint64_t* __restr
 }
 
 // The units of a launch (8 per source: quadrant x {x-major, y-major}) by falling length of their march, for launches of more workgroups
-// than the chip holds at once: a counting sort by steps / 8 in one workgroup (up to 1024 units).  The length of a march is what an
+// than the chip holds at once: a counting sort by steps / 8 in one workgroup (up to 1024 x kLatOrderPerThread units).  The length of a march is what an
 // octant's time goes by (T / 16 + T / 64 windows); units of sources outside the grid go last.
+constexpr int kLatOrderPerThread = 2;   // (256 sources)
 __global__ void __launch_bounds__(1024) vhp_lat_order(const int32_t* __restrict__ src_xy, int n_src, int nx, int ny, int* __restrict__ order) {
   __shared__ int hist[1024], start[1024];
   const int tid = (int)threadIdx.x, n_units = n_src * kUnits;
   hist[tid] = 0;
   __syncthreads();
-  int bucket = 1023, pos = 0;
-  if (tid < n_units) {
-    const int s = tid / kUnits, qo = tid - s * kUnits, q = qo >> 1;
-    const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
-    int T = 0;
-    if (sx >= 0 && sy >= 0 && sx < nx && sy < ny) {
-      const int dx = (q == 0 || q == 3) ? 1 : -1, dy = (q == 0 || q == 1) ? 1 : -1;   // (BandWorker::run's table of directions)
-      const int ni = dx > 0 ? nx - sx : sx, nj = dy > 0 ? ny - sy : sy;
-      T = (ni > 0 && nj > 0) ? ((qo & 1) == 0 ? ni : nj) : 0;
+  int bucket[kLatOrderPerThread], pos[kLatOrderPerThread];
+#pragma unroll
+  for (int r = 0; r < kLatOrderPerThread; ++r) {
+    const int u = tid + 1024 * r;
+    bucket[r] = 1023;
+    pos[r] = 0;
+    if (u < n_units) {
+      const int s = u / kUnits, qo = u - s * kUnits, q = qo >> 1;
+      const int sx = src_xy[2 * s], sy = src_xy[2 * s + 1];
+      int T = 0;
+      if (sx >= 0 && sy >= 0 && sx < nx && sy < ny) {
+        const int dx = (q == 0 || q == 3) ? 1 : -1, dy = (q == 0 || q == 1) ? 1 : -1;   // (BandWorker::run's table of directions)
+        const int ni = dx > 0 ? nx - sx : sx, nj = dy > 0 ? ny - sy : sy;
+        T = (ni > 0 && nj > 0) ? ((qo & 1) == 0 ? ni : nj) : 0;
+      }
+      bucket[r] = 1023 - imin(T >> 3, 1023);
+      pos[r] = atomicAdd(&hist[bucket[r]], 1);
     }
-    bucket = 1023 - imin(T >> 3, 1023);
-    pos = atomicAdd(&hist[bucket], 1);
   }
   __syncthreads();
   // inclusive prefix sums of the 1024 buckets (Hillis-Steele on the workgroup's 1024 threads)
@@ -146,7 +153,11 @@ __global__ void __launch_bounds__(1024) vhp_lat_order(const int32_t* __restrict_
     start[tid] += v;
     __syncthreads();
   }
-  if (tid < n_units) order[start[bucket] - hist[bucket] + pos] = tid;
+#pragma unroll
+  for (int r = 0; r < kLatOrderPerThread; ++r) {
+    const int u = tid + 1024 * r;
+    if (u < n_units) order[start[bucket[r]] - hist[bucket[r]] + pos[r]] = u;
+  }
 }
 
 }  // namespace pool
@@ -247,7 +258,7 @@ hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {
     }
   }
 #endif
-  if (g.halves == 1 && a.n_src * kUnits > (a.n_cus > 0 ? a.n_cus : 256) && a.n_src * kUnits <= 1024 && !a.d_pivot_rec && !a.d_src_index && !a.d_slot_base) {
+  if (g.halves == 1 && a.n_src * kUnits > (a.n_cus > 0 ? a.n_cus : 256) && a.n_src * kUnits <= 1024 * pool::kLatOrderPerThread && !a.d_pivot_rec && !a.d_src_index && !a.d_slot_base) {
     // more workgroups than the chip holds at once: the long units first
     int* d_order = reinterpret_cast<int*>(reinterpret_cast<char*>(a.d_queue) + lat_lines_bytes(a.n_src, a.nx, a.ny));
     hipLaunchKernelGGL(pool::vhp_lat_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, d_order);
