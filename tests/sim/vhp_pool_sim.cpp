@@ -357,7 +357,7 @@ int run_lat_t(const uint8_t* occ, int nx, int ny, const int32_t* src, int n_src,
       Shared sh;
       sh.lds = lds[gI].data();
       sh.L = L;
-      const int s_ = (gI % n_units) / kUnits, qo = gI % kUnits;
+      const int s_ = (gI / H) / kUnits, qo = (gI / H) % kUnits;
       UnitGeo ug;
       ug.init(nx, ny, qo, src[2 * s_], src[2 * s_ + 1]);
       fprintf(stderr, "unit %d (source %d,%d qo %d): strips %d diag ready %d\n   prog:", gI, src[2 * s_], src[2 * s_ + 1], qo, ug.n_strips, sh.ctx(0)[kDiagReady]);

@@ -379,7 +379,7 @@ struct BandX {
     }
     // (a reader in another workgroup sees this band's death in a record beside the lines; the line itself it has window by window,
     // Link::store_window, and never as whole blocks -- the entries of a block past a band's death were never swept)
-    if (MULTI && (dead || retires) && death_out) g_store_tagged(death_out, vi(0), vd((double)ta), lk.epoch);
+    if (MULTI && (dead || retires) && death_out) g_store_tagged_device(death_out, vi(0), vd((double)ta), lk.epoch);
     if (has_consumer && !(MULTI && death_out)) lk.store_block(imax(g.nbx(imin(imax(ta - 1, 0), i_last)), 0), blk);
     if (dead || retires) {
       // Everything from step ta - 1 on is +0.0, in this band and below it (or: the band has left the octant): the word of death
@@ -823,7 +823,7 @@ struct BandY {
       request(yw, DY > 0 ? blk - g.by0 : g.by0 - blk);
       if (b == 0) { origin_bits(yw); march<true>(ta, yw, dead); } else march<false>(ta, yw, dead);
     }
-    if (MULTI && (dead || retires) && death_out) g_store_tagged(death_out, vi(0), vd((double)ta), lk.epoch);   // (see BandX::run)
+    if (MULTI && (dead || retires) && death_out) g_store_tagged_device(death_out, vi(0), vd((double)ta), lk.epoch);   // (see BandX::run)
     if (has_consumer && !(MULTI && death_out)) lk.store_block(imax(g.nby(imin(imax(ta - 1, 0), j_last)), 0), blk);
     if (dead || retires) {  // (see BandX::run)
       lds_publish(dead_mine, ta);
@@ -1087,11 +1087,13 @@ struct BandWorker {
   }
 
   // the whole life of this wavefront in unit `unit` (8 * source + 2 * quadrant + {0: x-major, 1: y-major})
-  // (with two workgroups per unit: workgroup g is half g / n_units of unit g % n_units -- the halves of a unit eight workgroups x the
-  // sources apart, i.e. behind the same L2 where workgroups go round the XCDs by their number)
+  // (with H workgroups per unit: workgroup g is workgroup g % H of unit g / H -- the workgroups of a unit NEXT to each other in the
+  // launch.  A workgroup waits for workgroups of its own unit only, and the dispatcher hands out a launch's workgroups in order: whatever
+  // part of the chip the launch gets -- another stream's kernels beside it, fewer CUs than it was sized for --, at most one unit at
+  // the frontier of the dispatch is incomplete, every unit before it can finish, and the CUs they free go to that one)
   VHP_FN void run(int wg) {
-    half = H > 1 ? wg / a.n_units : 0;
-    const int unit = H > 1 ? wg - half * a.n_units : (a.order ? uniform(a.order[wg]) : wg);
+    half = H > 1 ? wg % H : 0;
+    const int unit = H > 1 ? wg / H : (a.order ? uniform(a.order[wg]) : wg);
     const int s = unit / kUnits, qo = unit - s * kUnits;
     // (the planners' control words together, before any of them is looked at: one trip to memory, then the source's)
     int sx, sy;

@@ -255,6 +255,7 @@ inline void lds_store_i_if(const vb& p, int* base, const vi& idx, int v) { for (
 inline void g_load_tagged_raw(const Tagged* base, const vi& idx, vu64& tag, vd& v) { for (int l = 0; l < kLanes; ++l) { v.v[l] = base[idx.v[l]].v; tag.v[l] = base[idx.v[l]].tag; } }
 inline vb tags_are(const vu64& tag, uint64_t want) { vb ok; for (int l = 0; l < kLanes; ++l) ok.v[l] = tag.v[l] == want; return ok; }
 inline void g_store_tagged_if(const vb& p, Tagged* base, const vi& idx, const vd& v, uint64_t tag) { for (int l = 0; l < kLanes; ++l) if (p.v[l]) { base[idx.v[l]].v = v.v[l]; base[idx.v[l]].tag = tag; } }
+inline void g_store_tagged_device(Tagged* base, const vi& idx, const vd& v, uint64_t tag) { g_store_tagged(base, idx, v, tag); }
 
 #else
 // ------------------------------------------------------------------------------------------------------------
@@ -551,7 +552,16 @@ VHP_LANE_FN void g_load_tagged_raw(const Tagged* base, vi idx, vu64& tag, vd& v)
   v = __hip_atomic_load(&base[idx].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 VHP_LANE_FN bool tags_are(vu64 tag, uint64_t want) { return tag == want; }
-VHP_LANE_FN void g_store_tagged_if(bool p, Tagged* base, vi idx, vd v, uint64_t tag) { if (p) base[idx] = Tagged{v, tag}; }
+// A tagged entry for a reader that may sit behind ANOTHER L2 (another XCD): agent-scope stores, which go through to memory, the value first
+// and the tag behind it (one wavefront's stores to one line leave in program order; the reader takes the tag first: g_load_tagged).  A
+// plain 16-byte store stays in the writer's L2 until the kernel ends -- a reader behind the same L2 sees it, any other never does (found
+// when a unit's workgroups were dealt to neighbouring XCDs: the launch hung).
+VHP_LANE_FN void g_store_tagged_device(Tagged* base, vi idx, vd v, uint64_t tag) {
+  __hip_atomic_store(&base[idx].v, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(&base[idx].tag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+VHP_LANE_FN void g_store_tagged_if(bool p, Tagged* base, vi idx, vd v, uint64_t tag) { if (p) g_store_tagged_device(base, idx, v, tag); }
 VHP_LANE_FN bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0ull; }
 VHP_LANE_FN void lds_store_i_if(bool p, int* base, vi idx, int v) { if (p) ((lds_int*)base)[idx] = v; }
 VHP_LANE_FN void backoff() { __builtin_amdgcn_s_sleep(VHP_BACKOFF_SLEEP); }
