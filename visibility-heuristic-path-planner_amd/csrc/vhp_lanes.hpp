@@ -552,14 +552,25 @@ VHP_LANE_FN void g_load_tagged_raw(const Tagged* base, vi idx, vu64& tag, vd& v)
   v = __hip_atomic_load(&base[idx].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 VHP_LANE_FN bool tags_are(vu64 tag, uint64_t want) { return tag == want; }
-// A tagged entry for a reader that may sit behind ANOTHER L2 (another XCD): agent-scope stores, which go through to memory, the value first
-// and the tag behind it (one wavefront's stores to one line leave in program order; the reader takes the tag first: g_load_tagged).  A
+// A tagged entry for a reader that may sit behind ANOTHER L2 (another XCD): an agent-scope store, which goes through to memory.  A
 // plain 16-byte store stays in the writer's L2 until the kernel ends -- a reader behind the same L2 sees it, any other never does (found
 // when a unit's workgroups were dealt to neighbouring XCDs: the launch hung).
 VHP_LANE_FN void g_store_tagged_device(Tagged* base, vi idx, vd v, uint64_t tag) {
+#ifdef VHP_TAGGED_STORE_TWO_HALVES
   __hip_atomic_store(&base[idx].v, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("" ::: "memory");
   __hip_atomic_store(&base[idx].tag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  // (one 16-byte store with the scope bit of an agent-scope atomic store -- the language has none that wide; the two halves as atomic
+  // stores cost the build eleven vector registers it does not have.  The s_nop behind it: a wide store's data registers must not be
+  // written by the next vector instruction, and the compiler does not look into an asm statement for that.)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+  u32x4 d;
+  d.x = (unsigned)vb; d.y = (unsigned)(vb >> 32); d.z = (unsigned)tag; d.w = (unsigned)(tag >> 32);
+  Tagged* p = base + idx;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+#endif
 }
 VHP_LANE_FN void g_store_tagged_if(bool p, Tagged* base, vi idx, vd v, uint64_t tag) { if (p) g_store_tagged_device(base, idx, v, tag); }
 VHP_LANE_FN bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0ull; }
