@@ -35,6 +35,7 @@ namespace vhp {
 namespace pool {
 
 constexpr int kLW = 16;        // steps per window
+static_assert(kLW == kLW16, "Link::store_window hands over windows of the latency sweep");
 constexpr int kLatDummy = 16;  // doubles of a wavefront's dummy slots (Layout::dummies holds 16 per wavefront)
 constexpr int kDiagZero = 7;   // the diagonal's "all +0.0 from here" word: a free word of the context's head (vhp_pool.hpp kCtxHead = 8)
 
