@@ -96,6 +96,11 @@ def test_lat_kernel_bad_source_is_reported(vhp):
     c = _ctx(vhp, occ)
     with pytest.raises(Exception):
         c.sweep_batch(np.array([[5, 5], [64, 3]], np.int32))
+    # ... and in a launch of more units than CUs, whose units go out in order of length (the units of a source outside the grid: last)
+    src = np.array([[k % 64, (7 * k) % 64] for k in range(40)], np.int32)
+    src[23] = (3, -1)
+    with pytest.raises(Exception):
+        c.sweep_batch(src)
 
 
 def _walled(nx, ny, seed, density):
