@@ -17,13 +17,23 @@ CSRC = os.path.join(ROOT, "visibility-heuristic-path-planner_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def _asm(src, tmp_path):
+_COMPILED = {}   # source file -> (assembly, the compiler's resource-usage remarks): one compilation per file and test session
+
+
+def _compile(src, tmp_path):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
-    out = str(tmp_path / (src + ".s"))
-    subprocess.check_call([HIPCC, "-std=c++17", "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-                           "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
-    return open(out).read()
+    if src not in _COMPILED:
+        out = str(tmp_path / (src + ".s"))
+        p = subprocess.run([HIPCC, "-std=c++17", "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                            "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src), "-Rpass-analysis=kernel-resource-usage"],
+                           stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, check=True)
+        _COMPILED[src] = (open(out).read(), p.stderr)
+    return _COMPILED[src]
+
+
+def _asm(src, tmp_path):
+    return _compile(src, tmp_path)[0]
 
 
 def _kernels(asm, name):
@@ -58,13 +68,8 @@ def test_latency_sweep_register_budget(tmp_path):
     """The latency sweep's workgroup is sixteen wavefronts (a sweeper and a storer per band in flight: csrc/vhp_band.hpp): four per
     SIMD, i.e. 128 vector registers each, with no scratch -- and its spilled scalars stay out of the window loops and few (the sweep
     in strips of rows, until round 6, spilled 559-677 of them at 256 vector registers and two wavefronts per SIMD)."""
-    if not os.path.exists(HIPCC):
-        pytest.skip("no hipcc")
-    out = str(tmp_path / "vhp_lat.s")
-    p = subprocess.run([HIPCC, "-std=c++17", "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-                        "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "vhp_lat.hip"), "-Rpass-analysis=kernel-resource-usage"],
-                       stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, check=True)
-    blocks = re.split(r"remark: Function Name: ", p.stderr)[1:]
+    asm, remarks = _compile("vhp_lat.hip", tmp_path)
+    blocks = re.split(r"remark: Function Name: ", remarks)[1:]
     seen = 0
     for blk in blocks:
         name = blk.split()[0]
@@ -82,7 +87,6 @@ def test_latency_sweep_register_budget(tmp_path):
         assert get(r"SGPRs Spill") <= (520 if multi else 240), (name, get(r"SGPRs Spill"))
     assert seen == 8, seen
     # ... and (next to) none of the spilled scalars is reloaded inside a window's sixteen steps (the blocks that hold the arithmetic)
-    asm = open(out).read()
     for name, body in _kernels(asm, "vhp_lat_sweep").items():
         for blk in re.split(r"^\.LBB\d+_\d+:", body, flags=re.M):
             fp64 = len(re.findall(r"v_(?:fma|mul|add|fmac)_f64", blk))
