@@ -173,14 +173,17 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // has at most 16 bands there, and what bands 8-15 gain by not waiting for the sweepers of bands 0-7 the hand-over through global
 // memory takes back (measured at 1000^2: 117.8 / 118.4 us over eight source positions).  Above: two up to 2048, four up to 4096, eight
 // beyond -- an octant of P bands is swept in rounds of 8 x that number, and every round waits for the one before (8192^2, one source:
-// 3.47 ms with one workgroup per unit, 1.92 with two, 1.18 with four).  All workgroups of a unit must be resident at once -- the
-// others spin on the first one's lines --: halved until workgroups <= CUs.  (asked: vhp_set_option "lat_workgroups", 1 / 2 / 4 / 8, for
+// 3.47 ms with one workgroup per unit, 1.92 with two, 1.18 with four), halved until the launch is at most twice the chip.  (asked: vhp_set_option "lat_workgroups", 1 / 2 / 4 / 8, for
 // measurements and tests; 0: by the size.)
 int lat_halves(int n_src, int nx, int ny, int n_cus, int asked) {
   const int cus = n_cus > 0 ? n_cus : 256, side = std::max(nx, ny);
   const int want = asked > 0 ? asked : side > 4 * VHP_LAT_HALVES_MIN_SIDE ? 8 : side > 2 * VHP_LAT_HALVES_MIN_SIDE ? 4 : side > VHP_LAT_HALVES_MIN_SIDE ? 2 : 1;
   int h = 1;
-  while (2 * h <= want && 2 * h <= 8 && 2 * h * pool::kUnits * n_src <= cus) h *= 2;
+  // (up to twice as many workgroups as CUs -- a launch of more workgroups than CUs is safe, BandWorker::run, and a unit's later
+  // workgroups start while its first ones are at their first bands: 16 sources at 4096^2 1265 us with two workgroups per unit, 1193 with
+  // four; 8 at 8192^2 2718 with four, 2447 with eight; a number that was asked for is taken as it is)
+  // (... beyond two that fit: 32 sources at 1536^2 take 280 us with one workgroup per unit and 316 with two on twice the chip)
+  while (2 * h <= want && 2 * h <= 8 && (asked > 0 || 2 * h * pool::kUnits * n_src <= (h >= 2 ? 2 : 1) * cus)) h *= 2;
   return h;
 }
 size_t lat_lds_bytes(int nx, int ny) { return (size_t)pool::make_layout(pool::kLatWaves, 1, nx, ny, pool::kLatTilePitch).total * 8; }
