@@ -180,6 +180,38 @@ def test_lat_kernel_workgroups_per_unit_option(vhp, oracle, workgroups):
             _assert_same(got[k], oracle.sweep_full(occ, int(sx), int(sy)), "%dx%d, %d workgroups per unit, source (%d,%d)" % (nx, ny, workgroups, sx, sy))
 
 
+def test_lat_kernel_two_contexts_side_by_side(vhp):
+    """Two contexts on two streams of one device, launches of several workgroups per unit in flight side by side (2100 x 2048: four per unit,
+    2 x 8 x 4 x 8 = 512 workgroups on 256 CUs): a launch sized for the whole device gets part of it and must neither hang nor differ -- a
+    unit's workgroups are next to each other in the launch and wait only for each other (tools/lat_side_by_side.py for larger grids)."""
+    import torch
+    nx, ny, n = 2100, 2048, 8
+    occ = maps.random_rect_map(nx, ny, 40, 20, 300, 20, 300, 9)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctxs, outs, d_src = [], [], []
+    for k in range(2):
+        c = vhp.Context(0)
+        c.set_stream(streams[k].cuda_stream)
+        c.set_map(occ)
+        ctxs.append(c)
+        outs.append(torch.full((n, ny, nx), float("nan"), dtype=torch.float64, device="cuda"))
+        d_src.append(torch.from_numpy(np.ascontiguousarray(maps.free_sources(occ, n, 3 + k), np.int32)).cuda())
+    torch.cuda.synchronize()
+    refs = []
+    for k in range(2):   # each launch alone
+        ctxs[k].sweep_batch_device(d_src[k].data_ptr(), n, outs[k].data_ptr())
+        torch.cuda.synchronize()
+        assert ctxs[k].last_sweep_kernel() == 4
+        refs.append(outs[k].clone())
+        outs[k].fill_(float("nan"))
+    torch.cuda.synchronize()
+    for it in range(5):   # ... and side by side
+        for k in range(2):
+            ctxs[k].sweep_batch_device(d_src[k].data_ptr(), n, outs[k].data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], refs[0]) and torch.equal(outs[1], refs[1])
+
+
 def test_lat_kernel_maze_6_pivots(vhp, oracle):
     occ = maps.maze_6()
     res = oracle.solve(occ, (345, 391), (341, 10), 0.1, 1000)
