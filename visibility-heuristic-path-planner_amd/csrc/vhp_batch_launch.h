@@ -25,6 +25,7 @@ struct BatchArgs {
   int* d_queue;           // the launch's scratch (pool_scratch_bytes / lat_scratch_bytes)
   int n_cus;              // compute units of the device (the persistent grid is sized to what the chip holds at once)
   int lat_workgroups = 0; // latency sweep: workgroups per octant asked for (0: by the grid's size, lat_halves)
+  int* d_lat_order = nullptr;  // latency sweep: room for the launch order of its units (lat_order_bytes; vhp_lat_order), or null: none
   hipStream_t stream;
   // called with (kernel, bytes) before a launch that needs more than the default dynamic LDS: the per-device
   // bookkeeping lives with the context
@@ -63,6 +64,7 @@ hipError_t launch_lat(const BatchArgs& a);
 // grid, the epilogue over d (union, labels, heuristic, next pivot: vhp_planner_dev.hip.h).  d.ticket[1] counts the sweep's workgroups.
 hipError_t launch_lat_planner(const BatchArgs& a, const PlannerDev& d);
 size_t lat_scratch_bytes(int n_src, int nx, int ny);
+size_t lat_order_bytes();
 // The latency sweep's lanes run along diagonals of the grid: it reads the occupancy packed along them (vhp_band.hpp DiagMaps),
 // built once per map from the byte map: lat_diag_map_bytes of device memory, zero-filled and packed by lat_pack_diag_maps.
 size_t lat_diag_map_bytes(int nx, int ny);

@@ -56,6 +56,7 @@ struct vhp_ctx {
   double* d_bnd = nullptr;  // boundary rows of multi-round sweeps (sides above W*64*R)
   size_t d_bnd_cap = 0;
   int* d_order = nullptr;   // launch order of the (source, quadrant) units (+ one int4 descriptor per workgroup)
+  int* d_lat_order = nullptr;  // launch order of the latency sweep's units where it launches more of them than the device has CUs
   size_t d_order_cap = 0;
   int* d_pool = nullptr;    // pool sweep: pull counter, unit order, diagonal lines, tagged boundary lines (zeroed when allocated)
   size_t d_pool_cap = 0;
@@ -396,6 +397,11 @@ hipError_t launch_batch_sweep(vhp_ctx* c, const int32_t* d_src, int n_src, OutT*
   a.d_run_if = lat ? c->lat_run_if : nullptr;
   a.lat_dead_cells_are_zero = lat && c->lat_dark_unwritten;
   a.lat_workgroups = c->opt_lat_workgroups;
+  if (lat && !c->d_lat_order) {
+    hipError_t eo = hipMalloc(&c->d_lat_order, vhp::lat_order_bytes());
+    if (eo != hipSuccess) return eo;
+  }
+  a.d_lat_order = c->d_lat_order;
   a.n_cus = c->n_cus;
   a.stream = c->stream;
   a.raise_lds = [c](const void* fn, size_t bytes) { return raise_lds_limit(c, fn, bytes); };
@@ -541,6 +547,7 @@ int vhp_destroy(vhp_ctx* ctx) {
   if (ctx->d_out) hipFree(ctx->d_out);
   if (ctx->d_bnd) hipFree(ctx->d_bnd);
   if (ctx->d_order) hipFree(ctx->d_order);
+  if (ctx->d_lat_order) hipFree(ctx->d_lat_order);
   if (ctx->d_pool) hipFree(ctx->d_pool);
   for (auto& pr : ctx->timed_launches) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

@@ -162,8 +162,6 @@ __global__ void __launch_bounds__(1024) vhp_lat_order(const int32_t* __restrict_
 
 }  // namespace pool
 
-size_t lat_lines_bytes(int n_src, int nx, int ny);
-
 namespace {
 constexpr size_t kLdsLimit = 160 * 1024;
 #ifndef VHP_LAT_HALVES_MIN_SIDE
@@ -261,11 +259,11 @@ hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {
     }
   }
 #endif
-  if (g.halves == 1 && a.n_src * kUnits > (a.n_cus > 0 ? a.n_cus : 256) && a.n_src * kUnits <= 1024 * pool::kLatOrderPerThread && !a.d_pivot_rec && !a.d_src_index && !a.d_slot_base) {
+  if (g.halves == 1 && a.n_src * kUnits > (a.n_cus > 0 ? a.n_cus : 256) && a.n_src * kUnits <= 1024 * pool::kLatOrderPerThread && a.d_lat_order && !a.d_pivot_rec && !a.d_src_index && !a.d_slot_base) {
     // more workgroups than the chip holds at once: the long units first
-    int* d_order = reinterpret_cast<int*>(reinterpret_cast<char*>(a.d_queue) + lat_lines_bytes(a.n_src, a.nx, a.ny));
-    hipLaunchKernelGGL(pool::vhp_lat_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, d_order);
-    g.order = d_order;
+    // (a list of its own, not a corner of the scratch: nothing but tagged entries may ever be written where a later launch looks for tags)
+    hipLaunchKernelGGL(pool::vhp_lat_order, dim3(1), dim3(1024), 0, a.stream, a.d_src, a.n_src, a.nx, a.ny, a.d_lat_order);
+    g.order = a.d_lat_order;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)(a.n_src * kUnits * g.halves)), dim3(kLatThreads), lds, a.stream, g);
   const hipError_t e = hipGetLastError();
@@ -274,9 +272,10 @@ hipError_t launch_lat_t(const BatchArgs& a, const PlannerDev* pd = nullptr) {
 }
 }  // namespace
 
-// (the boundary lines of the units and, behind them, the launch order of the units: vhp_lat_order)
-size_t lat_lines_bytes(int n_src, int nx, int ny) { return (size_t)pool::lat_unit_blocks(nx, ny) * pool::kUnits * (size_t)n_src * 64 * sizeof(vhp::lanes::Tagged); }
-size_t lat_scratch_bytes(int n_src, int nx, int ny) { return lat_lines_bytes(n_src, nx, ny) + (size_t)pool::kUnits * (size_t)n_src * sizeof(int) + 64; }
+size_t lat_scratch_bytes(int n_src, int nx, int ny) {
+  return (size_t)pool::lat_unit_blocks(nx, ny) * pool::kUnits * (size_t)n_src * 64 * sizeof(vhp::lanes::Tagged);
+}
+size_t lat_order_bytes() { return (size_t)1024 * pool::kLatOrderPerThread * sizeof(int); }
 
 size_t lat_diag_map_bytes(int nx, int ny) { return pool::DiagMaps::words(nx, ny) * sizeof(uint64_t); }
 
